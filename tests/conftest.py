@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def golden_vq():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests/golden/vq_cases.npz"))
+
+
+@pytest.fixture(scope="session")
+def golden_models():
+    import numpy as np
+    return np.load(os.path.join(ROOT, "tests/golden/model_cases.npz"))
+
+
+def have_reference():
+    return os.path.isdir(os.environ.get("VQVAE_REFERENCE", "/root/reference"))
