@@ -1,0 +1,70 @@
+"""CPU tests: the C-ABI library builds, loads, and exports exactly what include/vqvae_hip.h declares.
+No compute calls here (no GPU in this container)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from vqvae_amd import build
+    path = build.build()
+    import torch  # noqa: F401  HIP runtime first
+    return ctypes.CDLL(path)
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include/vqvae_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(vqvae_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_symbols_exported(lib):
+    syms = declared_symbols()
+    assert len(syms) >= 6
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/vqvae_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    from vqvae_amd import _lib
+    assert sorted(_lib.SIGNATURES) == declared_symbols()
+
+
+def test_no_torch_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include/vqvae_hip.h")).read()
+    assert "torch" not in hdr.lower().replace("pytorch", "") and "at::" not in hdr
+
+
+def test_argument_errors_without_gpu(lib):
+    """Argument validation happens before any HIP call."""
+    lib.vqvae_strerror.restype = ctypes.c_char_p
+    lib.vqvae_vq_workspace_bytes.restype = ctypes.c_size_t
+    lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
+    assert lib.vqvae_abi_version() == 1
+    assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
+    assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
+    assert b"NULL" in lib.vqvae_strerror(-1)
+    f = lib.vqvae_vq_forward_f32
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_int64] + [ctypes.c_int] * 4 + [ctypes.c_float, ctypes.c_int] + \
+        [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
+    assert f(None, None, 1, 64, 8, 8, 512, 0.25, 0, None, None, None, None, None, None, 0, None) == -1
+    one = ctypes.c_void_p(16)
+    assert f(one, one, 0, 64, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 1 << 30, None) == -2
+    assert f(one, one, 1, 48, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 1 << 30, None) == -3
+    assert f(one, one, 1, 64, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 16, None) == -4
+
+
+def test_product_path_does_not_import_oracle():
+    """The shipped package must not import, link or execute oracle/ (test infrastructure)."""
+    pat = re.compile(r"(^|\s)(from|import)\s+oracle\b|libvqvae_oracle|oracle[/.](c_oracle|torch_port|vqvae_oracle)")
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "vqvae_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert not pat.search(src), f"{fn} reaches into oracle/"

@@ -1,0 +1,58 @@
+"""ctypes binding of libvqvae_hip.so (the C ABI declared in include/vqvae_hip.h).
+
+There is deliberately NO fallback here: if the HIP library is missing or cannot be
+loaded, importing the product path raises.  torch must be imported first so that
+the library binds to the HIP runtime torch has already loaded (one runtime per
+process is required for shared streams and device pointers).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 first)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvqvae_hip.so")
+
+_i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/vqvae_hip.h one to one
+SIGNATURES = {
+    "vqvae_abi_version": (_i32, []),
+    "vqvae_strerror": (C.c_char_p, [_i32]),
+    "vqvae_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "vqvae_vq_forward_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "vqvae_vq_onehot_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "vqvae_vq_decode_indices_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+class VqvaeHipError(RuntimeError):
+    pass
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise VqvaeHipError(
+            f"{LIB_PATH} is missing: build it with `python -m vqvae_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for this path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the ABI drifted
+        fn.restype, fn.argtypes = res, args
+    if lib.vqvae_abi_version() != 1:
+        raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(code: int):
+    if code != 0:
+        raise VqvaeHipError(f"libvqvae_hip: {load().vqvae_strerror(code).decode()} (code {code})")

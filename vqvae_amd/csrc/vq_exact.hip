@@ -1,0 +1,537 @@
+// Fused VectorQuantizer forward for gfx950 -- exact-fp32 variant.
+//
+// Replaces models/quantizer.py:45-76 of the reference with ONE pass over z_e:
+//   distance  d[n,k] = fl(fl(||z_n||^2 + ||e_k||^2) - 2*m[n,k]),  m = z_n . e_k
+//   argmin (first index, NaN counts as minimum), gather e_k, z + (e_k - z),
+//   sum((e_k - z)^2), per-code histogram.
+//
+// Numerics (pinned by oracle/ and tests/):
+//   * m[n,k] is the c-ordered fp32 fmaf chain torch.matmul produces on CPU.  On
+//     gfx950 v_mfma_f32_32x32x2_f32 is bit-for-bit that chain (k = 0 then 1 per
+//     instruction, instructions chained through the accumulator), so the whole
+//     N x K x D contraction runs on the matrix cores with no rounding difference.
+//   * ||.||^2 follows ATen's cascade_sum order (8-lane vectors x 4-way ILP).
+//
+// Mapping: codes on the MFMA M side, latent rows on the N side.  A wave owns
+// RT tiles of 32 rows; lane l holds row (l & 31) and the channels c = 2s + (l>>5)
+// (exactly the B-operand layout), keeps them in registers for the whole sweep,
+// and receives 16 codes x 1 row per 32x32 tile in its accumulator, so the
+// running (min, argmin) is per-lane VALU work and only one cross-lane fold
+// (l <-> l+32) is needed per row.  The codebook lives in LDS as the A-operand
+// image [c/8][c&1][code][(c%8)/2], read conflict-free with ds_read_b128.
+#include "common.h"
+
+namespace vqvae {
+
+// Raw buffer descriptor over [p, p + 4 GiB): stride 0, no swizzle.  p must be
+// wave-uniform; lanes address it with 32-bit byte offsets.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0xFFFFFFFFu, 0x00020000);
+}
+
+// ---------------------------------------------------------------------------
+// ATen cascade_sum order for one row of D squares held fully by one thread.
+template <int D>
+__device__ __forceinline__ float aten_sqsum_full(const float (&sq)[D]) {
+    static_assert(D % 8 == 0 && D / 32 < 16, "D must be a multiple of 8 below 512");
+    constexpr int NV = D / 8, NI = NV / 4;
+    float part[4][8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) part[q][t] = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) part[q][t] = part[q][t] + sq[(4 * i + q) * 8 + t];
+#pragma unroll
+    for (int v = NI * 4; v < NV; ++v)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) part[0][t] = part[0][t] + sq[v * 8 + t];
+    float fin = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+        const float a = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
+        fin = fin + a;
+    }
+    return fin;
+}
+
+// ---------------------------------------------------------------------------
+// Prepare: one thread per (padded) code.  Writes ||e_k||^2 in ATen order, the
+// LDS image of the codebook, and raises cb_bad if any norm is not < 1e38.
+template <int D>
+__global__ __launch_bounds__(64) void vq_prepare_kernel(const float *__restrict__ cb, int K, int KC,
+                                                        int K_pad, float *__restrict__ ee,
+                                                        float *__restrict__ img,
+                                                        int *__restrict__ flags) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K_pad) return;
+    const int ch = k / KC, kl = k - ch * KC;
+    float *dst = img + (size_t)ch * KC * D;
+    float e[D];
+    if (k < K) {
+#pragma unroll
+        for (int c = 0; c < D; c += 4) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(cb + (size_t)k * D + c);
+            e[c] = v.x; e[c + 1] = v.y; e[c + 2] = v.z; e[c + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < D; ++c) e[c] = 0.0f;
+    }
+#pragma unroll
+    for (int c = 0; c < D; ++c) {
+        const int j = c >> 3, i = (c & 7) >> 1, h = c & 1;
+        dst[((size_t)(j * 2 + h) * KC + kl) * 4 + i] = e[c];
+    }
+    float n2 = __builtin_inff();     // padded codes can never win
+    if (k < K) {
+        float sq[D];
+#pragma unroll
+        for (int c = 0; c < D; ++c) sq[c] = e[c] * e[c];
+        n2 = aten_sqsum_full<D>(sq);
+        if (!(n2 < 1.0e38f)) atomicOr(flags, 1);
+    }
+    ee[k] = n2;
+}
+
+// ---------------------------------------------------------------------------
+// torch.argmin semantics for one row, scalar, used only for rows whose distances
+// may be non-finite (zz or some ||e||^2 not < 1e38): NaN is minimal, first wins.
+template <int D, bool ROWMAJOR>
+__device__ __noinline__ int vq_slow_argmin(const float *__restrict__ z, size_t zbase, size_t zstride,
+                                           const float *__restrict__ cb, const float *__restrict__ ee,
+                                           int K, float zz) {
+    if (zz != zz) return 0;          // every t = zz + ee is NaN -> first index
+    int best = 0;
+    float bd = 0.0f;
+    for (int k = 0; k < K; ++k) {
+        float m = 0.0f;
+        for (int c = 0; c < D; ++c)
+            m = __builtin_fmaf(z[zbase + (size_t)c * zstride], cb[(size_t)k * D + c], m);
+        const float t = zz + ee[k];
+        const float u = 2.0f * m;
+        const float d = t - u;
+        const bool dn = d != d, bn = bd != bd;
+        const bool better = (k == 0) || (dn ? !bn : (!bn && d < bd));
+        if (better) { best = k; bd = d; }
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------
+template <int D, int RT, bool ROWMAJOR>
+__global__ __launch_bounds__(512, 2) void vq_exact_kernel(
+    const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ img,
+    const float *__restrict__ ee_g, const int *__restrict__ flags, long long N, int HW, int K,
+    int KC, int nchunks, long long nblocks, float *__restrict__ zq, long long *__restrict__ idx,
+    int *__restrict__ hist, double *__restrict__ partials) {
+    constexpr int S = D / 2;                 // MFMA k-steps (2 channels each)
+    constexpr int ROWS_WG = 8 * 32 * RT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Es = smem;                         // [D/8][2][KC][4]
+    float *ee_s = Es + (size_t)KC * D;        // [KC]
+    int *hist_s = reinterpret_cast<int *>(ee_s + KC);   // [K]
+    double *red = reinterpret_cast<double *>(hist_s + ((K + 1) & ~1));
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int cb_bad = flags[0];
+
+    for (int k = tid; k < K; k += 512) hist_s[k] = 0;
+
+    auto stage = [&](int ch) {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(img + (size_t)ch * KC * D);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(Es);
+        const int n4 = KC * D / 4;
+        for (int i = tid; i < n4; i += 512) dst[i] = src[i];
+        for (int i = tid; i < KC; i += 512) ee_s[i] = ee_g[ch * KC + i];
+    };
+    if (nchunks == 1) stage(0);
+    __syncthreads();
+
+    double dacc = 0.0;
+
+    for (long long rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        // ---- load this wave's rows into the MFMA B-operand layout --------------
+        float zr[RT][S];
+        float zz[RT];
+        long long row[RT];
+        size_t zbase[RT];
+        size_t img0[RT];
+        unsigned voff[RT];
+        bool valid[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            row[t] = rb * ROWS_WG + wave * (32 * RT) + t * 32 + l31;
+            valid[t] = row[t] < N;
+            const long long rc = valid[t] ? row[t] : N - 1;
+            if (ROWMAJOR) {
+                zbase[t] = (size_t)rc * D;
+#pragma unroll
+                for (int q = 0; q < D / 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(z + zbase[t] + 4 * q);
+                    zr[t][2 * q] = h ? v.y : v.x;
+                    zr[t][2 * q + 1] = h ? v.w : v.z;
+                }
+            } else {
+                // NCHW: element (row, c) sits at ((b*D + c)*HW + hw).  One buffer
+                // descriptor per tile (base = first image the tile touches, wave
+                // uniform), one 32-bit VGPR offset per lane, and the channel step
+                // 2s*HW as a scalar offset: no per-load 64-bit address registers.
+                const long long r0 = rb * ROWS_WG + wave_u * (32 * RT) + t * 32;
+                const long long b0 = (r0 < N ? r0 : N - 1) / HW;
+                const long long b = rc / HW;
+                const int hw = (int)(rc - b * HW);
+                zbase[t] = (size_t)b * D * HW + hw;
+                img0[t] = (size_t)b0 * D * HW;
+                voff[t] = (unsigned)((((b - b0) * D + h) * HW + hw) * 4);
+                const auto rs = make_rsrc(z + img0[t]);
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    zr[t][s] = __builtin_bit_cast(
+                        float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff[t], (unsigned)(2 * s) * HW * 4u, 0));
+            }
+        }
+        // ---- ||z||^2 in ATen order: this lane owns elements t = 2u + h of every
+        //      8-vector; the partner lane (l ^ 32) owns the other parity ----------
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            constexpr int NV = D / 8, NI = NV / 4;
+            float A[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float P[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+                for (int i = 0; i < NI; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float x = zr[t][4 * (4 * i + q) + u];
+                        P[q] = P[q] + x * x;
+                    }
+#pragma unroll
+                for (int v = NI * 4; v < NV; ++v) {
+                    const float x = zr[t][4 * v + u];
+                    P[0] = P[0] + x * x;
+                }
+                A[u] = ((P[0] + P[1]) + P[2]) + P[3];
+            }
+            float fin = 0.0f;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float other = __shfl_xor(A[u], 32);
+                const float ev = h ? other : A[u];   // element t = 2u
+                const float od = h ? A[u] : other;   // element t = 2u + 1
+                fin = fin + ev;
+                fin = fin + od;
+            }
+            zz[t] = fin;
+        }
+
+        float bd[RT];
+        int bk[RT];
+#pragma unroll
+        for (int t = 0; t < RT; ++t) { bd[t] = __builtin_inff(); bk[t] = 0; }
+
+        // ---- sweep the codebook -------------------------------------------------
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (nchunks > 1) {
+                __syncthreads();
+                stage(ch);
+                __syncthreads();
+            }
+            const int ncode = min(KC, K - ch * KC);
+            const int ntile = (ncode + 31) >> 5;
+            for (int ct = 0; ct < ntile; ++ct) {
+                f32x16 acc[RT];
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+                const float *ap = Es + ((size_t)h * KC + ct * 32 + l31) * 4;
+#pragma unroll
+                for (int j = 0; j < D / 8; ++j) {
+                    const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (size_t)j * 2 * KC * 4);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int t = 0; t < RT; ++t)
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], zr[t][4 * j + i],
+                                                                           acc[t], 0, 0, 0);
+                }
+                const int code0 = ch * KC + ct * 32 + 4 * h;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ee_s + ct * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int t = 0; t < RT; ++t) {
+                            const float tt = zz[t] + e4[i];
+                            const float d = __builtin_fmaf(-2.0f, acc[t][4 * g + i], tt);
+                            const bool lt = d < bd[t];
+                            bd[t] = lt ? d : bd[t];
+                            bk[t] = lt ? code0 + 8 * g + i : bk[t];
+                        }
+                }
+            }
+        }
+
+        // ---- fold the two half-waves, fix up non-finite rows, epilogue ----------
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float pd = __shfl_xor(bd[t], 32);
+            const int pk = __shfl_xor(bk[t], 32);
+            const bool take = (pd < bd[t]) || (pd == bd[t] && pk < bk[t]);
+            int k = take ? pk : bk[t];
+
+            const bool bad = valid[t] && (cb_bad || !(zz[t] < 1.0e38f));
+            if (__any(bad)) {
+                int ks = 0;
+                if (bad && h == 0)
+                    ks = vq_slow_argmin<D, ROWMAJOR>(z, zbase[t], ROWMAJOR ? 1 : (size_t)HW, cb, ee_g,
+                                                     K, zz[t]);
+                ks = __shfl(ks, l31);
+                if (bad) k = ks;
+            }
+
+            float sq = 0.0f;
+            const float *e = cb + (size_t)k * D;
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                const float ev = e[2 * s + h];
+                const float diff = ev - zr[t][s];
+                sq = sq + diff * diff;
+                zr[t][s] = zr[t][s] + diff;          // z + (z_q - z), models/quantizer.py:67
+            }
+            if (valid[t]) {
+                dacc += (double)sq;
+                if (zq) {
+                    if (ROWMAJOR) {
+#pragma unroll
+                        for (int q = 0; q < D / 4; ++q) {
+                            const float o0 = __shfl_xor(zr[t][2 * q], 32);
+                            const float o1 = __shfl_xor(zr[t][2 * q + 1], 32);
+                            if ((q & 1) == h) {
+                                f32x4 v;
+                                v.x = h ? o0 : zr[t][2 * q];
+                                v.y = h ? zr[t][2 * q] : o0;
+                                v.z = h ? o1 : zr[t][2 * q + 1];
+                                v.w = h ? zr[t][2 * q + 1] : o1;
+                                *reinterpret_cast<f32x4 *>(zq + zbase[t] + 4 * q) = v;
+                            }
+                        }
+                    }
+                }
+                if (h == 0) {
+                    idx[row[t]] = k;
+                    atomicAdd(&hist_s[k], 1);
+                }
+            }
+            if (!ROWMAJOR && zq && valid[t]) {
+                const auto rs = make_rsrc(zq + img0[t]);
+#pragma unroll
+                for (int s = 0; s < S; ++s)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zr[t][s]), rs,
+                                                          voff[t], (unsigned)(2 * s) * HW * 4u, 0);
+            }
+        }
+    }
+
+    // ---- per-workgroup results: squared-error partial + histogram flush ---------
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = dacc;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 8; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+    for (int k = tid; k < K; k += 512) {
+        const int c = hist_s[k];
+        if (c) atomicAdd(&hist[k], c);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// loss = m + beta*m with m = sum((z_q-z)^2)/(N*D) (models/quantizer.py:63-64);
+// perplexity = exp(-sum p log(p + 1e-10)), p = hist/N (:70-71).
+__global__ __launch_bounds__(256) void vq_finalize_kernel(const double *__restrict__ partials, int nparts,
+                                                          const int *__restrict__ hist, int K,
+                                                          long long N, int D, float beta,
+                                                          float *__restrict__ loss,
+                                                          float *__restrict__ perplexity) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    double s = 0.0;
+    const float fn = (float)N;
+    for (int k = tid; k < K; k += 256) {
+        const float p = (float)hist[k] / fn;
+        const float lg = (float)log((double)(p + 1e-10f));
+        s += (double)(p * lg);
+    }
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *perplexity = (float)exp(-(double)(float)red[0]);
+        double q = 0.0;
+        for (int i = 0; i < nparts; ++i) q += partials[i];
+        const float m = (float)(q / ((double)N * (double)D));
+        const float bm = beta * m;
+        *loss = m + bm;
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_onehot_kernel(const long long *__restrict__ idx, long long N,
+                                                        int K, float *__restrict__ onehot) {
+    const long long total = N * (long long)K;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (long long)gridDim.x * 256) {
+        const long long n = i / K;
+        const int k = (int)(i - n * K);
+        onehot[i] = idx[n] == k ? 1.0f : 0.0f;
+    }
+}
+
+__global__ __launch_bounds__(256) void vq_decode_indices_kernel(const long long *__restrict__ idx,
+                                                                const float *__restrict__ cb,
+                                                                long long total, int D, int HW,
+                                                                float *__restrict__ zq) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
+         i += (long long)gridDim.x * 256) {
+        const int hw = (int)(i % HW);
+        const long long bc = i / HW;
+        const int c = (int)(bc % D);
+        const long long b = bc / D;
+        zq[i] = cb[(size_t)idx[b * HW + hw] * D + c];
+    }
+}
+
+// ---------------------------------------------------------------------------
+template <int D>
+static int launch_vq(const float *z, const float *cb, long long N, int HW, int K, float beta,
+                     int flags, float *zq, long long *idx, int *hist, float *loss, float *ppl,
+                     char *ws, hipStream_t st) {
+    const VqPlan p = vq_plan(K, D);
+    int *wflags = reinterpret_cast<int *>(ws + p.off_flags);
+    float *ee = reinterpret_cast<float *>(ws + p.off_ee);
+    float *img = reinterpret_cast<float *>(ws + p.off_img);
+    double *partials = reinterpret_cast<double *>(ws + p.off_partials);
+
+    hipError_t e;
+    if ((e = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)K, st)) != hipSuccess) return (int)e;
+    if (!(flags & VQVAE_VQ_CODEBOOK_PREPARED)) {
+        if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((p.K_pad + 63) / 64), dim3(64), 0, st, cb, K,
+                           p.KC, p.K_pad, ee, img, wflags);
+    }
+    const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
+    const int cus = num_cus();
+    // two row tiles per wave when that still leaves every CU at least two row blocks
+    int rt = (D <= 64 && (N + 511) / 512 >= 2LL * cus) ? 2 : 1;
+    const long long rows_wg = 256LL * rt;
+    const long long nblocks = (N + rows_wg - 1) / rows_wg;
+    long long grid = nblocks < cus ? nblocks : cus;
+    if (grid > kVqMaxGrid) grid = kVqMaxGrid;
+
+#define VQ_LAUNCH(RT_, RM_)                                                                        \
+    do {                                                                                           \
+        auto kfn = vq_exact_kernel<D, RT_, RM_>;                                                   \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);            \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), p.lds_bytes, st, z, cb, img, ee,  \
+                           wflags, N, HW, K, p.KC, p.nchunks, nblocks, zq, idx, hist, partials);   \
+    } while (0)
+
+    if (rt == 2) {
+        if constexpr (D <= 64) {
+            if (rowmajor) VQ_LAUNCH(2, true); else VQ_LAUNCH(2, false);
+        }
+    } else {
+        if (rowmajor) VQ_LAUNCH(1, true); else VQ_LAUNCH(1, false);
+    }
+#undef VQ_LAUNCH
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)grid, hist, K, N,
+                       D, beta, loss, ppl);
+    return (int)hipGetLastError();
+}
+
+}  // namespace vqvae
+
+using namespace vqvae;
+
+extern "C" {
+
+size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D) {
+    (void)n_rows;
+    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return 0;
+    return vq_plan(K, D).total;
+}
+
+int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int D, int H, int W,
+                         int K, float beta, int flags, float *z_q, int64_t *idx, int32_t *hist,
+                         float *loss, float *perplexity, void *workspace, size_t workspace_bytes,
+                         vqvae_stream_t stream) {
+    if (!z_e || !codebook || !idx || !hist || !loss || !perplexity) return VQVAE_ERR_NULL;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || K < 1) return VQVAE_ERR_SHAPE;
+    if (K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return VQVAE_ERR_UNSUPPORTED;
+    if ((int64_t)H * W > (int64_t)1 << 30) return VQVAE_ERR_OVERFLOW;
+    const int64_t N = B * (int64_t)H * W;
+    if (N / ((int64_t)H * W) != B || N > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
+    const size_t need = vqvae_vq_workspace_bytes(N, K, D);
+    if (!workspace || workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    char *ws = static_cast<char *>(workspace);
+    const int HW = H * W;
+    long long *idx_ll = reinterpret_cast<long long *>(idx);
+    switch (D) {
+        case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
+        case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
+        case 128: return launch_vq<128>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
+        case 256: return launch_vq<256>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
+    }
+    return VQVAE_ERR_UNSUPPORTED;
+}
+
+int vqvae_vq_onehot_f32(const int64_t *idx, int64_t N, int K, float *onehot, vqvae_stream_t stream) {
+    if (!idx || !onehot) return VQVAE_ERR_NULL;
+    if (N < 1 || K < 1) return VQVAE_ERR_SHAPE;
+    if (N > INT64_MAX / K) return VQVAE_ERR_OVERFLOW;
+    const long long total = N * (long long)K;
+    long long grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(vq_onehot_kernel, dim3((unsigned)grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const long long *>(idx), N, K,
+                       onehot);
+    return (int)hipGetLastError();
+}
+
+int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codebook, int64_t B, int D, int H,
+                                int W, int K, float *z_q, vqvae_stream_t stream) {
+    if (!idx || !codebook || !z_q) return VQVAE_ERR_NULL;
+    if (B < 1 || D < 1 || H < 1 || W < 1 || K < 1) return VQVAE_ERR_SHAPE;
+    const long long total = B * (long long)D * H * W;
+    long long grid = (total + 255) / 256;
+    if (grid > 256 * 16) grid = 256 * 16;
+    hipLaunchKernelGGL(vq_decode_indices_kernel, dim3((unsigned)grid), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), reinterpret_cast<const long long *>(idx),
+                       codebook, total, D, H * W, z_q);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,100 @@
+"""torch-tensor front end of the C ABI: allocates outputs/workspaces with torch's
+caching allocator, passes raw device pointers and the current HIP stream to
+libvqvae_hip.so.  PyTorch is plumbing here (memory + streams); every kernel that
+runs is ours.  No CPU path: CPU tensors are rejected.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+VQ_ROWMAJOR = 0x1
+VQ_CODEBOOK_PREPARED = 0x2
+
+
+def _stream_ptr(t: torch.Tensor) -> int:
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _check_dev(name, t, dtype=torch.float32):
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise _lib.VqvaeHipError(f"{name} must be a CUDA(HIP) tensor: the MI355X path has no CPU fallback")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype} (the reference path is fp32 only)")
+
+
+def vq_workspace(K: int, D: int, device) -> torch.Tensor:
+    n = _lib.load().vqvae_vq_workspace_bytes(0, K, D)
+    if n == 0:
+        raise _lib.VqvaeHipError(f"VectorQuantizer shape K={K}, D={D} not supported by the gfx950 kernels "
+                                 "(D in {32,64,128,256}, K <= 16384)")
+    return torch.empty(n, dtype=torch.uint8, device=device)
+
+
+def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
+               workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True):
+    """Fused VectorQuantizer forward (models/quantizer.py:29-76).
+
+    z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
+    Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
+    """
+    _check_dev("z_e", z_e)
+    _check_dev("codebook", codebook)
+    if z_e.dim() != 4:
+        raise ValueError("z_e must be 4-D")
+    if rowmajor:
+        B, H, W, D = z_e.shape
+    else:
+        B, D, H, W = z_e.shape
+    K, Dc = codebook.shape
+    if Dc != D:
+        # the reference silently mis-reshapes here (view(-1, e_dim), quantizer.py:46); be strict
+        raise ValueError(f"channel dim {D} != embedding dim {Dc}")
+    z_e = z_e.contiguous()
+    codebook = codebook.contiguous()
+    dev = z_e.device
+    with torch.cuda.device(dev):
+        if workspace is None:
+            workspace = vq_workspace(K, D, dev)
+            prepared = False
+        N = B * H * W
+        z_q = torch.empty_like(z_e) if want_zq else None
+        idx = torch.empty((N, 1), dtype=torch.int64, device=dev)
+        hist = torch.empty((K,), dtype=torch.int32, device=dev)
+        scal = torch.empty((2,), dtype=torch.float32, device=dev)
+        flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0)
+        rc = _lib.load().vqvae_vq_forward_f32(
+            z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
+            z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
+            scal.data_ptr(), scal.data_ptr() + 4, workspace.data_ptr(), workspace.numel(),
+            _stream_ptr(z_e))
+        _lib.check(rc)
+    return scal[0], z_q, scal[1], idx, hist
+
+
+def vq_onehot(idx: torch.Tensor, K: int) -> torch.Tensor:
+    """min_encodings (N,K) fp32 (models/quantizer.py:55-57)."""
+    _check_dev("idx", idx, torch.int64)
+    idx = idx.contiguous()
+    N = idx.numel()
+    out = torch.empty((N, K), dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.load().vqvae_vq_onehot_f32(idx.data_ptr(), N, K, out.data_ptr(), _stream_ptr(idx)))
+    return out
+
+
+def vq_decode_indices(idx: torch.Tensor, codebook: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """indices -> z_q (B,D,H,W) (visualization.ipynb:358-365)."""
+    _check_dev("idx", idx, torch.int64)
+    _check_dev("codebook", codebook)
+    idx = idx.contiguous()
+    codebook = codebook.contiguous()
+    K, D = codebook.shape
+    if idx.numel() != B * H * W:
+        raise ValueError("idx must hold B*H*W indices")
+    out = torch.empty((B, D, H, W), dtype=torch.float32, device=idx.device)
+    with torch.cuda.device(idx.device):
+        _lib.check(_lib.load().vqvae_vq_decode_indices_f32(idx.data_ptr(), codebook.data_ptr(), B, D, H, W, K,
+                                                           out.data_ptr(), _stream_ptr(idx)))
+    return out

@@ -1,0 +1,202 @@
+"""Host-side mirror of the reference's module interface for the forward hot path.
+
+Same class names, constructor signatures, attribute names, parameter names/shapes
+and `state_dict` layout as the reference, so checkpoints written by
+the reference (`utils.py:109-113`) load unchanged and callers (`main.py:74`,
+`visualization.ipynb:84-90`) keep working:
+
+    VQVAE(h_dim, res_h_dim, n_res_layers, n_embeddings, embedding_dim, beta,
+          save_img_embedding_map=False).forward(x) -> (embedding_loss, x_hat, perplexity)
+                                                              (models/vqvae.py:11-12,29-44)
+    VectorQuantizer(n_e, e_dim, beta).forward(z)
+          -> (loss, z_q, perplexity, min_encodings, min_encoding_indices)   (models/quantizer.py:20,29-76)
+    Encoder(in_dim, h_dim, n_res_layers, res_h_dim)                          (models/encoder.py:24)
+    Decoder(in_dim, h_dim, n_res_layers, res_h_dim)                          (models/decoder.py:22)
+    ResidualLayer(in_dim, h_dim, res_h_dim), ResidualStack(in_dim, h_dim, res_h_dim, n_res_layers)
+                                                                             (models/residual.py:16,41)
+
+The modules only HOLD parameters; the arithmetic is libvqvae_hip.so.  This is a
+forward-only path: it runs under `torch.no_grad()` semantics, on CUDA(HIP) fp32
+tensors only, and raises otherwise -- there is no CPU or autograd fallback
+(backward is a "next" row).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_hip
+from ._lib import VqvaeHipError
+
+
+def _require_forward_only(*tensors):
+    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+        raise VqvaeHipError(
+            "vqvae_amd implements the forward path only: call it under torch.no_grad() "
+            "(or model.requires_grad_(False)); backward is not implemented and there is no "
+            "autograd fallback")
+
+
+class VectorQuantizer(nn.Module):
+    """Discretisation bottleneck; mirrors models/quantizer.py:10-76."""
+
+    def __init__(self, n_e, e_dim, beta):
+        super().__init__()
+        self.n_e = n_e
+        self.e_dim = e_dim
+        self.beta = beta
+        self.embedding = nn.Embedding(self.n_e, self.e_dim)
+        self.embedding.weight.data.uniform_(-1.0 / self.n_e, 1.0 / self.n_e)   # quantizer.py:27
+        self._ws = None
+        self._ws_key = None
+
+    def _workspace(self):
+        """Per-module workspace holding the codebook's LDS image; re-prepared only
+        when the embedding tensor changes (in-place update bumps `_version`)."""
+        w = self.embedding.weight
+        key = (w.data_ptr(), w._version, w.device)
+        prepared = self._ws is not None and self._ws_key == key
+        if self._ws is None or self._ws.device != w.device:
+            self._ws = F_hip.vq_workspace(self.n_e, self.e_dim, w.device)
+            prepared = False
+        self._ws_key = key
+        return self._ws, prepared
+
+    def quantize(self, z, *, rowmajor=False, want_zq=True):
+        """-> (loss, z_q, perplexity, min_encoding_indices, hist); no one-hot."""
+        w = self.embedding.weight
+        _require_forward_only(z, w)
+        ws, prepared = self._workspace()
+        return F_hip.vq_forward(z, w.detach(), self.beta, rowmajor=rowmajor, workspace=ws,
+                                prepared=prepared, want_zq=want_zq)
+
+    def forward(self, z):
+        loss, z_q, perplexity, idx, _ = self.quantize(z)
+        min_encodings = F_hip.vq_onehot(idx, self.n_e)                         # quantizer.py:55-57
+        return loss, z_q, perplexity, min_encodings, idx
+
+
+class ResidualLayer(nn.Module):
+    """Parameter holder mirroring models/residual.py:8-29."""
+
+    def __init__(self, in_dim, h_dim, res_h_dim):
+        super().__init__()
+        self.res_block = nn.Sequential(
+            nn.ReLU(True),
+            nn.Conv2d(in_dim, res_h_dim, kernel_size=3, stride=1, padding=1, bias=False),
+            nn.ReLU(True),
+            nn.Conv2d(res_h_dim, h_dim, kernel_size=1, stride=1, bias=False),
+        )
+
+    def forward(self, x):
+        return ResidualStack._run(x, [self], final_relu=False, mutate_input=True)
+
+
+class ResidualStack(nn.Module):
+    """n_res_layers aliases of ONE ResidualLayer (models/residual.py:41-51): the
+    state_dict lists stack.0..n-1 keys that all share storage, exactly as upstream."""
+
+    def __init__(self, in_dim, h_dim, res_h_dim, n_res_layers):
+        super().__init__()
+        self.n_res_layers = n_res_layers
+        self.stack = nn.ModuleList([ResidualLayer(in_dim, h_dim, res_h_dim)] * n_res_layers)
+
+    @staticmethod
+    def _run(x, layers, final_relu, mutate_input):
+        from . import conv as C_hip
+        w_pairs = [(l.res_block[1].weight, l.res_block[3].weight) for l in layers]
+        _require_forward_only(x, *[w for p in w_pairs for w in p])
+        y = C_hip.residual_stack_nchw(x, w_pairs, final_relu=final_relu)
+        if mutate_input:
+            # nn.ReLU(True) upstream rewrites the caller's tensor to relu(x) (residual.py:19)
+            x.relu_()
+        return y
+
+    def forward(self, x):
+        return ResidualStack._run(x, list(self.stack), final_relu=True, mutate_input=True)
+
+
+class Encoder(nn.Module):
+    """q_theta(z|x) parameter holder mirroring models/encoder.py:24-43."""
+
+    def __init__(self, in_dim, h_dim, n_res_layers, res_h_dim):
+        super().__init__()
+        kernel, stride = 4, 2
+        self.conv_stack = nn.Sequential(
+            nn.Conv2d(in_dim, h_dim // 2, kernel_size=kernel, stride=stride, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(h_dim // 2, h_dim, kernel_size=kernel, stride=stride, padding=1),
+            nn.ReLU(),
+            nn.Conv2d(h_dim, h_dim, kernel_size=kernel - 1, stride=stride - 1, padding=1),
+            ResidualStack(h_dim, h_dim, res_h_dim, n_res_layers),
+        )
+
+    def forward(self, x):
+        from . import conv as C_hip
+        _require_forward_only(x, *self.parameters())
+        return C_hip.encoder_forward(self, x, pre_quant=None)
+
+
+class Decoder(nn.Module):
+    """p_phi(x|z) parameter holder mirroring models/decoder.py:22-39."""
+
+    def __init__(self, in_dim, h_dim, n_res_layers, res_h_dim):
+        super().__init__()
+        kernel, stride = 4, 2
+        self.inverse_conv_stack = nn.Sequential(
+            nn.ConvTranspose2d(in_dim, h_dim, kernel_size=kernel - 1, stride=stride - 1, padding=1),
+            ResidualStack(h_dim, h_dim, res_h_dim, n_res_layers),
+            nn.ConvTranspose2d(h_dim, h_dim // 2, kernel_size=kernel, stride=stride, padding=1),
+            nn.ReLU(),
+            nn.ConvTranspose2d(h_dim // 2, 3, kernel_size=kernel, stride=stride, padding=1),
+        )
+
+    def forward(self, x):
+        from . import conv as C_hip
+        _require_forward_only(x, *self.parameters())
+        return C_hip.decoder_forward(self, x, rowmajor_in=False)
+
+
+class VQVAE(nn.Module):
+    """Mirrors models/vqvae.py:10-44."""
+
+    def __init__(self, h_dim, res_h_dim, n_res_layers, n_embeddings, embedding_dim, beta,
+                 save_img_embedding_map=False):
+        super().__init__()
+        self.encoder = Encoder(3, h_dim, n_res_layers, res_h_dim)
+        self.pre_quantization_conv = nn.Conv2d(h_dim, embedding_dim, kernel_size=1, stride=1)
+        self.vector_quantization = VectorQuantizer(n_embeddings, embedding_dim, beta)
+        self.decoder = Decoder(embedding_dim, h_dim, n_res_layers, res_h_dim)
+        if save_img_embedding_map:
+            self.img_to_embedding_map = {i: [] for i in range(n_embeddings)}
+        else:
+            self.img_to_embedding_map = None
+
+    def forward(self, x, verbose=False):
+        from . import conv as C_hip
+        _require_forward_only(x, *self.parameters())
+        # encoder + 1x1 pre-quantisation conv, activations kept row-major (B,H,W,C)
+        z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
+        embedding_loss, z_q, perplexity, _, _ = self.vector_quantization.quantize(z_e, rowmajor=True)
+        x_hat = C_hip.decoder_forward(self.decoder, z_q, rowmajor_in=True)
+        if verbose:                                                    # models/vqvae.py:38-42
+            print('original data shape:', x.shape)
+            print('encoded data shape:', torch.Size((z_e.shape[0], z_e.shape[3], z_e.shape[1], z_e.shape[2])))
+            print('recon data shape:', x_hat.shape)
+            assert False
+        return embedding_loss, x_hat, perplexity
+
+    # ---- "next" rows of SURVEY.md 8f-1: the index wire format -------------------
+    @torch.no_grad()
+    def encode(self, x):
+        """x -> min_encoding_indices (N,1) int64 (README.md:56; notebook encode_data)."""
+        from . import conv as C_hip
+        z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
+        _, _, _, idx, _ = self.vector_quantization.quantize(z_e, rowmajor=True, want_zq=False)
+        return idx
+
+    @torch.no_grad()
+    def decode_indices(self, idx, B, H, W):
+        """indices -> x_hat (visualization.ipynb:358-365 generate_samples)."""
+        z_q = F_hip.vq_decode_indices(idx, self.vector_quantization.embedding.weight.detach(), B, H, W)
+        return self.decoder(z_q)
