@@ -50,6 +50,22 @@ typedef void *vqvae_stream_t;      /* hipStream_t */
 VQVAE_API int vqvae_abi_version(void);
 VQVAE_API const char *vqvae_strerror(int code);
 
+/* ---------------------------------------------------------------- profiling
+ * Measurement aid for bench.py (never used on the product path): while enabled,
+ * every launch of an instrumented kernel is bracketed by a pair of hipEvents
+ * recorded on the launch stream.  vqvae_profile_collect() is the only call in
+ * this library that synchronises: it waits for the recorded events of one
+ * kernel id, returns the summed kernel time and launch count, and resets them.
+ * At most 256 launches per id are recorded between collects.                  */
+#define VQVAE_PROF_VQ_MAIN     0   /* fused VectorQuantizer kernel                     */
+#define VQVAE_PROF_CONV_IGEMM  1   /* implicit-GEMM conv / conv-transpose kernels      */
+#define VQVAE_PROF_RES_LAYER   2   /* fused residual-layer kernel                      */
+#define VQVAE_PROF_CONV_IN     3   /* first conv (NCHW image in)                       */
+#define VQVAE_PROF_CONV_OUT    4   /* last conv-transpose (NCHW image out)             */
+#define VQVAE_PROF_NUM_IDS     5
+VQVAE_API int vqvae_profile_enable(int on);
+VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launches);
+
 /* ---------------------------------------------------------------- quantizer */
 
 /* flags for vqvae_vq_forward_f32 */

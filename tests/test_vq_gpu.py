@@ -39,7 +39,15 @@ def test_vq_matches_reference_golden(name, rowmajor, golden_vq):
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
-    assert cases.sha(zq) == sha[2], "z_q not bit-exact vs the reference"
+    if name == "nonfinite":
+        # NaN payload/sign is ISA-specific (x86 default NaN is 0xFFC00000, gfx950's 0x7FC00000):
+        # NaN positions must agree, every non-NaN element must be bit-identical
+        g = golden_vq[f"{name}/z_q"]
+        assert np.array_equal(np.isnan(zq), np.isnan(g))
+        m = ~np.isnan(g)
+        assert np.array_equal(zq[m].view(np.uint32), g[m].view(np.uint32))
+    else:
+        assert cases.sha(zq) == sha[2], "z_q not bit-exact vs the reference"
     np.testing.assert_allclose(loss, golden_vq[f"{name}/loss"], rtol=1e-6, equal_nan=True)
     np.testing.assert_allclose(ppl, golden_vq[f"{name}/perplexity"], rtol=1e-6)
     np.testing.assert_array_equal(hist, np.bincount(idx.reshape(-1), minlength=cb.shape[0]))
@@ -81,7 +89,9 @@ def test_vq_nonfinite_codebook_forces_slow_path():
     ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
     loss, zq, ppl, idx, hist = _run(z, cb, 0.25)
     np.testing.assert_array_equal(idx, ref["idx"])
-    assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
+    assert np.array_equal(np.isnan(zq), np.isnan(ref["z_q"]))
+    m = ~np.isnan(zq)
+    assert np.array_equal(zq[m].view(np.uint32), ref["z_q"][m].view(np.uint32))
 
 
 def test_vq_index_only_and_determinism():

@@ -21,6 +21,8 @@ _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size
 SIGNATURES = {
     "vqvae_abi_version": (_i32, []),
     "vqvae_strerror": (C.c_char_p, [_i32]),
+    "vqvae_profile_enable": (_i32, [_i32]),
+    "vqvae_profile_collect": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
     "vqvae_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vqvae_vq_forward_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -56,3 +58,17 @@ def load():
 def check(code: int):
     if code != 0:
         raise VqvaeHipError(f"libvqvae_hip: {load().vqvae_strerror(code).decode()} (code {code})")
+
+
+PROF_IDS = {"vq_main": 0, "conv_igemm": 1, "res_layer": 2, "conv_in": 3, "conv_out": 4}
+
+
+def profile_enable(on: bool):
+    check(load().vqvae_profile_enable(1 if on else 0))
+
+
+def profile_collect(name: str):
+    """-> (total_ms, launches) of one instrumented kernel since the last collect (synchronises)."""
+    ms, n = C.c_double(), _i32()
+    check(load().vqvae_profile_collect(PROF_IDS[name], C.byref(ms), C.byref(n)))
+    return ms.value, n.value

@@ -28,6 +28,10 @@ inline int num_cus() {
     return n;
 }
 
+// profiling hooks (capi.hip); no-ops unless vqvae_profile_enable(1)
+void prof_begin(int id, hipStream_t st);
+void prof_end(int id, hipStream_t st);
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // ---- quantizer workspace layout (host + device agree on it) -----------------

@@ -445,6 +445,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     long long grid = nblocks < cus ? nblocks : cus;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
 
+    prof_begin(VQVAE_PROF_VQ_MAIN, st);
 #define VQ_LAUNCH(RT_, RM_)                                                                        \
     do {                                                                                           \
         auto kfn = vq_exact_kernel<D, RT_, RM_>;                                                   \
@@ -466,6 +467,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
         if (rowmajor) VQ_LAUNCH(1, true); else VQ_LAUNCH(1, false);
     }
 #undef VQ_LAUNCH
+    prof_end(VQVAE_PROF_VQ_MAIN, st);
     hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, (int)grid, hist, K, N,
                        D, beta, loss, ppl);
     return (int)hipGetLastError();
