@@ -116,6 +116,66 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
                                 int64_t B, int D, int H, int W, int K,
                                 float *z_q, vqvae_stream_t stream);
 
+/* ------------------------------------------------------- conv / residual stacks
+ * Activations between layers are ROW-MAJOR (B,H,W,C): one contiguous C-vector per
+ * pixel.  NCHW appears only at the image boundaries (vqvae_conv_in_*, vqvae_convt_out_*)
+ * and, for callers that use sub-modules directly, through vqvae_transpose_f32.
+ * Weights are passed PACKED: vqvae_*_pack_f32 rewrites a torch-layout weight into the
+ * MFMA B-operand image once per weight version (bytes from vqvae_*_packed_bytes).
+ * All convs compute in exact fp32 on the matrix cores; parity with the reference is
+ * tolerance-level (oneDNN's summation order is opaque): |y - y_ref| <= 1e-5 + 1e-4|y_ref|. */
+#define VQVAE_CONV_4x4_S2   0   /* nn.Conv2d(k=4,s=2,p=1), weight (Cout,Cin,4,4)   encoder.py:29-33 */
+#define VQVAE_CONV_3x3_S1   1   /* nn.Conv2d(k=3,s=1,p=1), weight (Cout,Cin,3,3)   encoder.py:35, residual.py:20 */
+#define VQVAE_CONV_1x1      2   /* nn.Conv2d(k=1),         weight (Cout,Cin,1,1)   vqvae.py:16, residual.py:23 */
+#define VQVAE_CONVT_3x3_S1  3   /* nn.ConvTranspose2d(k=3,s=1,p=1), weight (Cin,Cout,3,3)  decoder.py:28 */
+#define VQVAE_CONVT_4x4_S2  4   /* nn.ConvTranspose2d(k=4,s=2,p=1), weight (Cin,Cout,4,4)  decoder.py:31 */
+
+#define VQVAE_CONV_RELU_IN  0x1 /* apply ReLU to the input as it is read (the in-place nn.ReLU(True)
+                                   in front of a conv, residual.py:19,22)                          */
+#define VQVAE_CONV_RELU_OUT 0x2 /* ReLU on the result (encoder.py:31,34, decoder.py:33)           */
+
+VQVAE_API size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout);
+VQVAE_API int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed,
+                                  vqvae_stream_t stream);
+/* y = conv(x) + bias [ReLU]; x (B,H,W,Cin) row-major, y (B,Hout,Wout,Cout) row-major; bias may be
+ * NULL.  Cin must be a multiple of 4.  Replaces one nn.Conv2d / nn.ConvTranspose2d call.          */
+VQVAE_API int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias,
+                                     int64_t B, int H, int W, int Cin, int Cout, int flags,
+                                     float *y, vqvae_stream_t stream);
+
+/* One ResidualLayer.forward (models/residual.py:27-29) as a single kernel:
+ *   y = r(x) + W2 (*) relu(W1 (*) r(x)),  r = ReLU if VQVAE_CONV_RELU_IN else identity,
+ *   followed by ReLU if VQVAE_CONV_RELU_OUT (the stack's final F.relu, residual.py:50, or the
+ *   next layer's in-place ReLU hoisted into this one).
+ * packed_w1 = pack(VQVAE_CONV_3x3_S1, res_block[1].weight (Rh,C,3,3)), packed_w2 =
+ * pack(VQVAE_CONV_1x1, res_block[3].weight (C,Rh,1,1)).  C in {32,64,128}, Rh <= 32, x != y.     */
+VQVAE_API int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1,
+                                          const float *packed_w2, int64_t B, int H, int W, int C,
+                                          int Rh, int flags, float *y, vqvae_stream_t stream);
+
+/* First encoder conv, nn.Conv2d(Cin,Cout,k=4,s=2,p=1) (models/encoder.py:29-31), reading the NCHW
+ * image x (B,Cin,H,W) and writing row-major (B,H/2,W/2,Cout).  Cin in {1,3,4}, Cout <= 128.      */
+VQVAE_API size_t vqvae_conv_in_packed_bytes(int Cin, int Cout);
+VQVAE_API int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed,
+                                     vqvae_stream_t stream);
+VQVAE_API int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const float *bias,
+                                        int64_t B, int H, int W, int Cin, int Cout, int flags,
+                                        float *y, vqvae_stream_t stream);
+
+/* Last decoder layer, nn.ConvTranspose2d(Cin,Cout,k=4,s=2,p=1) (models/decoder.py:34-35), reading
+ * row-major (B,H,W,Cin) and writing the NCHW image (B,Cout,2H,2W).  Cout <= 4, Cin % 4 == 0.      */
+VQVAE_API size_t vqvae_convt_out_packed_bytes(int Cin, int Cout);
+VQVAE_API int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed,
+                                       vqvae_stream_t stream);
+VQVAE_API int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float *bias,
+                                          int64_t B, int H, int W, int Cin, int Cout,
+                                          float *y_nchw, vqvae_stream_t stream);
+
+/* Batched transpose x[batch][R][C] -> y[batch][C][R]: (B,C,HW) <-> (B,HW,C) layout changes for
+ * callers that enter or leave the path at a sub-module boundary (visualization.ipynb:84-90).     */
+VQVAE_API int vqvae_transpose_f32(const float *x, int64_t batch, int R, int C, float *y,
+                                  vqvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,161 @@
+"""GPU parity tests (-m gpu) for the conv / conv-transpose / residual kernels, through the C ABI.
+
+Floating-point tolerance (stated per SURVEY.md 8c, tier P1): convs compute in exact fp32 on the
+matrix cores but oneDNN's summation order is opaque, so every layer is compared with
+    |y - y_ref| <= 1e-5 + 1e-4 * |y_ref|
+against (a) torch's CPU fp32 op (what the reference executes) and (b) the C oracle (correctly
+rounded, double accumulation).  Observed errors are ~1e-7.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+ATOL, RTOL = 1e-5, 1e-4
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rows(x):      # NCHW -> (B,H,W,C)
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def close(a, b):
+    np.testing.assert_allclose(a, b, atol=ATOL, rtol=RTOL)
+
+
+CONV_CASES = [
+    # kind name, module ctor, B, Cin, H, W
+    ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 3, 64, 128, 16, 16),
+    ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 2, 32, 64, 12, 20),
+    ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1), 3, 128, 128, 8, 8),
+    ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1, bias=False), 2, 128, 32, 7, 9),
+    ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1), 1, 16, 48, 5, 5),      # Cin < 32, Cout not /32
+    ("conv1x1", lambda ci, co: nn.Conv2d(ci, co, 1, 1), 5, 128, 64, 8, 8),
+    ("conv1x1", lambda ci, co: nn.Conv2d(ci, co, 1, 1, bias=False), 2, 32, 128, 8, 8),
+    ("convT3x3", lambda ci, co: nn.ConvTranspose2d(ci, co, 3, 1, 1), 3, 64, 128, 8, 8),
+    ("convT3x3", lambda ci, co: nn.ConvTranspose2d(ci, co, 3, 1, 1), 2, 128, 96, 6, 10),
+    ("convT4x4s2", lambda ci, co: nn.ConvTranspose2d(ci, co, 4, 2, 1), 3, 128, 64, 8, 8),
+    ("convT4x4s2", lambda ci, co: nn.ConvTranspose2d(ci, co, 4, 2, 1), 2, 64, 32, 5, 7),
+]
+KIND = {"conv4x4s2": 0, "conv3x3": 1, "conv1x1": 2, "convT3x3": 3, "convT4x4s2": 4}
+
+
+@pytest.mark.parametrize("relu_in,relu_out", [(False, False), (True, True)])
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}-{c[3]}to{c[4]}-{c[5]}x{c[6]}")
+def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out):
+    from vqvae_amd import conv_hip
+    name, ctor, B, Cin, Cout, H, W = case
+    torch.manual_seed(hash(name) % 1000 + Cin + Cout)
+    m = ctor(Cin, Cout)
+    x = torch.randn(B, Cin, H, W)
+    with torch.no_grad():
+        ref = m(torch.relu(x) if relu_in else x)
+        if relu_out:
+            ref = torch.relu(ref)
+    md = ctor(Cin, Cout).to(dev())
+    md.load_state_dict(m.state_dict())
+    flags = (1 if relu_in else 0) | (2 if relu_out else 0)
+    y = conv_hip.conv(KIND[name], rows(x.to(dev())), md, md.weight, md.bias, Cin, Cout, flags)
+    torch.cuda.synchronize()
+    close(nchw(y).cpu().numpy(), ref.numpy())
+
+
+def test_conv_vs_c_oracle():
+    from oracle import c_oracle
+    from vqvae_amd import conv_hip
+    torch.manual_seed(4)
+    m = nn.ConvTranspose2d(128, 64, 4, 2, 1).to(dev())
+    x = torch.randn(2, 128, 8, 8)
+    y = conv_hip.conv(4, rows(x.to(dev())), m, m.weight, m.bias, 128, 64, 2)
+    ref = c_oracle.conv_transpose2d(x.numpy(), m.weight.detach().cpu().numpy(), m.bias.detach().cpu().numpy(),
+                                    2, 1, relu_out=True)
+    close(nchw(y).cpu().numpy(), ref)
+
+
+@pytest.mark.parametrize("Cin,Cout,B,H,W", [(3, 64, 5, 32, 32), (3, 32, 2, 16, 24), (1, 16, 2, 8, 8), (4, 128, 1, 12, 12)])
+def test_conv_in_vs_torch_cpu(Cin, Cout, B, H, W):
+    from vqvae_amd.modules import Encoder
+    torch.manual_seed(Cin * 10 + Cout)
+    enc = Encoder(Cin, 2 * Cout, 0, 8)
+    x = torch.randn(B, Cin, H, W)
+    with torch.no_grad():
+        ref = torch.relu(enc.conv_stack[0](x))
+    from vqvae_amd import _lib, conv_hip
+    encd = Encoder(Cin, 2 * Cout, 0, 8).to(dev())
+    encd.load_state_dict(enc.state_dict())
+    c0 = encd.conv_stack[0]
+    L = _lib.load()
+    xd = x.to(dev())
+    p0 = conv_hip._packed(c0, ("conv_in",), c0.weight, lambda: L.vqvae_conv_in_packed_bytes(Cin, Cout),
+                          lambda w, buf: L.vqvae_conv_in_pack_f32(w.data_ptr(), Cin, Cout, buf.data_ptr(), None))
+    y = torch.empty((B, H // 2, W // 2, Cout), device=dev())
+    _lib.check(L.vqvae_conv_in_forward_f32(xd.data_ptr(), p0.data_ptr(), c0.bias.data_ptr(), B, H, W, Cin, Cout, 2,
+                                           y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    close(nchw(y).cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("C,Rh,n,B,H,W", [(128, 32, 2, 3, 8, 8), (64, 16, 3, 2, 4, 6), (32, 8, 1, 2, 5, 5)])
+def test_residual_stack_quirks_vs_torch_cpu(C, Rh, n, B, H, W):
+    """Shared weights + relu(x) on the skip + in-place mutation of the caller's tensor
+    (models/residual.py:19,28,44-45)."""
+    from oracle import torch_port
+    from vqvae_amd.modules import ResidualLayer, ResidualStack
+    torch.manual_seed(C + Rh)
+    rs = ResidualStack(C, C, Rh, n)
+    assert all(l is rs.stack[0] for l in rs.stack)
+    assert len(rs.state_dict()) == 2 * n
+    x = torch.randn(B, C, H, W)
+    w1, w2 = rs.stack[0].res_block[1].weight.detach(), rs.stack[0].res_block[3].weight.detach()
+    ref = torch_port.residual_stack(x.clone(), w1, w2, n).numpy()
+    rsd = rs.to(dev())
+    xd = x.to(dev())
+    with torch.no_grad():
+        y = rsd(xd)
+    close(y.cpu().numpy(), ref)
+    assert torch.equal(xd.cpu(), torch.relu(x)), "caller's tensor must become relu(x) like upstream"
+    # single layer: relu(x) + f(relu(x)), no final relu
+    with torch.no_grad():
+        xd2 = x.to(dev())
+        y1 = rsd.stack[0](xd2)
+    t = torch.relu(x)
+    ref1 = t + F.conv2d(torch.relu(F.conv2d(t, w1, None, 1, 1)), w2)
+    close(y1.cpu().numpy(), ref1.numpy())
+
+
+def test_convt_out_vs_torch_cpu():
+    from vqvae_amd import _lib, conv_hip
+    torch.manual_seed(9)
+    for Cin, Cout, B, H, W in [(64, 3, 3, 16, 16), (32, 3, 2, 5, 7), (16, 1, 1, 4, 4)]:
+        m = nn.ConvTranspose2d(Cin, Cout, 4, 2, 1)
+        x = torch.randn(B, Cin, H, W)
+        with torch.no_grad():
+            ref = m(x)
+        md = nn.ConvTranspose2d(Cin, Cout, 4, 2, 1).to(dev())
+        md.load_state_dict(m.state_dict())
+        L = _lib.load()
+        xr = rows(x.to(dev()))
+        p = conv_hip._packed(md, ("convt_out",), md.weight, lambda: L.vqvae_convt_out_packed_bytes(Cin, Cout),
+                             lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), Cin, Cout, buf.data_ptr(), None))
+        y = torch.empty((B, Cout, 2 * H, 2 * W), device=dev())
+        _lib.check(L.vqvae_convt_out_forward_f32(xr.data_ptr(), p.data_ptr(), md.bias.data_ptr(), B, H, W, Cin, Cout,
+                                                 y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        close(y.cpu().numpy(), ref.numpy())
+
+
+def test_transpose_roundtrip():
+    from vqvae_amd import conv_hip
+    x = torch.randn(3, 37, 5, 9, device=dev())
+    r = conv_hip.nchw_to_rows(x)
+    assert torch.equal(r, x.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(conv_hip.rows_to_nchw(r), x)

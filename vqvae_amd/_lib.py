@@ -28,6 +28,17 @@ SIGNATURES = {
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vqvae_vq_onehot_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
     "vqvae_vq_decode_indices_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_conv_packed_bytes": (_sz, [_i32, _i32, _i32]),
+    "vqvae_conv_pack_f32": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
+    "vqvae_conv_forward_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_res_layer_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_conv_in_packed_bytes": (_sz, [_i32, _i32]),
+    "vqvae_conv_in_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "vqvae_conv_in_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_convt_out_packed_bytes": (_sz, [_i32, _i32]),
+    "vqvae_convt_out_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),
+    "vqvae_convt_out_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_transpose_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
 }
 
 _lib = None

@@ -59,11 +59,12 @@ def _torch_decoder(dec, z_q, rowmajor_in):
 
 
 # --------------------------------------------------------------------------- dispatch
-def residual_stack_nchw(x, w_pairs, final_relu):
+def residual_stack_nchw(x, layers, final_relu):
+    """ResidualLayer / ResidualStack forward at the NCHW module boundary (models/residual.py:27-29,47-51)."""
     if _BACKEND == "torch":
-        return _torch_residual(x, w_pairs, final_relu)
+        return _torch_residual(x, [(l.res_block[1].weight, l.res_block[3].weight) for l in layers], final_relu)
     from . import conv_hip
-    return conv_hip.residual_stack_nchw(x, w_pairs, final_relu)
+    return conv_hip.residual_stack_nchw(x, layers, final_relu)
 
 
 def encoder_forward(enc, x, pre_quant):

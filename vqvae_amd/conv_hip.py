@@ -1,0 +1,176 @@
+"""HIP backend of vqvae_amd.conv: drives the conv / residual kernels of libvqvae_hip.so.
+
+Activations stay row-major (B,H,W,C) between layers; packed weight images are cached on
+the parameter-holding nn.Module and rebuilt when the parameter changes (data_ptr/_version).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+CONV_4x4_S2, CONV_3x3_S1, CONV_1x1, CONVT_3x3_S1, CONVT_4x4_S2 = range(5)
+RELU_IN, RELU_OUT = 1, 2
+
+
+def _sp(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _dev_f32(name, t):
+    if not t.is_cuda:
+        raise _lib.VqvaeHipError(f"{name} must be on the GPU: the HIP path has no CPU fallback")
+    if t.dtype != torch.float32:
+        raise TypeError(f"{name} must be float32 (the reference path is fp32 only)")
+
+
+def _packed(mod, kind, weight, nbytes_fn, pack_fn):
+    """Packed-weight cache on the owning module, keyed by the parameter's identity/version."""
+    w = weight.detach()
+    key = (kind, w.data_ptr(), w._version, str(w.device), tuple(w.shape))
+    cache = mod.__dict__.setdefault("_vqvae_amd_packed", {})
+    hit = cache.get(kind)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    n = nbytes_fn()
+    if n == 0:
+        raise _lib.VqvaeHipError(f"layer shape {tuple(w.shape)} not supported by the gfx950 conv kernels")
+    buf = torch.empty(n // 4, dtype=torch.float32, device=w.device)
+    _lib.check(pack_fn(w.contiguous(), buf))
+    cache[kind] = (key, buf)
+    return buf
+
+
+def _pack_conv(mod, kind, weight, Cin, Cout):
+    L = _lib.load()
+    return _packed(mod, ("conv", kind), weight,
+                   lambda: L.vqvae_conv_packed_bytes(kind, Cin, Cout),
+                   lambda w, buf: L.vqvae_conv_pack_f32(kind, w.data_ptr(), Cin, Cout, buf.data_ptr(), _sp(w)))
+
+
+def conv(kind, x, mod, weight, bias, Cin, Cout, flags):
+    """One nn.Conv2d / nn.ConvTranspose2d on row-major activations."""
+    B, H, W, C = x.shape
+    assert C == Cin
+    packed = _pack_conv(mod, kind, weight, Cin, Cout)
+    if kind == CONV_4x4_S2:
+        Ho, Wo = H // 2, W // 2
+    elif kind == CONVT_4x4_S2:
+        Ho, Wo = 2 * H, 2 * W
+    else:
+        Ho, Wo = H, W
+    y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
+    b = bias.detach() if bias is not None else None
+    _lib.check(_lib.load().vqvae_conv_forward_f32(kind, x.data_ptr(), packed.data_ptr(),
+                                                  b.data_ptr() if b is not None else None,
+                                                  B, H, W, Cin, Cout, flags, y.data_ptr(), _sp(x)))
+    return y
+
+
+def res_layer(x, layer, flags):
+    """One ResidualLayer on row-major activations (fused kernel)."""
+    c1, c2 = layer.res_block[1], layer.res_block[3]
+    B, H, W, C = x.shape
+    Rh = c1.weight.shape[0]
+    if Rh > 32 or C not in (32, 64, 128):
+        # unfused: conv3x3 -> conv1x1, skip added by torch-free kernels is not available for this
+        # shape; be explicit rather than silently slow
+        raise _lib.VqvaeHipError(f"residual layer C={C}, res_h={Rh} not supported by the fused gfx950 kernel "
+                                 "(C in {32,64,128}, res_h <= 32)")
+    p1 = _pack_conv(c1, CONV_3x3_S1, c1.weight, C, Rh)
+    p2 = _pack_conv(c2, CONV_1x1, c2.weight, Rh, C)
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().vqvae_res_layer_forward_f32(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, H, W, C, Rh,
+                                                       flags, y.data_ptr(), _sp(x)))
+    return y
+
+
+def transpose(x, batch, R, Cc):
+    y = torch.empty_like(x)
+    _lib.check(_lib.load().vqvae_transpose_f32(x.data_ptr(), batch, R, Cc, y.data_ptr(), _sp(x)))
+    return y
+
+
+def nchw_to_rows(x):
+    B, C, H, W = x.shape
+    return transpose(x.contiguous(), B, C, H * W).view(B, H, W, C)
+
+
+def rows_to_nchw(x):
+    B, H, W, C = x.shape
+    return transpose(x.contiguous(), B, H * W, C).view(B, C, H, W)
+
+
+def _res_stack_rows(t, layers, first_relu_in, final_relu):
+    """t row-major.  Every layer's output feeds either the next layer's in-place ReLU or the
+    stack's final ReLU, so the ReLU is applied once, by the producer."""
+    n = len(layers)
+    for i, layer in enumerate(layers):
+        flags = (RELU_IN if (i == 0 and first_relu_in) else 0)
+        if i < n - 1 or final_relu:
+            flags |= RELU_OUT
+        t = res_layer(t, layer, flags)
+    if n == 0 and final_relu:
+        t = torch.relu(t)
+    return t
+
+
+def residual_stack_nchw(x, layers, final_relu):
+    _dev_f32("x", x)
+    t = _res_stack_rows(nchw_to_rows(x), layers, True, final_relu)
+    return rows_to_nchw(t)
+
+
+def encoder_forward(enc, x, pre_quant):
+    """models/encoder.py:28-43 (+ models/vqvae.py:33 when pre_quant is given)."""
+    _dev_f32("x", x)
+    cs = enc.conv_stack
+    c0, c2, c4, stack = cs[0], cs[2], cs[4], cs[5]
+    x = x.contiguous()
+    B, Cin, H, W = x.shape
+    if Cin != c0.weight.shape[1]:
+        raise ValueError(f"expected {c0.weight.shape[1]} input channels, got {Cin}")
+    L = _lib.load()
+    C0 = c0.weight.shape[0]
+    p0 = _packed(c0, ("conv_in",), c0.weight,
+                 lambda: L.vqvae_conv_in_packed_bytes(Cin, C0),
+                 lambda w, buf: L.vqvae_conv_in_pack_f32(w.data_ptr(), Cin, C0, buf.data_ptr(), _sp(w)))
+    a0 = torch.empty((B, H // 2, W // 2, C0), dtype=torch.float32, device=x.device)
+    _lib.check(L.vqvae_conv_in_forward_f32(x.data_ptr(), p0.data_ptr(), c0.bias.detach().data_ptr(), B, H, W, Cin,
+                                           C0, RELU_OUT, a0.data_ptr(), _sp(x)))                       # :29-31
+    C1 = c2.weight.shape[0]
+    a1 = conv(CONV_4x4_S2, a0, c2, c2.weight, c2.bias, C0, C1, RELU_OUT)                               # :32-34
+    # conv_stack[4] feeds ResidualStack, whose first in-place ReLU (residual.py:19) or final
+    # F.relu (:50) is the only consumer -> fuse that ReLU here
+    a2 = conv(CONV_3x3_S1, a1, c4, c4.weight, c4.bias, C1, c4.weight.shape[0], RELU_OUT)               # :35-36
+    t = _res_stack_rows(a2, list(stack.stack), False, True)                                            # :37-38
+    if pre_quant is None:
+        return rows_to_nchw(t)
+    D = pre_quant.weight.shape[0]
+    return conv(CONV_1x1, t, pre_quant, pre_quant.weight, pre_quant.bias, t.shape[3], D, 0)            # vqvae.py:33
+
+
+def decoder_forward(dec, z_q, rowmajor_in):
+    """models/decoder.py:27-39."""
+    _dev_f32("z_q", z_q)
+    ds = dec.inverse_conv_stack
+    d0, stack, d2, d4 = ds[0], ds[1], ds[2], ds[4]
+    t = z_q.contiguous() if rowmajor_in else nchw_to_rows(z_q)
+    Din = d0.weight.shape[0]
+    if t.shape[3] != Din:
+        raise ValueError(f"expected {Din} latent channels, got {t.shape[3]}")
+    h_dim = d0.weight.shape[1]
+    a0 = conv(CONVT_3x3_S1, t, d0, d0.weight, d0.bias, Din, h_dim, RELU_OUT)                           # :28-29 (+ stack ReLU)
+    a1 = _res_stack_rows(a0, list(stack.stack), False, True)                                           # :30
+    C2 = d2.weight.shape[1]
+    a2 = conv(CONVT_4x4_S2, a1, d2, d2.weight, d2.bias, h_dim, C2, RELU_OUT)                           # :31-33
+    B, H2, W2, _ = a2.shape
+    Cout = d4.weight.shape[1]
+    L = _lib.load()
+    p4 = _packed(d4, ("convt_out",), d4.weight,
+                 lambda: L.vqvae_convt_out_packed_bytes(C2, Cout),
+                 lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), C2, Cout, buf.data_ptr(), _sp(w)))
+    x_hat = torch.empty((B, Cout, 2 * H2, 2 * W2), dtype=torch.float32, device=a2.device)
+    _lib.check(L.vqvae_convt_out_forward_f32(a2.data_ptr(), p4.data_ptr(), d4.bias.detach().data_ptr(), B, H2, W2,
+                                             C2, Cout, x_hat.data_ptr(), _sp(a2)))                     # :34-35
+    return x_hat

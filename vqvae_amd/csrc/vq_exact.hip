@@ -383,11 +383,20 @@ __global__ __launch_bounds__(256) void vq_finalize_kernel(const double *__restri
         if (tid < o) red[tid] += red[tid + o];
         __syncthreads();
     }
+    const double ent = red[0];
+    __syncthreads();
+    // squared-error partials: fixed-order tree (deterministic run to run)
+    double q = 0.0;
+    for (int i = tid; i < nparts; i += 256) q += partials[i];
+    red[tid] = q;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
     if (tid == 0) {
-        *perplexity = (float)exp(-(double)(float)red[0]);
-        double q = 0.0;
-        for (int i = 0; i < nparts; ++i) q += partials[i];
-        const float m = (float)(q / ((double)N * (double)D));
+        *perplexity = (float)exp(-(double)(float)ent);
+        const float m = (float)(red[0] / ((double)N * (double)D));
         const float bm = beta * m;
         *loss = m + bm;
     }

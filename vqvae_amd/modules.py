@@ -104,9 +104,8 @@ class ResidualStack(nn.Module):
     @staticmethod
     def _run(x, layers, final_relu, mutate_input):
         from . import conv as C_hip
-        w_pairs = [(l.res_block[1].weight, l.res_block[3].weight) for l in layers]
-        _require_forward_only(x, *[w for p in w_pairs for w in p])
-        y = C_hip.residual_stack_nchw(x, w_pairs, final_relu=final_relu)
+        _require_forward_only(x, *[p for l in layers for p in l.parameters()])
+        y = C_hip.residual_stack_nchw(x, layers, final_relu=final_relu)
         if mutate_input:
             # nn.ReLU(True) upstream rewrites the caller's tensor to relu(x) (residual.py:19)
             x.relu_()
