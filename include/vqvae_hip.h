@@ -163,7 +163,8 @@ VQVAE_API int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed
                                         float *y, vqvae_stream_t stream);
 
 /* Last decoder layer, nn.ConvTranspose2d(Cin,Cout,k=4,s=2,p=1) (models/decoder.py:34-35), reading
- * row-major (B,H,W,Cin) and writing the NCHW image (B,Cout,2H,2W).  Cout <= 4, Cin % 4 == 0.      */
+ * row-major (B,H,W,Cin) and writing the NCHW image (B,Cout,2H,2W).  Cout <= 4, Cin % 4 == 0,
+ * Cin <= 256.  Runs as GEMM (pixels x Cin x 16*Cout on the MFMA) + in-LDS col2im.                 */
 VQVAE_API size_t vqvae_convt_out_packed_bytes(int Cin, int Cout);
 VQVAE_API int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed,
                                        vqvae_stream_t stream);

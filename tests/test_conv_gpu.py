@@ -135,7 +135,8 @@ def test_residual_stack_quirks_vs_torch_cpu(C, Rh, n, B, H, W):
 def test_convt_out_vs_torch_cpu():
     from vqvae_amd import _lib, conv_hip
     torch.manual_seed(9)
-    for Cin, Cout, B, H, W in [(64, 3, 3, 16, 16), (32, 3, 2, 5, 7), (16, 1, 1, 4, 4)]:
+    for Cin, Cout, B, H, W in [(64, 3, 3, 16, 16), (32, 3, 2, 5, 7), (16, 1, 1, 4, 4), (64, 3, 2, 20, 37),
+                                  (128, 4, 1, 33, 16), (8, 2, 1, 17, 17)]:
         m = nn.ConvTranspose2d(Cin, Cout, 4, 2, 1)
         x = torch.randn(B, Cin, H, W)
         with torch.no_grad():

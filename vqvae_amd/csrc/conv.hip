@@ -39,6 +39,7 @@ struct ConvGeom {
     signed char dy[4][16], dx[4][16];   // [phase][tap]
     signed char kyx[4][16];             // [phase][tap] -> ky*kw + kx in the torch weight
     signed char opy[4], opx[4];
+    unsigned long long dymask[4], dxmask[4];   // 4 bits per tap: (dy + 8), (dx + 8) -- scalar decode
     int kk;                     // kh*kw
     int transposed;             // weight is (Cin,Cout,kh,kw)
 };
@@ -75,18 +76,25 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict_
 
 // ---------------------------------------------------------------------------
 // Generic implicit-GEMM kernel.  Workgroup = 4 waves x (MT x 32 pixels) x (NT x 32 channels).
+// Each loop iteration covers KC = 2 reduction chunks (64 channels of one tap): one barrier per
+// 2*16*MT*NT MFMAs per wave.  The A operand lives in a 2-deep register ring: the registers of a
+// chunk are re-loaded for chunk+2 right after that chunk's MFMAs were issued, so the loads fly
+// under the other chunk's MFMAs.  Weights for the next iteration are fetched to registers at the
+// top of the iteration and written to the other LDS buffer at its end.
 template <int MT, int NT>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict__ in,
                                                          const float *__restrict__ wimg,
                                                          const float *__restrict__ bias,
                                                          float *__restrict__ out, ConvGeom g) {
-    __shared__ __attribute__((aligned(16))) float Bs[2][NT * 1024];
+    constexpr int KC = 2;
+    __shared__ __attribute__((aligned(16))) float Bs[2][KC][NT * 1024];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int phase = blockIdx.y % g.nphase, nb = blockIdx.y / g.nphase;
     const long long M = (long long)g.B * g.Hg * g.Wg;
     const int nchunk = g.ntaps * g.cpt;
     const bool relu_in = g.flags & kFlagReluIn;
+    const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
 
     bool valid[MT];
     int gy[MT], gx[MT];
@@ -105,11 +113,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
         myoff[mt] = valid[mt] ? ((b * g.Hout + gy[mt] * g.ostride + g.opy[phase]) * g.Wout +
                                  gx[mt] * g.ostride + g.opx[phase]) * (long long)g.Cout
                               : -1;
+        gy[mt] *= g.istride;
+        gx[mt] *= g.istride;
     }
     const float *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 1024;
     const size_t wchunk = (size_t)g.ntile * 1024;
 
-    f32x4 a_cur[MT][4], a_nxt[MT][4], b_nxt[NT];
+    f32x4 a[KC][MT][4], b_nxt[KC][NT];
     f32x16 acc[MT][NT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -120,11 +130,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 
     auto load_a = [&](int c, f32x4(&dst)[MT][4]) {
         const int tap = c / g.cpt, cc = c - tap * g.cpt;
-        const int dy = g.dy[phase][tap], dx = g.dx[phase][tap];
+        const int dy = (int)((dym >> (4 * tap)) & 15) - 8, dx = (int)((dxm >> (4 * tap)) & 15) - 8;
         const int ch0 = cc * 32 + 16 * h;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int iy = gy[mt] * g.istride + dy, ix = gx[mt] * g.istride + dx;
+            const int iy = gy[mt] + dy, ix = gx[mt] + dx;
             const bool ok = valid[mt] && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
             const float *src = in + ((bimg[mt] + iy) * g.Win + ix) * (long long)g.Cin + ch0;
 #pragma unroll
@@ -135,49 +145,57 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
             }
         }
     };
-    auto load_b = [&](int c) {
-        const f32x4 *src = reinterpret_cast<const f32x4 *>(wbase + (size_t)c * wchunk);
+    auto load_b = [&](int c0) {
 #pragma unroll
-        for (int q = 0; q < NT; ++q) b_nxt[q] = src[tid + 256 * q];
+        for (int k = 0; k < KC; ++k)
+            if (c0 + k < nchunk) {
+                const f32x4 *src = reinterpret_cast<const f32x4 *>(wbase + (size_t)(c0 + k) * wchunk);
+#pragma unroll
+                for (int q = 0; q < NT; ++q) b_nxt[k][q] = src[tid + 256 * q];
+            }
     };
     auto store_b = [&](int buf) {
-        f32x4 *dst = reinterpret_cast<f32x4 *>(Bs[buf]);
 #pragma unroll
-        for (int q = 0; q < NT; ++q) dst[tid + 256 * q] = b_nxt[q];
+        for (int k = 0; k < KC; ++k) {
+            f32x4 *dst = reinterpret_cast<f32x4 *>(Bs[buf][k]);
+#pragma unroll
+            for (int q = 0; q < NT; ++q) dst[tid + 256 * q] = b_nxt[k][q];
+        }
     };
 
-    load_a(0, a_cur);
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < nchunk) load_a(k, a[k]);
     load_b(0);
     store_b(0);
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;
-        if (more) {
-            load_a(c + 1, a_nxt);
-            load_b(c + 1);
+    const int niter = (nchunk + KC - 1) / KC;
+    for (int it = 0; it < niter; ++it) {
+        const int c0 = it * KC;
+        const bool more = it + 1 < niter;
+        if (more) load_b(c0 + KC);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (c0 + k < nchunk) {
+                const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[it & 1][k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 b4[NT];
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) b4[nt] = bs[((nt * 4 + j) * 2 + h) * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mt][j][i], b4[nt][i],
+                                                                                   acc[mt][nt], 0, 0, 0);
+                }
+                if (c0 + k + KC < nchunk) load_a(c0 + k + KC, a[k]);
+            }
         }
-        const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[c & 1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 b4[NT];
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) b4[nt] = bs[((nt * 4 + j) * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j][i], b4[nt][i],
-                                                                           acc[mt][nt], 0, 0, 0);
-        }
-        if (more) {
-            store_b((c + 1) & 1);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a_cur[mt][j] = a_nxt[mt][j];
-        }
+        if (more) store_b((it + 1) & 1);
         __syncthreads();
     }
 
@@ -215,15 +233,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
 // The hidden 32-channel tile goes accumulator -> LDS -> A operand inside the wave.
 template <int NT2>
-__global__ __launch_bounds__(256) void res_layer_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ w1img,
                                                         const float *__restrict__ w2img,
                                                         float *__restrict__ out, int B, int H, int W,
                                                         int C, int flags) {
     constexpr int MT = 2;
-    __shared__ __attribute__((aligned(16))) float Bs[2][1024];
-    __shared__ __attribute__((aligned(16))) float W2s[NT2 * 1024];
-    __shared__ float Hs[4][MT][32 * 33];
+    // one LDS block: W2 image | union { double-buffered W1 chunk pairs (GEMM1), hidden tiles (after it) }
+    __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1024 + 4 * MT * 32 * 33];
+    float *W2s = smem_res;
+    float(*Bs)[2][1024] = reinterpret_cast<float(*)[2][1024]>(smem_res + NT2 * 1024);
+    float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const long long M = (long long)B * H * W;
@@ -254,7 +274,8 @@ __global__ __launch_bounds__(256) void res_layer_kernel(const float *__restrict_
         bimg[mt] = b * H;
     }
 
-    f32x4 a_cur[MT][4], a_nxt[MT][4], b_nxt;
+    constexpr int KC = 2;
+    f32x4 a[KC][MT][4], b_nxt[KC];
     f32x16 acc1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -278,33 +299,43 @@ __global__ __launch_bounds__(256) void res_layer_kernel(const float *__restrict_
             }
         }
     };
+    auto load_b = [&](int c0) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k)
+            if (c0 + k < nchunk) b_nxt[k] = reinterpret_cast<const f32x4 *>(w1img + (size_t)(c0 + k) * 1024)[tid];
+    };
 
-    load_a(0, a_cur);
-    b_nxt = reinterpret_cast<const f32x4 *>(w1img)[tid];
-    reinterpret_cast<f32x4 *>(Bs[0])[tid] = b_nxt;
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < nchunk) load_a(k, a[k]);
+    load_b(0);
+#pragma unroll
+    for (int k = 0; k < KC; ++k) reinterpret_cast<f32x4 *>(Bs[0][k])[tid] = b_nxt[k];
     __syncthreads();
-    for (int c = 0; c < nchunk; ++c) {
-        const bool more = c + 1 < nchunk;
-        if (more) {
-            load_a(c + 1, a_nxt);
-            b_nxt = reinterpret_cast<const f32x4 *>(w1img + (size_t)(c + 1) * 1024)[tid];
+    const int niter = (nchunk + KC - 1) / KC;
+    for (int it = 0; it < niter; ++it) {
+        const int c0 = it * KC;
+        const bool more = it + 1 < niter;
+        if (more) load_b(c0 + KC);
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (c0 + k < nchunk) {
+                const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[it & 1][k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 b4 = bs[(j * 2 + h) * 32 + l31];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mt][j][i], b4[i], acc1[mt], 0, 0, 0);
+                }
+                if (c0 + k + KC < nchunk) load_a(c0 + k + KC, a[k]);
+            }
         }
-        const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[c & 1]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const f32x4 b4 = bs[(j * 2 + h) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[mt][j][i], b4[i], acc1[mt], 0, 0, 0);
-        }
         if (more) {
-            reinterpret_cast<f32x4 *>(Bs[(c + 1) & 1])[tid] = b_nxt;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) a_cur[mt][j] = a_nxt[mt][j];
+            for (int k = 0; k < KC; ++k) reinterpret_cast<f32x4 *>(Bs[(it + 1) & 1][k])[tid] = b_nxt[k];
         }
         __syncthreads();
     }
@@ -475,86 +506,132 @@ __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float *__restri
 }
 
 // ---------------------------------------------------------------------------
-// Last layer: nn.ConvTranspose2d(Cin, COUT<=4, k=4, s=2, p=1), row-major in, NCHW image out
-// (models/decoder.py:34-35).  3 output channels cannot feed a 32-wide MFMA tile, so this one
-// is a VALU kernel: one lane per input-grid pixel produces its 2x2 output pixels x COUT from
-// the 3x3 input neighbourhood; weights are wave-uniform (scalar loads).
-// Packed weights: [tap 9][ci][phase 4][COUT] with zeros where a phase does not use a tap.
-template <int COUT>
+// Last layer: nn.ConvTranspose2d(Cin, Cout<=4, k=4, s=2, p=1), row-major in, NCHW image out
+// (models/decoder.py:34-35).  Cout = 3 cannot fill a 32-wide MFMA tile as an output-channel
+// dimension, so the layer runs in its GEMM + col2im form inside ONE kernel:
+//   T[pixel][tap*Cout + co] = sum_ci x[pixel][ci] * w[ci][co][tap]     (N = 16*Cout <= 64 on the MFMA)
+//   out[co][oy][ox] = bias[co] + sum over the 4 (ky,kx) with matching parity of T[(oy+1-ky)/2][(ox+1-kx)/2][ky][kx][co]
+// A workgroup owns a 16x16 region of input pixels (a 14x14 interior + 1-pixel halo, or the whole
+// image when it is at most 16 wide/high), keeps T for the region in LDS and writes the interior's
+// 2x upsampled outputs with coalesced NCHW stores.
+template <int NT>
 __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict__ in,
-                                                        const float *__restrict__ wp,
+                                                        const float *__restrict__ wimg,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ out, int B, int H, int W,
-                                                        int Cin) {
-    const long long M = (long long)B * H * W;
-    const long long p = (long long)blockIdx.x * 256 + threadIdx.x;
-    const bool valid = p < M;
-    const long long pc = valid ? p : 0;
-    const long long b = pc / ((long long)H * W);
-    const int rem = (int)(pc - b * H * W);
-    const int gy = rem / W, gx = rem - gy * W;
-    float acc[4][COUT];
+                                                        int Cin, int Cout, int TH, int TW, int halo_y,
+                                                        int halo_x, int tiles_y, int tiles_x) {
+    constexpr int MT = 2, STRIDE = NT * 32 + 1;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int cpt = (Cin + 31) / 32;
+    float *Ws = smem;                               // [cpt][NT][1024]
+    float *Ts = smem + (size_t)cpt * NT * 1024;     // [256][STRIDE]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const long long b = t / tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int ry = y0 - halo_y, rx = x0 - halo_x;
+
+    for (int i = tid; i < cpt * NT * 256; i += 256)
+        reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
+
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int ph = 0; ph < 4; ++ph)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int co = 0; co < COUT; ++co) acc[ph][co] = bias ? bias[co] : 0.0f;
-    // phase (py,px) uses input rows {gy, gy-1} (py=0) or {gy+1, gy} (py=1); same for columns
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
-        const int dy = t / 3 - 1, dx = t % 3 - 1;
-        const int iy = gy + dy, ix = gx + dx;
-        const bool ok = valid && iy >= 0 && iy < H && ix >= 0 && ix < W;
-        const float *src = in + ((b * H + iy) * (long long)W + ix) * Cin;
-        const float *wt = wp + (size_t)t * Cin * 4 * COUT;
-        for (int c4 = 0; c4 < Cin; c4 += 4) {
-            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-            if (ok) v = *reinterpret_cast<const f32x4 *>(src + c4);
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    bool ok[MT];
+    const float *src[MT];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float xv = v[q];
-                const float *wq = wt + (size_t)(c4 + q) * 4 * COUT;
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = wave * 64 + mt * 32 + l31;
+        const int iy = ry + (p >> 4), ix = rx + (p & 15);
+        ok[mt] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+        src[mt] = in + ((b * H + iy) * (long long)W + ix) * Cin + 16 * h;
+    }
+    __syncthreads();
+    for (int c = 0; c < cpt; ++c) {
+        f32x4 a[MT][4];
 #pragma unroll
-                for (int ph = 0; ph < 4; ++ph) {
-                    const int py = ph >> 1, px = ph & 1;
-                    const bool uses = (dy == 0 || (dy == -1 && py == 0) || (dy == 1 && py == 1)) &&
-                                      (dx == 0 || (dx == -1 && px == 0) || (dx == 1 && px == 1));
-                    if (uses) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int co = 0; co < COUT; ++co)
-                            acc[ph][co] = __builtin_fmaf(xv, wq[ph * COUT + co], acc[ph][co]);
-                    }
-                }
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (ok[mt] && c * 32 + 16 * h + 4 * j < Cin)
+                    v = *reinterpret_cast<const f32x4 *>(src[mt] + c * 32 + 4 * j);
+                a[mt][j] = v;
             }
+        const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws + (size_t)c * NT * 1024);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b4[nt] = ws[((nt * 4 + j) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j][i], b4[nt][i], acc[mt][nt],
+                                                                           0, 0, 0);
         }
     }
-    if (valid) {
-        const int Ho = 2 * H, Wo = 2 * W;
 #pragma unroll
-        for (int co = 0; co < COUT; ++co)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int py = 0; py < 2; ++py) {
-                float2 v;
-                v.x = acc[py * 2 + 0][co];
-                v.y = acc[py * 2 + 1][co];
-                *reinterpret_cast<float2 *>(out + ((b * COUT + co) * Ho + 2 * gy + py) * (long long)Wo + 2 * gx) = v;
+        for (int r = 0; r < 16; ++r) {
+            const int p = wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) Ts[p * STRIDE + nt * 32 + l31] = acc[mt][nt][r];
+        }
+    __syncthreads();
+
+    // col2im over the interior's outputs, ox fastest (coalesced NCHW rows)
+    const int th = min(TH, H - y0), tw = min(TW, W - x0);
+    const int OH = 2 * th, OW = 2 * tw, Ho = 2 * H, Wo = 2 * W;
+    const int total = Cout * OH * OW;
+    for (int e = tid; e < total; e += 256) {
+        const int oxl = e % OW;
+        const int q = e / OW;
+        const int oyl = q % OH, co = q / OH;
+        const int oy = 2 * y0 + oyl, ox = 2 * x0 + oxl;
+        float s = bias ? bias[co] : 0.0f;
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+            const int ky = ((oy + 1) & 1) + 2 * a2;
+            const int iy = (oy + 1 - ky) >> 1;
+            if (iy < 0 || iy >= H) continue;
+#pragma unroll
+            for (int b2 = 0; b2 < 2; ++b2) {
+                const int kx = ((ox + 1) & 1) + 2 * b2;
+                const int ix = (ox + 1 - kx) >> 1;
+                if (ix < 0 || ix >= W) continue;
+                s += Ts[((iy - ry) * 16 + (ix - rx)) * STRIDE + (ky * 4 + kx) * Cout + co];
             }
+        }
+        out[((b * Cout + co) * Ho + oy) * (long long)Wo + ox] = s;
     }
 }
 
-__global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__restrict__ w, float *__restrict__ wp,
-                                                             int Cin, int Cout) {
-    // w: (Cin, Cout, 4, 4).  oy = 2*iy - 1 + ky  ->  for tap dy: py=0: dy=0->ky=1, dy=-1->ky=3;
-    //                                                           py=1: dy=+1->ky=0, dy=0->ky=2
-    const int total = 9 * Cin * 4 * Cout;
+__global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__restrict__ w, float *__restrict__ img,
+                                                             int Cin, int Cout, int ntile) {
+    // w: (Cin, Cout, 4, 4) -> B-operand image [chunk][ntile][4][2][32][4], column n = tap*Cout + co
+    const int cpt = (Cin + 31) / 32;
+    const int total = cpt * ntile * 1024;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
-        const int co = e % Cout;
-        int t = e / Cout;
-        const int ph = t & 3; t >>= 2;
-        const int ci = t % Cin, tap = t / Cin;
-        const int dy = tap / 3 - 1, dx = tap % 3 - 1, py = ph >> 1, px = ph & 1;
-        const int ky = py == 0 ? (dy == 0 ? 1 : (dy == -1 ? 3 : -1)) : (dy == 1 ? 0 : (dy == 0 ? 2 : -1));
-        const int kx = px == 0 ? (dx == 0 ? 1 : (dx == -1 ? 3 : -1)) : (dx == 1 ? 0 : (dx == 0 ? 2 : -1));
-        wp[e] = (ky >= 0 && kx >= 0) ? w[((ci * Cout + co) * 4 + ky) * 4 + kx] : 0.0f;
+        const int i = e & 3, n = (e >> 2) & 31, h = (e >> 7) & 1, j = (e >> 8) & 3;
+        const int t = e >> 10;
+        const int nt = t % ntile, chunk = t / ntile;
+        const int ci = chunk * 32 + 16 * h + 4 * j + i, col = nt * 32 + n;
+        const int tap = col / Cout, co = col - tap * Cout;
+        img[e] = (ci < Cin && tap < 16) ? w[((size_t)ci * Cout + co) * 16 + tap] : 0.0f;
     }
 }
 
@@ -634,6 +711,11 @@ static int make_geom(int kind, long long B, int H, int W, int Cin, int Cout, int
         }
         default: return VQVAE_ERR_UNSUPPORTED;
     }
+    for (int ph = 0; ph < g.nphase; ++ph)
+        for (int t = 0; t < g.ntaps; ++t) {
+            g.dymask[ph] |= (unsigned long long)(g.dy[ph][t] + 8) << (4 * t);
+            g.dxmask[ph] |= (unsigned long long)(g.dx[ph][t] + 8) << (4 * t);
+        }
     return VQVAE_OK;
 }
 
@@ -766,15 +848,16 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
 }
 
 size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
-    if (Cin < 4 || Cin % 4 || Cout < 1 || Cout > 4) return 0;
-    return (size_t)9 * Cin * 4 * Cout * sizeof(float);
+    if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;
+    const int ntile = (16 * Cout + 31) / 32;
+    return (size_t)((Cin + 31) / 32) * ntile * 1024 * sizeof(float);
 }
 
 int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
     if (!w || !packed) return VQVAE_ERR_NULL;
     if (vqvae_convt_out_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(convt_out_pack_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed,
-                       Cin, Cout);
+                       Cin, Cout, (16 * Cout + 31) / 32);
     return (int)hipGetLastError();
 }
 
@@ -784,14 +867,24 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
     if (B < 1 || H < 1 || W < 1) return VQVAE_ERR_SHAPE;
     if (vqvae_convt_out_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const long long M = B * (long long)H * W;
-    const unsigned gx = (unsigned)((M + 255) / 256);
+    const int halo_y = H > 16, halo_x = W > 16;
+    const int TH = halo_y ? 14 : H, TW = halo_x ? 14 : W;
+    const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
+    const long long ntiles = B * (long long)tiles_y * tiles_x;
+    if (ntiles > INT32_MAX) return VQVAE_ERR_OVERFLOW;
+    const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
+    const size_t lds = ((size_t)cpt * ntile * 1024 + 256 * (ntile * 32 + 1)) * sizeof(float);
     prof_begin(VQVAE_PROF_CONV_OUT, st);
-    switch (Cout) {
-        case 1: hipLaunchKernelGGL((convt_out_kernel<1>), dim3(gx), dim3(256), 0, st, x, packed, bias, y_nchw, (int)B, H, W, Cin); break;
-        case 2: hipLaunchKernelGGL((convt_out_kernel<2>), dim3(gx), dim3(256), 0, st, x, packed, bias, y_nchw, (int)B, H, W, Cin); break;
-        case 3: hipLaunchKernelGGL((convt_out_kernel<3>), dim3(gx), dim3(256), 0, st, x, packed, bias, y_nchw, (int)B, H, W, Cin); break;
-        case 4: hipLaunchKernelGGL((convt_out_kernel<4>), dim3(gx), dim3(256), 0, st, x, packed, bias, y_nchw, (int)B, H, W, Cin); break;
+    if (ntile == 1) {
+        auto k = convt_out_kernel<1>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, packed, bias, y_nchw, (int)B, H, W, Cin,
+                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);
+    } else {
+        auto k = convt_out_kernel<2>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, packed, bias, y_nchw, (int)B, H, W, Cin,
+                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);
     }
     prof_end(VQVAE_PROF_CONV_OUT, st);
     return (int)hipGetLastError();

@@ -123,6 +123,55 @@ __device__ __noinline__ int vq_slow_argmin(const float *__restrict__ z, size_t z
 }
 
 // ---------------------------------------------------------------------------
+// One software-pipeline step of the codebook sweep: issue the D/2 MFMAs of code tile M into accM
+// while the running (min, argmin) absorbs the finished accumulators accA of the previous tile.
+// Program order interleaves the two so the VALU work issues in the shadow of this wave's own MFMAs
+// (the two waves of a SIMD run in lock-step, so they cannot cover for each other).
+template <int D, int RT, bool DO_MFMA, bool DO_ARG>
+__device__ __forceinline__ void vq_tile_step(const float *__restrict__ ap, size_t jstride,
+                                             const float (&zr)[RT][D / 2], f32x16 (&accM)[RT],
+                                             const float *__restrict__ ee_t, int code0,
+                                             const f32x16 (&accA)[RT], const float (&zz)[RT],
+                                             float (&bd)[RT], int (&bk)[RT]) {
+    constexpr int NJ = D / 8;
+    if (DO_MFMA) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accM[t][r] = 0.0f;
+    }
+    f32x4 e4 = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        if (DO_MFMA) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (size_t)j * jstride);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < RT; ++t)
+                    accM[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], zr[t][4 * j + i], accM[t], 0, 0, 0);
+        }
+        if (DO_ARG) {
+            // accumulator registers [r0, r1) of the previous tile are folded in during this j
+            const int r0 = (16 * j) / NJ, r1 = (16 * (j + 1)) / NJ;
+#pragma unroll
+            for (int r = r0; r < r1; ++r) {
+                if ((r & 3) == 0) e4 = *reinterpret_cast<const f32x4 *>(ee_t + 8 * (r >> 2));
+                const int code = code0 + 8 * (r >> 2) + (r & 3);
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const float tt = zz[t] + e4[r & 3];
+                    const float d = __builtin_fmaf(-2.0f, accA[t][r], tt);
+                    const bool lt = d < bd[t];
+                    bd[t] = lt ? d : bd[t];
+                    bk[t] = lt ? code : bk[t];
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 template <int D, int RT, bool ROWMAJOR>
 __global__ __launch_bounds__(512, 2) void vq_exact_kernel(
     const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ img,
@@ -142,7 +191,6 @@ __global__ __launch_bounds__(512, 2) void vq_exact_kernel(
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     const int cb_bad = flags[0];
-
     for (int k = tid; k < K; k += 512) hist_s[k] = 0;
 
     auto stage = [&](int ch) {
@@ -247,38 +295,27 @@ __global__ __launch_bounds__(512, 2) void vq_exact_kernel(
             }
             const int ncode = min(KC, K - ch * KC);
             const int ntile = (ncode + 31) >> 5;
-            for (int ct = 0; ct < ntile; ++ct) {
-                f32x16 acc[RT];
-#pragma unroll
-                for (int t = 0; t < RT; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
-                const float *ap = Es + ((size_t)h * KC + ct * 32 + l31) * 4;
-#pragma unroll
-                for (int j = 0; j < D / 8; ++j) {
-                    const f32x4 a = *reinterpret_cast<const f32x4 *>(ap + (size_t)j * 2 * KC * 4);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int t = 0; t < RT; ++t)
-                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], zr[t][4 * j + i],
-                                                                           acc[t], 0, 0, 0);
-                }
-                const int code0 = ch * KC + ct * 32 + 4 * h;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(ee_s + ct * 32 + 8 * g + 4 * h);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int t = 0; t < RT; ++t) {
-                            const float tt = zz[t] + e4[i];
-                            const float d = __builtin_fmaf(-2.0f, acc[t][4 * g + i], tt);
-                            const bool lt = d < bd[t];
-                            bd[t] = lt ? d : bd[t];
-                            bk[t] = lt ? code0 + 8 * g + i : bk[t];
-                        }
-                }
+            const size_t jstride = (size_t)2 * KC * 4;
+            const float *ap0 = Es + ((size_t)h * KC + l31) * 4;      // + ct*128 per code tile
+            const float *ee0 = ee_s + 4 * h;                          // + ct*32 per code tile
+            const int cbase = ch * KC + 4 * h;
+            f32x16 accA[RT], accB[RT];
+            vq_tile_step<D, RT, true, false>(ap0, jstride, zr, accA, ee0, cbase, accB, zz, bd, bk);
+            int ct = 1;
+            for (; ct + 1 < ntile; ct += 2) {
+                vq_tile_step<D, RT, true, true>(ap0 + ct * 128, jstride, zr, accB, ee0 + (ct - 1) * 32,
+                                                cbase + (ct - 1) * 32, accA, zz, bd, bk);
+                vq_tile_step<D, RT, true, true>(ap0 + (ct + 1) * 128, jstride, zr, accA, ee0 + ct * 32,
+                                                cbase + ct * 32, accB, zz, bd, bk);
+            }
+            if (ct < ntile) {
+                vq_tile_step<D, RT, true, true>(ap0 + ct * 128, jstride, zr, accB, ee0 + (ct - 1) * 32,
+                                                cbase + (ct - 1) * 32, accA, zz, bd, bk);
+                vq_tile_step<D, RT, false, true>(ap0, jstride, zr, accA, ee0 + ct * 32, cbase + ct * 32, accB, zz,
+                                                 bd, bk);
+            } else {
+                vq_tile_step<D, RT, false, true>(ap0, jstride, zr, accB, ee0 + (ct - 1) * 32,
+                                                 cbase + (ct - 1) * 32, accA, zz, bd, bk);
             }
         }
 
