@@ -49,23 +49,28 @@ def parse():
 
 def cpu_baseline(seconds: float):
     """Reference algorithm on the host: same ATen CPU ops in the same order as the reference
-    (oracle/torch_port.py), main.py defaults, eval + no_grad, on a bounded sample."""
+    (oracle/torch_port.py), main.py defaults, eval + no_grad, on a bounded sample.  A few thread
+    counts are tried briefly (big hosts thrash on 32-image batches) and the best is reported with
+    the thread count that produced it."""
     from oracle import torch_port
-    threads = torch.get_num_threads()
     sd = torch_port.init_state_dict()
-    best, detail = 0.0, []
-    for B in (32, 256):
-        x = torch.randn(B, 3, 32, 32)
-        for _ in range(3):
+    ncpu = os.cpu_count() or 1
+    cands = sorted({t for t in (8, 16, 32, 64, torch.get_num_threads()) if t <= ncpu})
+    per = max(0.5, seconds / (2 * len(cands)))
+    best, best_t, detail = 0.0, cands[0], []
+    for t in cands:
+        torch.set_num_threads(t)
+        for B in (32, 256):
+            x = torch.randn(B, 3, 32, 32)
             torch_port.forward(sd, x, 0.25, 2)
-        n, t0 = 0, time.perf_counter()
-        while time.perf_counter() - t0 < seconds / 2:
-            torch_port.forward(sd, x, 0.25, 2)
-            n += 1
-        dt = time.perf_counter() - t0
-        ips = n * B / dt
-        detail.append(f"B={B}: {n} forwards in {dt:.1f}s = {ips:.0f} img/s")
-        best = max(best, ips)
+            n, t0 = 0, time.perf_counter()
+            while time.perf_counter() - t0 < per:
+                torch_port.forward(sd, x, 0.25, 2)
+                n += 1
+            ips = n * B / (time.perf_counter() - t0)
+            detail.append(f"T={t},B={B}:{ips:.0f}")
+            if ips > best:
+                best, best_t = ips, t
     cpu = "unknown"
     try:
         for line in open("/proc/cpuinfo"):
@@ -74,9 +79,9 @@ def cpu_baseline(seconds: float):
                 break
     except OSError:
         pass
-    return {"value": round(best, 1), "unit": "images/s", "cores": threads, "kind": "port",
+    return {"value": round(best, 1), "unit": "images/s", "cores": best_t, "kind": "port",
             "sample": "VQVAE.forward 32x32x3 K=512 D=64 fp32 eval/no_grad on the host CPU (" + cpu +
-                      f", {os.cpu_count()} logical cpus, torch threads={threads}); " + "; ".join(detail)}
+                      f", {ncpu} logical cpus); ~{per:.1f}s per (threads,batch) point, img/s: " + " ".join(detail)}
 
 
 def main():
@@ -160,15 +165,17 @@ def main():
         achieved = alg_bytes / t_vq / 1e9
         flops = 2.0 * rows * K * D
         roofline = {
-            "kernel": "vq_exact_kernel (fused distance+argmin+gather, exact fp32 MFMA)",
+            "kernel": "vq_filter_kernel_d64 (fused VQ: bf16-MFMA screen with a rigorous bound + exact fp32 "
+                      "refine of the surviving codes; bit-exact indices)",
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None,
             "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
             "alg_bytes_per_row": 8 * D + 8,
-            "mfma_f32_tflops": round(flops / t_vq / 1e12, 1),
-            "mfma_f32_frac": round(flops / t_vq / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
-            "note": "exact-fp32 distances make this kernel MFMA-bound: ceiling 15.6% of HBM peak at "
-                    "K=512,D=64 (SURVEY.md 8d); mfma_f32_frac is the binding roofline",
+            "screen_tflops_bf16": round(2 * flops / t_vq / 1e12, 1),
+            "hbm_achievable_frac": round(achieved / 6290.0, 4),
+            "note": "algorithmic bytes = rows x (8D+8): read z_e, write z_q, write int64 idx; the screen "
+                    "sweeps the codebook twice on the bf16 matrix cores (2 x 2KD flop/row); an exhaustive "
+                    "exact-fp32 sweep (VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic",
         }
         line = {
             "metric": METRIC, "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",

@@ -75,6 +75,9 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
                                         (a previous call with the same codebook, K, D
                                         and workspace): skip the prepare kernel        */
 
+#define VQVAE_VQ_EXACT_SWEEP    0x4  /* force the exhaustive exact-fp32 MFMA sweep instead of the
+                                        bf16-screened + exactly-refined kernel (identical outputs) */
+
 /* Bytes of workspace vqvae_vq_forward_f32 needs for n_rows = B*H*W latent rows. */
 VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);
 

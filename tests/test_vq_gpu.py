@@ -18,12 +18,13 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
-    loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq)
+    loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
+                                            exact_sweep=exact)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -31,11 +32,14 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True):
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
-def test_vq_matches_reference_golden(name, rowmajor, golden_vq):
+def test_vq_matches_reference_golden(name, rowmajor, exact, golden_vq):
+    """Both kernels -- the bf16-screened + exactly-refined one (default where it applies: D=64) and
+    the exhaustive fp32-MFMA sweep -- must reproduce the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
-    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor)
+    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=exact)
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -68,13 +72,40 @@ def test_vq_matches_oracle_fresh(K, D, B, H, W, scale):
     cb = ((torch.rand(K, D, generator=g) * 2 - 1) / K) if scale < 1 else torch.randn(K, D, generator=g)
     z = torch.randn(B, D, H, W, generator=g) * scale
     ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
-    for rowmajor in (False, True):
-        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor)
+    for rowmajor, exact in ((False, False), (True, False), (False, True), (True, True)):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, exact=exact)
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
         np.testing.assert_allclose(ppl, ref["perplexity"], rtol=1e-6)
         np.testing.assert_array_equal(hist, ref["hist"])
+
+
+def test_vq_filter_adversarial_near_ties():
+    """Stress the screen's bound: codes that differ from each other by ~1 ulp-level perturbations, rows
+    sitting almost exactly between codes, huge dynamic range, and > CAP near-duplicates per row
+    (candidate-list overflow -> scalar path).  The filter kernel must still equal the oracle bit for bit."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(77)
+    K, D = 512, 64
+    base = torch.randn(8, D, generator=g)
+    cb = base[torch.randint(0, 8, (K,), generator=g)].clone()
+    cb += torch.randn(K, D, generator=g) * 1e-6            # 64 near-duplicates of each of 8 prototypes
+    cb[100:140] = cb[100]                                   # 40 exact duplicates
+    cb[300:] *= torch.logspace(-3, 3, K - 300).unsqueeze(1)
+    z = torch.empty(6, D, 8, 8)
+    zr = base[torch.randint(0, 8, (384,), generator=g)] + torch.randn(384, D, generator=g) * 1e-3
+    zr[::7] = 0.5 * (cb[5] + cb[200])                       # midpoints
+    zr[3::11] = cb[100]
+    zr[5::13] *= 1e3
+    zr[6::17] *= 1e-4
+    z = zr.view(6, 8, 8, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    for rowmajor in (False, True):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor)
+        np.testing.assert_array_equal(idx, ref["idx"])
+        assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
+        np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
 
 
 def test_vq_nonfinite_codebook_forces_slow_path():

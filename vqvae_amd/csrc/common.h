@@ -39,9 +39,14 @@ struct VqPlan {
     int KC;           // codes per LDS chunk (multiple of 32)
     int nchunks;      // ceil(K / KC)
     int K_pad;        // nchunks * KC
-    size_t off_flags, off_ee, off_img, off_partials, total;
+    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, total;
     size_t lds_bytes;
+    // filter-and-refine kernel (bf16 screening): usable when the whole bf16 image fits LDS
+    bool filter_ok;
+    int K32;                 // K rounded up to 32
+    size_t filter_lds_bytes;
 };
+constexpr int kVqCandCap = 8;   // per lane half (16 per row), unsigned short entries   // candidate list capacity per row in the filter kernel
 constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many workgroups
 
 inline VqPlan vq_plan(int K, int D) {
@@ -61,8 +66,19 @@ inline VqPlan vq_plan(int K, int D) {
     p.off_ee = 256;
     p.off_img = align_up(p.off_ee + (size_t)p.K_pad * 4, 256);
     p.off_partials = align_up(p.off_img + (size_t)p.K_pad * D * 4, 256);
-    p.total = align_up(p.off_partials + sizeof(double) * kVqMaxGrid, 256);
+    p.K32 = (K + 31) / 32 * 32;
+    p.off_img16 = align_up(p.off_partials + sizeof(double) * kVqMaxGrid, 256);
+    p.off_neh = align_up(p.off_img16 + (size_t)p.K32 * D * 2, 256);
+    p.total = align_up(p.off_neh + (size_t)p.K32 * 4, 256);
+    // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
+    p.filter_lds_bytes = (size_t)p.K32 * D * 2 + (size_t)p.K32 * 4 + (size_t)K * 4 +
+                         8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4 + 256 + 8;
+    p.filter_ok = (D == 64) && p.filter_lds_bytes <= (size_t)kLdsBytes;
     return p;
 }
+
+// vq_filter.hip: bf16-screened, exactly-refined VectorQuantizer kernel (same outputs as the exact one)
+int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
+                         float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out);
 
 }  // namespace vqvae

@@ -20,44 +20,9 @@
 // (l <-> l+32) is needed per row.  The codebook lives in LDS as the A-operand
 // image [c/8][c&1][code][(c%8)/2], read conflict-free with ds_read_b128.
 #include "common.h"
+#include "vq_device.h"
 
 namespace vqvae {
-
-// Raw buffer descriptor over [p, p + 4 GiB): stride 0, no swizzle.  p must be
-// wave-uniform; lanes address it with 32-bit byte offsets.
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, 0xFFFFFFFFu, 0x00020000);
-}
-
-// ---------------------------------------------------------------------------
-// ATen cascade_sum order for one row of D squares held fully by one thread.
-template <int D>
-__device__ __forceinline__ float aten_sqsum_full(const float (&sq)[D]) {
-    static_assert(D % 8 == 0 && D / 32 < 16, "D must be a multiple of 8 below 512");
-    constexpr int NV = D / 8, NI = NV / 4;
-    float part[4][8];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) part[q][t] = 0.0f;
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) part[q][t] = part[q][t] + sq[(4 * i + q) * 8 + t];
-#pragma unroll
-    for (int v = NI * 4; v < NV; ++v)
-#pragma unroll
-        for (int t = 0; t < 8; ++t) part[0][t] = part[0][t] + sq[v * 8 + t];
-    float fin = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 8; ++t) {
-        const float a = ((part[0][t] + part[1][t]) + part[2][t]) + part[3][t];
-        fin = fin + a;
-    }
-    return fin;
-}
 
 // ---------------------------------------------------------------------------
 // Prepare: one thread per (padded) code.  Writes ||e_k||^2 in ATen order, the
@@ -66,9 +31,16 @@ template <int D>
 __global__ __launch_bounds__(64) void vq_prepare_kernel(const float *__restrict__ cb, int K, int KC,
                                                         int K_pad, float *__restrict__ ee,
                                                         float *__restrict__ img,
-                                                        int *__restrict__ flags) {
+                                                        int *__restrict__ flags, int K32,
+                                                        unsigned short *__restrict__ img16,
+                                                        float *__restrict__ neh) {
     const int k = blockIdx.x * 64 + threadIdx.x;
-    if (k >= K_pad) return;
+    if (k >= K_pad && k >= K32) return;
+    if (k >= K_pad) {                      // only the bf16 image is padded further than the fp32 one
+        for (int c = 0; c < D; ++c) img16[(((c % (D / 2)) / 8 * 2 + c / (D / 2)) * (size_t)K32 + k) * 8 + (c & 7)] = 0;
+        neh[k] = -__builtin_inff();
+        return;
+    }
     const int ch = k / KC, kl = k - ch * KC;
     float *dst = img + (size_t)ch * KC * D;
     float e[D];
@@ -94,32 +66,21 @@ __global__ __launch_bounds__(64) void vq_prepare_kernel(const float *__restrict_
         for (int c = 0; c < D; ++c) sq[c] = e[c] * e[c];
         n2 = aten_sqsum_full<D>(sq);
         if (!(n2 < 1.0e38f)) atomicOr(flags, 1);
+        // statistics for the screening bound: max ||e||^2 (non-negative floats order like ints)
+        atomicMax(flags + 1, __float_as_int(n2));
     }
     ee[k] = n2;
-}
-
-// ---------------------------------------------------------------------------
-// torch.argmin semantics for one row, scalar, used only for rows whose distances
-// may be non-finite (zz or some ||e||^2 not < 1e38): NaN is minimal, first wins.
-template <int D, bool ROWMAJOR>
-__device__ __noinline__ int vq_slow_argmin(const float *__restrict__ z, size_t zbase, size_t zstride,
-                                           const float *__restrict__ cb, const float *__restrict__ ee,
-                                           int K, float zz) {
-    if (zz != zz) return 0;          // every t = zz + ee is NaN -> first index
-    int best = 0;
-    float bd = 0.0f;
-    for (int k = 0; k < K; ++k) {
-        float m = 0.0f;
-        for (int c = 0; c < D; ++c)
-            m = __builtin_fmaf(z[zbase + (size_t)c * zstride], cb[(size_t)k * D + c], m);
-        const float t = zz + ee[k];
-        const float u = 2.0f * m;
-        const float d = t - u;
-        const bool dn = d != d, bn = bd != bd;
-        const bool better = (k == 0) || (dn ? !bn : (!bn && d < bd));
-        if (better) { best = k; bd = d; }
+    if (k < K32) {
+        // bf16 (round-to-nearest-even) A-operand image [c'/8][c/(D/2)][code][8], c' = c mod D/2
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            const unsigned u = __float_as_uint(e[c]);
+            const unsigned r = (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
+            const unsigned short bf = (e[c] != e[c]) ? 0x7FC0 : (unsigned short)r;
+            img16[(((c % (D / 2)) / 8 * 2 + c / (D / 2)) * (size_t)K32 + k) * 8 + (c & 7)] = bf;
+        }
+        neh[k] = k < K ? -0.5f * n2 : -__builtin_inff();
     }
-    return best;
 }
 
 // ---------------------------------------------------------------------------
@@ -479,10 +440,25 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     if ((e = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)K, st)) != hipSuccess) return (int)e;
     if (!(flags & VQVAE_VQ_CODEBOOK_PREPARED)) {
         if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((p.K_pad + 63) / 64), dim3(64), 0, st, cb, K,
-                           p.KC, p.K_pad, ee, img, wflags);
+        const int kmax = p.K_pad > p.K32 ? p.K_pad : p.K32;
+        hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((kmax + 63) / 64), dim3(64), 0, st, cb, K, p.KC,
+                           p.K_pad, ee, img, wflags, p.K32,
+                           reinterpret_cast<unsigned short *>(ws + p.off_img16),
+                           reinterpret_cast<float *>(ws + p.off_neh));
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
+    if constexpr (D == 64) {
+        if (p.filter_ok && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
+            int fgrid = 0;
+            prof_begin(VQVAE_PROF_VQ_MAIN, st);
+            const int rc = launch_vq_filter_d64(z, cb, N, HW, K, rowmajor, zq, idx, hist, ws, st, &fgrid);
+            prof_end(VQVAE_PROF_VQ_MAIN, st);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
+                               beta, loss, ppl);
+            return (int)hipGetLastError();
+        }
+    }
     const int cus = num_cus();
     // two row tiles per wave when that still leaves every CU at least two row blocks
     int rt = (D <= 64 && (N + 511) / 512 >= 2LL * cus) ? 2 : 1;

@@ -1,0 +1,426 @@
+// Fused VectorQuantizer forward for gfx950 -- filter-and-refine variant (D = 64).
+//
+// Same contract and the same bits out as vq_exact.hip (indices and z_q bit-identical to the
+// reference, models/quantizer.py:45-74), but the N x K distance sweep runs on the bf16 matrix
+// cores (2.5 PF) instead of the fp32 ones (157 TF), which is what lets the kernel approach its
+// HBM roofline.  Per 32-row wave tile:
+//
+//   screen   acc[n,k] = bf16(z_n) . bf16(e_k) - ||e_k||^2/2   (v_mfma_f32_32x32x16_bf16, fp32 accumulate;
+//            the accumulator is initialised with -||e_k||^2/2, so argmax acc ~ argmin distance)
+//            sweep 1: row maximum;  sweep 2: every code with acc >= max - DELTA goes to the row's
+//            candidate list.  DELTA is a rigorous bound (derivation below) on how far the screen can
+//            misplace the reference's fp32 argmin, so the list provably contains it.
+//   refine   rows with one candidate are done.  Rows with several recompute the reference's distance
+//            d = fl(fl(zz + ee_k) - 2 m_k) exactly -- m_k as the c-ordered fp32 fmaf chain, zz in ATen's
+//            summation order -- for the listed codes only, and take the lexicographic (d, k) minimum
+//            (= torch.argmin's first-index rule).  Non-finite rows / codebooks and list overflows fall
+//            back to the scalar torch.argmin-semantics path shared with the exact kernel.
+//
+// Bound.  Let u = 2^-9 (bf16 RNE), g = 65*2^-24 (fp32 accumulation of <= 65 terms).  For every code
+//   |acc_k - (z.e_k - ee_k/2)| <= (2u + u^2 + 1.01 g) |z||e_k| + g ee_k/2           (screen)
+//   |m_k^ref - z.e_k|          <= 1.01 g |z||e_k|                                  (reference chain)
+//   |d_k^ref - (zz + ee_k - 2 m_k^ref)| <= 2^-22 (zz + ee_k)                       (its two roundings)
+// so the reference's argmin k* satisfies acc_k* >= max_k acc_k - DELTA with
+//   DELTA = 2 [ (2u + u^2 + 2.02 g) |z| Emax + g EEmax/2 + 2^-23 (zz + EEmax) ],  Emax = max|e_k|, EEmax = Emax^2.
+// The code evaluates DELTA with every factor rounded up (constants below carry > 1 % slack).
+#include "common.h"
+#include "vq_device.h"
+
+namespace vqvae {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+template <bool ROWMAJOR>
+__global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
+    const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img16,
+    const float *__restrict__ neh_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
+    long long N, int HW, int K, int K32, long long nblocks, float *__restrict__ zq,
+    long long *__restrict__ idx, int *__restrict__ hist, double *__restrict__ partials) {
+    constexpr int D = 64, HALF = 32, NQ = 4, CAPH = kVqCandCap;   // list capacity per lane half
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                       // [NQ][2][K32] x 16 B
+    float *neh = reinterpret_cast<float *>(Eimg + (size_t)NQ * 2 * K32);      // [K32]  -||e||^2/2
+    int *hist_s = reinterpret_cast<int *>(neh + K32);                         // [K]
+    unsigned short *cand_list = reinterpret_cast<unsigned short *>(hist_s + K + (K & 1));   // [8][32][2][CAPH]
+    float *wave_f = reinterpret_cast<float *>(cand_list + 8 * 32 * 2 * CAPH);  // [8][96]: zz | job | result
+    double *red = reinterpret_cast<double *>(wave_f + 8 * 96);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int cb_bad = flags[0];
+    const float EEmax = __int_as_float(flags[1]) * 1.0001f;
+    const float Emax = __builtin_sqrtf(EEmax) * 1.0001f;
+
+    for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
+    for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
+    for (int k = tid; k < K; k += 512) hist_s[k] = 0;
+    __syncthreads();
+    unsigned short *my_list = cand_list + wave_u * (32 * 2 * CAPH);          // this wave's lists
+    unsigned short *own_list = my_list + (l31 * 2 + h) * CAPH;               // this lane's private part
+    const unsigned short *row_list = my_list + l31 * 2 * CAPH;
+    float *zz_s = wave_f + wave_u * 96;                                      // exact ||z||^2 per row
+    int *job_s = reinterpret_cast<int *>(zz_s + 32);                         // refine batch: (row<<16)|code
+    float *res_s = zz_s + 64;                                                // refine batch: distances
+    const int ntile = K32 >> 5;
+    const uint4 *ap0 = Eimg + (size_t)h * K32 + l31;
+    const float *np0 = neh + 4 * h;
+
+    // one 32-code x 32-row screen tile: acc = -||e||^2/2 + bf16(e) . bf16(z)
+    auto screen_tile = [&](int ct, const bf16x8(&zb)[NQ], f32x16 &acc) {
+        const float *np = np0 + ct * 32;
+        uint4 a[NQ];
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) a[q] = ap0[(size_t)q * 2 * K32 + ct * 32];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(np + 8 * g);
+            acc[4 * g] = e4.x; acc[4 * g + 1] = e4.y; acc[4 * g + 2] = e4.z; acc[4 * g + 3] = e4.w;
+        }
+#pragma unroll
+        for (int q = 0; q < NQ; ++q)
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q]), zb[q], acc, 0, 0, 0);
+    };
+    auto tile_max = [](const f32x16 &acc) -> float {
+        const float m0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), m1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
+        const float m2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), m3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
+        const float m4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
+        return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[15]));
+    };
+    // this lane's half row (channels [32h, 32h+32)) as fp32, straight from memory (L2-hot on re-reads)
+    auto load_half = [&](size_t zbase, size_t img0, unsigned voff, float(&zf)[HALF]) {
+        if (ROWMAJOR) {
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(z + zbase + 4 * q);
+                zf[4 * q] = v.x; zf[4 * q + 1] = v.y; zf[4 * q + 2] = v.z; zf[4 * q + 3] = v.w;
+            }
+        } else {
+            const auto rs = make_rsrc(z + img0);
+#pragma unroll
+            for (int c = 0; c < HALF; ++c)
+                zf[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)c * HW * 4u, 0));
+        }
+    };
+
+    double dacc = 0.0;
+    for (long long rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        const long long r0 = rb * 256 + wave_u * 32;
+        const long long row = r0 + l31;
+        const bool valid = row < N;
+        const long long rc = valid ? row : N - 1;
+        size_t zbase, img0 = 0;        // ROWMAJOR: this lane's half row; NCHW: channel 0 of the row
+        unsigned voff = 0;
+        if (ROWMAJOR) {
+            zbase = (size_t)rc * D + HALF * h;
+        } else {
+            const long long b0 = (r0 < N ? r0 : N - 1) / HW;
+            const long long b = rc / HW;
+            const int hw = (int)(rc - b * HW);
+            zbase = (size_t)b * D * HW + hw;
+            img0 = (size_t)b0 * D * HW;
+            voff = (unsigned)((((b - b0) * D + HALF * h) * HW + hw) * 4);
+        }
+        // ---- load, approximate ||z||^2, bf16 B operands (the fp32 copy is NOT kept in registers) ------
+        bf16x8 zb[NQ];
+        float zs;
+        {
+            float zf[HALF];
+            load_half(zbase, img0, voff, zf);
+            zs = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HALF; ++c) zs = __builtin_fmaf(zf[c], zf[c], zs);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint4 pk;
+                pk.x = cvt_pk_bf16(zf[8 * q], zf[8 * q + 1]);
+                pk.y = cvt_pk_bf16(zf[8 * q + 2], zf[8 * q + 3]);
+                pk.z = cvt_pk_bf16(zf[8 * q + 4], zf[8 * q + 5]);
+                pk.w = cvt_pk_bf16(zf[8 * q + 6], zf[8 * q + 7]);
+                zb[q] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+        zs += __shfl_xor(zs, 32);
+        bool bad = valid && (cb_bad || !(zs < 1.0e38f));
+        const float zn = __builtin_sqrtf(zs) * 1.0001f;
+        const float delta0 = 2.0f * ((0.00396f + 8.0e-6f) * zn * Emax + 2.0e-6f * EEmax + 1.2e-7f * (zs * 1.0001f + EEmax));
+
+        // ---- sweep 1: row maximum of the screen (two independent tiles in flight) ---------------------
+        float best = -__builtin_inff();
+        {
+            int ct = 0;
+            for (; ct + 1 < ntile; ct += 2) {
+                f32x16 accA, accB;
+                screen_tile(ct, zb, accA);
+                screen_tile(ct + 1, zb, accB);
+                best = fmaxf(best, fmaxf(tile_max(accA), tile_max(accB)));
+            }
+            if (ct < ntile) {
+                f32x16 accA;
+                screen_tile(ct, zb, accA);
+                best = fmaxf(best, tile_max(accA));
+            }
+        }
+        best = fmaxf(best, __shfl_xor(best, 32));
+        const float thr = best - (delta0 + 4.0e-7f * __builtin_fabsf(best));
+
+        // ---- sweep 2: collect every code the bound cannot exclude.  Group maxima (4 codes each) are
+        //      balloted first; only groups with a hit somewhere in the wave are looked at per element.
+        //      Each lane half appends to its own private list (no LDS atomics). ------------------------
+        int cnt = 0;
+        auto collect = [&](int ct, const f32x16 &acc) {
+            float gm[4];
+            unsigned long long gb[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                gm[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
+                gb[g] = __builtin_amdgcn_ballot_w64(gm[g] >= thr);
+            }
+            if (gb[0] | gb[1] | gb[2] | gb[3]) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    if (gb[g]) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            if (acc[4 * g + i] >= thr) {
+                                if (cnt < CAPH) own_list[cnt] = (unsigned short)(ct * 32 + 8 * g + 4 * h + i);
+                                ++cnt;
+                            }
+                        }
+                    }
+                }
+            }
+        };
+        {
+            int ct = 0;
+            for (; ct + 1 < ntile; ct += 2) {
+                f32x16 accA, accB;
+                screen_tile(ct, zb, accA);
+                screen_tile(ct + 1, zb, accB);
+                collect(ct, accA);
+                collect(ct + 1, accB);
+            }
+            if (ct < ntile) {
+                f32x16 accA;
+                screen_tile(ct, zb, accA);
+                collect(ct, accA);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int cnt_o = __shfl_xor(cnt, 32);
+        const int n0 = h ? cnt_o : cnt, n1 = h ? cnt : cnt_o;         // counts of half 0 / half 1
+        const int ncand = n0 + n1;
+        auto cand_at = [&](int j) -> int { return j < n0 ? row_list[j] : row_list[CAPH + (j - n0)]; };
+        if (valid && (ncand < 1 || n0 > CAPH || n1 > CAPH)) bad = true;   // NaN screens / overflow: scalar path
+        int k = (ncand > 0 && !bad) ? cand_at(0) : 0;
+        const bool refine = valid && !bad && ncand > 1;
+
+        float zz = 0.0f;
+        if (__builtin_amdgcn_ballot_w64(refine || bad)) {
+            // ---- ||z||^2 in ATen's order (8-lane vectors x 4-way ILP).  Lane halves hold channels
+            //      [0,32) and [32,64): swap so each lane owns matching (c, c+32) pairs, then chain. ----
+            float zf[HALF];
+            load_half(zbase, img0, voff, zf);
+            float P[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float slo = zf[i] * zf[i], shi = zf[16 + i] * zf[16 + i];
+                const float recv = __shfl_xor(h ? slo : shi, 32);
+                const float lo = h ? recv : slo;           // channel 16h + i       (first  32)
+                const float hi = h ? shi : recv;           // channel 32 + 16h + i  (second 32)
+                P[i] = lo + hi;                            // P_q[t], q = 2h + i/8, t = i%8
+            }
+            float fin = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const float s01 = P[t] + P[8 + t];                 // lane h=0: P0+P1
+                const float from0 = __shfl_xor(s01, 32);           // lane h=1 receives P0+P1
+                const float A = (from0 + P[t]) + P[8 + t];         // valid on h=1: ((P0+P1)+P2)+P3
+                fin = fin + A;
+            }
+            const float other = __shfl_xor(fin, 32);
+            zz = h ? fin : other;
+            if (h == 0) zz_s[l31] = zz;
+        }
+
+        if (__builtin_amdgcn_ballot_w64(refine)) {
+            // ---- exact reference distances, compacted: every (row, candidate) pair of the tile is a
+            //      job; jobs are dealt 32 at a time to the 32 lane pairs, so rows with many candidates
+            //      do not serialise the wave.  job = (row << 16) | code ---------------------------------
+            const int nj = (h == 0 && refine) ? ncand : 0;
+            int incl = nj;                                          // inclusive scan over lanes 0..31
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const int up = __shfl_up(incl, o);
+                if (l31 >= o) incl += up;
+            }
+            const int total = __shfl(incl, 31);
+            int off = incl - nj;
+            off = __shfl(off, l31);                                 // both halves know the row's offset
+            float bd = __builtin_inff();
+            int bk = 0x7fffffff;
+            for (int base = 0; base < total; base += 32) {
+                if (h == 0 && refine) {
+                    for (int j = 0; j < ncand; ++j) {
+                        const int slot = off + j - base;
+                        if (slot >= 0 && slot < 32) job_s[slot] = (l31 << 16) | cand_at(j);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool act = base + l31 < total;
+                const int job = act ? job_s[l31] : 0;
+                const int jr = job >> 16, jk = job & 0xffff;
+                // the job's row half and code half
+                float zj[HALF];
+                {
+                    const long long rj = r0 + jr;
+                    if (ROWMAJOR) {
+                        load_half((size_t)rj * D + HALF * h, 0, 0, zj);
+                    } else {
+                        const long long b0 = (r0 < N ? r0 : N - 1) / HW;
+                        const long long bj = rj / HW;
+                        const int hwj = (int)(rj - bj * HW);
+                        load_half(0, img0, (unsigned)((((bj - b0) * D + HALF * h) * HW + hwj) * 4), zj);
+                    }
+                }
+                const float *e = cb + (size_t)jk * D + HALF * h;
+                float ef[HALF];
+#pragma unroll
+                for (int q = 0; q < HALF / 4; ++q) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(e + 4 * q);
+                    ef[4 * q] = v.x; ef[4 * q + 1] = v.y; ef[4 * q + 2] = v.z; ef[4 * q + 3] = v.w;
+                }
+                float p = 0.0f;                                       // channels 0..31, valid on h=0
+#pragma unroll
+                for (int c = 0; c < HALF; ++c) p = __builtin_fmaf(zj[c], ef[c], p);
+                float m = __shfl_xor(p, 32);                          // h=1 continues lane h=0's chain
+#pragma unroll
+                for (int c = 0; c < HALF; ++c) m = __builtin_fmaf(zj[c], ef[c], m);
+                if (h == 1 && act) {                                  // full 64-term chain lives on h=1
+                    const float t = zz_s[jr] + ee_g[jk];
+                    const float u2 = 2.0f * m;
+                    res_s[l31] = t - u2;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (refine) {
+                    for (int j = 0; j < ncand; ++j) {
+                        const int slot = off + j - base;
+                        if (slot >= 0 && slot < 32) {
+                            const float d = res_s[slot];
+                            const int kc = cand_at(j);
+                            const bool better = d < bd || (d == bd && kc < bk);
+                            bd = better ? d : bd;
+                            bk = better ? kc : bk;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (refine) k = bk;
+        }
+        if (__builtin_amdgcn_ballot_w64(bad)) {
+            int ks = 0;
+            if (bad && h == 0)
+                ks = vq_slow_argmin<D, ROWMAJOR>(z, ROWMAJOR ? (size_t)rc * D : zbase, ROWMAJOR ? 1 : (size_t)HW,
+                                                 cb, ee_g, K, zz);
+            ks = __shfl(ks, l31);
+            if (bad) k = ks;
+        }
+
+        // ---- epilogue: re-read the half row, gather e_k, z + (e_k - z), squared error, index, histogram -
+        {
+            float zf[HALF];
+            load_half(zbase, img0, voff, zf);
+            const float *e = cb + (size_t)k * D + HALF * h;
+            float sq = 0.0f;
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(e + 4 * q);
+                const float ev[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float diff = ev[i] - zf[4 * q + i];
+                    sq = sq + diff * diff;
+                    zf[4 * q + i] = zf[4 * q + i] + diff;
+                }
+            }
+            if (valid) {
+                dacc += (double)sq;
+                if (zq) {
+                    if (ROWMAJOR) {
+#pragma unroll
+                        for (int q = 0; q < HALF / 4; ++q) {
+                            f32x4 v;
+                            v.x = zf[4 * q]; v.y = zf[4 * q + 1]; v.z = zf[4 * q + 2]; v.w = zf[4 * q + 3];
+                            *reinterpret_cast<f32x4 *>(zq + zbase + 4 * q) = v;
+                        }
+                    } else {
+                        const auto rs = make_rsrc(zq + img0);
+#pragma unroll
+                        for (int c = 0; c < HALF; ++c)
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zf[c]), rs, voff,
+                                                                  (unsigned)c * HW * 4u, 0);
+                    }
+                }
+                if (h == 0) {
+                    idx[row] = k;
+                    atomicAdd(&hist_s[k], 1);
+                }
+            }
+        }
+    }
+
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+    __syncthreads();
+    if (lane == 0) red[wave] = dacc;
+    __syncthreads();
+    if (tid == 0) {
+        double s = 0.0;
+        for (int w = 0; w < 8; ++w) s += red[w];
+        partials[blockIdx.x] = s;
+    }
+    for (int k = tid; k < K; k += 512) {
+        const int c = hist_s[k];
+        if (c) atomicAdd(&hist[k], c);
+    }
+}
+
+int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
+                         float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out) {
+    const VqPlan p = vq_plan(K, 64);
+    const long long nblocks = (N + 255) / 256;
+    const int cus = num_cus();
+    const int per_cu = p.filter_lds_bytes * 2 <= (size_t)kLdsBytes ? 2 : 1;
+    long long grid = nblocks < (long long)cus * per_cu ? nblocks : (long long)cus * per_cu;
+    if (grid > kVqMaxGrid) grid = kVqMaxGrid;
+    *grid_out = (int)grid;
+    const int *wflags = reinterpret_cast<const int *>(ws + p.off_flags);
+    const float *ee = reinterpret_cast<const float *>(ws + p.off_ee);
+    const uint4 *img16 = reinterpret_cast<const uint4 *>(ws + p.off_img16);
+    const float *neh = reinterpret_cast<const float *>(ws + p.off_neh);
+    double *partials = reinterpret_cast<double *>(ws + p.off_partials);
+#define VQF_LAUNCH(RM_)                                                                              \
+    do {                                                                                             \
+        auto kfn = vq_filter_kernel_d64<RM_>;                                                        \
+        static bool attr_set = false;                                                                \
+        if (!attr_set) {                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);        \
+            attr_set = true;                                                                         \
+        }                                                                                            \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), p.filter_lds_bytes, st, z, cb, img16, neh, ee, \
+                           wflags, N, HW, K, p.K32, nblocks, zq, idx, hist, partials);               \
+    } while (0)
+    if (rowmajor) VQF_LAUNCH(true); else VQF_LAUNCH(false);
+#undef VQF_LAUNCH
+    return (int)hipGetLastError();
+}
+
+}  // namespace vqvae
