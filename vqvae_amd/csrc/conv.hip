@@ -46,6 +46,18 @@ struct ConvGeom {
 
 constexpr int kFlagReluIn = 1, kFlagReluOut = 2;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOobOffset = 0x80000000u;      // >= num_records of every descriptor (and no wrap when the
+                                                  // chunk / float4 offsets are added): the load returns 0
+
+// Buffer descriptor over the activation tensor starting at `p` (wave-uniform), `bytes` long: loads
+// past the end -- and lanes whose offset is forced to kOobOffset (padding taps) -- read as zero, so
+// the im2col border handling costs one select per tap instead of per-load predication.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float *p, unsigned long long bytes) {
+    const unsigned n = bytes > 0x7FFFFFF0ull ? 0x7FFFFFF0u : (unsigned)bytes;
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n, 0x00020000);
+}
+
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
     return v;
@@ -96,25 +108,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
     const bool relu_in = g.flags & kFlagReluIn;
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
 
-    bool valid[MT];
-    int gy[MT], gx[MT];
-    long long bimg[MT];
+    // Per-lane pixel bookkeeping, done once: byte offset of the (tap 0,0) input pixel relative to
+    // the first image this workgroup touches, and one validity bit per tap (image-border padding).
+    const long long img_px = (long long)g.Hg * g.Wg;
+    const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
+    const unsigned long long in_img_bytes = (unsigned long long)g.Hin * g.Win * g.Cin * 4ull;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * g.Hin * g.Win * g.Cin,
+                                (unsigned long long)(g.B - b_first) * in_img_bytes);
+    unsigned pbase[MT], tapmask[MT];
     long long myoff[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const long long p = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT) + mt * 32 + l31;
-        valid[mt] = p < M;
-        const long long pc = valid[mt] ? p : 0;
-        const long long b = pc / ((long long)g.Hg * g.Wg);
-        const int rem = (int)(pc - b * g.Hg * g.Wg);
-        gy[mt] = rem / g.Wg;
-        gx[mt] = rem - gy[mt] * g.Wg;
-        bimg[mt] = b * g.Hin;
-        myoff[mt] = valid[mt] ? ((b * g.Hout + gy[mt] * g.ostride + g.opy[phase]) * g.Wout +
-                                 gx[mt] * g.ostride + g.opx[phase]) * (long long)g.Cout
-                              : -1;
-        gy[mt] *= g.istride;
-        gx[mt] *= g.istride;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / g.Wg, gx = rem - gy * g.Wg;
+        const int iy0 = gy * g.istride, ix0 = gx * g.istride;
+        pbase[mt] = (unsigned)((((b - b_first) * g.Hin + iy0) * g.Win + ix0) * g.Cin * 4 + 64 * h);
+        unsigned m = 0;
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int iy = iy0 + (int)((dym >> (4 * t)) & 15) - 8, ix = ix0 + (int)((dxm >> (4 * t)) & 15) - 8;
+            if (valid && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) m |= 1u << t;
+        }
+        tapmask[mt] = m;
+        myoff[mt] = valid ? ((b * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout +
+                             gx * g.ostride + g.opx[phase]) * (long long)g.Cout
+                          : -1;
     }
     const float *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 1024;
     const size_t wchunk = (size_t)g.ntile * 1024;
@@ -128,22 +149,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
+    const bool ragged_c = (g.Cin & 31) != 0;
     auto load_a = [&](int c, f32x4(&dst)[MT][4]) {
         const int tap = c / g.cpt, cc = c - tap * g.cpt;
         const int dy = (int)((dym >> (4 * tap)) & 15) - 8, dx = (int)((dxm >> (4 * tap)) & 15) - 8;
-        const int ch0 = cc * 32 + 16 * h;
+        const int tapbytes = (dy * g.Win + dx) * g.Cin * 4;          // scalar
+        const unsigned soff = (unsigned)cc * 128u;                    // scalar: 32-channel chunk
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int iy = gy[mt] + dy, ix = gx[mt] + dx;
-            const bool ok = valid[mt] && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
-            const float *src = in + ((bimg[mt] + iy) * g.Win + ix) * (long long)g.Cin + ch0;
+            const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+        }
+    };
+    // rare fix-ups, applied once per chunk right before its MFMAs (never between the loads):
+    // input ReLU (standalone residual modules) and channel counts that are not a multiple of 32
+    const bool needs_fix = relu_in || ragged_c;
+    auto fix_a = [&](int c, f32x4(&dst)[MT][4]) {
+        const int cc = c % g.cpt;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ok && ch0 + 4 * j < g.Cin) v = *reinterpret_cast<const f32x4 *>(src + 4 * j);
+                f32x4 v = dst[mt][j];
+                if (cc * 32 + 16 * h + 4 * j >= g.Cin) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 dst[mt][j] = relu_in ? relu4(v) : v;
             }
-        }
     };
     auto load_b = [&](int c0) {
 #pragma unroll
@@ -177,6 +209,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             if (c0 + k < nchunk) {
+                if (needs_fix) fix_a(c0 + k, a[k]);
                 const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[it & 1][k]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -258,20 +291,27 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
         for (int q = 0; q < NT2; ++q) dst[tid + 256 * q] = src[tid + 256 * q];
     }
 
-    bool valid[MT];
-    int gy[MT], gx[MT];
-    long long bimg[MT];
     const long long wbase = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT);
+    const long long img_px = (long long)H * W;
+    const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
+    unsigned pbase[MT], tapmask[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const long long p = wbase + mt * 32 + l31;
-        valid[mt] = p < M;
-        const long long pc = valid[mt] ? p : 0;
-        const long long b = pc / ((long long)H * W);
-        const int rem = (int)(pc - b * H * W);
-        gy[mt] = rem / W;
-        gx[mt] = rem - gy[mt] * W;
-        bimg[mt] = b * H;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / W, gx = rem - gy * W;
+        pbase[mt] = (unsigned)((((b - b_first) * H + gy) * W + gx) * C * 4 + 64 * h);
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = gy + t / 3 - 1, ix = gx + t % 3 - 1;
+            if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) m |= 1u << t;
+        }
+        tapmask[mt] = m;
     }
 
     constexpr int KC = 2;
@@ -282,22 +322,31 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
 
+    const bool ragged_c = (C & 31) != 0;
     auto load_a = [&](int c, f32x4(&dst)[MT][4]) {
         const int tap = c / cpt, cc = c - tap * cpt;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const int ch0 = cc * 32 + 16 * h;
+        const int tapbytes = (dy * W + dx) * C * 4;                   // scalar
+        const unsigned soff = (unsigned)cc * 128u;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const int iy = gy[mt] + dy, ix = gx[mt] + dx;
-            const bool ok = valid[mt] && iy >= 0 && iy < H && ix >= 0 && ix < W;
-            const float *src = in + ((bimg[mt] + iy) * W + ix) * (long long)C + ch0;
+            const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+        }
+    };
+    const bool needs_fix = relu_in || ragged_c;
+    auto fix_a = [&](int c, f32x4(&dst)[MT][4]) {
+        const int cc = c % cpt;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ok && ch0 + 4 * j < C) v = *reinterpret_cast<const f32x4 *>(src + 4 * j);
+                f32x4 v = dst[mt][j];
+                if (cc * 32 + 16 * h + 4 * j >= C) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
                 dst[mt][j] = relu_in ? relu4(v) : v;
             }
-        }
     };
     auto load_b = [&](int c0) {
 #pragma unroll
@@ -320,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             if (c0 + k < nchunk) {
+                if (needs_fix) fix_a(c0 + k, a[k]);
                 const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[it & 1][k]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
