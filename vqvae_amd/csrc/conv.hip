@@ -272,10 +272,9 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
                                                         float *__restrict__ out, int B, int H, int W,
                                                         int C, int flags) {
     constexpr int MT = 2;
-    // one LDS block: W2 image | union { double-buffered W1 chunk pairs (GEMM1), hidden tiles (after it) }
+    // LDS: W2 image (shared, read-only after the first barrier) | per-wave hidden tiles
     __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1024 + 4 * MT * 32 * 33];
     float *W2s = smem_res;
-    float(*Bs)[2][1024] = reinterpret_cast<float(*)[2][1024]>(smem_res + NT2 * 1024);
     float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1024);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -314,8 +313,12 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
         tapmask[mt] = m;
     }
 
+    // GEMM1 (3x3, C -> 32 hidden): barrier-free.  With a single 32-wide n-tile the weight chunk a
+    // wave needs per step is only 4 KiB, so every wave reads its B operands straight from L1/L2
+    // (coalesced float4, same image layout) next to its A operands: no LDS staging, no workgroup
+    // barrier in the reduction loop, and the waves of a SIMD drift apart instead of stalling together.
     constexpr int KC = 2;
-    f32x4 a[KC][MT][4], b_nxt[KC];
+    f32x4 a[KC][MT][4], bq[KC][4];
     f32x16 acc1[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -323,11 +326,14 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
         for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
 
     const bool ragged_c = (C & 31) != 0;
-    auto load_a = [&](int c, f32x4(&dst)[MT][4]) {
+    const f32x4 *w1v = reinterpret_cast<const f32x4 *>(w1img) + h * 32 + l31;     // + (chunk*4 + j)*64
+    auto load_ab = [&](int c, f32x4(&dst)[MT][4], f32x4(&bd)[4]) {
         const int tap = c / cpt, cc = c - tap * cpt;
         const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
         const int tapbytes = (dy * W + dx) * C * 4;                   // scalar
         const unsigned soff = (unsigned)cc * 128u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bd[j] = w1v[(size_t)(c * 4 + j) * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
@@ -348,47 +354,27 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
                 dst[mt][j] = relu_in ? relu4(v) : v;
             }
     };
-    auto load_b = [&](int c0) {
-#pragma unroll
-        for (int k = 0; k < KC; ++k)
-            if (c0 + k < nchunk) b_nxt[k] = reinterpret_cast<const f32x4 *>(w1img + (size_t)(c0 + k) * 1024)[tid];
-    };
 
 #pragma unroll
     for (int k = 0; k < KC; ++k)
-        if (k < nchunk) load_a(k, a[k]);
-    load_b(0);
-#pragma unroll
-    for (int k = 0; k < KC; ++k) reinterpret_cast<f32x4 *>(Bs[0][k])[tid] = b_nxt[k];
-    __syncthreads();
-    const int niter = (nchunk + KC - 1) / KC;
-    for (int it = 0; it < niter; ++it) {
-        const int c0 = it * KC;
-        const bool more = it + 1 < niter;
-        if (more) load_b(c0 + KC);
+        if (k < nchunk) load_ab(k, a[k], bq[k]);
+    for (int c0 = 0; c0 < nchunk; c0 += KC) {
 #pragma unroll
         for (int k = 0; k < KC; ++k) {
             if (c0 + k < nchunk) {
                 if (needs_fix) fix_a(c0 + k, a[k]);
-                const f32x4 *bs = reinterpret_cast<const f32x4 *>(Bs[it & 1][k]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 b4 = bs[(j * 2 + h) * 32 + l31];
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mt][j][i], b4[i], acc1[mt], 0, 0, 0);
-                }
-                if (c0 + k + KC < nchunk) load_a(c0 + k + KC, a[k]);
+                            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mt][j][i], bq[k][j][i], acc1[mt], 0, 0, 0);
+                if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
             }
         }
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < KC; ++k) reinterpret_cast<f32x4 *>(Bs[(it + 1) & 1][k])[tid] = b_nxt[k];
-        }
-        __syncthreads();
     }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
 
     // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33: conflict-free)
 #pragma unroll
@@ -398,7 +384,8 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
             Hs[wave][mt][prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
         }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // wave-private tile: LDS ops of a wave stay in order
+    __builtin_amdgcn_wave_barrier();
     float a2[MT][16];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
