@@ -184,7 +184,11 @@ def main():
             "metric": METRIC, "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            # fp32 in/out and fp32 accumulation everywhere; conv products are formed from exact
+            # three-term bf16 splits of the fp32 operands (error <= 3*2^-24 per product, fp32-grade;
+            # VQVAE_CONV_EXACT_FP32 selects the plain fp32-MFMA kernels); quantizer indices bit-exact
+            "dtype": "f32", "data": "synthetic",
             "config": {"workload": {"c3": "BASELINE config 3: full HIP path (Encoder+VQ+Decoder), "
                                           "32x32x3, K=512, D=64",
                                     "c2": "BASELINE config 2: HIP VectorQuantizer kernel, torch (MIOpen) "

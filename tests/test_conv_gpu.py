@@ -49,9 +49,12 @@ CONV_CASES = [
 KIND = {"conv4x4s2": 0, "conv3x3": 1, "conv1x1": 2, "convT3x3": 3, "convT4x4s2": 4}
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["splitbf16", "fp32mfma"])
 @pytest.mark.parametrize("relu_in,relu_out", [(False, False), (True, True)])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}-{c[3]}to{c[4]}-{c[5]}x{c[6]}")
-def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out):
+def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out, exact):
+    """Both product paths: the default split-bf16 one (three exact bf16 terms per operand, six term
+    products on the bf16 matrix cores, fp32 accumulate) and the exact-fp32 MFMA one (flag 0x4)."""
     from vqvae_amd import conv_hip
     name, ctor, B, Cin, Cout, H, W = case
     torch.manual_seed(hash(name) % 1000 + Cin + Cout)
@@ -63,7 +66,7 @@ def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out):
             ref = torch.relu(ref)
     md = ctor(Cin, Cout).to(dev())
     md.load_state_dict(m.state_dict())
-    flags = (1 if relu_in else 0) | (2 if relu_out else 0)
+    flags = (1 if relu_in else 0) | (2 if relu_out else 0) | (4 if exact else 0)
     y = conv_hip.conv(KIND[name], rows(x.to(dev())), md, md.weight, md.bias, Cin, Cout, flags)
     torch.cuda.synchronize()
     close(nchw(y).cpu().numpy(), ref.numpy())
@@ -122,6 +125,12 @@ def test_residual_stack_quirks_vs_torch_cpu(C, Rh, n, B, H, W):
     with torch.no_grad():
         y = rsd(xd)
     close(y.cpu().numpy(), ref)
+    # the exact-fp32 MFMA variant of the fused layer kernel
+    from vqvae_amd import conv_hip
+    t = conv_hip.nchw_to_rows(x.to(dev()))
+    for i in range(n):
+        t = conv_hip.res_layer(t, rsd.stack[0], (1 if i == 0 else 0) | 2 | 4)
+    close(conv_hip.rows_to_nchw(t).cpu().numpy(), ref)
     assert torch.equal(xd.cpu(), torch.relu(x)), "caller's tensor must become relu(x) like upstream"
     # single layer: relu(x) + f(relu(x)), no final relu
     with torch.no_grad():

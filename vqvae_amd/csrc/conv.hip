@@ -260,6 +260,438 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
         }
 }
 
+
+// ===========================================================================
+// Split-bf16 ("bf16x3") implicit GEMM: fp32-grade products on the bf16 matrix cores.
+//
+// gfx950's exact-fp32 MFMA runs at the vector rate (157 TF) and blocks the VALU while it does;
+// its bf16 MFMA is 16x faster per reduction element.  Every fp32 operand is split exactly into
+// three bf16 terms, x = x1 + x2 + x3 (8 significand bits each, round-to-nearest, remainders are
+// exact in fp32), and a product keeps the six term pairs whose weight is >= 2^-16 relative:
+//     x*w ~ x1w1 + (x1w2 + x2w1) + (x1w3 + x2w2 + x3w1)          (dropped pairs are <= 2^-24 |xw|)
+// accumulated in fp32 inside v_mfma_f32_32x32x16_bf16.  The per-product error (<= 3*2^-24 relative)
+// is the size of fp32's own product rounding, so results stay inside the conv parity tolerance
+// (tests/test_conv_gpu.py, tests/test_model_gpu.py: z_e atol 2e-6, no index flips on the goldens)
+// while the reduction costs 6 x 2 = 12 matrix-pipe cycles per element pair instead of 32.
+// Weights are split once at pack time; activations are split in registers (11 VALU ops per pair,
+// which overlap with the matrix pipe -- bf16 MFMA does not occupy the VALU).
+// Weight image per (phase, chunk, n_tile): [term 3][step 2][half 2][n 32] x 16 B, element i of a
+// 16-B group = channel 32*chunk + 16*half + 8*step + i.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ unsigned cvt_pk_bf16_rne(float lo, float hi) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+
+// split two fp32 values into three packed-bf16 term pairs
+__device__ __forceinline__ void split2(float a, float b, unsigned &p1, unsigned &p2, unsigned &p3) {
+    p1 = cvt_pk_bf16_rne(a, b);
+    const float ra = a - __uint_as_float(p1 << 16), rb = b - __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16_rne(ra, rb);
+    const float sa = ra - __uint_as_float(p2 << 16), sb = rb - __uint_as_float(p2 & 0xffff0000u);
+    p3 = cvt_pk_bf16_rne(sa, sb);
+}
+// split 8 consecutive fp32 channels (two float4) into three bf16x8 terms
+__device__ __forceinline__ void split8(const f32x4 &u, const f32x4 &v, u32x4 &t1, u32x4 &t2, u32x4 &t3) {
+    unsigned a1, a2, a3, b1, b2, b3, c1, c2, c3, d1, d2, d3;
+    split2(u.x, u.y, a1, a2, a3);
+    split2(u.z, u.w, b1, b2, b3);
+    split2(v.x, v.y, c1, c2, c3);
+    split2(v.z, v.w, d1, d2, d3);
+    t1 = u32x4{a1, b1, c1, d1};
+    t2 = u32x4{a2, b2, c2, d2};
+    t3 = u32x4{a3, b3, c3, d3};
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    const unsigned u = __float_as_uint(f);
+    if (f != f) return 0x7FC0;
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+
+__global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restrict__ w,
+                                                            unsigned short *__restrict__ img, ConvGeom g,
+                                                            long long total) {
+    // one thread per (phase, chunk, ntile, step, half, n, i) element; writes the three term images
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int i = e & 7, n = (e >> 3) & 31, hh = (e >> 8) & 1, t = (e >> 9) & 1;
+        long long r = e >> 10;
+        const int nt = (int)(r % g.ntile); r /= g.ntile;
+        const int nchunk = g.ntaps * g.cpt;
+        const int chunk = (int)(r % nchunk);
+        const int phase = (int)(r / nchunk);
+        const int tap = chunk / g.cpt, cc = chunk - tap * g.cpt;
+        const int ci = cc * 32 + 16 * hh + 8 * t + i, co = nt * 32 + n;
+        float v = 0.0f;
+        if (ci < g.Cin && co < g.Cout) {
+            const int kyx = g.kyx[phase][tap];
+            v = g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx]
+                             : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
+        }
+        const unsigned short b1 = f32_to_bf16_rne(v);
+        const float r1 = v - __uint_as_float((unsigned)b1 << 16);
+        const unsigned short b2 = f32_to_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
+        const unsigned short b3 = f32_to_bf16_rne(r2);
+        // image: [(phase*nchunk + chunk)*ntile + nt][term][t][hh][n][i]
+        const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 3072;
+        const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
+        img[base + pos] = b1;
+        img[base + 1024 + pos] = b2;
+        img[base + 2048 + pos] = b3;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const float *__restrict__ in,
+                                                             const u32x4 *__restrict__ wimg,
+                                                             const float *__restrict__ bias,
+                                                             float *__restrict__ out, ConvGeom g) {
+    constexpr int CH4 = NT * 384;                      // uint4 per chunk of this n-block (6 KiB per n-tile)
+    __shared__ u32x4 Bs[2][CH4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int phase = blockIdx.y % g.nphase, nb = blockIdx.y / g.nphase;
+    const long long M = (long long)g.B * g.Hg * g.Wg;
+    const int nchunk = g.ntaps * g.cpt;
+    const bool relu_in = g.flags & kFlagReluIn;
+    const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
+
+    const long long img_px = (long long)g.Hg * g.Wg;
+    const long long b_first = ((long long)blockIdx.x * 128) / img_px;
+    const unsigned long long in_img_bytes = (unsigned long long)g.Hin * g.Win * g.Cin * 4ull;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * g.Hin * g.Win * g.Cin,
+                                (unsigned long long)(g.B - b_first) * in_img_bytes);
+    unsigned pbase, tapmask;
+    long long myoff;
+    {
+        const long long p = (long long)blockIdx.x * 128 + wave * 32 + l31;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / g.Wg, gx = rem - gy * g.Wg;
+        const int iy0 = gy * g.istride, ix0 = gx * g.istride;
+        pbase = (unsigned)((((b - b_first) * g.Hin + iy0) * g.Win + ix0) * g.Cin * 4 + 64 * h);
+        unsigned m = 0;
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int iy = iy0 + (int)((dym >> (4 * t)) & 15) - 8, ix = ix0 + (int)((dxm >> (4 * t)) & 15) - 8;
+            if (valid && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) m |= 1u << t;
+        }
+        tapmask = m;
+        myoff = valid ? ((b * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride + g.opx[phase]) *
+                            (long long)g.Cout
+                      : -1;
+    }
+    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 384;
+    const size_t wchunk = (size_t)g.ntile * 384;
+
+    // Software pipeline over 32-channel chunks (static register names, loop unrolled by two):
+    //   raw A ring of depth 2: the registers of chunk c+1 are split while chunk c's MFMAs run, then
+    //   immediately re-loaded with chunk c+3; weights for chunk c+1 go global -> registers at the top of
+    //   iteration c and registers -> the other LDS buffer at its end (one barrier per chunk).
+    f32x4 ra0[4], ra1[4];
+    u32x4 b_nxt[CH4 / 256 > 0 ? CH4 / 256 : 1];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[nt][r] = 0.0f;
+
+    auto load_a = [&](int c, f32x4(&dst)[4]) {
+        const int tap = c / g.cpt, cc = c - tap * g.cpt;
+        const int dy = (int)((dym >> (4 * tap)) & 15) - 8, dx = (int)((dxm >> (4 * tap)) & 15) - 8;
+        const int tapbytes = (dy * g.Win + dx) * g.Cin * 4;
+        const unsigned soff = (unsigned)cc * 128u;
+        const unsigned vo = ((tapmask >> tap) & 1u) ? pbase + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+    };
+    constexpr int NBQ = CH4 / 256, BREM = CH4 % 256;    // 384 uint4 per n-tile: NT = 1 leaves a 128-thread tail
+    u32x4 b_tail = {0, 0, 0, 0};
+    auto load_b = [&](int c) {
+        const u32x4 *src = wbase + (size_t)c * wchunk;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) b_nxt[q] = src[tid + 256 * q];
+        if (BREM && tid < BREM) b_tail = src[tid + 256 * NBQ];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + 256 * q] = b_nxt[q];
+        if (BREM && tid < BREM) Bs[buf][tid + 256 * NBQ] = b_tail;
+    };
+    // split this lane's 16 channels of a chunk: MFMA step t covers channels 16h + 8t .. +7
+    auto split_a = [&](f32x4(&raw)[4], u32x4(&S1)[2], u32x4(&S2)[2], u32x4(&S3)[2]) {
+        if (relu_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
+        }
+        split8(raw[0], raw[1], S1[0], S2[0], S3[0]);
+        split8(raw[2], raw[3], S1[1], S2[1], S3[1]);
+    };
+    // one chunk: MFMAs of chunk c from (S1,S2,S3); meanwhile split chunk c+1 (raw `rn`) into (T1,T2,T3)
+    // and re-issue `rn`'s loads for chunk c+3
+    auto chunk_step = [&](int c, const u32x4(&S1)[2], const u32x4(&S2)[2], const u32x4(&S3)[2], f32x4(&rn)[4],
+                          u32x4(&T1)[2], u32x4(&T2)[2], u32x4(&T3)[2]) {
+        const bool more = c + 1 < nchunk;
+        if (more) load_b(c + 1);
+        const u32x4 *bs = Bs[c & 1];
+        constexpr int NP = NT >= 2 ? 2 : 1;               // n-tiles interleaved per product chain
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const bf16x8 a1 = __builtin_bit_cast(bf16x8, S1[t]), a2 = __builtin_bit_cast(bf16x8, S2[t]),
+                         a3 = __builtin_bit_cast(bf16x8, S3[t]);
+#pragma unroll
+            for (int n0 = 0; n0 < NT; n0 += NP) {
+                bf16x8 B1[NP], B2[NP], B3[NP];
+#pragma unroll
+                for (int u = 0; u < NP; ++u) {
+                    const u32x4 *bp = bs + (n0 + u) * 384 + (t * 2 + h) * 32 + l31;
+                    B1[u] = __builtin_bit_cast(bf16x8, bp[0]);
+                    B2[u] = __builtin_bit_cast(bf16x8, bp[128]);
+                    B3[u] = __builtin_bit_cast(bf16x8, bp[256]);
+                }
+                // smallest terms first; consecutive MFMAs alternate accumulators (8-pass MFMAs have a
+                // dependent latency above their issue interval)
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3, B1[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, B2[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B3[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, B1[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B2[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, B1[u], acc[n0 + u], 0, 0, 0);
+            }
+            if (t == 0 && more) split_a(rn, T1, T2, T3);          // VALU work in the shadow of the MFMAs
+        }
+        if (more) {
+            if (c + 3 < nchunk) load_a(c + 3, rn);
+            store_b((c + 1) & 1);
+        }
+        __syncthreads();
+    };
+
+    u32x4 P1[2], P2[2], P3[2], Q1[2], Q2[2], Q3[2];
+    load_a(0, ra0);
+    if (nchunk > 1) load_a(1, ra1);
+    load_b(0);
+    store_b(0);
+    split_a(ra0, P1, P2, P3);
+    if (nchunk > 2) load_a(2, ra0);
+    __syncthreads();
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk_step(c, P1, P2, P3, ra1, Q1, Q2, Q3);                       // splits chunk c+1 from ra1
+        if (c + 1 < nchunk) chunk_step(c + 1, Q1, Q2, Q3, ra0, P1, P2, P3);   // splits chunk c+2 from ra0
+    }
+
+    const bool relu_out = g.flags & kFlagReluOut;
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nb * NT + nt) * 32 + l31;
+        bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
+        const long long off = __shfl(myoff, src);
+        if (off >= 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (nb * NT + nt) * 32 + l31;
+                if (n < g.Cout) {
+                    float v = acc[nt][r] + bv[nt];
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    out[off + n] = v;
+                }
+            }
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------
+// Fused residual layer on the split-bf16 product path (same math and layout as res_layer_kernel below;
+// see conv_igemm_bf3_kernel for the split).  GEMM1 (3x3, C -> 32 hidden) is barrier-free: each wave
+// reads its 6-KiB weight chunk (three bf16 terms) straight from L1/L2 next to its A operands.
+// GEMM2 (1x1, 32 -> C) takes the three-term W2 image from LDS.
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__restrict__ in,
+                                                            const u32x4 *__restrict__ w1img,
+                                                            const u32x4 *__restrict__ w2img,
+                                                            float *__restrict__ out, int B, int H, int W,
+                                                            int C, int flags) {
+    constexpr int MT = 2;
+    __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1536 + 4 * MT * 32 * 33];
+    u32x4 *W2s = reinterpret_cast<u32x4 *>(smem_res);                       // [NT2][384]
+    float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1536);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const long long M = (long long)B * H * W;
+    const int cpt = (C + 31) / 32;
+    const int nchunk = 9 * cpt;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+
+    for (int i = tid; i < NT2 * 384; i += 256) W2s[i] = w2img[i];
+
+    const long long wbase = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT);
+    const long long img_px = (long long)H * W;
+    const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
+    unsigned pbase[MT], tapmask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long p = wbase + mt * 32 + l31;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / W, gx = rem - gy * W;
+        pbase[mt] = (unsigned)((((b - b_first) * H + gy) * W + gx) * C * 4 + 64 * h);
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = gy + t / 3 - 1, ix = gx + t % 3 - 1;
+            if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) m |= 1u << t;
+        }
+        tapmask[mt] = m;
+    }
+
+    constexpr int KC = 2;
+    f32x4 a[KC][MT][4];
+    u32x4 bq[KC][6];                                   // [term*2 + step] for this lane's half
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    const u32x4 *w1v = w1img + h * 32 + l31;          // + chunk*384 + (term*2 + step)*64
+    auto load_ab = [&](int c, f32x4(&dst)[MT][4], u32x4(&bd)[6]) {
+        const int tap = c / cpt, cc = c - tap * cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int tapbytes = (dy * W + dx) * C * 4;
+        const unsigned soff = (unsigned)cc * 128u;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bd[q] = w1v[(size_t)c * 384 + q * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+        }
+    };
+    // six significant term products of one 16-deep MFMA step, two accumulators interleaved
+    auto prod6 = [&](const u32x4 &s1, const u32x4 &s2, const u32x4 &s3, const u32x4 &t1, const u32x4 &t2,
+                     const u32x4 &t3, const u32x4 &w1, const u32x4 &w2, const u32x4 &w3, const u32x4 &x1,
+                     const u32x4 &x2, const u32x4 &x3, f32x16 &accA, f32x16 &accB) {
+        // accA += s (x) w ; accB += t (x) x   (smallest terms first)
+#define BF(v) __builtin_bit_cast(bf16x8, v)
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s3), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t3), BF(x1), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w2), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(x2), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w3), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x3), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(x1), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w2), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x2), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x1), accB, 0, 0, 0);
+#undef BF
+    };
+
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < nchunk) load_ab(k, a[k], bq[k]);
+    for (int c0 = 0; c0 < nchunk; c0 += KC) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (c0 + k < nchunk) {
+                u32x4 S1[MT][2], S2[MT][2], S3[MT][2], bw[6];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (relu_in) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[k][mt][j] = relu4(a[k][mt][j]);
+                    }
+                    split8(a[k][mt][0], a[k][mt][1], S1[mt][0], S2[mt][0], S3[mt][0]);
+                    split8(a[k][mt][2], a[k][mt][3], S1[mt][1], S2[mt][1], S3[mt][1]);
+                }
+#pragma unroll
+                for (int q = 0; q < 6; ++q) bw[q] = bq[k][q];
+                if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t)           // the two pixel tiles share the weights, separate accumulators
+                    prod6(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
+                          bw[t], bw[2 + t], bw[4 + t], acc1[0], acc1[1]);
+            }
+        }
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+
+    // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33: conflict-free)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[wave][mt][prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");   // wave-private tile: LDS ops of a wave stay in order
+    __builtin_amdgcn_wave_barrier();
+    u32x4 H1[MT][2], H2[MT][2], H3[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[wave][mt][l31 * 33 + 16 * h + q];
+        split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], H2[mt][0], H3[mt][0]);
+        split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], H2[mt][1],
+               H3[mt][1]);
+    }
+
+    // second GEMM, one n-tile at a time (two pixel tiles = two interleaved accumulators)
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        f32x16 acc2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
+            const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+            prod6(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, w1, w2, w3, acc2[0], acc2[1]);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int n = nt * 32 + l31;
+                if (prow < M && n < C) {
+                    float u = in[prow * C + n];
+                    if (relu_in) u = fmaxf(u, 0.0f);
+                    float v = u + acc2[mt][r];
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    out[prow * C + n] = v;
+                }
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
@@ -759,6 +1191,10 @@ static int make_geom(int kind, long long B, int H, int W, int Cin, int Cout, int
 static size_t packed_floats(const ConvGeom &g) {
     return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 1024;
 }
+// split-bf16 image: 3 terms x 32x32 bf16 per (phase, chunk, n_tile) = 6 KiB
+static size_t packed_bf3_bytes(const ConvGeom &g) {
+    return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 3072 * sizeof(unsigned short);
+}
 
 }  // namespace vqvae
 
@@ -769,7 +1205,8 @@ extern "C" {
 size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout) {
     ConvGeom g;
     if (Cin < 1 || Cout < 1 || make_geom(kind, 1, 4, 4, Cin, Cout, 0, g) != VQVAE_OK) return 0;
-    return packed_floats(g) * sizeof(float);
+    // [fp32 B-operand image][split-bf16 image]
+    return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g);
 }
 
 int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -783,6 +1220,10 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        packed, g, total);
+    // split-bf16 image right behind it (1024 bf16 elements per term per (phase, chunk, n_tile))
+    const long long total3 = total;
+    hipLaunchKernelGGL(conv_pack_bf3_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       reinterpret_cast<unsigned short *>(packed + total), g, total3);
     return (int)hipGetLastError();
 }
 
@@ -798,9 +1239,21 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long M = (long long)B * g.Hg * g.Wg;
     prof_begin(VQVAE_PROF_CONV_IGEMM, st);
-    // tile shape: 32 pixels x 128 channels per wave when Cout fills it (3 waves/SIMD resident),
-    // else 64 pixels x 64 / 32 channels
-    if (g.ntile % 4 == 0) {
+    if (!(flags & VQVAE_CONV_EXACT_FP32)) {
+        // default: split-bf16 products on the bf16 matrix cores (fp32-grade accuracy, ~2.7x the rate)
+        const u32x4 *img3 = reinterpret_cast<const u32x4 *>(packed + packed_floats(g));
+        const unsigned gx = (unsigned)((M + 127) / 128);
+        if (g.ntile % 4 == 0)
+            hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
+                               img3, bias, y, g);
+        else if (g.ntile % 2 == 0)
+            hipLaunchKernelGGL((conv_igemm_bf3_kernel<2>), dim3(gx, g.nphase * (g.ntile / 2)), dim3(256), 0, st, x,
+                               img3, bias, y, g);
+        else
+            hipLaunchKernelGGL((conv_igemm_bf3_kernel<1>), dim3(gx, g.nphase * g.ntile), dim3(256), 0, st, x, img3,
+                               bias, y, g);
+    } else if (g.ntile % 4 == 0) {
+        // exact-fp32 MFMA kernels: 32 pixels x 128 channels per wave when Cout fills it, else 64 x 64 / 32
         const unsigned gx = (unsigned)((M + 127) / 128);
         hipLaunchKernelGGL((conv_igemm_kernel<1, 4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
                            packed, bias, y, g);
@@ -827,10 +1280,22 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
     const long long M = (long long)B * H * W;
     const unsigned gx = (unsigned)((M + 255) / 256);
     prof_begin(VQVAE_PROF_RES_LAYER, st);
-    switch (C / 32) {
-        case 1: hipLaunchKernelGGL((res_layer_kernel<1>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
-        case 2: hipLaunchKernelGGL((res_layer_kernel<2>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
-        case 4: hipLaunchKernelGGL((res_layer_kernel<4>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+    if (!(flags & VQVAE_CONV_EXACT_FP32)) {
+        // split-bf16 images sit behind the fp32 ones in each packed buffer
+        const int cpt = (C + 31) / 32;
+        const u32x4 *w1b = reinterpret_cast<const u32x4 *>(packed_w1 + (size_t)9 * cpt * 1024);          // 3x3, C -> Rh
+        const u32x4 *w2b = reinterpret_cast<const u32x4 *>(packed_w2 + (size_t)((C + 31) / 32) * 1024);   // 1x1, Rh -> C
+        switch (C / 32) {
+            case 1: hipLaunchKernelGGL((res_layer_bf3_kernel<1>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
+            case 2: hipLaunchKernelGGL((res_layer_bf3_kernel<2>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
+            case 4: hipLaunchKernelGGL((res_layer_bf3_kernel<4>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
+        }
+    } else {
+        switch (C / 32) {
+            case 1: hipLaunchKernelGGL((res_layer_kernel<1>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+            case 2: hipLaunchKernelGGL((res_layer_kernel<2>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+            case 4: hipLaunchKernelGGL((res_layer_kernel<4>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+        }
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();
