@@ -3,7 +3,7 @@
 import sys, os, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from vqvae_amd import functional as F
+from vqvae_amd import functional as F, _lib
 
 def run(K, D, B, H, W, rowmajor=False, iters=20, exact=False, trained=False):
     dev = torch.device("cuda:0")
@@ -24,8 +24,12 @@ def run(K, D, B, H, W, rowmajor=False, iters=20, exact=False, trained=False):
     for _ in range(iters): F.vq_forward(z, cb, 0.25, rowmajor=rowmajor, workspace=ws, prepared=True, exact_sweep=exact)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
+    _lib.profile_enable(True)
+    for _ in range(iters): F.vq_forward(z, cb, 0.25, rowmajor=rowmajor, workspace=ws, prepared=True, exact_sweep=exact)
+    kms, kn = _lib.profile_collect('vq_main')
+    _lib.profile_enable(False)
     N = B * H * W
-    print(json.dumps(dict(K=K, D=D, N=N, rowmajor=rowmajor, kernel='exact' if exact else 'auto', data='trained-like' if trained else 'init', us=round(ms * 1e3, 2), Grows_s=round(N / ms / 1e6, 3),
+    print(json.dumps(dict(K=K, D=D, N=N, rowmajor=rowmajor, kernel='exact' if exact else 'auto', data='trained-like' if trained else 'init', us=round(ms * 1e3, 2), kernel_us=round(kms / max(kn, 1) * 1e3, 2), Grows_s=round(N / ms / 1e6, 3),
                           alg_GBps=round(N * (8 * D + 8) / ms / 1e6, 1), TFLOPs=round(2.0 * N * K * D / ms / 1e9, 1))))
 
 if __name__ == "__main__":

@@ -8,8 +8,10 @@
 //   screen   acc[n,k] = bf16(z_n) . bf16(e_k) - ||e_k||^2/2   (v_mfma_f32_32x32x16_bf16, fp32 accumulate;
 //            the accumulator is initialised with -||e_k||^2/2, so argmax acc ~ argmin distance)
 //            sweep 1: row maximum;  sweep 2: every code with acc >= max - DELTA goes to the row's
-//            candidate list.  DELTA is a rigorous bound (derivation below) on how far the screen can
-//            misplace the reference's fp32 argmin, so the list provably contains it.
+//            candidate list (the sign bits of acc - thr are shifted into a per-lane hit mask, one
+//            v_sub + one v_alignbit per element; codes are extracted only for lanes with a hit and kept
+//            packed in registers).  DELTA is a rigorous bound (derivation below) on how far the screen
+//            can misplace the reference's fp32 argmin, so the list provably contains it.
 //   refine   rows with one candidate are done.  Rows with several recompute the reference's distance
 //            d = fl(fl(zz + ee_k) - 2 m_k) exactly -- m_k as the c-ordered fp32 fmaf chain, zz in ATen's
 //            summation order -- for the listed codes only, and take the lexicographic (d, k) minimum
@@ -29,6 +31,7 @@
 namespace vqvae {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     unsigned r;
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
     long long N, int HW, int K, int K32, long long nblocks, float *__restrict__ zq,
     long long *__restrict__ idx, int *__restrict__ hist, double *__restrict__ partials) {
     constexpr int D = 64, HALF = 32, NQ = 4, CAPH = kVqCandCap;   // list capacity per lane half
+    static_assert(CAPH == 8, "candidate lists are packed into four registers / one 16-byte LDS slot");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                       // [NQ][2][K32] x 16 B
     float *neh = reinterpret_cast<float *>(Eimg + (size_t)NQ * 2 * K32);      // [K32]  -||e||^2/2
@@ -58,10 +62,6 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
     const float EEmax = __int_as_float(flags[1]) * 1.0001f;
     const float Emax = __builtin_sqrtf(EEmax) * 1.0001f;
 
-    for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
-    for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
-    for (int k = tid; k < K; k += 512) hist_s[k] = 0;
-    __syncthreads();
     unsigned short *my_list = cand_list + wave_u * (32 * 2 * CAPH);          // this wave's lists
     unsigned short *own_list = my_list + (l31 * 2 + h) * CAPH;               // this lane's private part
     const unsigned short *row_list = my_list + l31 * 2 * CAPH;
@@ -109,14 +109,16 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
         }
     };
 
-    double dacc = 0.0;
-    for (long long rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        const long long r0 = rb * 256 + wave_u * 32;
-        const long long row = r0 + l31;
-        const bool valid = row < N;
-        const long long rc = valid ? row : N - 1;
-        size_t zbase, img0 = 0;        // ROWMAJOR: this lane's half row; NCHW: channel 0 of the row
-        unsigned voff = 0;
+    // per row block: this lane's row and addressing (ROWMAJOR: half row base; NCHW: channel 0 of the row)
+    long long r0 = 0, row = 0, rc = 0;
+    bool valid = false;
+    size_t zbase = 0, img0 = 0;
+    unsigned voff = 0;
+    auto setup = [&](long long rb) {
+        r0 = rb * 256 + wave_u * 32;
+        row = r0 + l31;
+        valid = row < N;
+        rc = valid ? row : N - 1;
         if (ROWMAJOR) {
             zbase = (size_t)rc * D + HALF * h;
         } else {
@@ -127,24 +129,36 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
             img0 = (size_t)b0 * D * HW;
             voff = (unsigned)((((b - b0) * D + HALF * h) * HW + hw) * 4);
         }
-        // ---- load, approximate ||z||^2, bf16 B operands (the fp32 copy is NOT kept in registers) ------
-        bf16x8 zb[NQ];
-        float zs;
-        {
-            float zf[HALF];
+    };
+    // The half row stays in registers from its load to the epilogue (one HBM read per element).  The first
+    // block's rows are requested before the codebook image is copied to LDS, so the two latencies overlap.
+    float zf[HALF];
+    setup(blockIdx.x);
+    load_half(zbase, img0, voff, zf);
+    for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
+    for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
+    for (int k = tid; k < K; k += 512) hist_s[k] = 0;
+    __syncthreads();
+
+    double dacc = 0.0;
+    for (long long rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
+        if (rb != (long long)blockIdx.x) {
+            setup(rb);
             load_half(zbase, img0, voff, zf);
-            zs = 0.0f;
+        }
+        // ---- approximate ||z||^2 and the bf16 B operands --------------------------------------------
+        bf16x8 zb[NQ];
+        float zs = 0.0f;
 #pragma unroll
-            for (int c = 0; c < HALF; ++c) zs = __builtin_fmaf(zf[c], zf[c], zs);
+        for (int c = 0; c < HALF; ++c) zs = __builtin_fmaf(zf[c], zf[c], zs);
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                uint4 pk;
-                pk.x = cvt_pk_bf16(zf[8 * q], zf[8 * q + 1]);
-                pk.y = cvt_pk_bf16(zf[8 * q + 2], zf[8 * q + 3]);
-                pk.z = cvt_pk_bf16(zf[8 * q + 4], zf[8 * q + 5]);
-                pk.w = cvt_pk_bf16(zf[8 * q + 6], zf[8 * q + 7]);
-                zb[q] = __builtin_bit_cast(bf16x8, pk);
-            }
+        for (int q = 0; q < NQ; ++q) {
+            uint4 pk;
+            pk.x = cvt_pk_bf16(zf[8 * q], zf[8 * q + 1]);
+            pk.y = cvt_pk_bf16(zf[8 * q + 2], zf[8 * q + 3]);
+            pk.z = cvt_pk_bf16(zf[8 * q + 4], zf[8 * q + 5]);
+            pk.w = cvt_pk_bf16(zf[8 * q + 6], zf[8 * q + 7]);
+            zb[q] = __builtin_bit_cast(bf16x8, pk);
         }
         zs += __shfl_xor(zs, 32);
         bool bad = valid && (cb_bad || !(zs < 1.0e38f));
@@ -170,30 +184,32 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
         best = fmaxf(best, __shfl_xor(best, 32));
         const float thr = best - (delta0 + 4.0e-7f * __builtin_fabsf(best));
 
-        // ---- sweep 2: collect every code the bound cannot exclude.  Group maxima (4 codes each) are
-        //      balloted first; only groups with a hit somewhere in the wave are looked at per element.
-        //      Each lane half appends to its own private list (no LDS atomics). ------------------------
+        // ---- sweep 2: collect every code the bound cannot exclude.  Per element one subtract and one
+        //      v_alignbit shift the sign of (acc - thr) into a 32-bit miss mask covering two code tiles; only
+        //      lanes with a hit decode it.  Up to CAPH codes per lane half stay packed in four registers. ----
         int cnt = 0;
-        auto collect = [&](int ct, const f32x16 &acc) {
-            float gm[4];
-            unsigned long long gb[4];
+        unsigned cl[CAPH / 2];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                gm[g] = fmaxf(fmaxf(fmaxf(acc[4 * g], acc[4 * g + 1]), acc[4 * g + 2]), acc[4 * g + 3]);
-                gb[g] = __builtin_amdgcn_ballot_w64(gm[g] >= thr);
-            }
-            if (gb[0] | gb[1] | gb[2] | gb[3]) {
+        for (int i = 0; i < CAPH / 2; ++i) cl[i] = 0;
+        auto miss_mask = [&](unsigned m, const f32x16 &acc) -> unsigned {
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (gb[g]) {
+            for (int r = 0; r < 16; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r] - thr), 31);
+            return m;
+        };
+        // hits: bit 31-r = element r of tile ct, bit 15-r = element r of tile ct+1
+        auto extract = [&](int ct, unsigned hits) {
+            if (__builtin_amdgcn_ballot_w64(hits != 0)) {
+                while (hits) {
+                    const int b = 31 - __builtin_clz(hits);
+                    hits &= ~(1u << b);
+                    const int r = (31 - b) & 15;
+                    const unsigned code = (unsigned)((ct + (b < 16 ? 1 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
+                    if (cnt < CAPH) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            if (acc[4 * g + i] >= thr) {
-                                if (cnt < CAPH) own_list[cnt] = (unsigned short)(ct * 32 + 8 * g + 4 * h + i);
-                                ++cnt;
-                            }
-                        }
+                        for (int i = CAPH / 2 - 1; i > 0; --i) cl[i] = (cl[i] << 16) | (cl[i - 1] >> 16);
+                        cl[0] = (cl[0] << 16) | code;
                     }
+                    ++cnt;
                 }
             }
         };
@@ -203,14 +219,19 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
                 f32x16 accA, accB;
                 screen_tile(ct, zb, accA);
                 screen_tile(ct + 1, zb, accB);
-                collect(ct, accA);
-                collect(ct + 1, accB);
+                extract(ct, ~miss_mask(miss_mask(0u, accA), accB));
             }
             if (ct < ntile) {
                 f32x16 accA;
                 screen_tile(ct, zb, accA);
-                collect(ct, accA);
+                extract(ct, ~(miss_mask(0u, accA) << 16) & 0xffff0000u);
             }
+        }
+        // publish the packed lists (newest first) for the refine stage
+        if (cnt > 0) {
+            u32x4 w;
+            w.x = cl[0]; w.y = cl[1]; w.z = cl[2]; w.w = cl[3];
+            *reinterpret_cast<u32x4 *>(own_list) = w;
         }
         __builtin_amdgcn_wave_barrier();
         const int cnt_o = __shfl_xor(cnt, 32);
@@ -225,8 +246,6 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
         if (__builtin_amdgcn_ballot_w64(refine || bad)) {
             // ---- ||z||^2 in ATen's order (8-lane vectors x 4-way ILP).  Lane halves hold channels
             //      [0,32) and [32,64): swap so each lane owns matching (c, c+32) pairs, then chain. ----
-            float zf[HALF];
-            load_half(zbase, img0, voff, zf);
             float P[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -276,19 +295,8 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
                 const bool act = base + l31 < total;
                 const int job = act ? job_s[l31] : 0;
                 const int jr = job >> 16, jk = job & 0xffff;
-                // the job's row half and code half
-                float zj[HALF];
-                {
-                    const long long rj = r0 + jr;
-                    if (ROWMAJOR) {
-                        load_half((size_t)rj * D + HALF * h, 0, 0, zj);
-                    } else {
-                        const long long b0 = (r0 < N ? r0 : N - 1) / HW;
-                        const long long bj = rj / HW;
-                        const int hwj = (int)(rj - bj * HW);
-                        load_half(0, img0, (unsigned)((((bj - b0) * D + HALF * h) * HW + hwj) * 4), zj);
-                    }
-                }
+                // the job's row half comes from its owner lane's registers (ds_bpermute), the code half from L2
+                int src = (jr + 32 * h) << 2;
                 const float *e = cb + (size_t)jk * D + HALF * h;
                 float ef[HALF];
 #pragma unroll
@@ -298,10 +306,13 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
                 }
                 float p = 0.0f;                                       // channels 0..31, valid on h=0
 #pragma unroll
-                for (int c = 0; c < HALF; ++c) p = __builtin_fmaf(zj[c], ef[c], p);
+                for (int c = 0; c < HALF; ++c)
+                    p = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[c]))), ef[c], p);
                 float m = __shfl_xor(p, 32);                          // h=1 continues lane h=0's chain
+                asm volatile("" : "+v"(src));                         // fetch again rather than hold 32 more registers
 #pragma unroll
-                for (int c = 0; c < HALF; ++c) m = __builtin_fmaf(zj[c], ef[c], m);
+                for (int c = 0; c < HALF; ++c)
+                    m = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[c]))), ef[c], m);
                 if (h == 1 && act) {                                  // full 64-term chain lives on h=1
                     const float t = zz_s[jr] + ee_g[jk];
                     const float u2 = 2.0f * m;
@@ -333,10 +344,8 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
             if (bad) k = ks;
         }
 
-        // ---- epilogue: re-read the half row, gather e_k, z + (e_k - z), squared error, index, histogram -
+        // ---- epilogue: gather e_k, z + (e_k - z), squared error, index, histogram ---------------------
         {
-            float zf[HALF];
-            load_half(zbase, img0, voff, zf);
             const float *e = cb + (size_t)k * D + HALF * h;
             float sq = 0.0f;
 #pragma unroll
