@@ -184,6 +184,37 @@ VQVAE_API int vqvae_convt_out_forward_f32(const float *x, const float *packed, c
 VQVAE_API int vqvae_transpose_f32(const float *x, int64_t batch, int R, int C, float *y,
                                   vqvae_stream_t stream);
 
+/* ------------------------------------------------------- training-step companions
+ * what main.py:74-83 needs around the forward path.
+ *
+ * vqvae_vq_backward_f32 -- the gradients autograd derives from models/quantizer.py:63-67:
+ *     grad_z        = grad_zq + g * 2 (z - e_idx) / (N D)             (:63 first term, :67 straight-through)
+ *     grad_codebook = g * 2 beta * sum_{i: idx_i=k} (e_k - z_i) / (N D)   (:63-64; beta sits on the codebook
+ *                     term in the reference, the reverse of the paper -- reproduced as written)
+ *   g = *grad_loss (device scalar; NULL = 1), grad_zq = upstream gradient of the returned z_q (NULL = 0).
+ *   z_e / grad_zq / grad_z share the layout selected by VQVAE_VQ_ROWMAJOR.  Either output may be NULL.
+ *   The codebook gradient uses no floating-point atomics: rows are stably sorted by code and summed in a
+ *   fixed order in fp64, so it is bit-reproducible run to run.  Parity with torch autograd: rtol 1e-5.   */
+VQVAE_API size_t vqvae_vq_backward_workspace_bytes(int64_t N, int K, int D);
+VQVAE_API int vqvae_vq_backward_f32(const float *z_e, const float *codebook, const int64_t *idx,
+                                    const float *grad_zq, const float *grad_loss,
+                                    int64_t B, int D, int H, int W, int K, float beta, int flags,
+                                    float *grad_z, float *grad_codebook,
+                                    void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+
+/* recon_loss = mean((x_hat - x)^2) / x_train_var; loss = recon_loss + embedding_loss (main.py:75-76).
+ * out3 = {recon_loss, loss, perplexity}: the three values main.py:81-83 copies to the host one by one,
+ * packed so that a step needs one D2H copy.  embedding_loss / perplexity are device scalars (NULL = 0);
+ * x_hat and x must be 16-byte aligned.  inv_var = 1 / x_train_var.                                    */
+VQVAE_API size_t vqvae_recon_loss_workspace_bytes(void);
+VQVAE_API int vqvae_recon_loss_f32(const float *x_hat, const float *x, int64_t n, float inv_var,
+                                   const float *embedding_loss, const float *perplexity, float *out3,
+                                   void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* grad_x_hat = g * 2 (x_hat - x) inv_var / n,  g = *grad_loss (NULL = 1) */
+VQVAE_API int vqvae_recon_loss_backward_f32(const float *x_hat, const float *x, int64_t n, float inv_var,
+                                            const float *grad_loss, float *grad_x_hat,
+                                            vqvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,25 @@ def quantize(z_e, codebook, beta):
     return loss, z_q.permute(0, 3, 1, 2).contiguous(), perplexity, onehot, idx
 
 
+def quantize_train(z_e, codebook, beta):
+    """models/quantizer.py:45-76 with its .detach() calls (:63-64, :67), for autograd: the gradients
+    torch derives from this are the oracle of vqvae_vq_backward_f32.  Same forward values as quantize()."""
+    K, D = codebook.shape
+    z = z_e.permute(0, 2, 3, 1).contiguous()
+    zf = z.view(-1, D)
+    d = torch.sum(zf ** 2, dim=1, keepdim=True) + torch.sum(codebook ** 2, dim=1) \
+        - 2 * torch.matmul(zf, codebook.t())
+    idx = torch.argmin(d, dim=1).unsqueeze(1)
+    onehot = torch.zeros(idx.shape[0], K)
+    onehot.scatter_(1, idx, 1)
+    z_q = torch.matmul(onehot, codebook).view(z.shape)
+    loss = torch.mean((z_q.detach() - z) ** 2) + beta * torch.mean((z_q - z.detach()) ** 2)
+    z_q = z + (z_q - z).detach()
+    e_mean = torch.mean(onehot, dim=0)
+    perplexity = torch.exp(-torch.sum(e_mean * torch.log(e_mean + 1e-10)))
+    return loss, z_q.permute(0, 3, 1, 2).contiguous(), perplexity, onehot, idx
+
+
 def decode(sd, z_q, n_res_layers):
     """models/decoder.py:27-39."""
     t = F.conv_transpose2d(z_q, sd[Dk + "0.weight"], sd[Dk + "0.bias"], 1, 1)

@@ -15,10 +15,11 @@ the reference (`utils.py:109-113`) load unchanged and callers (`main.py:74`,
     ResidualLayer(in_dim, h_dim, res_h_dim), ResidualStack(in_dim, h_dim, res_h_dim, n_res_layers)
                                                                              (models/residual.py:16,41)
 
-The modules only HOLD parameters; the arithmetic is libvqvae_hip.so.  This is a
-forward-only path: it runs under `torch.no_grad()` semantics, on CUDA(HIP) fp32
-tensors only, and raises otherwise -- there is no CPU or autograd fallback
-(backward is a "next" row).
+The modules only HOLD parameters; the arithmetic is libvqvae_hip.so, on CUDA(HIP)
+fp32 tensors only -- there is no CPU fallback.  The HIP conv kernels are forward-only
+and raise when a graph is being recorded.  The VectorQuantizer also has a HIP backward
+(SURVEY.md 8f row 2): with the convs on the "torch" backend (`set_conv_backend("torch")`,
+BASELINE config 2) `loss.backward()` of main.py:78 runs through training.VQStraightThrough.
 """
 from __future__ import annotations
 
@@ -30,11 +31,16 @@ from ._lib import VqvaeHipError
 
 
 def _require_forward_only(*tensors):
+    """The HIP conv / residual kernels have no backward: refuse to run them while a graph is recorded."""
+    from . import conv as C_hip
+    if C_hip.get_conv_backend() == "torch":
+        return                                          # torch's own convs carry their autograd
     if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
         raise VqvaeHipError(
-            "vqvae_amd implements the forward path only: call it under torch.no_grad() "
-            "(or model.requires_grad_(False)); backward is not implemented and there is no "
-            "autograd fallback")
+            "the HIP conv kernels are forward-only: call them under torch.no_grad() (or "
+            "model.requires_grad_(False)).  For training, select set_conv_backend('torch'): the "
+            "VectorQuantizer then runs its HIP forward and backward, the convs use torch autograd. "
+            "There is no silent fallback")
 
 
 class VectorQuantizer(nn.Module):
@@ -65,8 +71,10 @@ class VectorQuantizer(nn.Module):
     def quantize(self, z, *, rowmajor=False, want_zq=True):
         """-> (loss, z_q, perplexity, min_encoding_indices, hist); no one-hot."""
         w = self.embedding.weight
-        _require_forward_only(z, w)
         ws, prepared = self._workspace()
+        if torch.is_grad_enabled() and (z.requires_grad or w.requires_grad):
+            from .training import VQStraightThrough          # HIP forward + HIP backward
+            return VQStraightThrough.apply(z, w, self.beta, rowmajor, ws, prepared)
         return F_hip.vq_forward(z, w.detach(), self.beta, rowmajor=rowmajor, workspace=ws,
                                 prepared=prepared, want_zq=want_zq)
 
