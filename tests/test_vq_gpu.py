@@ -187,5 +187,5 @@ def test_module_interface_matches_reference_signature():
     assert torch.equal(z_q, z_q2) and torch.equal(loss, loss2)
     with pytest.raises(Exception):
         vq(z.cpu())                          # no CPU fallback
-    with pytest.raises(Exception):
-        vq(z.requires_grad_())               # forward-only
+    out = vq(z.clone().requires_grad_())     # under autograd: HIP forward + HIP backward (tests/test_training_gpu.py)
+    assert out[0].requires_grad and out[1].requires_grad and torch.equal(out[1].detach(), z_q)

@@ -7,6 +7,9 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import torch.nn as nn
+from vqvae_amd import _lib
+if os.environ.get("VQVAE_BENCH_LIB"):          # A/B runs against another build of the library
+    _lib.LIB_PATH = os.environ["VQVAE_BENCH_LIB"]
 from vqvae_amd import conv_hip
 from vqvae_amd.modules import ResidualLayer
 
@@ -45,4 +48,4 @@ layer = ResidualLayer(128, 128, 32).to(dev)
 x = torch.randn(B, 8, 8, 128, device=dev)
 us = timeit(lambda: conv_hip.res_layer(x, layer, 2 | (flags & 4)))
 print(f"{'res 3x3 128->32->128':22s} {us:7.1f} us  {12 * 64 * (1152 * 32 + 32 * 128) * B / us / 1e6:6.0f} TF")
-print(f"sum of convs + 4 x res: {tot + 4 * us:.0f} us")
+print(f"sum of convs + 4 x res: {tot + 4 * us:.0f} us  [{os.path.basename(_lib.LIB_PATH)}]")

@@ -345,8 +345,10 @@ __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restr
     }
 }
 
+// The waves-per-SIMD hint of 2 keeps the accumulators in VGPRs: without it the compiler parks them in AGPRs
+// and copies all of them to VGPRs and back once per loop iteration (128 v_accvgpr moves per 96 MFMAs).
 template <int NT>
-__global__ __launch_bounds__(256) void conv_igemm_bf3_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__restrict__ in,
                                                              const u32x4 *__restrict__ wimg,
                                                              const float *__restrict__ bias,
                                                              float *__restrict__ out, ConvGeom g) {
