@@ -24,6 +24,8 @@
 // ConvTranspose2d(k=3,s=1,p=1) is a 3x3 conv with mirrored taps.
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 namespace vqvae {
@@ -695,6 +697,196 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 }
 
 // ---------------------------------------------------------------------------
+// Fused residual layer for 8x8 feature maps (the reference's 32x32 images: both residual stacks run at 8x8).
+// One wave owns one whole image, so every 3x3 tap of every pixel lives inside the wave's own tile:
+//   for each 16-channel slice of the input (one MFMA k-step of the packed weight image; slice outer, tap inner):
+//       load the slice of the image once, apply the in-place ReLU, split it ONCE into its three bf16
+//       terms and park them in a wave-private LDS tile (64 pixels + one all-zero "padding" pixel);
+//       the nine taps then read their A operands from that tile with ds_read_b128 at shifted pixel indices.
+// Compared with res_layer_bf3_kernel (A re-loaded from L2 and re-split for each of the 9 taps) this cuts
+// the L1/TA traffic and the split VALU work of the 3x3 GEMM 9x; no workgroup barrier in the reduction.
+// The hidden tile and the 1x1 GEMM / skip / ReLU epilogue are the same as in res_layer_bf3_kernel.
+template <int NT2>
+__global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__restrict__ in,
+                                                               const u32x4 *__restrict__ w1img,
+                                                               const u32x4 *__restrict__ w2img,
+                                                               float *__restrict__ out, int B, int C, int flags) {
+    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][pixel + zero][2]
+    static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
+    __shared__ u32x4 W2s[NT2 * 384];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 384; i += 256) W2s[i] = w2img[i];
+    if (lane < 6) As[(lane >> 1) * ((PX + 1) * 2) + PX * 2 + (lane & 1)] = u32x4{0, 0, 0, 0};   // padding pixel
+
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+    const float *src = in + (size_t)(img_ok ? img : 0) * PX * C + (size_t)lane * C;   // this lane's pixel row
+
+    // operand pixel index per (tap, m-tile): the shifted pixel, or the zero pixel outside the image
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        }
+        tapok[mt] = m;
+    }
+
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    auto prod6 = [&](const u32x4 &s1, const u32x4 &s2, const u32x4 &s3, const u32x4 &t1, const u32x4 &t2,
+                     const u32x4 &t3, const u32x4 &w1, const u32x4 &w2, const u32x4 &w3, f32x16 &accA,
+                     f32x16 &accB) {
+#define BF(v) __builtin_bit_cast(bf16x8, v)
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s3), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t3), BF(w1), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w2), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w2), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w3), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w3), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w1), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w2), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w2), accB, 0, 0, 0);
+        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w1), accA, 0, 0, 0);
+        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w1), accB, 0, 0, 0);
+#undef BF
+    };
+    // slice sl = k-step (sl & 1) of 32-channel chunk (sl >> 1) of the packed weight image: channels
+    // 32*chunk + 8*step + [0,8) for the h = 0 operand half and 32*chunk + 16 + 8*step + [0,8) for h = 1
+    auto load_raw = [&](int sl, f32x4(&r)[4]) {
+        const float *q = src + 32 * (sl >> 1) + 8 * (sl & 1);
+        r[0] = *reinterpret_cast<const f32x4 *>(q);
+        r[1] = *reinterpret_cast<const f32x4 *>(q + 4);
+        r[2] = *reinterpret_cast<const f32x4 *>(q + 16);
+        r[3] = *reinterpret_cast<const f32x4 *>(q + 20);
+    };
+    // weights of (tap, slice): 16 k x 32 hidden x 3 terms, this lane's 8 k of each term.  The image is the
+    // conv_pack_bf3 layout: chunk = tap*cpt + slice/2, k-step = slice & 1
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[3]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 384 + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128]; bw[2] = p[256];
+    };
+
+    f32x4 raw[4];
+    u32x4 bw[2][3];
+    load_raw(0, raw);
+    load_w(0, 0, bw[0]);
+    // one 16-channel slice; PAR = slice parity (nine taps per slice flip which weight register set is "current")
+    auto slice = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        // ---- stage this slice: ReLU, split once, park the three terms (the tile is wave-private) ----
+        {
+            if (relu_in) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
+            }
+            u32x4 t1a, t2a, t3a, t1b, t2b, t3b;
+            split8(raw[0], raw[1], t1a, t2a, t3a);
+            split8(raw[2], raw[3], t1b, t2b, t3b);
+            if (sl + 1 < nslice) load_raw(sl + 1, raw);
+            __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+            u32x4 *dst = As + lane * 2;
+            dst[0] = t1a; dst[1] = t1b;
+            dst[(PX + 1) * 2] = t2a; dst[(PX + 1) * 2 + 1] = t2b;
+            dst[(PX + 1) * 4] = t3a; dst[(PX + 1) * 4 + 1] = t3b;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+            u32x4 S[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + p * 2 + h;
+                S[mt][0] = ap[0]; S[mt][1] = ap[(PX + 1) * 2]; S[mt][2] = ap[(PX + 1) * 4];
+            }
+            prod6(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
+                  acc1[1]);
+        }
+    };
+    for (int sl = 0; sl < nslice; sl += 2) {                  // C % 32 == 0: an even number of slices
+        slice(sl, std::integral_constant<int, 0>{});
+        slice(sl + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete; operand tile no longer read
+
+    // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33), one m-tile at a time in the
+    // (now free) operand tile
+    float *Hs = reinterpret_cast<float *>(As);
+    u32x4 H1[MT][2], H2[MT][2], H3[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+        split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], H2[mt][0], H3[mt][0]);
+        split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], H2[mt][1],
+               H3[mt][1]);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const long long wbase = img * PX;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        f32x16 acc2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
+            const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+            prod6(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+        }
+        if (img_ok) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int n = nt * 32 + l31;
+                    float u = in[prow * C + n];
+                    if (relu_in) u = fmaxf(u, 0.0f);
+                    float v = u + acc2[mt][r];
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    out[prow * C + n] = v;
+                }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
@@ -1287,7 +1479,15 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
         const int cpt = (C + 31) / 32;
         const u32x4 *w1b = reinterpret_cast<const u32x4 *>(packed_w1 + (size_t)9 * cpt * 1024);          // 3x3, C -> Rh
         const u32x4 *w2b = reinterpret_cast<const u32x4 *>(packed_w2 + (size_t)((C + 31) / 32) * 1024);   // 1x1, Rh -> C
-        switch (C / 32) {
+        if (H == 8 && W == 8) {
+            // whole 8x8 images per wave: operands split once and kept in LDS for all nine taps
+            const unsigned gt = (unsigned)((B + 3) / 4);
+            switch (C / 32) {
+                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
+                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
+                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
+            }
+        } else switch (C / 32) {
             case 1: hipLaunchKernelGGL((res_layer_bf3_kernel<1>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
             case 2: hipLaunchKernelGGL((res_layer_bf3_kernel<2>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
             case 4: hipLaunchKernelGGL((res_layer_bf3_kernel<4>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
