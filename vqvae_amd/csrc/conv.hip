@@ -523,6 +523,190 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 
 
 // ---------------------------------------------------------------------------
+// Split-bf16 implicit GEMM for layers whose INPUT map is 8x8 and is sampled at stride 1 (the reference's
+// enc conv 3x3, dec convT 3x3, dec convT 4x4 s2 phases, 1x1 pre-quantisation conv at 32x32 images).
+// One wave owns one whole input image (64 pixels = two 32-pixel MFMA tiles) and 64 output channels:
+//   for each 32-channel chunk:   (reduction order: chunk outer, tap inner)
+//       the image's chunk is loaded ONCE (one contiguous 128 B per pixel), ReLU'd, split ONCE into three bf16
+//       terms and parked in a wave-private LDS tile with an all-zero padding pixel;
+//       every tap reads its A operands from that tile at a shifted pixel index (ds_read_b128).
+//   Weights: the same three-term chunk images as conv_igemm_bf3_kernel, streamed through double-buffered LDS
+//   and shared by the workgroup's four images (256 pixels x 64 channels per workgroup and chunk).
+// Versus conv_igemm_bf3_kernel: activation traffic through L1/TA and the split VALU work drop by the number
+// of taps (9x / 4x), and the per-load tap decode disappears.
+template <int NT>
+__global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
+                                                                const u32x4 *__restrict__ wimg,
+                                                                const float *__restrict__ bias,
+                                                                float *__restrict__ out, ConvGeom g) {
+    constexpr int MT = 2, PX = 64, PLANE = (PX + 1) * 2;        // u32x4 per (k-step, term) plane: [pixel + zero][half]
+    constexpr int TILE4 = 2 * 3 * PLANE;                         // [k-step 2][term 3][PLANE]
+    constexpr int CH4 = NT * 384;
+    __shared__ u32x4 Bs[2][CH4];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    const int phase = blockIdx.y % g.nphase, nb = blockIdx.y / g.nphase;
+    const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
+    const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
+    const int ntaps = g.ntaps, cpt = g.cpt, nchunk = ntaps * cpt;
+
+    if (lane < 12) As[(lane >> 1) * PLANE + PX * 2 + (lane & 1)] = u32x4{0, 0, 0, 0};      // padding pixels
+
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < g.B;
+    const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * g.Cin;             // this lane's pixel row
+
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0;
+        for (int t = 0; t < ntaps; ++t) {
+            const int yy = y + (int)((dym >> (4 * t)) & 15) - 8, xx = x + (int)((dxm >> (4 * t)) & 15) - 8;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        }
+        tapok[mt] = m;
+    }
+
+    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 384;
+    const size_t wchunk = (size_t)g.ntile * 384;
+    constexpr int NBQ = CH4 / 256;                     // NT in {2, 4}: 3 or 6 u32x4 per thread
+    u32x4 b_nxt[NBQ];
+    auto load_b = [&](int c) {
+        const u32x4 *p = wbase + (size_t)c * wchunk;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) b_nxt[q] = p[tid + 256 * q];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + 256 * q] = b_nxt[q];
+    };
+    f32x4 raw[8];
+    auto load_raw = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(src + 32 * cc + 4 * j);
+    };
+    // park chunk `raw`: k-step t, operand half hh hold channels 16*hh + 8*t + [0,8) (the weight image's order)
+    auto stage = [&]() {
+        if (relu_in) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = relu4(raw[j]);
+        }
+        u32x4 *dst = As + lane * 2;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                u32x4 t1, t2, t3;
+                split8(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], t1, t2, t3);
+                dst[(t * 3 + 0) * PLANE + hh] = t1;
+                dst[(t * 3 + 1) * PLANE + hh] = t2;
+                dst[(t * 3 + 2) * PLANE + hh] = t3;
+            }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    // iteration it = cc * ntaps + tap  ->  weight chunk tap * cpt + cc
+    const int niter = nchunk;
+    load_raw(0);
+    load_b(0);
+    store_b(0);
+    if (niter > 1) load_b(ntaps > 1 ? cpt : 1);
+    int cc = 0, tap = 0;
+    for (int it = 0; it < niter; ++it) {
+        if (tap == 0) {
+            // the tile is wave-private and a wave's LDS operations execute in order: the previous chunk's
+            // operand reads are behind us, no barrier needed to overwrite it
+            stage();
+            if (cc + 1 < cpt) load_raw(cc + 1);
+        }
+        __syncthreads();                                   // weights of this iteration + (tap 0) the fresh tile
+        const u32x4 *bs = Bs[it & 1];
+        const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm >> (4 * tap)) & 15) - 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            bf16x8 A[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + (t * 3) * PLANE + p * 2 + h;
+                A[mt][0] = __builtin_bit_cast(bf16x8, ap[0]);
+                A[mt][1] = __builtin_bit_cast(bf16x8, ap[PLANE]);
+                A[mt][2] = __builtin_bit_cast(bf16x8, ap[2 * PLANE]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 *bp = bs + nt * 384 + (t * 2 + h) * 32 + l31;
+                const bf16x8 B1 = __builtin_bit_cast(bf16x8, bp[0]), B2 = __builtin_bit_cast(bf16x8, bp[128]),
+                             B3 = __builtin_bit_cast(bf16x8, bp[256]);
+                // smallest terms first; the two pixel tiles alternate accumulators
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][2], B1, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], B2, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], B3, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][1], B1, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], B2, acc[mt][nt], 0, 0, 0);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[mt][0], B1, acc[mt][nt], 0, 0, 0);
+            }
+        }
+        // next iteration's weights: registers -> the other LDS buffer (its last readers passed the barrier above);
+        // then fetch the iteration after that
+        int ntap = tap + 1, ncc = cc;
+        if (ntap == ntaps) { ntap = 0; ++ncc; }
+        if (it + 1 < niter) {
+            store_b((it + 1) & 1);
+            int t2 = ntap + 1, c2 = ncc;
+            if (t2 == ntaps) { t2 = 0; ++c2; }
+            if (it + 2 < niter) load_b(t2 * cpt + c2);
+        }
+        tap = ntap; cc = ncc;
+    }
+
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nb * NT + nt) * 32 + l31;
+        bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+    }
+    if (img_ok) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = 32 * mt + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int gy = px >> 3, gx = px & 7;
+                const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
+                                       g.opx[phase]) * (long long)g.Cout;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int n = (nb * NT + nt) * 32 + l31;
+                    if (n < g.Cout) {
+                        float v = acc[mt][nt][r] + bv[nt];
+                        if (relu_out) v = fmaxf(v, 0.0f);
+                        out[off + n] = v;
+                    }
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer on the split-bf16 product path (same math and layout as res_layer_kernel below;
 // see conv_igemm_bf3_kernel for the split).  GEMM1 (3x3, C -> 32 hidden) is barrier-free: each wave
 // reads its 6-KiB weight chunk (three bf16 terms) straight from L1/L2 next to its A operands.
@@ -1437,7 +1621,11 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
         // default: split-bf16 products on the bf16 matrix cores (fp32-grade accuracy, ~2.7x the rate)
         const u32x4 *img3 = reinterpret_cast<const u32x4 *>(packed + packed_floats(g));
         const unsigned gx = (unsigned)((M + 127) / 128);
-        if (g.ntile % 4 == 0)
+        if (g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0)
+            // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps
+            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2>), dim3((unsigned)((B + 3) / 4), g.nphase * (g.ntile / 2)),
+                               dim3(256), 0, st, x, img3, bias, y, g);
+        else if (g.ntile % 4 == 0)
             hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
                                img3, bias, y, g);
         else if (g.ntile % 2 == 0)
