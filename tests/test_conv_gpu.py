@@ -36,6 +36,7 @@ CONV_CASES = [
     # kind name, module ctor, B, Cin, H, W
     ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 3, 64, 128, 16, 16),
     ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 2, 32, 64, 12, 20),
+    ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 5, 32, 64, 16, 16),     # space-to-depth tile kernel, ragged batch
     ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1), 3, 128, 128, 8, 8),
     ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1, bias=False), 2, 128, 32, 7, 9),
     ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1), 1, 16, 48, 5, 5),      # Cin < 32, Cout not /32

@@ -44,6 +44,7 @@ struct ConvGeom {
     unsigned long long dymask[4], dxmask[4];   // 4 bits per tap: (dy + 8), (dx + 8) -- scalar decode
     int kk;                     // kh*kw
     int transposed;             // weight is (Cin,Cout,kh,kw)
+    int s2d;                    // pack only: space-to-depth chunk order of the 4x4 s2 conv (conv_tile8_bf3_kernel<., true>)
 };
 
 constexpr int kFlagReluIn = 1, kFlagReluOut = 2;
@@ -325,14 +326,26 @@ __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restr
         const int nchunk = g.ntaps * g.cpt;
         const int chunk = (int)(r % nchunk);
         const int phase = (int)(r / nchunk);
-        const int tap = chunk / g.cpt, cc = chunk - tap * g.cpt;
-        const int ci = cc * 32 + 16 * hh + 8 * t + i, co = nt * 32 + n;
+        int ci, kyx;
+        const int co = nt * 32 + n;
+        if (g.s2d) {
+            // chunk = cc * 4 + vt: cc = (input sub-position (py,px) of the 2x2 block) * cpt + 32-channel slice,
+            // vt = (block offset ay + py, ax + px) in {0,1}^2;  ky = 2*ay + py + 1 (same for x)
+            const int cc = chunk >> 2, vt = chunk & 3;
+            const int sub = cc / g.cpt, sl = cc - sub * g.cpt;
+            const int py = sub >> 1, px = sub & 1;
+            const int ay = (vt >> 1) - py, ax = (vt & 1) - px;
+            kyx = (2 * ay + py + 1) * 4 + (2 * ax + px + 1);
+            ci = sl * 32 + 16 * hh + 8 * t + i;
+        } else {
+            const int tap = chunk / g.cpt, cc = chunk - tap * g.cpt;
+            ci = cc * 32 + 16 * hh + 8 * t + i;
+            kyx = g.kyx[phase][tap];
+        }
         float v = 0.0f;
-        if (ci < g.Cin && co < g.Cout) {
-            const int kyx = g.kyx[phase][tap];
+        if (ci < g.Cin && co < g.Cout)
             v = g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx]
                              : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
-        }
         const unsigned short b1 = f32_to_bf16_rne(v);
         const float r1 = v - __uint_as_float((unsigned)b1 << 16);
         const unsigned short b2 = f32_to_bf16_rne(r1);
@@ -534,7 +547,10 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 //   and shared by the workgroup's four images (256 pixels x 64 channels per workgroup and chunk).
 // Versus conv_igemm_bf3_kernel: activation traffic through L1/TA and the split VALU work drop by the number
 // of taps (9x / 4x), and the per-load tap decode disappears.
-template <int NT>
+// S2D: the 4x4 stride-2 conv on a 16x16 map, read as a conv over the 8x8 grid of 2x2 input blocks: a chunk is
+// (sub-position (py,px) of the block, 32-channel slice) and meets four block offsets ("virtual taps"), so every
+// input element is still split once and used four times (weights in the s2d chunk order, conv_pack_bf3_kernel).
+template <int NT, bool S2D>
 __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
                                                                 const u32x4 *__restrict__ wimg,
                                                                 const float *__restrict__ bias,
@@ -550,13 +566,15 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
     const int phase = blockIdx.y % g.nphase, nb = blockIdx.y / g.nphase;
     const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
-    const int ntaps = g.ntaps, cpt = g.cpt, nchunk = ntaps * cpt;
+    const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt, nchunk = ntaps * cpt;
 
     if (lane < 12) As[(lane >> 1) * PLANE + PX * 2 + (lane & 1)] = u32x4{0, 0, 0, 0};      // padding pixels
 
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < g.B;
-    const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * g.Cin;             // this lane's pixel row
+    // this lane's pixel row (S2D: the top-left pixel of this lane's 2x2 input block)
+    const float *src = S2D ? in + (((size_t)(img_ok ? img : 0) * 16 + 2 * (lane >> 3)) * 16 + 2 * (lane & 7)) * g.Cin
+                           : in + ((size_t)(img_ok ? img : 0) * PX + lane) * g.Cin;
 
     int spx[MT];
     unsigned tapok[MT];
@@ -565,9 +583,17 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
         spx[mt] = 32 * mt + l31;
         const int y = spx[mt] >> 3, x = spx[mt] & 7;
         unsigned m = 0;
-        for (int t = 0; t < ntaps; ++t) {
-            const int yy = y + (int)((dym >> (4 * t)) & 15) - 8, xx = x + (int)((dxm >> (4 * t)) & 15) - 8;
-            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        if (S2D) {
+            // bit sub*4 + vt: block offset (vt>>1) - py, (vt&1) - px
+            for (int q = 0; q < 16; ++q) {
+                const int yy = y + ((q >> 1) & 1) - (q >> 3), xx = x + (q & 1) - ((q >> 2) & 1);
+                if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << q;
+            }
+        } else {
+            for (int t = 0; t < ntaps; ++t) {
+                const int yy = y + (int)((dym >> (4 * t)) & 15) - 8, xx = x + (int)((dxm >> (4 * t)) & 15) - 8;
+                if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+            }
         }
         tapok[mt] = m;
     }
@@ -587,8 +613,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
     };
     f32x4 raw[8];
     auto load_raw = [&](int cc) {
+        const float *q = src + 32 * cc;
+        if (S2D) {
+            const int sub = cc / g.cpt, sl = cc - sub * g.cpt;
+            q = src + ((sub >> 1) * 16 + (sub & 1)) * g.Cin + 32 * sl;
+        }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(src + 32 * cc + 4 * j);
+        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(q + 4 * j);
     };
     // park chunk `raw`: k-step t, operand half hh hold channels 16*hh + 8*t + [0,8) (the weight image's order)
     auto stage = [&]() {
@@ -622,7 +653,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
     load_raw(0);
     load_b(0);
     store_b(0);
-    if (niter > 1) load_b(ntaps > 1 ? cpt : 1);
+    if (niter > 1) load_b(S2D ? 1 : (ntaps > 1 ? cpt : 1));
     int cc = 0, tap = 0;
     for (int it = 0; it < niter; ++it) {
         if (tap == 0) {
@@ -633,13 +664,21 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
         }
         __syncthreads();                                   // weights of this iteration + (tap 0) the fresh tile
         const u32x4 *bs = Bs[it & 1];
-        const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm >> (4 * tap)) & 15) - 8);
+        int shift, okbit;
+        if (S2D) {
+            const int sub = cc / g.cpt;
+            shift = ((tap >> 1) - (sub >> 1)) * 8 + ((tap & 1) - (sub & 1));
+            okbit = sub * 4 + tap;
+        } else {
+            shift = ((int)((dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm >> (4 * tap)) & 15) - 8);
+            okbit = tap;
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             bf16x8 A[MT][3];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const int p = ((tapok[mt] >> okbit) & 1u) ? spx[mt] + shift : PX;
                 const u32x4 *ap = As + (t * 3) * PLANE + p * 2 + h;
                 A[mt][0] = __builtin_bit_cast(bf16x8, ap[0]);
                 A[mt][1] = __builtin_bit_cast(bf16x8, ap[PLANE]);
@@ -673,7 +712,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
             store_b((it + 1) & 1);
             int t2 = ntap + 1, c2 = ncc;
             if (t2 == ntaps) { t2 = 0; ++c2; }
-            if (it + 2 < niter) load_b(t2 * cpt + c2);
+            if (it + 2 < niter) load_b(S2D ? c2 * 4 + t2 : t2 * cpt + c2);
         }
         tap = ntap; cc = ncc;
     }
@@ -1583,8 +1622,8 @@ extern "C" {
 size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout) {
     ConvGeom g;
     if (Cin < 1 || Cout < 1 || make_geom(kind, 1, 4, 4, Cin, Cout, 0, g) != VQVAE_OK) return 0;
-    // [fp32 B-operand image][split-bf16 image]
-    return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g);
+    // [fp32 B-operand image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]
+    return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
 }
 
 int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -1602,6 +1641,11 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
     const long long total3 = total;
     hipLaunchKernelGGL(conv_pack_bf3_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
                        reinterpret_cast<unsigned short *>(packed + total), g, total3);
+    if (kind == VQVAE_CONV_4x4_S2) {
+        g.s2d = 1;
+        hipLaunchKernelGGL(conv_pack_bf3_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                           reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2, g, total3);
+    }
     return (int)hipGetLastError();
 }
 
@@ -1623,8 +1667,12 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
         const unsigned gx = (unsigned)((M + 127) / 128);
         if (g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0)
             // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps
-            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2>), dim3((unsigned)((B + 3) / 4), g.nphase * (g.ntile / 2)),
+            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false>), dim3((unsigned)((B + 3) / 4), g.nphase * (g.ntile / 2)),
                                dim3(256), 0, st, x, img3, bias, y, g);
+        else if (kind == VQVAE_CONV_4x4_S2 && g.Hin == 16 && g.Win == 16 && Cin % 32 == 0 && g.ntile % 2 == 0)
+            // 16x16 -> 8x8: the same kernel over 2x2 input blocks, weights in the s2d chunk order (third image)
+            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true>), dim3((unsigned)((B + 3) / 4), g.ntile / 2), dim3(256), 0,
+                               st, x, img3 + packed_bf3_bytes(g) / sizeof(u32x4), bias, y, g);
         else if (g.ntile % 4 == 0)
             hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
                                img3, bias, y, g);
