@@ -44,6 +44,26 @@ for name, kind, m, shp, ci, co, macs in cases:
     us = timeit(lambda: conv_hip.conv(kind, x, m, m.weight, m.bias, ci, co, flags))
     tot += us
     print(f"{name:22s} {us:7.1f} us  {12 * macs * B / us / 1e6:6.0f} TF")
+from vqvae_amd.modules import Decoder, Encoder
+enc, dec = Encoder(3, 128, 2, 32).to(dev), Decoder(64, 128, 2, 32).to(dev)
+L = _lib.load()
+ximg = torch.randn(B, 3, 32, 32, device=dev)
+c0 = enc.conv_stack[0]
+p0 = conv_hip._packed(c0, ("conv_in",), c0.weight, lambda: L.vqvae_conv_in_packed_bytes(3, 64),
+                      lambda w, buf: L.vqvae_conv_in_pack_f32(w.data_ptr(), 3, 64, buf.data_ptr(), None))
+y0 = torch.empty(B, 16, 16, 64, device=dev)
+us = timeit(lambda: _lib.check(L.vqvae_conv_in_forward_f32(ximg.data_ptr(), p0.data_ptr(), c0.bias.data_ptr(), B, 32, 32, 3, 64, 2,
+                                                           y0.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+tot += us
+print(f"{'conv_in 4x4s2 3->64':22s} {us:7.1f} us  {(B * 256 * 64 * 4 + B * 3072 * 4) / us / 1e3:6.0f} GB/s")
+d4 = dec.inverse_conv_stack[4]
+p4 = conv_hip._packed(d4, ("convt_out",), d4.weight, lambda: L.vqvae_convt_out_packed_bytes(64, 3),
+                      lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), 64, 3, buf.data_ptr(), None))
+xh = torch.empty(B, 3, 32, 32, device=dev)
+us = timeit(lambda: _lib.check(L.vqvae_convt_out_forward_f32(y0.data_ptr(), p4.data_ptr(), d4.bias.data_ptr(), B, 16, 16, 64, 3,
+                                                             xh.data_ptr(), torch.cuda.current_stream().cuda_stream)))
+tot += us
+print(f"{'convT_out 4x4s2 64->3':22s} {us:7.1f} us  {(B * 256 * 64 * 4 + B * 3072 * 4) / us / 1e3:6.0f} GB/s")
 layer = ResidualLayer(128, 128, 32).to(dev)
 x = torch.randn(B, 8, 8, 128, device=dev)
 us = timeit(lambda: conv_hip.res_layer(x, layer, 2 | (flags & 4)))

@@ -66,6 +66,28 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     return v;
 }
 
+// Epilogue helper: move one 32-pixel x 32-channel accumulator tile (this wave's) through a wave-private
+// 32 x 36-float LDS tile so that every lane ends up with 8 consecutive channels of one pixel, and finish it
+// there with 16-byte accesses.  fin(p, n, a, b): pixel row p of the tile (0..31), first channel n, the two
+// float4 of accumulator values.  Dword stores straight from the accumulator layout cost ~6x more per byte.
+template <typename Fin>
+__device__ __forceinline__ void tile_epilogue(float *tile, const float (&v)[16], int lane, int nbase, Fin fin) {
+    const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = v[r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    const int g8 = (lane & 3) * 8;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int p = (lane >> 2) + 16 * u;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(tile + p * 36 + g8);
+        const f32x4 b = *reinterpret_cast<const f32x4 *>(tile + p * 36 + g8 + 4);
+        fin(p, nbase + g8, a, b);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // ---------------------------------------------------------------------------
 // Weight packing (once per layer / weight version).
 __global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ w, float *__restrict__ img,
@@ -723,7 +745,29 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
     }
-    if (img_ok) {
+    if (img_ok && (g.Cout & 7) == 0) {
+        // the operand tile is free now (wave-private): stage the outputs through it, 16-byte stores
+        float *tile = reinterpret_cast<float *>(As);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[mt][nt][r] + bv[nt];
+                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                }
+                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, f32x4 b) {
+                    const int px = 32 * mt + p;
+                    const int gy = px >> 3, gx = px & 7;
+                    const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
+                                           g.opx[phase]) * (long long)g.Cout;
+                    *reinterpret_cast<f32x4 *>(out + off + n) = a;
+                    *reinterpret_cast<f32x4 *>(out + off + n + 4) = b;
+                });
+            }
+    } else if (img_ok) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1093,18 +1137,22 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
             prod6(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
         }
         if (img_ok) {
+            // skip connection, activation and store in the staged layout: 16-byte loads and stores
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt) {
+                float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    const int n = nt * 32 + l31;
-                    float u = in[prow * C + n];
-                    if (relu_in) u = fmaxf(u, 0.0f);
-                    float v = u + acc2[mt][r];
-                    if (relu_out) v = fmaxf(v, 0.0f);
-                    out[prow * C + n] = v;
-                }
+                for (int r = 0; r < 16; ++r) v[r] = acc2[mt][r];
+                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, f32x4 b4) {
+                    const long long o = (wbase + mt * 32 + p) * C + n;
+                    f32x4 u0 = *reinterpret_cast<const f32x4 *>(in + o), u1 = *reinterpret_cast<const f32x4 *>(in + o + 4);
+                    if (relu_in) { u0 = relu4(u0); u1 = relu4(u1); }
+                    f32x4 y0 = u0 + a4, y1 = u1 + b4;
+                    if (relu_out) { y0 = relu4(y0); y1 = relu4(y1); }
+                    *reinterpret_cast<f32x4 *>(out + o) = y0;
+                    *reinterpret_cast<f32x4 *>(out + o + 4) = y1;
+                });
+            }
         }
     }
 }
@@ -1373,6 +1421,128 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
         }
 }
 
+// Same layer when a workgroup's 256 output pixels are whole output rows of one image (Wg | 256 and
+// 256 | Hg*Wg: 32x32 and 256x256 images): the 2R+2 input rows the band needs are staged once in LDS with
+// coalesced 16-byte loads and a zero border, and the 8*CIN gathers per pixel become LDS reads without
+// bounds checks (the plain kernel issues them as predicated 4-byte global loads).
+template <int CIN, int NT>
+__global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restrict__ x,
+                                                           const float *__restrict__ wimg,
+                                                           const float *__restrict__ bias,
+                                                           float *__restrict__ out, int B, int H, int W,
+                                                           int Cout, int flags) {
+    constexpr int MT = 2, S = CIN * 8, JG = (S + 3) / 4;
+    extern __shared__ __attribute__((aligned(16))) float smem_ci[];
+    float *Ws = smem_ci;                                   // [NT * JG * 256]
+    float *Xs = smem_ci + NT * JG * 256;                   // [CIN][2R + 2][W + 8], column ix at 4 + ix
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int Hg = H / 2, Wg = W / 2;
+    const int R = 256 / Wg, NR = 2 * R + 2, XS = W + 8;
+    const long long band = blockIdx.x;                     // 256 consecutive output pixels = R output rows
+    const long long b = band / (Hg / R);
+    const int gy0 = (int)(band - b * (Hg / R)) * R;
+    const int iy0 = 2 * gy0 - 1;
+    for (int i = tid; i < NT * JG * 64; i += 256)
+        reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
+    const int w4 = W / 4;
+    for (int i = tid; i < CIN * NR * w4; i += 256) {
+        const int x4 = i % w4, q = i / w4;
+        const int r = q % NR, ci = q / NR;
+        const int iy = iy0 + r;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (iy >= 0 && iy < H) v = *reinterpret_cast<const f32x4 *>(x + ((b * CIN + ci) * H + iy) * (long long)W + 4 * x4);
+        *reinterpret_cast<f32x4 *>(Xs + (ci * NR + r) * XS + 4 + 4 * x4) = v;
+    }
+    for (int i = tid; i < CIN * NR; i += 256) {            // the ix = -1 and ix = W columns
+        Xs[i * XS + 3] = 0.0f;
+        Xs[i * XS + 4 + W] = 0.0f;
+    }
+    __syncthreads();
+
+    float a[MT][JG * 4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = wave * (32 * MT) + mt * 32 + l31;    // pixel within the band
+        const int ly = p / Wg, gx = p - ly * Wg;
+        const float *base = Xs + (2 * ly) * XS + 2 * gx + 2 * h + 3;
+#pragma unroll
+        for (int s = 0; s < JG * 4; ++s) {
+            float v = 0.0f;
+            if (s < S) {
+                const int ci = s >> 3, ky = (s >> 1) & 3, kxl = s & 1;
+                v = base[(ci * NR + ky) * XS + kxl];
+            }
+            a[mt][s] = v;
+        }
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws);
+#pragma unroll
+    for (int j = 0; j < JG; ++j) {
+        f32x4 b4[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) b4[nt] = ws[((nt * JG + j) * 2 + h) * 32 + l31];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][4 * j + i], b4[nt][i],
+                                                                       acc[mt][nt], 0, 0, 0);
+    }
+    const bool relu_out = flags & kFlagReluOut;
+    const long long wbase = band * 256 + wave * (32 * MT);
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && nt * 32 + l31 < Cout) ? bias[nt * 32 + l31] : 0.0f;
+    if ((Cout & 7) == 0) {
+        __syncthreads();                                   // every wave is done with Ws / Xs: reuse them as output tiles
+        float *tile = smem_ci + wave * (32 * 36);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[mt][nt][r] + bv[nt];
+                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                }
+                tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, f32x4 b4) {
+                    if (n < Cout) {
+                        float *o = out + (wbase + mt * 32 + p) * Cout + n;
+                        *reinterpret_cast<f32x4 *>(o) = a4;
+                        *reinterpret_cast<f32x4 *>(o + 4) = b4;
+                    }
+                });
+            }
+        return;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = nt * 32 + l31;
+                if (n < Cout) {
+                    float v = acc[mt][nt][r] + bv[nt];
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    out[prow * Cout + n] = v;
+                }
+            }
+        }
+}
+
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float *__restrict__ w, float *__restrict__ img,
                                                            int Cout, int ntile) {
@@ -1407,7 +1577,8 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                                                         float *__restrict__ out, int B, int H, int W,
                                                         int Cin, int Cout, int TH, int TW, int halo_y,
                                                         int halo_x, int tiles_y, int tiles_x) {
-    constexpr int MT = 2, STRIDE = NT * 32 + 1;
+    constexpr int MT = 2;
+    const int STRIDE = 16 * Cout + 1;              // T row: the 16*Cout used columns (odd stride: conflict-free)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cpt = (Cin + 31) / 32;
     float *Ws = smem;                               // [cpt][NT][1024]
@@ -1441,9 +1612,9 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         ok[mt] = iy >= 0 && iy < H && ix >= 0 && ix < W;
         src[mt] = in + ((b * H + iy) * (long long)W + ix) * Cin + 16 * h;
     }
-    __syncthreads();
-    for (int c = 0; c < cpt; ++c) {
-        f32x4 a[MT][4];
+    // A operands: chunk c+1 is in flight while chunk c multiplies (two register sets); chunk 0 is requested
+    // before the barrier so its latency overlaps the weight copy
+    auto load_a = [&](int c, f32x4(&a)[MT][4]) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -1453,6 +1624,8 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                     v = *reinterpret_cast<const f32x4 *>(src[mt] + c * 32 + 4 * j);
                 a[mt][j] = v;
             }
+    };
+    auto mma = [&](int c, const f32x4(&a)[MT][4]) {
         const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws + (size_t)c * NT * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1468,6 +1641,17 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][j][i], b4[nt][i], acc[mt][nt],
                                                                            0, 0, 0);
         }
+    };
+    f32x4 a0[MT][4], a1[MT][4];
+    load_a(0, a0);
+    __syncthreads();
+    for (int c = 0; c < cpt; c += 2) {
+        if (c + 1 < cpt) load_a(c + 1, a1);
+        mma(c, a0);
+        if (c + 1 < cpt) {
+            if (c + 2 < cpt) load_a(c + 2, a0);
+            mma(c + 1, a1);
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1475,19 +1659,15 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         for (int r = 0; r < 16; ++r) {
             const int p = wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) Ts[p * STRIDE + nt * 32 + l31] = acc[mt][nt][r];
+            for (int nt = 0; nt < NT; ++nt)
+                if (nt * 32 + l31 < STRIDE - 1) Ts[p * STRIDE + nt * 32 + l31] = acc[mt][nt][r];
         }
     __syncthreads();
 
     // col2im over the interior's outputs, ox fastest (coalesced NCHW rows)
     const int th = min(TH, H - y0), tw = min(TW, W - x0);
     const int OH = 2 * th, OW = 2 * tw, Ho = 2 * H, Wo = 2 * W;
-    const int total = Cout * OH * OW;
-    for (int e = tid; e < total; e += 256) {
-        const int oxl = e % OW;
-        const int q = e / OW;
-        const int oyl = q % OH, co = q / OH;
-        const int oy = 2 * y0 + oyl, ox = 2 * x0 + oxl;
+    auto gather = [&](int co, int oy, int ox) -> float {
         float s = bias ? bias[co] : 0.0f;
 #pragma unroll
         for (int a2 = 0; a2 < 2; ++a2) {
@@ -1502,7 +1682,29 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                 s += Ts[((iy - ry) * 16 + (ix - rx)) * STRIDE + (ky * 4 + kx) * Cout + co];
             }
         }
-        out[((b * Cout + co) * Ho + oy) * (long long)Wo + ox] = s;
+        return s;
+    };
+    if ((OW & 3) == 0 && (Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
+        // four consecutive ox per thread: one 16-byte store per quad
+        const int qw = OW >> 2, nquad = Cout * OH * qw;
+        for (int e = tid; e < nquad; e += 256) {
+            const int xq = e % qw;
+            const int q = e / qw;
+            const int oyl = q % OH, co = q / OH;
+            const int oy = 2 * y0 + oyl, ox = 2 * x0 + 4 * xq;
+            f32x4 v;
+            v.x = gather(co, oy, ox); v.y = gather(co, oy, ox + 1); v.z = gather(co, oy, ox + 2); v.w = gather(co, oy, ox + 3);
+            *reinterpret_cast<f32x4 *>(out + ((b * Cout + co) * Ho + oy) * (long long)Wo + ox) = v;
+        }
+    } else {
+        const int total = Cout * OH * OW;
+        for (int e = tid; e < total; e += 256) {
+            const int oxl = e % OW;
+            const int q = e / OW;
+            const int oyl = q % OH, co = q / OH;
+            const int oy = 2 * y0 + oyl, ox = 2 * x0 + oxl;
+            out[((b * Cout + co) * Ho + oy) * (long long)Wo + ox] = gather(co, oy, ox);
+        }
     }
 }
 
@@ -1654,6 +1856,7 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
     if (!x || !packed || !y) return VQVAE_ERR_NULL;
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return VQVAE_ERR_SHAPE;
     if (Cin % 4) return VQVAE_ERR_UNSUPPORTED;          // float4 activation loads
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte accesses
     if (B * (int64_t)H * W * 4 > (int64_t)INT32_MAX * 4 || B > INT32_MAX) return VQVAE_ERR_OVERFLOW;
     ConvGeom g;
     int rc = make_geom(kind, B, H, W, Cin, Cout, flags, g);
@@ -1706,6 +1909,7 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
     if (B < 1 || H < 1 || W < 1 || C < 1 || Rh < 1) return VQVAE_ERR_SHAPE;
     if (Rh > 32 || C % 4 || !(C == 32 || C == 64 || C == 128)) return VQVAE_ERR_UNSUPPORTED;
     if (x == y) return VQVAE_ERR_UNSUPPORTED;           // 3x3 halo: not in place
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte accesses
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long M = (long long)B * H * W;
     const unsigned gx = (unsigned)((M + 255) / 256);
@@ -1768,7 +1972,22 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
     const unsigned gx = (unsigned)((M + 255) / 256);
     const int ntile = (Cout + 31) / 32;
     prof_begin(VQVAE_PROF_CONV_IN, st);
-#define CI_LAUNCH(CIN_, NT_) hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y, (int)B, H, W, Cout, flags)
+    // whole output rows per workgroup -> LDS-staged input band (conv_in_rows_kernel)
+    const int Hg = H / 2, Wg = W / 2;
+    const bool rows = Wg <= 256 && 256 % Wg == 0 && ((long long)Hg * Wg) % 256 == 0 && W % 4 == 0 &&
+                      ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
+    const int jg = (Cin * 8 + 3) / 4;
+    size_t rows_lds = rows ? ((size_t)ntile * jg * 256 + (size_t)Cin * (2 * (256 / Wg) + 2) * (W + 8)) * sizeof(float) : 0;
+    if (rows_lds < 4 * 32 * 36 * sizeof(float)) rows_lds = 4 * 32 * 36 * sizeof(float);   // the epilogue's output tiles
+#define CI_LAUNCH(CIN_, NT_)                                                                                       \
+    do {                                                                                                           \
+        if (rows && rows_lds <= 64 * 1024)                                                                         \
+            hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_>), dim3(gx), dim3(256), rows_lds, st, x_nchw, packed, \
+                               bias, y, (int)B, H, W, Cout, flags);                                                \
+        else                                                                                                       \
+            hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
+                               (int)B, H, W, Cout, flags);                                                         \
+    } while (0)
 #define CI_NT(CIN_)                                                       \
     switch (ntile) {                                                      \
         case 1: CI_LAUNCH(CIN_, 1); break;                                \
@@ -1813,7 +2032,7 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
     const long long ntiles = B * (long long)tiles_y * tiles_x;
     if (ntiles > INT32_MAX) return VQVAE_ERR_OVERFLOW;
     const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
-    const size_t lds = ((size_t)cpt * ntile * 1024 + 256 * (ntile * 32 + 1)) * sizeof(float);
+    const size_t lds = ((size_t)cpt * ntile * 1024 + 256 * (16 * Cout + 1)) * sizeof(float);
     prof_begin(VQVAE_PROF_CONV_OUT, st);
     if (ntile == 1) {
         auto k = convt_out_kernel<1>;
