@@ -145,3 +145,46 @@ def test_large_batch_config3_properties():
     assert torch.equal(x_hat[:2048], xh0) and torch.equal(x_hat[2048:], xh1)
     np.testing.assert_allclose(loss.item(), 0.5 * (l0.item() + l1.item()), rtol=1e-5)
     assert torch.isfinite(x_hat).all()
+
+
+# BASELINE configs 4 and 5 (and an odd-sized one) at batch 1-2: the generic (non-tile) conv kernels, the
+# chunked-codebook exact VQ kernel and the halo-tiled last layer, stage by stage against the live CPU oracle
+# (oracle/torch_port.py issues the reference's ATen ops).  Each stage is fed the ORACLE's input bits so a
+# near-tie index flip cannot blur the comparison of the later stages.
+BIG_SHAPES = {
+    # name: h_dim, res_h, n_res, K, D, B, H, W
+    "c4_224_k1024_d64": (128, 32, 2, 1024, 64, 1, 224, 224),
+    "c5_256_k8192_d128": (128, 32, 2, 8192, 128, 1, 256, 256),
+    "odd_40x56_k100_d32": (64, 16, 2, 100, 32, 2, 40, 56),
+}
+
+
+@pytest.mark.parametrize("name", list(BIG_SHAPES))
+def test_large_and_odd_shapes_stagewise_vs_oracle(name):
+    from oracle import torch_port
+    from vqvae_amd import conv, conv_hip
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    h, rh, nl, K, D, B, H, W = BIG_SHAPES[name]
+    torch.manual_seed(0)
+    m = VQVAE(h, rh, nl, K, D, 0.25).eval()
+    x = torch.randn(B, 3, H, W)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        z_e_ref = torch_port.encode(sd, x.clone(), nl)
+        loss_ref, z_q_ref, ppl_ref, _, idx_ref = torch_port.quantize(z_e_ref, sd["vector_quantization.embedding.weight"], 0.25)
+        x_hat_ref = torch_port.decode(sd, z_q_ref.clone(), nl)
+    md = m.to(dev())
+    with torch.no_grad():
+        z_e = conv_hip.encoder_forward(md.encoder, x.to(dev()), md.pre_quantization_conv)      # (B,h,w,D)
+        np.testing.assert_allclose(z_e.permute(0, 3, 1, 2).cpu().numpy(), z_e_ref.numpy(), atol=2e-6, rtol=0)
+        loss, z_q, ppl, _, idx = md.vector_quantization(z_e_ref.to(dev()))                        # P0: same z_e bits
+        assert torch.equal(idx.cpu(), idx_ref), "indices must be bit-exact on identical z_e bits"
+        assert torch.equal(z_q.cpu(), z_q_ref)
+        np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-6)
+        np.testing.assert_allclose(ppl.item(), ppl_ref.item(), rtol=1e-5)
+        x_hat = md.decoder(z_q_ref.to(dev()))
+        np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.numpy(), atol=1e-5, rtol=1e-4)
+        # and the composed forward runs and agrees wherever no index flipped
+        loss2, x_hat2, ppl2 = md(x.to(dev()))
+        assert x_hat2.shape == x.shape and torch.isfinite(x_hat2).all() and torch.isfinite(loss2)
