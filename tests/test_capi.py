@@ -61,6 +61,36 @@ def test_argument_errors_without_gpu(lib):
     assert f(one, one, 1, 64, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 16, None) == -4
 
 
+def test_conv_and_training_argument_errors_without_gpu():
+    """Same for the conv / residual / training entry points: NULL, shape, unsupported and alignment errors
+    come back as negative codes before anything is launched."""
+    from vqvae_amd import _lib
+    L = _lib.load()
+    a = 256                                   # a fake, 16-byte aligned "device pointer" (never dereferenced)
+    assert L.vqvae_conv_packed_bytes(1, 128, 128) > 0
+    assert L.vqvae_conv_packed_bytes(9, 128, 128) == 0                                   # unknown kind
+    assert L.vqvae_conv_packed_bytes(0, 64, 128) > 2 * L.vqvae_conv_packed_bytes(1, 64, 128) * 16 // 9 // 2
+    assert L.vqvae_conv_forward_f32(1, None, a, a, 1, 8, 8, 128, 128, 0, a, None) == -1
+    assert L.vqvae_conv_forward_f32(1, a, a, a, 0, 8, 8, 128, 128, 0, a, None) == -2
+    assert L.vqvae_conv_forward_f32(1, a, a, a, 1, 8, 8, 126, 128, 0, a, None) == -3        # Cin % 4
+    assert L.vqvae_conv_forward_f32(1, a + 4, a, a, 1, 8, 8, 128, 128, 0, a, None) == -3    # misaligned x
+    assert L.vqvae_conv_forward_f32(0, a, a, a, 1, 7, 8, 128, 128, 0, a, None) == -3        # odd H for stride 2
+    assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 96, 32, 0, a + 4096, None) == -3   # C not in {32,64,128}
+    assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 128, 64, 0, a + 4096, None) == -3  # res_h > 32
+    assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 128, 32, 0, a, None) == -3         # in place
+    assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 31, 32, 3, 64, 0, a, None) == -3
+    assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 32, 32, 2, 64, 0, a, None) == -3           # Cin not in {1,3,4}
+    assert L.vqvae_convt_out_forward_f32(a, a, a, 1, 16, 16, 64, 5, a, None) == -3            # Cout > 4
+    assert L.vqvae_vq_backward_workspace_bytes(2048, 512, 64) > 2048 * 16
+    assert L.vqvae_vq_backward_workspace_bytes(2048, 20000, 64) == 0
+    assert L.vqvae_vq_backward_f32(a, a, None, None, None, 1, 64, 8, 8, 512, 0.25, 0, a, a, a, 1 << 30, None) == -1
+    assert L.vqvae_vq_backward_f32(a, a, a, None, None, 1, 64, 8, 8, 512, 0.25, 0, None, a, a, 16, None) == -4
+    assert L.vqvae_recon_loss_f32(a, a, 0, 1.0, None, None, a, a, 1 << 20, None) == -2
+    assert L.vqvae_recon_loss_f32(a, a + 4, 16, 1.0, None, None, a, a, 1 << 20, None) == -3
+    assert L.vqvae_recon_loss_f32(a, a, 16, 1.0, None, None, a, a, 8, None) == -4
+    assert L.vqvae_transpose_f32(None, 1, 8, 8, a, None) == -1
+
+
 def test_product_path_does_not_import_oracle():
     """The shipped package must not import, link or execute oracle/ (test infrastructure)."""
     pat = re.compile(r"(^|\s)(from|import)\s+oracle\b|libvqvae_oracle|oracle[/.](c_oracle|torch_port|vqvae_oracle)")
