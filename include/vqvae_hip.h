@@ -125,8 +125,13 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
  * and, for callers that use sub-modules directly, through vqvae_transpose_f32.
  * Weights are passed PACKED: vqvae_*_pack_f32 rewrites a torch-layout weight into the
  * MFMA B-operand image once per weight version (bytes from vqvae_*_packed_bytes).
- * All convs compute in exact fp32 on the matrix cores; parity with the reference is
- * tolerance-level (oneDNN's summation order is opaque): |y - y_ref| <= 1e-5 + 1e-4|y_ref|. */
+ * fp32 in, fp32 out, fp32 accumulation.  By default products are formed from exact three-term bf16 splits of
+ * both fp32 operands on the bf16 matrix cores (per-product error <= 3*2^-24, fp32-grade);
+ * VQVAE_CONV_EXACT_FP32 selects the exact-fp32 MFMA kernels.  Parity with the reference is
+ * tolerance-level either way (oneDNN's summation order is opaque): |y - y_ref| <= 1e-5 + 1e-4|y_ref|.
+ * All activation pointers must be 16-byte aligned (VQVAE_ERR_UNSUPPORTED otherwise).
+ * Shapes the reference uses at 32x32 images (8x8 maps, and the 4x4 s2 conv on 16x16 maps) take
+ * tile-resident kernels (one image per wavefront); every other shape takes the generic implicit-GEMM ones. */
 #define VQVAE_CONV_4x4_S2   0   /* nn.Conv2d(k=4,s=2,p=1), weight (Cout,Cin,4,4)   encoder.py:29-33 */
 #define VQVAE_CONV_3x3_S1   1   /* nn.Conv2d(k=3,s=1,p=1), weight (Cout,Cin,3,3)   encoder.py:35, residual.py:20 */
 #define VQVAE_CONV_1x1      2   /* nn.Conv2d(k=1),         weight (Cout,Cin,1,1)   vqvae.py:16, residual.py:23 */
@@ -145,7 +150,8 @@ VQVAE_API size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout);
 VQVAE_API int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed,
                                   vqvae_stream_t stream);
 /* y = conv(x) + bias [ReLU]; x (B,H,W,Cin) row-major, y (B,Hout,Wout,Cout) row-major; bias may be
- * NULL.  Cin must be a multiple of 4.  Replaces one nn.Conv2d / nn.ConvTranspose2d call.          */
+ * NULL.  Cin must be a multiple of 4.  Replaces one nn.Conv2d / nn.ConvTranspose2d call.
+ * packed: [fp32 image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]. */
 VQVAE_API int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias,
                                      int64_t B, int H, int W, int Cin, int Cout, int flags,
                                      float *y, vqvae_stream_t stream);
