@@ -91,13 +91,22 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a MI355X: the HIP path has no CPU fallback")
+    # dry-run switches for a 1-GPU box (exercise the N>1 control flow without N GPUs): all ranks on device 0
+    # and gloo for the barrier / max-reduce.  The driver's real runs use neither.
+    share_gpu = os.environ.get("VQVAE_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("VQVAE_BENCH_DIST_BACKEND", "nccl")
+    if share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
     n_gpus = world
 
@@ -140,7 +149,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(out[1]).all()
@@ -180,6 +189,23 @@ def main():
                     "sweeps the codebook twice on the bf16 matrix cores (2 x 2KD flop/row); an exhaustive "
                     "exact-fp32 sweep (VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic",
         }
+        # the convs dominate the step time: their matrix-pipe roofline next to the quantizer's HBM one.
+        # MAC*2 per image at 32x32: enc 4x4s2 16.8 M + enc 3x3 18.9 M + 1x1 1.05 M + dec convT3x3
+        # 9.4 M + dec convT4x4s2 16.8 M + 4 residual layers 21.0 M = 83.9 MF on the split-bf16 path (6 bf16 MFMA
+        # term products per fp32 product); the first/last layers (3.1 MF) run on the fp32 MFMA
+        roofline_conv = None
+        if workload == "c3" and "conv_igemm" in extra and "res_layer" in extra:
+            t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
+            bf16_tf = B * 83.9e6 * 6 / t_conv / 1e12
+            roofline_conv = {
+                "kernel": "conv_tile8_bf3_kernel + res_tile8_bf3_kernel (9 launches per step, split-bf16 products)",
+                "bound": "mfma", "achieved": round(bf16_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
+                "frac": round(bf16_tf / 2500.0, 4), "traffic": None,
+                "fp32_equivalent_tflops": round(bf16_tf / 6, 1), "ms_per_step": round(t_conv * 1e3, 4),
+                "note": "achieved = bf16 MFMA flop issued (6 term products per fp32 product) / live HIP-event time of "
+                        "those kernels; the matrix pipe sustains ~1900 TF with random operands "
+                        "(tools/ubench/mfma_bf16_peak.hip), 2500 TF is the dense spec peak",
+            }
         line = {
             "metric": METRIC, "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -196,6 +222,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * n_gpus, "image": [3, H, W],
                        "K": K, "D": D, "parallelism": f"batch-sharded replicas x{n_gpus}, no collective"},
             "roofline": roofline,
+            "roofline_conv": roofline_conv,
             "kernels": extra,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
