@@ -1,0 +1,168 @@
+"""Seeded random-shape sweep through the C ABI (-m gpu): the quantizer against the C oracle (bit-exact
+indices / z_q), every conv kind and the fused residual layer against torch's CPU fp32 ops
+(|y - y_ref| <= 1e-5 + 1e-4 |y_ref|).  Shapes are drawn inside the documented support of each entry point,
+deliberately hitting ragged tails (pixel counts not a multiple of 32/64/128/256, odd maps, K not a multiple
+of 32, partial last workgroups) and both the tile-resident (8x8 / 16x16) and the generic kernels."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def _rng(seed):
+    return np.random.default_rng(seed)
+
+
+VQ_SEEDS = list(range(48))
+
+
+@pytest.mark.parametrize("seed", VQ_SEEDS)
+def test_vq_random_shapes_bit_exact(seed):
+    from oracle import c_oracle
+    from vqvae_amd import functional as Fh
+    r = _rng(1000 + seed)
+    D = int(r.choice([32, 64, 64, 64, 128, 256]))
+    K = int(r.integers(1, 700)) if seed % 3 else int(r.choice([1, 31, 32, 33, 512, 513, 1024]))
+    B, H, W = int(r.integers(1, 6)), int(r.integers(1, 12)), int(r.integers(1, 12))
+    kind = seed % 4
+    g = torch.Generator().manual_seed(seed)
+    if kind == 0:                                   # reference init scale: tiny margins
+        cb = (torch.rand(K, D, generator=g) * 2 - 1) / max(K, 2)
+        z = torch.randn(B, D, H, W, generator=g) * 0.07
+    elif kind == 1:                                 # unit normal
+        cb, z = torch.randn(K, D, generator=g), torch.randn(B, D, H, W, generator=g)
+    elif kind == 2:                                 # rows near codes (trained-like) with duplicated codes
+        cb = torch.randn(K, D, generator=g)
+        if K > 3:
+            cb[K // 2] = cb[0]
+        sel = torch.randint(0, K, (B * H * W,), generator=g)
+        z = (cb[sel] + 0.05 * torch.randn(B * H * W, D, generator=g)).view(B, H, W, D).permute(0, 3, 1, 2).contiguous()
+    else:                                           # wide dynamic range
+        cb = torch.randn(K, D, generator=g) * torch.logspace(-3, 2, K).unsqueeze(1)
+        z = torch.randn(B, D, H, W, generator=g) * 10
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    for rowmajor in (False, True):
+        zd = z.to(dev())
+        if rowmajor:
+            zd = zd.permute(0, 2, 3, 1).contiguous()
+        loss, z_q, ppl, idx, hist = Fh.vq_forward(zd, cb.to(dev()), 0.25, rowmajor=rowmajor)
+        if rowmajor:
+            z_q = z_q.permute(0, 3, 1, 2)
+        assert np.array_equal(idx.cpu().numpy(), ref["idx"]), f"K={K} D={D} N={B*H*W} kind={kind}"
+        assert np.array_equal(z_q.contiguous().cpu().numpy().view(np.uint32), ref["z_q"].view(np.uint32))
+        assert np.array_equal(hist.cpu().numpy(), ref["hist"])
+        np.testing.assert_allclose(loss.item(), ref["loss"], rtol=2e-6)
+        np.testing.assert_allclose(ppl.item(), ref["perplexity"], rtol=1e-5)
+
+
+CONV_SEEDS = list(range(90))
+
+
+@pytest.mark.parametrize("seed", CONV_SEEDS)
+def test_conv_random_shapes_vs_torch_cpu(seed):
+    from vqvae_amd import conv_hip
+    r = _rng(2000 + seed)
+    kind = int(r.integers(0, 5))
+    Cin = int(r.choice([4, 8, 16, 32, 64, 96, 128]))
+    Cout = int(r.choice([3, 8, 32, 48, 64, 128]))
+    B = int(r.integers(1, 7))
+    if seed % 3 == 0:                               # the benchmark's map sizes: tile-resident kernels
+        H = W = 16 if kind == 0 else 8
+    else:
+        H, W = int(r.integers(1, 8)) * 2, int(r.integers(1, 11)) * 2 if kind == 0 else int(r.integers(1, 19))
+        if kind != 0:
+            H = int(r.integers(1, 15))
+    bias = bool(r.integers(0, 2))
+    relu_in, relu_out = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+    torch.manual_seed(seed)
+    m = [lambda: nn.Conv2d(Cin, Cout, 4, 2, 1, bias=bias), lambda: nn.Conv2d(Cin, Cout, 3, 1, 1, bias=bias),
+         lambda: nn.Conv2d(Cin, Cout, 1, 1, 0, bias=bias), lambda: nn.ConvTranspose2d(Cin, Cout, 3, 1, 1, bias=bias),
+         lambda: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1, bias=bias)][kind]()
+    x = torch.randn(B, Cin, H, W)
+    with torch.no_grad():
+        ref = m(torch.relu(x) if relu_in else x)
+        if relu_out:
+            ref = torch.relu(ref)
+    md = m.to(dev())
+    for exact in (False, True):
+        flags = (1 if relu_in else 0) | (2 if relu_out else 0) | (4 if exact else 0)
+        y = conv_hip.conv(kind, x.to(dev()).permute(0, 2, 3, 1).contiguous(), md, md.weight, md.bias, Cin, Cout, flags)
+        np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-4,
+                                   err_msg=f"kind={kind} B={B} {Cin}->{Cout} {H}x{W} exact={exact}")
+
+
+@pytest.mark.parametrize("seed", list(range(30)))
+def test_res_layer_random_shapes_vs_torch_cpu(seed):
+    from vqvae_amd import conv_hip
+    from vqvae_amd.modules import ResidualLayer
+    r = _rng(3000 + seed)
+    C = int(r.choice([32, 64, 128]))
+    Rh = int(r.choice([4, 8, 16, 32]))
+    B = int(r.integers(1, 10))
+    H, W = (8, 8) if seed % 2 == 0 else (int(r.integers(1, 13)), int(r.integers(1, 13)))
+    relu_in, relu_out = bool(r.integers(0, 2)), bool(r.integers(0, 2))
+    torch.manual_seed(seed)
+    layer = ResidualLayer(C, C, Rh)
+    x = torch.randn(B, C, H, W)
+    w1, w2 = layer.res_block[1].weight.detach(), layer.res_block[3].weight.detach()
+    t = torch.relu(x) if relu_in else x
+    ref = t + F.conv2d(torch.relu(F.conv2d(t, w1, None, 1, 1)), w2)
+    if relu_out:
+        ref = torch.relu(ref)
+    ld = layer.to(dev())
+    for exact in (False, True):
+        flags = (1 if relu_in else 0) | (2 if relu_out else 0) | (4 if exact else 0)
+        y = conv_hip.res_layer(x.to(dev()).permute(0, 2, 3, 1).contiguous(), ld, flags)
+        np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-4,
+                                   err_msg=f"C={C} Rh={Rh} B={B} {H}x{W} exact={exact}")
+
+
+@pytest.mark.parametrize("seed", list(range(16)))
+def test_first_and_last_layer_random_shapes_vs_torch_cpu(seed):
+    """conv_in (NCHW image -> row-major) and convT_out (row-major -> NCHW image), incl. the LDS-staged row-band
+    path (32x32, 64x64, 256-wide) and the halo-tiled last layer (maps larger than 16x16)."""
+    from vqvae_amd import _lib, conv_hip
+    r = _rng(4000 + seed)
+    L = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    Cin = int(r.choice([1, 3, 3, 4]))
+    C0 = int(r.choice([8, 16, 32, 64, 96, 128]))
+    B = int(r.integers(1, 5))
+    H, W = [(32, 32), (64, 64), (16, 256), (int(r.integers(1, 20)) * 2, int(r.integers(1, 20)) * 2)][seed % 4]
+    torch.manual_seed(seed)
+    c0 = nn.Conv2d(Cin, C0, 4, 2, 1)
+    x = torch.randn(B, Cin, H, W)
+    with torch.no_grad():
+        ref = torch.relu(c0(x))
+    cd = c0.to(dev())
+    p0 = conv_hip._packed(cd, ("conv_in",), cd.weight, lambda: L.vqvae_conv_in_packed_bytes(Cin, C0),
+                          lambda w, buf: L.vqvae_conv_in_pack_f32(w.data_ptr(), Cin, C0, buf.data_ptr(), None))
+    y = torch.empty((B, H // 2, W // 2, C0), device=dev())
+    _lib.check(L.vqvae_conv_in_forward_f32(x.to(dev()).data_ptr(), p0.data_ptr(), cd.bias.data_ptr(), B, H, W, Cin, C0, 2,
+                                           y.data_ptr(), st))
+    np.testing.assert_allclose(y.permute(0, 3, 1, 2).cpu().numpy(), ref.numpy(), atol=1e-5, rtol=1e-4,
+                               err_msg=f"conv_in {Cin}->{C0} B={B} {H}x{W}")
+    # last layer on a (B, h, w, Ci) map
+    Ci = int(r.choice([8, 32, 64, 128]))
+    Co = int(r.choice([1, 3, 3, 4]))
+    h, w = [(16, 16), (8, 8), (int(r.integers(1, 40)), int(r.integers(1, 40))), (17, 33)][seed % 4]
+    d4 = nn.ConvTranspose2d(Ci, Co, 4, 2, 1)
+    t = torch.randn(B, Ci, h, w)
+    with torch.no_grad():
+        ref2 = d4(t)
+    dd = d4.to(dev())
+    p4 = conv_hip._packed(dd, ("convt_out",), dd.weight, lambda: L.vqvae_convt_out_packed_bytes(Ci, Co),
+                          lambda wt, buf: L.vqvae_convt_out_pack_f32(wt.data_ptr(), Ci, Co, buf.data_ptr(), None))
+    xh = torch.empty((B, Co, 2 * h, 2 * w), device=dev())
+    td = t.to(dev()).permute(0, 2, 3, 1).contiguous()
+    _lib.check(L.vqvae_convt_out_forward_f32(td.data_ptr(), p4.data_ptr(), dd.bias.data_ptr(), B, h, w, Ci, Co,
+                                             xh.data_ptr(), st))
+    np.testing.assert_allclose(xh.cpu().numpy(), ref2.numpy(), atol=1e-5, rtol=1e-4,
+                               err_msg=f"convT_out {Ci}->{Co} B={B} {h}x{w}")

@@ -763,8 +763,10 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
                     const int gy = px >> 3, gx = px & 7;
                     const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
                                            g.opx[phase]) * (long long)g.Cout;
-                    *reinterpret_cast<f32x4 *>(out + off + n) = a;
-                    *reinterpret_cast<f32x4 *>(out + off + n + 4) = b;
+                    if (n < g.Cout) {                          // Cout % 8 == 0: an 8-channel group is all in or all out
+                        *reinterpret_cast<f32x4 *>(out + off + n) = a;
+                        *reinterpret_cast<f32x4 *>(out + off + n + 4) = b;
+                    }
                 });
             }
     } else if (img_ok) {
