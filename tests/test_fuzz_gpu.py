@@ -166,3 +166,45 @@ def test_first_and_last_layer_random_shapes_vs_torch_cpu(seed):
                                              xh.data_ptr(), st))
     np.testing.assert_allclose(xh.cpu().numpy(), ref2.numpy(), atol=1e-5, rtol=1e-4,
                                err_msg=f"convT_out {Ci}->{Co} B={B} {h}x{w}")
+
+
+@pytest.mark.parametrize("seed", list(range(12)))
+def test_model_random_configs_stagewise_vs_oracle(seed):
+    """Random VQVAE configurations (widths, residual depth incl. 0, K, D, image size), each stage fed the
+    live oracle's input bits (oracle/torch_port.py = the reference's ATen ops) as in test_model_gpu.py."""
+    from oracle import torch_port
+    from vqvae_amd import conv, conv_hip
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    r = _rng(5000 + seed)
+    h = int(r.choice([64, 128]))
+    rh = int(r.choice([8, 16, 32]))
+    nl = int(r.integers(0, 4))
+    K = int(r.integers(2, 600))
+    D = int(r.choice([32, 64, 128]))
+    B = int(r.integers(1, 6))
+    H, W = (32, 32) if seed % 3 == 0 else (int(r.integers(2, 13)) * 4, int(r.integers(2, 13)) * 4)
+    torch.manual_seed(seed)
+    m = VQVAE(h, rh, nl, K, D, 0.25).eval()
+    x = torch.randn(B, 3, H, W)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    if nl == 0:     # torch_port indexes stack.0 weights unconditionally; an empty stack has none
+        sd["encoder.conv_stack.5.stack.0.res_block.1.weight"] = sd["encoder.conv_stack.5.stack.0.res_block.3.weight"] = None
+        sd["decoder.inverse_conv_stack.1.stack.0.res_block.1.weight"] = sd["decoder.inverse_conv_stack.1.stack.0.res_block.3.weight"] = None
+    with torch.no_grad():
+        z_e_ref = torch_port.encode(sd, x.clone(), nl)
+        loss_ref, z_q_ref, ppl_ref, _, idx_ref = torch_port.quantize(z_e_ref, sd["vector_quantization.embedding.weight"], 0.25)
+        x_hat_ref = torch_port.decode(sd, z_q_ref.clone(), nl)
+    md = m.to(dev())
+    tag = f"h={h} rh={rh} nl={nl} K={K} D={D} B={B} {H}x{W}"
+    with torch.no_grad():
+        z_e = conv_hip.encoder_forward(md.encoder, x.to(dev()), md.pre_quantization_conv)
+        np.testing.assert_allclose(z_e.permute(0, 3, 1, 2).cpu().numpy(), z_e_ref.numpy(), atol=2e-6, rtol=1e-5, err_msg=tag)
+        loss, z_q, ppl, _, idx = md.vector_quantization(z_e_ref.to(dev()))
+        assert torch.equal(idx.cpu(), idx_ref), tag
+        assert torch.equal(z_q.cpu(), z_q_ref), tag
+        np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=2e-6, err_msg=tag)
+        x_hat = md.decoder(z_q_ref.to(dev()))
+        np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.numpy(), atol=1e-5, rtol=1e-4, err_msg=tag)
+        out = md(x.to(dev()))
+        assert out[1].shape == x.shape and torch.isfinite(out[1]).all()
