@@ -337,6 +337,28 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 
+// The six significant term products of one 16-deep MFMA step for two pixel tiles (s*, t*) against one weight
+// operand (w1..w3), smallest terms first, the two accumulators interleaved:
+//   accA += s (x) w,  accB += t (x) w      with  x (x) w = x3 w1 + x2 w2 + x1 w3 + x2 w1 + x1 w2 + x1 w1
+__device__ __forceinline__ void prod6x2(const u32x4 &s1, const u32x4 &s2, const u32x4 &s3, const u32x4 &t1,
+                                        const u32x4 &t2, const u32x4 &t3, const u32x4 &w1, const u32x4 &w2,
+                                        const u32x4 &w3, f32x16 &accA, f32x16 &accB) {
+#define BF(v) __builtin_bit_cast(bf16x8, v)
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s3), BF(w1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t3), BF(w1), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w2), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w2), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w3), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w3), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w1), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w2), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w2), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w1), accB, 0, 0, 0);
+#undef BF
+}
+
 __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restrict__ w,
                                                             unsigned short *__restrict__ img, ConvGeom g,
                                                             long long total) {
@@ -863,26 +885,6 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
                 dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
         }
     };
-    // six significant term products of one 16-deep MFMA step, two accumulators interleaved
-    auto prod6 = [&](const u32x4 &s1, const u32x4 &s2, const u32x4 &s3, const u32x4 &t1, const u32x4 &t2,
-                     const u32x4 &t3, const u32x4 &w1, const u32x4 &w2, const u32x4 &w3, const u32x4 &x1,
-                     const u32x4 &x2, const u32x4 &x3, f32x16 &accA, f32x16 &accB) {
-        // accA += s (x) w ; accB += t (x) x   (smallest terms first)
-#define BF(v) __builtin_bit_cast(bf16x8, v)
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s3), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t3), BF(x1), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w2), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(x2), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w3), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x3), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(x1), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w2), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x2), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(x1), accB, 0, 0, 0);
-#undef BF
-    };
 
 #pragma unroll
     for (int k = 0; k < KC; ++k)
@@ -906,8 +908,8 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
                 if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
 #pragma unroll
                 for (int t = 0; t < 2; ++t)           // the two pixel tiles share the weights, separate accumulators
-                    prod6(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
-                          bw[t], bw[2 + t], bw[4 + t], acc1[0], acc1[1]);
+                    prod6x2(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
+                            acc1[0], acc1[1]);
             }
         }
     }
@@ -946,7 +948,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
         for (int t = 0; t < 2; ++t) {
             const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
             const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
-            prod6(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, w1, w2, w3, acc2[0], acc2[1]);
+            prod6x2(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -1019,24 +1021,6 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
 
-    auto prod6 = [&](const u32x4 &s1, const u32x4 &s2, const u32x4 &s3, const u32x4 &t1, const u32x4 &t2,
-                     const u32x4 &t3, const u32x4 &w1, const u32x4 &w2, const u32x4 &w3, f32x16 &accA,
-                     f32x16 &accB) {
-#define BF(v) __builtin_bit_cast(bf16x8, v)
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s3), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t3), BF(w1), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w2), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w2), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w3), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w3), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s2), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t2), BF(w1), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w2), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w2), accB, 0, 0, 0);
-        accA = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(s1), BF(w1), accA, 0, 0, 0);
-        accB = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BF(t1), BF(w1), accB, 0, 0, 0);
-#undef BF
-    };
     // slice sl = k-step (sl & 1) of 32-channel chunk (sl >> 1) of the packed weight image: channels
     // 32*chunk + 8*step + [0,8) for the h = 0 operand half and 32*chunk + 16 + 8*step + [0,8) for h = 1
     auto load_raw = [&](int sl, f32x4(&r)[4]) {
@@ -1092,8 +1076,8 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                 const u32x4 *ap = As + p * 2 + h;
                 S[mt][0] = ap[0]; S[mt][1] = ap[(PX + 1) * 2]; S[mt][2] = ap[(PX + 1) * 4];
             }
-            prod6(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
-                  acc1[1]);
+            prod6x2(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
+                    acc1[1]);
         }
     };
     for (int sl = 0; sl < nslice; sl += 2) {                  // C % 32 == 0: an even number of slices
@@ -1136,7 +1120,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
         for (int t = 0; t < 2; ++t) {
             const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
             const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
-            prod6(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            prod6x2(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
         }
         if (img_ok) {
             // skip connection, activation and store in the staged layout: 16-byte loads and stores
