@@ -137,6 +137,7 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
 #define VQVAE_CONV_1x1      2   /* nn.Conv2d(k=1),         weight (Cout,Cin,1,1)   vqvae.py:16, residual.py:23 */
 #define VQVAE_CONVT_3x3_S1  3   /* nn.ConvTranspose2d(k=3,s=1,p=1), weight (Cin,Cout,3,3)  decoder.py:28 */
 #define VQVAE_CONVT_4x4_S2  4   /* nn.ConvTranspose2d(k=4,s=2,p=1), weight (Cin,Cout,4,4)  decoder.py:31 */
+#define VQVAE_CONVT_1x1     5   /* nn.ConvTranspose2d(k=1), weight (Cin,Cout,1,1): the data gradient of a 1x1 nn.Conv2d */
 
 #define VQVAE_CONV_RELU_IN  0x1 /* apply ReLU to the input as it is read (the in-place nn.ReLU(True)
                                    in front of a conv, residual.py:19,22)                          */
@@ -220,6 +221,30 @@ VQVAE_API int vqvae_recon_loss_f32(const float *x_hat, const float *x, int64_t n
 VQVAE_API int vqvae_recon_loss_backward_f32(const float *x_hat, const float *x, int64_t n, float inv_var,
                                             const float *grad_loss, float *grad_x_hat,
                                             vqvae_stream_t stream);
+
+/* ------------------------------------------------------- conv backward
+ * Data gradients reuse the forward kernels: d/dx of nn.Conv2d(k,s,p) is the ConvTranspose2d with the SAME weight
+ * tensor and vice versa (kinds 0<->4, 1<->3, 2<->5; ReLU masks via vqvae_relu_backward_f32); d/dx of the last
+ * layer (convT 4x4 s2, Cout<=4) is vqvae_conv_in_forward_f32 on the NCHW gradient with that layer's weight.
+ *
+ * vqvae_conv_wgrad_f32 -- weight gradient of one conv / conv-transpose layer:
+ *     grad_w[ca][cb][ky][kx] = sum_{b,y,x} a[b,y,x,ca] * bt[b, y*stride + ky - pad, x*stride + kx - pad, cb]
+ *   nn.Conv2d:          a = grad_y (B,Ho,Wo,Cout), bt = x (B,H,W,Cin)        -> grad_w is (Cout,Cin,k,k)
+ *   nn.ConvTranspose2d: a = x (B,H,W,Cin),         bt = grad_y (B,Ho,Wo,Cout) -> grad_w is (Cin,Cout,k,k)
+ *   a is row-major; bt is row-major, or an NCHW image tensor when bt_nchw != 0 (first / last layer).
+ *   Exact fp32 products (fp32 MFMA), fixed-order reduction: bit-reproducible.  k <= 4.                       */
+VQVAE_API size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k);
+VQVAE_API int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA,
+                                   int HB, int WB, int CB, int k, int stride, int pad, int bt_nchw,
+                                   float *grad_w, void *workspace, size_t workspace_bytes,
+                                   vqvae_stream_t stream);
+/* grad_b[c] = sum over pixels of grad_y[.., c]; grad_y (B*HW, C) row-major, or (B,C,HW) when nchw != 0.  C <= 256. */
+VQVAE_API size_t vqvae_bias_grad_workspace_bytes(int C);
+VQVAE_API int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw, float *grad_b,
+                                  void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* grad_in = grad_out * (y > 0): backward of y = relu(.)                                                      */
+VQVAE_API int vqvae_relu_backward_f32(const float *grad_out, const float *y, int64_t n, float *grad_in,
+                                      vqvae_stream_t stream);
 
 #ifdef __cplusplus
 }

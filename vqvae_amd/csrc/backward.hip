@@ -1,0 +1,263 @@
+// Weight / bias gradients and ReLU masks for the conv layers of the path, gfx950.
+// The DATA gradients need no kernels of their own: the gradient of a conv w.r.t. its input is the transposed
+// conv with the same weight tensor and vice versa, i.e. the forward kernels of conv.hip with the other `kind`
+// (vqvae_amd/autograd_conv.py does that mapping).
+//
+//   vqvae_conv_wgrad_f32   dW[ca][cb][ky][kx] = sum over pixels of  A[pixel][ca] * Bt[pixel*s + (ky,kx) - p][cb]
+//        nn.Conv2d:           A = grad_y (B,Ho,Wo,Cout), Bt = x      -> dW in the (Cout,Cin,kh,kw) layout
+//        nn.ConvTranspose2d:  A = x (B,H,W,Cin),         Bt = grad_y -> dW in the (Cin,Cout,kh,kw) layout
+//      (the same index formula serves both: y_Bt = y_A * stride + ky - pad).  Exact fp32 products on the fp32
+//      matrix cores (v_mfma_f32_32x32x2_f32: the reduction index is the PIXEL, two pixels per MFMA step, and
+//      with row-major activations both operands are plain coalesced 128-byte reads -- no transposition);
+//      the pixel range is split over workgroups and waves, partial sums are combined in a fixed order
+//      (no floating-point atomics: gradients are bit-reproducible run to run).
+//   vqvae_bias_grad_f32    db[c] = sum over pixels of grad_y[pixel][c]   (fixed-order two-stage reduction, fp64)
+//   vqvae_relu_backward_f32  g_in = g_out * (y > 0)
+#include "common.h"
+
+namespace vqvae {
+
+constexpr int kWgMaxSplit = 64;       // pixel-range splits across workgroups
+
+struct WgradGeom {
+    int B, HA, WA, CA, HB, WB, CB;
+    int k, stride, pad;
+    int bt_nchw;                      // Bt is an NCHW image tensor (first / last layer), else row-major
+    int nsplit;
+    long long rows_per_split;         // A rows (b, yA) per workgroup
+};
+
+// Workgroup = 4 waves; tile = 64 ca x 64 cb for one tap; each wave takes every 4th A row of the split and the
+// four partial tiles are summed through LDS in wave order.
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                         float *__restrict__ partial, WgradGeom g) {
+    constexpr int MT = 2, NT = 2;
+    __shared__ float red[3][MT * NT * 1024];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_b = (g.CB + 63) / 64, tiles_a = (g.CA + 63) / 64;
+    int t = blockIdx.x;
+    const int tb = t % tiles_b; t /= tiles_b;
+    const int ta = t % tiles_a; t /= tiles_a;
+    const int tap = t;                                  // ky * k + kx
+    const int ky = tap / g.k, kx = tap - ky * g.k;
+    const int split = blockIdx.y;
+    const long long nrows = (long long)g.B * g.HA;
+    const long long r_lo = (long long)split * g.rows_per_split;
+    long long r_hi = r_lo + g.rows_per_split;
+    if (r_hi > nrows) r_hi = nrows;
+
+    int ca[MT], cb[NT];
+    bool ca_ok[MT], cb_ok[NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) { ca[mt] = ta * 64 + mt * 32 + l31; ca_ok[mt] = ca[mt] < g.CA; }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { cb[nt] = tb * 64 + nt * 32 + l31; cb_ok[nt] = cb[nt] < g.CB; }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    for (long long row = r_lo + wave; row < r_hi; row += 4) {
+        const long long b = row / g.HA;
+        const int yA = (int)(row - b * g.HA);
+        const int yB = yA * g.stride + ky - g.pad;
+        if (yB < 0 || yB >= g.HB) continue;             // wave-uniform
+        const float *arow = A + (size_t)row * g.WA * g.CA;
+        // this lane handles pixel x0 + h of every pair
+        for (int x0 = 0; x0 < g.WA; x0 += 2) {
+            const int xA = x0 + h;
+            const int xB = xA * g.stride + kx - g.pad;
+            const bool pa = xA < g.WA, pb = pa && xB >= 0 && xB < g.WB;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = (pa && ca_ok[mt]) ? arow[(size_t)xA * g.CA + ca[mt]] : 0.0f;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = 0.0f;
+                if (pb && cb_ok[nt])
+                    v = g.bt_nchw ? Bt[(((size_t)b * g.CB + cb[nt]) * g.HB + yB) * g.WB + xB]
+                                  : Bt[(((size_t)b * g.HB + yB) * g.WB + xB) * g.CB + cb[nt]];
+                bv[nt] = v;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    // waves 1..3 park their tiles; wave 0 adds them in wave order and writes the partial
+    if (wave > 0) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float *dst = partial + ((size_t)split * g.k * g.k + tap) * g.CA * g.CB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[mt][nt][r];
+                    for (int w = 0; w < 3; ++w) v += red[w][((mt * NT + nt) * 16 + r) * 64 + lane];
+                    const int a = ta * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // accumulator row = ca
+                    if (a < g.CA && cb_ok[nt]) dst[(size_t)a * g.CB + cb[nt]] = v;
+                }
+    }
+}
+
+// dW[ca][cb][tap] = sum_split partial[split][tap][ca][cb]   (fixed order)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, int ntap,
+                                                                int CA, int CB, float *__restrict__ dw) {
+    const long long total = (long long)ntap * CA * CB;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        float s = 0.0f;
+        for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * total + e];
+        const int tap = (int)(e / ((long long)CA * CB));
+        const long long rem = e - (long long)tap * CA * CB;          // ca * CB + cb
+        dw[rem * ntap + tap] = s;
+    }
+}
+
+// per-channel sums of a (P, C) row-major tensor [or an NCHW one: (B, C, HW)] -- stage 1: one partial per block
+__global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__restrict__ g, long long P, int C,
+                                                                long long HW, int nchw, long long rows_per_block,
+                                                                double *__restrict__ partial) {
+    __shared__ double red[256];
+    const int tid = threadIdx.x;
+    const int G = 256 / C > 0 ? 256 / C : 1;            // C <= 256
+    const int grp = tid / C, c = tid - grp * C;
+    const long long lo = (long long)blockIdx.x * rows_per_block;
+    long long hi = lo + rows_per_block;
+    if (hi > P) hi = P;
+    double acc = 0.0;
+    if (grp < G) {
+        for (long long p = lo + grp; p < hi; p += G) {
+            float v;
+            if (nchw) {
+                const long long b = p / HW;
+                v = g[((size_t)b * C + c) * HW + (p - b * HW)];
+            } else {
+                v = g[(size_t)p * C + c];
+            }
+            acc += (double)v;
+        }
+    }
+    red[tid] = acc;
+    __syncthreads();
+    if (tid < C) {
+        double s = 0.0;
+        for (int q = 0; q < G; ++q) s += red[q * C + tid];
+        partial[(size_t)blockIdx.x * C + tid] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void bias_grad_final_kernel(const double *__restrict__ partial, int nblocks, int C,
+                                                              float *__restrict__ db) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * C + c];
+    db[c] = (float)s;
+}
+
+__global__ __launch_bounds__(256) void relu_backward_kernel(const float *__restrict__ gout, const float *__restrict__ y,
+                                                            long long n, float *__restrict__ gin) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
+        gin[i] = y[i] > 0.0f ? gout[i] : 0.0f;
+}
+
+static int wgrad_plan(int64_t B, int HA, int WA, int CA, int CB, int k, WgradGeom &g) {
+    const long long nrows = (long long)B * HA;
+    long long ns = (nrows + 15) / 16;                   // at least ~16 rows per workgroup (4 per wave)
+    // enough workgroups to fill the chip: tiles * taps * splits >= ~4 per CU
+    const long long tiles = (long long)((CA + 63) / 64) * ((CB + 63) / 64) * k * k;
+    long long want = (4LL * num_cus() + tiles - 1) / tiles;
+    if (want < 1) want = 1;
+    if (ns > want) ns = want;
+    if (ns > kWgMaxSplit) ns = kWgMaxSplit;
+    if (ns < 1) ns = 1;
+    g.nsplit = (int)ns;
+    g.rows_per_split = (nrows + ns - 1) / ns;
+    return VQVAE_OK;
+}
+
+}  // namespace vqvae
+
+using namespace vqvae;
+
+extern "C" {
+
+size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k) {
+    if (CA < 1 || CB < 1 || k < 1 || k > 4) return 0;
+    return (size_t)kWgMaxSplit * k * k * CA * CB * sizeof(float);
+}
+
+int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA, int HB, int WB, int CB,
+                         int k, int stride, int pad, int bt_nchw, float *grad_w, void *workspace,
+                         size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!a || !bt || !grad_w) return VQVAE_ERR_NULL;
+    if (B < 1 || HA < 1 || WA < 1 || CA < 1 || HB < 1 || WB < 1 || CB < 1 || stride < 1 || pad < 0) return VQVAE_ERR_SHAPE;
+    if (k < 1 || k > 4) return VQVAE_ERR_UNSUPPORTED;
+    if (B * (int64_t)HA > INT32_MAX || B * (int64_t)HB * WB * CB > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
+    if (!workspace || workspace_bytes < vqvae_conv_wgrad_workspace_bytes(CA, CB, k)) return VQVAE_ERR_WORKSPACE;
+    WgradGeom g;
+    g.B = (int)B; g.HA = HA; g.WA = WA; g.CA = CA; g.HB = HB; g.WB = WB; g.CB = CB;
+    g.k = k; g.stride = stride; g.pad = pad; g.bt_nchw = bt_nchw ? 1 : 0;
+    wgrad_plan(B, HA, WA, CA, CB, k, g);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *partial = static_cast<float *>(workspace);
+    const unsigned gx = (unsigned)(((CA + 63) / 64) * ((CB + 63) / 64) * k * k);
+    hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, (unsigned)g.nsplit), dim3(256), 0, st, a, bt, partial, g);
+    const long long total = (long long)k * k * CA * CB;
+    long long grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st, partial, g.nsplit, k * k, CA,
+                       CB, grad_w);
+    return (int)hipGetLastError();
+}
+
+size_t vqvae_bias_grad_workspace_bytes(int C) { return C < 1 || C > 256 ? 0 : (size_t)1024 * C * sizeof(double); }
+
+int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw, float *grad_b, void *workspace,
+                        size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!grad_y || !grad_b) return VQVAE_ERR_NULL;
+    if (B < 1 || HW < 1 || C < 1) return VQVAE_ERR_SHAPE;
+    if (C > 256) return VQVAE_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < vqvae_bias_grad_workspace_bytes(C)) return VQVAE_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long P = (long long)B * HW;
+    long long nb = (P + 1023) / 1024;
+    if (nb > 1024) nb = 1024;
+    const long long rpb = (P + nb - 1) / nb;
+    nb = (P + rpb - 1) / rpb;
+    double *partial = static_cast<double *>(workspace);
+    hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, grad_y, P, C, (long long)HW,
+                       nchw ? 1 : 0, rpb, partial);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, (int)nb, C,
+                       grad_b);
+    return (int)hipGetLastError();
+}
+
+int vqvae_relu_backward_f32(const float *grad_out, const float *y, int64_t n, float *grad_in, vqvae_stream_t stream) {
+    if (!grad_out || !y || !grad_in) return VQVAE_ERR_NULL;
+    if (n < 1) return VQVAE_ERR_SHAPE;
+    long long grid = (n + 255) / 256;
+    if (grid > 65536) grid = 65536;
+    hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       grad_out, y, (long long)n, grad_in);
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1755,6 +1755,8 @@ static int make_geom(int kind, long long B, int H, int W, int Cin, int Cout, int
             conv_taps(3, 1); g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
         case VQVAE_CONV_1x1:
             conv_taps(1, 0); g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
+        case VQVAE_CONVT_1x1:                     // = the data gradient of a 1x1 nn.Conv2d (weight read transposed)
+            conv_taps(1, 0); g.transposed = 1; g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
         case VQVAE_CONVT_3x3_S1:
             g.transposed = 1; g.ntaps = 9; g.kk = 9;
             for (int ky = 0; ky < 3; ++ky)

@@ -16,10 +16,10 @@ the reference (`utils.py:109-113`) load unchanged and callers (`main.py:74`,
                                                                              (models/residual.py:16,41)
 
 The modules only HOLD parameters; the arithmetic is libvqvae_hip.so, on CUDA(HIP)
-fp32 tensors only -- there is no CPU fallback.  The HIP conv kernels are forward-only
-and raise when a graph is being recorded.  The VectorQuantizer also has a HIP backward
-(SURVEY.md 8f row 2): with the convs on the "torch" backend (`set_conv_backend("torch")`,
-BASELINE config 2) `loss.backward()` of main.py:78 runs through training.VQStraightThrough.
+fp32 tensors only -- there is no CPU fallback.  `VQVAE.forward` under autograd (main.py:74-79) runs every
+layer forward and backward on the HIP kernels (autograd_conv.py, training.VQStraightThrough; SURVEY.md 8f
+row 2).  The sub-modules called on their own (`Encoder`, `Decoder`, `ResidualStack`) are forward-only on the
+HIP backend and raise while a graph is being recorded.
 """
 from __future__ import annotations
 
@@ -181,6 +181,16 @@ class VQVAE(nn.Module):
 
     def forward(self, x, verbose=False):
         from . import conv as C_hip
+        if (C_hip.get_conv_backend() == "hip" and torch.is_grad_enabled()
+                and any(p.requires_grad for p in self.parameters())):
+            # training (main.py:74-79): every layer forward AND backward on the HIP kernels
+            from . import autograd_conv as A_hip
+            if not x.is_cuda or x.dtype != torch.float32:
+                raise VqvaeHipError("VQVAE.forward needs a CUDA(HIP) fp32 input: there is no CPU path")
+            z_e = A_hip.encoder_forward_train(self.encoder, x, self.pre_quantization_conv)
+            embedding_loss, z_q, perplexity, _, _ = self.vector_quantization.quantize(z_e, rowmajor=True)
+            x_hat = A_hip.decoder_forward_train(self.decoder, z_q)
+            return embedding_loss, x_hat, perplexity
         _require_forward_only(x, *self.parameters())
         # encoder + 1x1 pre-quantisation conv, activations kept row-major (B,H,W,C)
         z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
