@@ -28,11 +28,12 @@ struct WgradGeom {
 };
 
 // Workgroup = 4 waves; tile = 64 ca x 64 cb for one tap; each wave takes every 4th A row of the split and the
-// four partial tiles are summed through LDS in wave order.
+// four partial tiles are summed through LDS in wave order.  The reduction runs over "items" of eight pixels
+// (four MFMA k-steps): the sixteen operand loads of item i+1 are in flight while item i multiplies.
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
                                                          float *__restrict__ partial, WgradGeom g) {
-    constexpr int MT = 2, NT = 2;
-    __shared__ float red[3][MT * NT * 1024];
+    constexpr int MT = 2, NT = 2, PAIRS = 4;
+    __shared__ float red[MT * NT * 1024];               // one wave's tile at a time
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_b = (g.CB + 63) / 64, tiles_a = (g.CA + 63) / 64;
@@ -62,45 +63,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    for (long long row = r_lo + wave; row < r_hi; row += 4) {
+    // item i of this wave: row = r_lo + wave + 4 * (i / cpr), pixels [8 * (i % cpr), +8)
+    const int cpr = (g.WA + 2 * PAIRS - 1) / (2 * PAIRS);
+    const long long my_rows = r_hi > r_lo + wave ? (r_hi - r_lo - wave + 3) / 4 : 0;
+    const long long nitem = my_rows * cpr;
+    auto load_item = [&](long long i, float(&av)[PAIRS][MT], float(&bv)[PAIRS][NT]) {
+        const long long ri = i / cpr;
+        const int x00 = (int)(i - ri * cpr) * 2 * PAIRS;
+        const long long row = r_lo + wave + 4 * ri;
         const long long b = row / g.HA;
         const int yA = (int)(row - b * g.HA);
         const int yB = yA * g.stride + ky - g.pad;
-        if (yB < 0 || yB >= g.HB) continue;             // wave-uniform
+        const bool yok = yB >= 0 && yB < g.HB;
         const float *arow = A + (size_t)row * g.WA * g.CA;
-        // this lane handles pixel x0 + h of every pair
-        for (int x0 = 0; x0 < g.WA; x0 += 2) {
-            const int xA = x0 + h;
-            const int xB = xA * g.stride + kx - g.pad;
-            const bool pa = xA < g.WA, pb = pa && xB >= 0 && xB < g.WB;
-            float av[MT], bv[NT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[mt] = (pa && ca_ok[mt]) ? arow[(size_t)xA * g.CA + ca[mt]] : 0.0f;
+        for (int q = 0; q < PAIRS; ++q) {
+            const int xA = x00 + 2 * q + h;
+            const int xB = xA * g.stride + kx - g.pad;
+            const bool pa = yok && xA < g.WA, pb = pa && xB >= 0 && xB < g.WB;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[q][mt] = (pa && ca_ok[mt]) ? arow[(size_t)xA * g.CA + ca[mt]] : 0.0f;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float v = 0.0f;
                 if (pb && cb_ok[nt])
                     v = g.bt_nchw ? Bt[(((size_t)b * g.CB + cb[nt]) * g.HB + yB) * g.WB + xB]
                                   : Bt[(((size_t)b * g.HB + yB) * g.WB + xB) * g.CB + cb[nt]];
-                bv[nt] = v;
+                bv[q][nt] = v;
             }
+        }
+    };
+    auto mma_item = [&](const float(&av)[PAIRS][MT], const float(&bv)[PAIRS][NT]) {
+#pragma unroll
+        for (int q = 0; q < PAIRS; ++q)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt], bv[q][nt], acc[mt][nt], 0, 0, 0);
+    };
+    float a0[PAIRS][MT], b0[PAIRS][NT], a1[PAIRS][MT], b1[PAIRS][NT];
+    if (nitem > 0) load_item(0, a0, b0);
+    for (long long i = 0; i < nitem; i += 2) {
+        if (i + 1 < nitem) load_item(i + 1, a1, b1);
+        mma_item(a0, b0);
+        if (i + 1 < nitem) {
+            if (i + 2 < nitem) load_item(i + 2, a0, b0);
+            mma_item(a1, b1);
         }
     }
-    // waves 1..3 park their tiles; wave 0 adds them in wave order and writes the partial
-    if (wave > 0) {
+    // the four waves' tiles are added in wave order (0 + 1 + 2 + 3) through one LDS tile; wave 0 writes
+    for (int w = 3; w >= 1; --w) {
+        __syncthreads();
+        if (wave == w) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+                for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[wave - 1][((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+                    for (int r = 0; r < 16; ++r) red[((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] += red[((mt * NT + nt) * 16 + r) * 64 + lane];
+        }
     }
-    __syncthreads();
     if (wave == 0) {
         float *dst = partial + ((size_t)split * g.k * g.k + tap) * g.CA * g.CB;
 #pragma unroll
@@ -109,10 +141,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = acc[mt][nt][r];
-                    for (int w = 0; w < 3; ++w) v += red[w][((mt * NT + nt) * 16 + r) * 64 + lane];
                     const int a = ta * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // accumulator row = ca
-                    if (a < g.CA && cb_ok[nt]) dst[(size_t)a * g.CB + cb[nt]] = v;
+                    if (a < g.CA && cb_ok[nt]) dst[(size_t)a * g.CB + cb[nt]] = acc[mt][nt][r];
                 }
     }
 }
@@ -130,17 +160,42 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
     }
 }
 
-// per-channel sums of a (P, C) row-major tensor [or an NCHW one: (B, C, HW)] -- stage 1: one partial per block
+// per-channel sums of a (P, C) row-major tensor [or an NCHW one: (B, C, HW)] -- stage 1: one partial per block.
+// Row-major with C % 4 == 0: a thread owns four consecutive channels (16-byte loads), 1024 / C rows in flight per
+// block iteration, fp64 accumulators; otherwise one channel per thread.
 __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__restrict__ g, long long P, int C,
                                                                 long long HW, int nchw, long long rows_per_block,
                                                                 double *__restrict__ partial) {
-    __shared__ double red[256];
+    __shared__ double red[1024];
     const int tid = threadIdx.x;
-    const int G = 256 / C > 0 ? 256 / C : 1;            // C <= 256
-    const int grp = tid / C, c = tid - grp * C;
     const long long lo = (long long)blockIdx.x * rows_per_block;
     long long hi = lo + rows_per_block;
     if (hi > P) hi = P;
+    if (!nchw && (C & 3) == 0 && C <= 1024) {
+        const int c4 = C >> 2;                              // threads per row
+        const int G = 256 / c4 > 0 ? 256 / c4 : 1;          // rows per block iteration (C <= 1024)
+        const int grp = tid / c4, q = tid - grp * c4;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        if (grp < G) {
+            for (long long p = lo + grp; p < hi; p += G) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(g + (size_t)p * C + 4 * q);
+                a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
+            }
+        }
+        // red[(grp * C) + channel]
+        if (grp < G) {
+            red[grp * C + 4 * q] = a0; red[grp * C + 4 * q + 1] = a1; red[grp * C + 4 * q + 2] = a2; red[grp * C + 4 * q + 3] = a3;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 256) {
+            double s = 0.0;
+            for (int w = 0; w < G; ++w) s += red[w * C + c];
+            partial[(size_t)blockIdx.x * C + c] = s;
+        }
+        return;
+    }
+    const int G = 256 / C > 0 ? 256 / C : 1;            // C <= 256
+    const int grp = tid / C, c = tid - grp * C;
     double acc = 0.0;
     if (grp < G) {
         for (long long p = lo + grp; p < hi; p += G) {
@@ -174,8 +229,18 @@ __global__ __launch_bounds__(256) void bias_grad_final_kernel(const double *__re
 
 __global__ __launch_bounds__(256) void relu_backward_kernel(const float *__restrict__ gout, const float *__restrict__ y,
                                                             long long n, float *__restrict__ gin) {
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256)
-        gin[i] = y[i] > 0.0f ? gout[i] : 0.0f;
+    const long long n4 = n >> 2;
+    const f32x4 *g4 = reinterpret_cast<const f32x4 *>(gout), *y4 = reinterpret_cast<const f32x4 *>(y);
+    f32x4 *o4 = reinterpret_cast<f32x4 *>(gin);
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 gv = g4[i], yv = y4[i];
+        f32x4 o;
+        o.x = yv.x > 0.0f ? gv.x : 0.0f; o.y = yv.y > 0.0f ? gv.y : 0.0f;
+        o.z = yv.z > 0.0f ? gv.z : 0.0f; o.w = yv.w > 0.0f ? gv.w : 0.0f;
+        o4[i] = o;
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) gin[i] = y[i] > 0.0f ? gout[i] : 0.0f;
 }
 
 static int wgrad_plan(int64_t B, int HA, int WA, int CA, int CB, int k, WgradGeom &g) {
@@ -239,7 +304,7 @@ int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long P = (long long)B * HW;
     long long nb = (P + 1023) / 1024;
-    if (nb > 1024) nb = 1024;
+    if (nb > 512) nb = 512;
     const long long rpb = (P + nb - 1) / nb;
     nb = (P + rpb - 1) / rpb;
     double *partial = static_cast<double *>(workspace);
@@ -253,8 +318,11 @@ int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw,
 int vqvae_relu_backward_f32(const float *grad_out, const float *y, int64_t n, float *grad_in, vqvae_stream_t stream) {
     if (!grad_out || !y || !grad_in) return VQVAE_ERR_NULL;
     if (n < 1) return VQVAE_ERR_SHAPE;
-    long long grid = (n + 255) / 256;
+    if ((reinterpret_cast<uintptr_t>(grad_out) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(grad_in)) & 15)
+        return VQVAE_ERR_UNSUPPORTED;                    // 16-byte accesses
+    long long grid = ((n >> 2) + 255) / 256;
     if (grid > 65536) grid = 65536;
+    if (grid < 1) grid = 1;
     hipLaunchKernelGGL(relu_backward_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream),
                        grad_out, y, (long long)n, grad_in);
     return (int)hipGetLastError();

@@ -6,9 +6,10 @@
 //                                dL/dE_k = g_loss * 2 beta * sum_{i: idx_i = k} (e_k - z_i) / (N D)   (:63-64)
 //                              The codebook gradient is a segmented sum over the rows of each code.  It is
 //                              computed WITHOUT floating-point atomics: rows are sorted by code (stable radix
-//                              sort, so row order inside a code is ascending), every (code, split) workgroup
-//                              adds its rows in a fixed order in fp64, and the splits are combined in a fixed
-//                              order -- the result is bit-reproducible from run to run.
+//                              sort, so row order inside a code is ascending), every 512-row chunk of a code is
+//                              added in a fixed order in fp64 by one workgroup, and a code's chunks are combined in a
+//                              fixed order -- the result is bit-reproducible from run to run, and the work is
+//                              proportional to the rows however skewed the code histogram is.
 //   vqvae_recon_loss_f32       main.py:75-76 and the three scalars of :81-83 packed into one 3-float buffer
 //                              (one D2H copy per step instead of three).
 //   vqvae_recon_loss_backward_f32   d/dx_hat of mean((x_hat - x)^2) / var.
@@ -18,11 +19,12 @@
 
 namespace vqvae {
 
-constexpr int kBwdSplit = 8;          // workgroups per code in the segmented sum
+constexpr int kBwdChunk = 512;        // rows per workgroup of the segmented sum (a code owns ceil(count/512) units)
 constexpr int kReconGrid = 1024;      // partial sums of the reconstruction loss
 
 struct BwdPlan {
-    size_t off_keys, off_keys_out, off_vals, off_vals_out, off_offsets, off_partials, off_sort, sort_bytes, total;
+    size_t off_keys, off_keys_out, off_vals, off_vals_out, off_offsets, off_units, off_partials, off_sort, sort_bytes, total;
+    long long max_units;
     int key_bits;
 };
 
@@ -35,8 +37,10 @@ static BwdPlan bwd_plan(long long N, int K, int D) {
     p.off_vals = align_up(p.off_keys_out + (size_t)N * 4, 256);
     p.off_vals_out = align_up(p.off_vals + (size_t)N * 4, 256);
     p.off_offsets = align_up(p.off_vals_out + (size_t)N * 4, 256);
-    p.off_partials = align_up(p.off_offsets + (size_t)(K + 1) * 4, 256);
-    p.off_sort = align_up(p.off_partials + (size_t)K * kBwdSplit * D * sizeof(double), 256);
+    p.off_units = align_up(p.off_offsets + (size_t)(K + 1) * 4, 256);
+    p.max_units = N / kBwdChunk + K;                       // sum_k ceil(count_k / chunk) <= N/chunk + K
+    p.off_partials = align_up(p.off_units + (size_t)(K + 1) * 4, 256);
+    p.off_sort = align_up(p.off_partials + (size_t)p.max_units * D * sizeof(double), 256);
     size_t sb = 0;
     (void)hipcub::DeviceRadixSort::SortPairs(nullptr, sb, (const unsigned *)nullptr, (unsigned *)nullptr,
                                              (const int *)nullptr, (int *)nullptr, (int)N, 0, p.key_bits, 0);
@@ -67,17 +71,52 @@ __global__ __launch_bounds__(256) void vqb_offsets_kernel(const unsigned *__rest
     offsets[k] = (int)lo;
 }
 
-// partial[k][s][c] = sum over this split's rows of z_i[c]  (fp64, fixed order)
+// unit_start[k] = number of work units (chunks of kBwdChunk sorted rows) owned by codes < k; one block scans K+1
+__global__ __launch_bounds__(1024) void vqb_units_kernel(const int *__restrict__ offsets, int K, int *__restrict__ unit_start) {
+    __shared__ int part[1024];
+    const int tid = threadIdx.x;
+    const int per = (K + 1023) / 1024;
+    int local = 0;
+    for (int j = 0; j < per; ++j) {
+        const int k = tid * per + j;
+        if (k < K) local += (offsets[k + 1] - offsets[k] + kBwdChunk - 1) / kBwdChunk;
+    }
+    part[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {                    // inclusive scan
+        const int v = tid >= o ? part[tid - o] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    int run = part[tid] - local;                             // exclusive prefix of this thread's codes
+    for (int j = 0; j < per; ++j) {
+        const int k = tid * per + j;
+        if (k < K) {
+            unit_start[k] = run;
+            run += (offsets[k + 1] - offsets[k] + kBwdChunk - 1) / kBwdChunk;
+        }
+    }
+    if (tid == 1023) unit_start[K] = part[1023];
+}
+
+// partial[unit][c] = sum over the unit's (<= kBwdChunk, sorted) rows of z_i[c]   (fp64, fixed order).  Work is
+// proportional to the rows, however skewed the histogram (a freshly initialised codebook uses a handful of codes).
 __global__ __launch_bounds__(256) void vqb_segsum_kernel(const float *__restrict__ z, const int *__restrict__ rows,
-                                                         const int *__restrict__ offsets, int D, int HW,
+                                                         const int *__restrict__ offsets,
+                                                         const int *__restrict__ unit_start, int K, int D, int HW,
                                                          int rowmajor, double *__restrict__ partial) {
     __shared__ double red[256];
-    const int k = blockIdx.x, s = blockIdx.y, tid = threadIdx.x;
-    const int lo = offsets[k], hi = offsets[k + 1];
-    const int len = hi - lo;
-    const int per = (len + kBwdSplit - 1) / kBwdSplit;
-    const int a = lo + s * per;
-    const int b = a + per < hi ? a + per : hi;
+    const int unit = blockIdx.x, tid = threadIdx.x;
+    if (unit >= unit_start[K]) return;
+    int lo_k = 0, hi_k = K;                                  // last k with unit_start[k] <= unit
+    while (hi_k - lo_k > 1) {
+        const int mid = (lo_k + hi_k) >> 1;
+        if (unit_start[mid] <= unit) lo_k = mid; else hi_k = mid;
+    }
+    const int k = lo_k;
+    const int a = offsets[k] + (unit - unit_start[k]) * kBwdChunk;
+    const int b = a + kBwdChunk < offsets[k + 1] ? a + kBwdChunk : offsets[k + 1];
     // D <= 256: threads [0, G*D) are G row groups of D channels each
     const int G = 256 / D;
     const int g = tid / D, c = tid - g * D;
@@ -101,12 +140,13 @@ __global__ __launch_bounds__(256) void vqb_segsum_kernel(const float *__restrict
     if (tid < D) {
         double t = 0.0;
         for (int q = 0; q < G; ++q) t += red[q * D + tid];
-        partial[((size_t)k * kBwdSplit + s) * D + tid] = t;
+        partial[(size_t)unit * D + tid] = t;
     }
 }
 
 __global__ __launch_bounds__(256) void vqb_codebook_grad_kernel(const float *__restrict__ cb,
                                                                 const int *__restrict__ offsets,
+                                                                const int *__restrict__ unit_start,
                                                                 const double *__restrict__ partial,
                                                                 const float *__restrict__ g_loss, int K, int D,
                                                                 double scale, float *__restrict__ grad_cb) {
@@ -114,7 +154,7 @@ __global__ __launch_bounds__(256) void vqb_codebook_grad_kernel(const float *__r
     if (e >= (long long)K * D) return;
     const int k = (int)(e / D), c = (int)(e - (long long)k * D);
     double zsum = 0.0;
-    for (int s = 0; s < kBwdSplit; ++s) zsum += partial[((size_t)k * kBwdSplit + s) * D + c];
+    for (int u = unit_start[k]; u < unit_start[k + 1]; ++u) zsum += partial[(size_t)u * D + c];
     const double cnt = (double)(offsets[k + 1] - offsets[k]);
     const double gl = g_loss ? (double)g_loss[0] : 1.0;
     grad_cb[e] = (float)(gl * scale * (cnt * (double)cb[e] - zsum));
@@ -255,10 +295,13 @@ int vqvae_vq_backward_f32(const float *z_e, const float *codebook, const int64_t
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(vqb_offsets_kernel, dim3((unsigned)((K + 1 + 255) / 256)), dim3(256), 0, st, keys_out, N, K,
                            offsets);
-        hipLaunchKernelGGL(vqb_segsum_kernel, dim3((unsigned)K, kBwdSplit), dim3(256), 0, st, z_e, vals_out, offsets,
-                           D, (int)HW, rowmajor, partial);
+        int *unit_start = reinterpret_cast<int *>(ws + p.off_units);
+        hipLaunchKernelGGL(vqb_units_kernel, dim3(1), dim3(1024), 0, st, offsets, K, unit_start);
+        hipLaunchKernelGGL(vqb_segsum_kernel, dim3((unsigned)p.max_units), dim3(256), 0, st, z_e, vals_out, offsets,
+                           unit_start, K, D, (int)HW, rowmajor, partial);
         hipLaunchKernelGGL(vqb_codebook_grad_kernel, dim3((unsigned)(((long long)K * D + 255) / 256)), dim3(256), 0,
-                           st, codebook, offsets, partial, grad_loss, K, D, 2.0 * (double)beta / nd, grad_codebook);
+                           st, codebook, offsets, unit_start, partial, grad_loss, K, D, 2.0 * (double)beta / nd,
+                           grad_codebook);
     }
     return (int)hipGetLastError();
 }
