@@ -24,16 +24,19 @@ struct WgradGeom {
     int k, stride, pad;
     int bt_nchw;                      // Bt is an NCHW image tensor (first / last layer), else row-major
     int nsplit;
-    long long rows_per_split;         // A rows (b, yA) per workgroup
+    long long rows_per_split;         // 32-pixel blocks of A per workgroup
 };
 
-// Workgroup = 4 waves; tile = 64 ca x 64 cb for one tap; each wave takes every 4th A row of the split and the
-// four partial tiles are summed through LDS in wave order.  The reduction runs over "items" of eight pixels
-// (four MFMA k-steps): the sixteen operand loads of item i+1 are in flight while item i multiplies.
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
-                                                         float *__restrict__ partial, WgradGeom g) {
-    constexpr int MT = 2, NT = 2, PAIRS = 4;
-    __shared__ float red[MT * NT * 1024];               // one wave's tile at a time
+// Workgroup = 4 waves; output tile = 64 ca x 64 cb for one tap.  The reduction runs over blocks of 32 A-pixels:
+// the block's A rows and the tap-shifted Bt rows (zero outside the map) are staged in LDS with coalesced 16-byte
+// loads (double-buffered, one barrier per block); wave w multiplies pixels [8w, 8w+8) of the block -- four MFMA
+// k-steps whose operands are plain ds_read_b32 of one channel per lane, so the fp32 matrix pipe (which shares its
+// issue slots with the VALU) sees almost no address arithmetic.  The four waves' tiles are then added in wave
+// order through LDS and wave 0 writes the split's partial.
+__global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                            float *__restrict__ partial, WgradGeom g) {
+    constexpr int MT = 2, NT = 2, PB = 32, LD = 68;     // LD: padded row (64 channels + 4) -> conflict-free reads
+    __shared__ __attribute__((aligned(16))) float smem[2 * 2 * PB * LD];     // [buf][A | B][pixel][LD]; reused as `red`
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_b = (g.CB + 63) / 64, tiles_a = (g.CA + 63) / 64;
@@ -43,17 +46,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     const int tap = t;                                  // ky * k + kx
     const int ky = tap / g.k, kx = tap - ky * g.k;
     const int split = blockIdx.y;
-    const long long nrows = (long long)g.B * g.HA;
-    const long long r_lo = (long long)split * g.rows_per_split;
-    long long r_hi = r_lo + g.rows_per_split;
-    if (r_hi > nrows) r_hi = nrows;
-
-    int ca[MT], cb[NT];
-    bool ca_ok[MT], cb_ok[NT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) { ca[mt] = ta * 64 + mt * 32 + l31; ca_ok[mt] = ca[mt] < g.CA; }
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) { cb[nt] = tb * 64 + nt * 32 + l31; cb_ok[nt] = cb[nt] < g.CB; }
+    const unsigned npix = (unsigned)g.B * g.HA * g.WA, img_px = (unsigned)g.HA * g.WA;
+    const unsigned nblk = (npix + PB - 1) / PB;
+    const unsigned blk_lo = (unsigned)(split * g.rows_per_split);            // rows_per_split counts pixel blocks here
+    unsigned blk_hi = blk_lo + (unsigned)g.rows_per_split;
+    if (blk_hi > nblk) blk_hi = nblk;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -63,56 +60,93 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
 
-    // item i of this wave: row = r_lo + wave + 4 * (i / cpr), pixels [8 * (i % cpr), +8)
-    const int cpr = (g.WA + 2 * PAIRS - 1) / (2 * PAIRS);
-    const long long my_rows = r_hi > r_lo + wave ? (r_hi - r_lo - wave + 3) / 4 : 0;
-    const long long nitem = my_rows * cpr;
-    auto load_item = [&](long long i, float(&av)[PAIRS][MT], float(&bv)[PAIRS][NT]) {
-        const long long ri = i / cpr;
-        const int x00 = (int)(i - ri * cpr) * 2 * PAIRS;
-        const long long row = r_lo + wave + 4 * ri;
-        const long long b = row / g.HA;
-        const int yA = (int)(row - b * g.HA);
-        const int yB = yA * g.stride + ky - g.pad;
-        const bool yok = yB >= 0 && yB < g.HB;
-        const float *arow = A + (size_t)row * g.WA * g.CA;
+    // staging role of this thread: pixel pi of the block, channels [8*cg, 8*cg + 8) of the 64-channel tile
+    const int pi = tid >> 3, cg = tid & 7;
+    const int ca0 = ta * 64 + 8 * cg, cb0 = tb * 64 + 8 * cg;
+    const bool va = (g.CA & 3) == 0, vb = !g.bt_nchw && (g.CB & 3) == 0;      // 16-byte loads allowed
+    f32x4 ra[2], rb[2];
+    auto fetch = [&](unsigned blk) {
+        const unsigned p = blk * PB + pi;
+        const f32x4 z4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        ra[0] = ra[1] = rb[0] = rb[1] = z4;
+        if (p >= npix) return;
+        const unsigned b = p / img_px, rem = p - b * img_px;
+        const int yA = (int)(rem / (unsigned)g.WA), xA = (int)(rem - (unsigned)yA * g.WA);
+        const float *ap = A + (size_t)p * g.CA;
 #pragma unroll
-        for (int q = 0; q < PAIRS; ++q) {
-            const int xA = x00 + 2 * q + h;
-            const int xB = xA * g.stride + kx - g.pad;
-            const bool pa = yok && xA < g.WA, pb = pa && xB >= 0 && xB < g.WB;
+        for (int q = 0; q < 2; ++q) {
+            const int c = ca0 + 4 * q;
+            if (va && c + 3 < g.CA) ra[q] = *reinterpret_cast<const f32x4 *>(ap + c);
+            else {
+                if (c < g.CA) ra[q].x = ap[c];
+                if (c + 1 < g.CA) ra[q].y = ap[c + 1];
+                if (c + 2 < g.CA) ra[q].z = ap[c + 2];
+                if (c + 3 < g.CA) ra[q].w = ap[c + 3];
+            }
+        }
+        const int yB = yA * g.stride + ky - g.pad, xB = xA * g.stride + kx - g.pad;
+        if (yB < 0 || yB >= g.HB || xB < 0 || xB >= g.WB) return;
+        if (g.bt_nchw) {
+            const float *bp = Bt + ((size_t)b * g.CB * g.HB + yB) * g.WB + xB;    // + c * HB * WB
+            const size_t cs = (size_t)g.HB * g.WB;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) av[q][mt] = (pa && ca_ok[mt]) ? arow[(size_t)xA * g.CA + ca[mt]] : 0.0f;
+            for (int q = 0; q < 2; ++q) {
+                const int c = cb0 + 4 * q;
+                if (c < g.CB) rb[q].x = bp[c * cs];
+                if (c + 1 < g.CB) rb[q].y = bp[(c + 1) * cs];
+                if (c + 2 < g.CB) rb[q].z = bp[(c + 2) * cs];
+                if (c + 3 < g.CB) rb[q].w = bp[(c + 3) * cs];
+            }
+        } else {
+            const float *bp = Bt + (((size_t)b * g.HB + yB) * g.WB + xB) * g.CB;
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float v = 0.0f;
-                if (pb && cb_ok[nt])
-                    v = g.bt_nchw ? Bt[(((size_t)b * g.CB + cb[nt]) * g.HB + yB) * g.WB + xB]
-                                  : Bt[(((size_t)b * g.HB + yB) * g.WB + xB) * g.CB + cb[nt]];
-                bv[q][nt] = v;
+            for (int q = 0; q < 2; ++q) {
+                const int c = cb0 + 4 * q;
+                if (vb && c + 3 < g.CB) rb[q] = *reinterpret_cast<const f32x4 *>(bp + c);
+                else {
+                    if (c < g.CB) rb[q].x = bp[c];
+                    if (c + 1 < g.CB) rb[q].y = bp[c + 1];
+                    if (c + 2 < g.CB) rb[q].z = bp[c + 2];
+                    if (c + 3 < g.CB) rb[q].w = bp[c + 3];
+                }
             }
         }
     };
-    auto mma_item = [&](const float(&av)[PAIRS][MT], const float(&bv)[PAIRS][NT]) {
+    auto park = [&](int buf) {
+        float *as = smem + (buf * 2 + 0) * PB * LD + pi * LD + 8 * cg;
+        float *bs = smem + (buf * 2 + 1) * PB * LD + pi * LD + 8 * cg;
+        *reinterpret_cast<f32x4 *>(as) = ra[0]; *reinterpret_cast<f32x4 *>(as + 4) = ra[1];
+        *reinterpret_cast<f32x4 *>(bs) = rb[0]; *reinterpret_cast<f32x4 *>(bs + 4) = rb[1];
+    };
+
+    if (blk_lo < blk_hi) {
+        fetch(blk_lo);
+        park(0);
+    }
+    __syncthreads();
+    for (unsigned blk = blk_lo; blk < blk_hi; ++blk) {
+        const int buf = (blk - blk_lo) & 1;
+        if (blk + 1 < blk_hi) fetch(blk + 1);
+        const float *as = smem + (buf * 2 + 0) * PB * LD + (8 * wave + h) * LD + l31;
+        const float *bs = smem + (buf * 2 + 1) * PB * LD + (8 * wave + h) * LD + l31;
 #pragma unroll
-        for (int q = 0; q < PAIRS; ++q)
+        for (int q = 0; q < 4; ++q) {                       // k-step q: pixels 8*wave + 2q + h
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) av[mt] = as[2 * q * LD + 32 * mt];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bv[nt] = bs[2 * q * LD + 32 * nt];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[q][mt], bv[q][nt], acc[mt][nt], 0, 0, 0);
-    };
-    float a0[PAIRS][MT], b0[PAIRS][NT], a1[PAIRS][MT], b1[PAIRS][NT];
-    if (nitem > 0) load_item(0, a0, b0);
-    for (long long i = 0; i < nitem; i += 2) {
-        if (i + 1 < nitem) load_item(i + 1, a1, b1);
-        mma_item(a0, b0);
-        if (i + 1 < nitem) {
-            if (i + 2 < nitem) load_item(i + 2, a0, b0);
-            mma_item(a1, b1);
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         }
+        if (blk + 1 < blk_hi) park(buf ^ 1);                // its last readers passed the barrier of the previous block
+        __syncthreads();
     }
     // the four waves' tiles are added in wave order (0 + 1 + 2 + 3) through one LDS tile; wave 0 writes
+    float *red = smem;                                       // 4096 floats <= 2*2*32*68
     for (int w = 3; w >= 1; --w) {
         __syncthreads();
         if (wave == w) {
@@ -142,7 +176,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int a = ta * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;     // accumulator row = ca
-                    if (a < g.CA && cb_ok[nt]) dst[(size_t)a * g.CB + cb[nt]] = acc[mt][nt][r];
+                    const int c = tb * 64 + nt * 32 + l31;
+                    if (a < g.CA && c < g.CB) dst[(size_t)a * g.CB + c] = acc[mt][nt][r];
                 }
     }
 }
@@ -244,17 +279,15 @@ __global__ __launch_bounds__(256) void relu_backward_kernel(const float *__restr
 }
 
 static int wgrad_plan(int64_t B, int HA, int WA, int CA, int CB, int k, WgradGeom &g) {
-    const long long nrows = (long long)B * HA;
-    long long ns = (nrows + 15) / 16;                   // at least ~16 rows per workgroup (4 per wave)
-    // enough workgroups to fill the chip: tiles * taps * splits >= ~4 per CU
+    const long long nblk = ((long long)B * HA * WA + 31) / 32;        // 32-pixel blocks
+    // enough workgroups to fill the chip a few times over: tiles * taps * splits >= ~8 per CU
     const long long tiles = (long long)((CA + 63) / 64) * ((CB + 63) / 64) * k * k;
-    long long want = (4LL * num_cus() + tiles - 1) / tiles;
-    if (want < 1) want = 1;
-    if (ns > want) ns = want;
+    long long ns = (8LL * num_cus() + tiles - 1) / tiles;
+    if (ns > (nblk + 7) / 8) ns = (nblk + 7) / 8;         // at least 8 blocks per workgroup
     if (ns > kWgMaxSplit) ns = kWgMaxSplit;
     if (ns < 1) ns = 1;
     g.nsplit = (int)ns;
-    g.rows_per_split = (nrows + ns - 1) / ns;
+    g.rows_per_split = (nblk + ns - 1) / ns;
     return VQVAE_OK;
 }
 
@@ -275,7 +308,8 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
     if (!a || !bt || !grad_w) return VQVAE_ERR_NULL;
     if (B < 1 || HA < 1 || WA < 1 || CA < 1 || HB < 1 || WB < 1 || CB < 1 || stride < 1 || pad < 0) return VQVAE_ERR_SHAPE;
     if (k < 1 || k > 4) return VQVAE_ERR_UNSUPPORTED;
-    if (B * (int64_t)HA > INT32_MAX || B * (int64_t)HB * WB * CB > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
+    if (B * (int64_t)HA * WA > INT32_MAX || B * (int64_t)HB * WB * CB > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
+    if ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(bt)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte loads
     if (!workspace || workspace_bytes < vqvae_conv_wgrad_workspace_bytes(CA, CB, k)) return VQVAE_ERR_WORKSPACE;
     WgradGeom g;
     g.B = (int)B; g.HA = HA; g.WA = WA; g.CA = CA; g.HB = HB; g.WB = WB; g.CB = CB;
