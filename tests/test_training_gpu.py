@@ -261,3 +261,43 @@ def test_full_model_backward_on_hip_matches_cpu_reference():
         ref = sd[name].grad
         assert ref is not None and p.grad is not None, name
         _close_grad(p.grad, ref, name)
+
+
+@pytest.mark.parametrize("Cin,C0,B,H,W", [(3, 64, 5, 32, 32), (1, 32, 2, 16, 24), (4, 64, 3, 8, 12), (3, 16, 1, 64, 64)])
+def test_first_layer_backward_vs_torch_autograd(Cin, C0, B, H, W):
+    from vqvae_amd import autograd_conv as A
+    dev = torch.device("cuda:0")
+    torch.manual_seed(Cin * 7 + C0)
+    m = torch.nn.Conv2d(Cin, C0, 4, 2, 1)
+    x = torch.randn(B, Cin, H, W)
+    y = torch.relu(m(x))
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    md = torch.nn.Conv2d(Cin, C0, 4, 2, 1).to(dev)
+    md.load_state_dict(m.state_dict())
+    yd = A.ConvInFn.apply(x.to(dev), md.weight, md.bias, md)
+    yd.backward(gy.to(dev).permute(0, 2, 3, 1).contiguous())
+    _close_grad(md.weight.grad, m.weight.grad, "grad_w")
+    _close_grad(md.bias.grad, m.bias.grad, "grad_b")
+
+
+@pytest.mark.parametrize("C,Cout,B,H,W", [(64, 3, 5, 16, 16), (32, 1, 2, 8, 12), (128, 4, 2, 5, 7), (64, 3, 1, 20, 18)])
+def test_last_layer_backward_vs_torch_autograd(C, Cout, B, H, W):
+    from vqvae_amd import autograd_conv as A
+    dev = torch.device("cuda:0")
+    torch.manual_seed(C + Cout)
+    m = torch.nn.ConvTranspose2d(C, Cout, 4, 2, 1)
+    t = torch.randn(B, C, H, W)
+    tr = t.clone().requires_grad_(True)
+    y = m(tr)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    md = torch.nn.ConvTranspose2d(C, Cout, 4, 2, 1).to(dev)
+    md.load_state_dict(m.state_dict())
+    td = t.to(dev).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    yd = A.ConvTOutFn.apply(td, md.weight, md.bias, md)
+    np.testing.assert_allclose(yd.detach().cpu().numpy(), y.detach().numpy(), atol=1e-5, rtol=1e-4)
+    yd.backward(gy.to(dev))
+    _close_grad(td.grad.permute(0, 3, 1, 2), tr.grad, "grad_t")
+    _close_grad(md.weight.grad, m.weight.grad, "grad_w")
+    _close_grad(md.bias.grad, m.bias.grad, "grad_b")

@@ -18,6 +18,7 @@
 namespace vqvae {
 
 constexpr int kWgMaxSplit = 64;       // pixel-range splits across workgroups
+constexpr int kWgImgSplit = 512;      // workgroups (= partials) of the image-operand kernel
 
 struct WgradGeom {
     int B, HA, WA, CA, HB, WB, CB;
@@ -182,6 +183,114 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float *__restr
     }
 }
 
+// Weight gradient when Bt is a small NCHW image tensor (first / last layer: CB <= 4 image channels): the k*k taps
+// are folded into the MFMA N dimension (column n = tap*CB + cb, k*k*CB <= 64), so one pass over the pixels serves
+// every tap instead of k*k passes that each fill 3 of 64 columns.  One wave owns one image at a time: the image's
+// CB planes are staged in LDS (wave-private), the B operand is gathered from them at the tap-shifted position,
+// the A operand (row-major, CA <= 64) is one coalesced channel per lane straight from global memory.
+__global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                             float *__restrict__ partial, WgradGeom g, int imgs_per_wg) {
+    constexpr int MT = 2, NT = 2;
+    extern __shared__ __attribute__((aligned(16))) float smem_img[];         // [4 waves][CB*HB*WB], later `red`
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int plane = g.HB * g.WB, img_f = g.CB * plane;
+    float *img = smem_img + (size_t)wave * img_f;
+    const int ntap = g.k * g.k, ncol = ntap * g.CB;
+
+    // this lane's B columns: n = nt*32 + l31 -> (tap, cb)
+    int ky[NT], kx[NT], cbo[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = nt * 32 + l31;
+        nok[nt] = n < ncol;
+        const int tap = nok[nt] ? n / g.CB : 0;
+        cbo[nt] = (nok[nt] ? n - tap * g.CB : 0) * plane;
+        ky[nt] = tap / g.k; kx[nt] = tap - ky[nt] * g.k;
+    }
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    const long long b_lo = (long long)blockIdx.x * imgs_per_wg;
+    long long b_hi = b_lo + imgs_per_wg;
+    if (b_hi > g.B) b_hi = g.B;
+    const int npx = g.HA * g.WA;
+    for (long long b = b_lo + wave; b < b_hi; b += 4) {
+        __builtin_amdgcn_wave_barrier();
+        const float *src = Bt + (size_t)b * img_f;
+        for (int i = lane; i < img_f; i += 64) img[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const float *ab = A + (size_t)b * npx * g.CA;
+        for (int p0 = 0; p0 < npx; p0 += 2) {
+            const int p = p0 + h;
+            const bool pok = p < npx;
+            const int yA = p / g.WA, xA = p - yA * g.WA;
+            float av[MT], bv[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int c = mt * 32 + l31;
+                av[mt] = (pok && c < g.CA) ? ab[(size_t)p * g.CA + c] : 0.0f;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int yB = yA * g.stride + ky[nt] - g.pad, xB = xA * g.stride + kx[nt] - g.pad;
+                const bool ok = pok && nok[nt] && yB >= 0 && yB < g.HB && xB >= 0 && xB < g.WB;
+                bv[nt] = ok ? img[cbo[nt] + yB * g.WB + xB] : 0.0f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    float *red = smem_img;                                   // 4096 floats (the launch sizes LDS for it)
+    for (int w = 3; w >= 1; --w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) red[((mt * NT + nt) * 16 + r) * 64 + lane] = acc[mt][nt][r];
+        }
+        __syncthreads();
+        if (wave == w - 1) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mt][nt][r] += red[((mt * NT + nt) * 16 + r) * 64 + lane];
+        }
+    }
+    if (wave == 0) {
+        // partial layout of the generic kernel: [split = workgroup][tap][ca][cb]
+        float *dst = partial + (size_t)blockIdx.x * ntap * g.CA * g.CB;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int a = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int n = nt * 32 + l31;
+                    if (a < g.CA && n < ncol) {
+                        const int tap = n / g.CB, cb = n - tap * g.CB;
+                        dst[((size_t)tap * g.CA + a) * g.CB + cb] = acc[mt][nt][r];
+                    }
+                }
+    }
+}
+
 // dW[ca][cb][tap] = sum_split partial[split][tap][ca][cb]   (fixed order)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__restrict__ partial, int nsplit, int ntap,
                                                                 int CA, int CB, float *__restrict__ dw) {
@@ -299,7 +408,8 @@ extern "C" {
 
 size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k) {
     if (CA < 1 || CB < 1 || k < 1 || k > 4) return 0;
-    return (size_t)kWgMaxSplit * k * k * CA * CB * sizeof(float);
+    const int splits = (k * k * CB <= 64 && CA <= 64) ? kWgImgSplit : kWgMaxSplit;      // image-operand kernel
+    return (size_t)splits * k * k * CA * CB * sizeof(float);
 }
 
 int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA, int HB, int WB, int CB,
@@ -317,6 +427,22 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
     wgrad_plan(B, HA, WA, CA, CB, k, g);
     hipStream_t st = static_cast<hipStream_t>(stream);
     float *partial = static_cast<float *>(workspace);
+    const size_t img_lds = (size_t)4 * CB * HB * WB * sizeof(float);
+    if (bt_nchw && CA <= 64 && k * k * CB <= 64 && img_lds <= 96 * 1024) {
+        // small NCHW image operand: taps folded into the MFMA N dimension, one image per wave
+        long long nwg = (B + 3) / 4;
+        if (nwg > kWgImgSplit) nwg = kWgImgSplit;
+        const int ipw = (int)((B + nwg - 1) / nwg);
+        nwg = (B + ipw - 1) / ipw;
+        const size_t lds = img_lds > 16384 ? img_lds : 16384;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(conv_wgrad_img_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL(conv_wgrad_img_kernel, dim3((unsigned)nwg), dim3(256), lds, st, a, bt, partial, g, ipw);
+        const long long tot = (long long)k * k * CA * CB;
+        hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, partial,
+                           (int)nwg, k * k, CA, CB, grad_w);
+        return (int)hipGetLastError();
+    }
     const unsigned gx = (unsigned)(((CA + 63) / 64) * ((CB + 63) / 64) * k * k);
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, (unsigned)g.nsplit), dim3(256), 0, st, a, bt, partial, g);
     const long long total = (long long)k * k * CA * CB;
