@@ -362,13 +362,20 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__r
     }
 }
 
+// stage 2: one workgroup per channel, fixed-order tree over the block partials
 __global__ __launch_bounds__(256) void bias_grad_final_kernel(const double *__restrict__ partial, int nblocks, int C,
                                                               float *__restrict__ db) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    __shared__ double red[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partial[(size_t)b * C + c];
-    db[c] = (float)s;
+    for (int b = tid; b < nblocks; b += 256) s += partial[(size_t)b * C + c];
+    red[tid] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) red[tid] += red[tid + o];
+        __syncthreads();
+    }
+    if (tid == 0) db[c] = (float)red[0];
 }
 
 __global__ __launch_bounds__(256) void relu_backward_kernel(const float *__restrict__ gout, const float *__restrict__ y,
@@ -470,8 +477,7 @@ int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw,
     double *partial = static_cast<double *>(workspace);
     hipLaunchKernelGGL(bias_grad_partial_kernel, dim3((unsigned)nb), dim3(256), 0, st, grad_y, P, C, (long long)HW,
                        nchw ? 1 : 0, rpb, partial);
-    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)((C + 255) / 256)), dim3(256), 0, st, partial, (int)nb, C,
-                       grad_b);
+    hipLaunchKernelGGL(bias_grad_final_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, (int)nb, C, grad_b);
     return (int)hipGetLastError();
 }
 
