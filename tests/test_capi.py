@@ -89,6 +89,16 @@ def test_conv_and_training_argument_errors_without_gpu():
     assert L.vqvae_recon_loss_f32(a, a + 4, 16, 1.0, None, None, a, a, 1 << 20, None) == -3
     assert L.vqvae_recon_loss_f32(a, a, 16, 1.0, None, None, a, a, 8, None) == -4
     assert L.vqvae_transpose_f32(None, 1, 8, 8, a, None) == -1
+    assert L.vqvae_conv_wgrad_workspace_bytes(128, 128, 3) == 64 * 9 * 128 * 128 * 4
+    assert L.vqvae_conv_wgrad_workspace_bytes(128, 128, 5) == 0
+    assert L.vqvae_conv_wgrad_f32(a, None, 1, 8, 8, 128, 8, 8, 128, 3, 1, 1, 0, a, a, 1 << 30, None) == -1
+    assert L.vqvae_conv_wgrad_f32(a, a, 1, 8, 8, 128, 8, 8, 128, 5, 1, 1, 0, a, a, 1 << 30, None) == -3
+    assert L.vqvae_conv_wgrad_f32(a, a, 1, 8, 8, 128, 8, 8, 128, 3, 1, 1, 0, a, a, 16, None) == -4
+    assert L.vqvae_conv_wgrad_f32(a + 4, a, 1, 8, 8, 128, 8, 8, 128, 3, 1, 1, 0, a, a, 1 << 30, None) == -3
+    assert L.vqvae_bias_grad_f32(a, 1, 64, 300, 0, a, a, 1 << 30, None) == -3
+    assert L.vqvae_bias_grad_f32(a, 0, 64, 128, 0, a, a, 1 << 30, None) == -2
+    assert L.vqvae_relu_backward_f32(a, None, 16, a, None) == -1
+    assert L.vqvae_relu_backward_f32(a, a + 4, 16, a, None) == -3
 
 
 def test_product_path_does_not_import_oracle():

@@ -208,3 +208,42 @@ def test_model_random_configs_stagewise_vs_oracle(seed):
         np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.numpy(), atol=1e-5, rtol=1e-4, err_msg=tag)
         out = md(x.to(dev()))
         assert out[1].shape == x.shape and torch.isfinite(out[1]).all()
+
+
+@pytest.mark.parametrize("seed", list(range(24)))
+def test_conv_backward_random_shapes_vs_torch_autograd(seed):
+    """Data, weight and bias gradients of every conv kind on random shapes (tile-resident and generic kernels,
+    ragged channel counts, pixel counts that are not multiples of the 32-pixel wgrad block)."""
+    from vqvae_amd import autograd_conv as A
+    r = _rng(6000 + seed)
+    kind = int(r.integers(0, 5))
+    Cin = int(r.choice([4, 8, 16, 32, 64, 128]))
+    Cout = int(r.choice([4, 8, 24, 32, 64, 128]))          # Cout % 4: the data gradient reads it as its input
+    B = int(r.integers(1, 6))
+    if seed % 3 == 0:
+        H = W = 16 if kind == 0 else 8
+    else:
+        H = int(r.integers(1, 8)) * 2 if kind == 0 else int(r.integers(1, 13))
+        W = int(r.integers(1, 8)) * 2 if kind == 0 else int(r.integers(1, 13))
+    relu_out = bool(r.integers(0, 2))
+    torch.manual_seed(seed)
+    ctor = [lambda: nn.Conv2d(Cin, Cout, 4, 2, 1), lambda: nn.Conv2d(Cin, Cout, 3, 1, 1), lambda: nn.Conv2d(Cin, Cout, 1),
+            lambda: nn.ConvTranspose2d(Cin, Cout, 3, 1, 1), lambda: nn.ConvTranspose2d(Cin, Cout, 4, 2, 1)][kind]
+    m = ctor()
+    x = torch.randn(B, Cin, H, W)
+    xr = x.clone().requires_grad_(True)
+    y = m(xr)
+    if relu_out:
+        y = torch.relu(y)
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    md = ctor().to(dev())
+    md.load_state_dict(m.state_dict())
+    xd = x.to(dev()).permute(0, 2, 3, 1).contiguous().requires_grad_(True)
+    yd = A.ConvFn.apply(xd, md.weight, md.bias, md, kind, relu_out)
+    yd.backward(gy.to(dev()).permute(0, 2, 3, 1).contiguous())
+    tag = f"kind={kind} B={B} {Cin}->{Cout} {H}x{W} relu={relu_out}"
+    for got, ref, what in ((xd.grad.permute(0, 3, 1, 2), xr.grad, "grad_x"), (md.weight.grad, m.weight.grad, "grad_w"),
+                           (md.bias.grad, m.bias.grad, "grad_b")):
+        scale = float(ref.abs().max()) + 1e-30
+        np.testing.assert_allclose(got.cpu().numpy(), ref.numpy(), rtol=2e-4, atol=2e-5 * scale, err_msg=f"{what} {tag}")
