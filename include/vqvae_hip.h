@@ -246,6 +246,24 @@ VQVAE_API int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C,
 VQVAE_API int vqvae_relu_backward_f32(const float *grad_out, const float *y, int64_t n, float *grad_in,
                                       vqvae_stream_t stream);
 
+/* ------------------------------------------------------- GatedPixelCNN prior
+ * pixelcnn/models.py: the masked convolutions run as im2col over their causal tap list followed by the 1x1 conv
+ * (vqvae_conv_forward_f32, kind VQVAE_CONV_1x1); these are the memory-bound pieces around it, all on row-major
+ * (B,H,W,C) activations, C % 4 == 0, pointers 16-byte aligned.
+ *   gather_rows       out[i][:] = table[idx[i]][:]            nn.Embedding (:119-121; class_cond_embedding :68)
+ *   im2col_rows       out[b,y,x,t*C+c] = x[b,y+dy[t],x+dx[t],c], 0 outside the map; dy/dx are HOST arrays, ntaps <= 32
+ *   gated_activation  out[.., c] = tanh(a) * sigmoid(g), a = t1[.., c] (+ t2[.., c]) (+ cond[b][c]),
+ *                     g = the same at channel dim + c (GatedActivation :21-27 with the sums of :71 / :77);
+ *                     t1, t2 (B,HW,2*dim), cond (B,2*dim), out (B,HW,dim); t2 and cond may be NULL
+ *   add               out = a + b                              the horizontal residual (:79)                 */
+VQVAE_API int vqvae_gather_rows_f32(const int64_t *idx, const float *table, int64_t n, int C, int rows,
+                                    float *out, vqvae_stream_t stream);
+VQVAE_API int vqvae_im2col_rows_f32(const float *x, int64_t B, int H, int W, int C, int ntaps,
+                                    const int8_t *dy, const int8_t *dx, float *out, vqvae_stream_t stream);
+VQVAE_API int vqvae_gated_activation_f32(const float *t1, const float *t2, const float *cond, int64_t B,
+                                         int HW, int dim, float *out, vqvae_stream_t stream);
+VQVAE_API int vqvae_add_f32(const float *a, const float *b, int64_t n, float *out, vqvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -51,6 +51,10 @@ SIGNATURES = {
     "vqvae_bias_grad_workspace_bytes": (_sz, [_i32]),
     "vqvae_bias_grad_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "vqvae_gather_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "vqvae_im2col_rows_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vqvae_gated_activation_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),
+    "vqvae_add_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib = None
