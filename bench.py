@@ -179,8 +179,8 @@ def main():
             "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4),
             # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-            # measured offline on a 4.19 M-row stream: 662 B/row (profiles/r01_vq_hbm_traffic.txt)
-            "traffic": rows * 662,
+            # measured offline on a 4.19 M-row stream: 520.7 B/row (profiles/r01_vq_hbm_traffic.txt)
+            "traffic": rows * 521,
             "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
             "alg_bytes_per_row": 8 * D + 8,
             "screen_tflops_bf16": round(2 * flops / t_vq / 1e12, 1),

@@ -47,6 +47,7 @@ struct VqPlan {
     size_t filter_lds_bytes;
 };
 constexpr int kVqCandCap = 8;   // per lane half (16 per row), unsigned short entries   // candidate list capacity per row in the filter kernel
+constexpr int kVqTilesPerWave = 2;   // 32-row tiles a wave of the filter kernel walks per iteration
 constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many workgroups
 
 inline VqPlan vq_plan(int K, int D) {
@@ -72,7 +73,7 @@ inline VqPlan vq_plan(int K, int D) {
     p.total = align_up(p.off_neh + (size_t)p.K32 * 4, 256);
     // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
     p.filter_lds_bytes = (size_t)p.K32 * D * 2 + (size_t)p.K32 * 4 + (size_t)K * 4 +
-                         8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4 + 256 + 8;
+                         kVqTilesPerWave * (8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4) + 256 + 8;
     p.filter_ok = (D == 64) && p.filter_lds_bytes <= (size_t)kLdsBytes;
     return p;
 }

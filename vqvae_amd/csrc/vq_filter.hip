@@ -39,21 +39,26 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
     return r;
 }
 
+// Each wave owns TWO 32-row tiles per iteration (TPW = 2) and walks them phase by phase -- both tiles' rows are
+// requested up front, then convert / sweep 1 / sweep 2 / refine / epilogue run for tile 0 and tile 1 back to back,
+// with both epilogue gathers issued before either is consumed -- so one tile's memory round trips hide under the
+// other tile's matrix / vector work.  One 512-thread workgroup per CU (the 256-VGPR budget holds both tiles' rows
+// in registers from load to store; the codebook image is staged once per CU).
 template <bool ROWMAJOR>
-__global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
+__global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img16,
     const float *__restrict__ neh_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
     long long N, int HW, int K, int K32, long long nblocks, float *__restrict__ zq,
     long long *__restrict__ idx, int *__restrict__ hist, double *__restrict__ partials) {
-    constexpr int D = 64, HALF = 32, NQ = 4, CAPH = kVqCandCap;   // list capacity per lane half
+    constexpr int D = 64, HALF = 32, NQ = 4, CAPH = kVqCandCap, TPW = kVqTilesPerWave;
     static_assert(CAPH == 8, "candidate lists are packed into four registers / one 16-byte LDS slot");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                       // [NQ][2][K32] x 16 B
     float *neh = reinterpret_cast<float *>(Eimg + (size_t)NQ * 2 * K32);      // [K32]  -||e||^2/2
     int *hist_s = reinterpret_cast<int *>(neh + K32);                         // [K]
-    unsigned short *cand_list = reinterpret_cast<unsigned short *>(hist_s + K + (K & 1));   // [8][32][2][CAPH]
-    float *wave_f = reinterpret_cast<float *>(cand_list + 8 * 32 * 2 * CAPH);  // [8][96]: zz | job | result
-    double *red = reinterpret_cast<double *>(wave_f + 8 * 96);
+    unsigned short *cand_list = reinterpret_cast<unsigned short *>(hist_s + K + (K & 1));   // [8][TPW][32][2][CAPH]
+    float *wave_f = reinterpret_cast<float *>(cand_list + 8 * TPW * 32 * 2 * CAPH);          // [8][TPW][96]
+    double *red = reinterpret_cast<double *>(wave_f + 8 * TPW * 96);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -61,39 +66,17 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
     const int cb_bad = flags[0];
     const float EEmax = __int_as_float(flags[1]) * 1.0001f;
     const float Emax = __builtin_sqrtf(EEmax) * 1.0001f;
-
-    unsigned short *my_list = cand_list + wave_u * (32 * 2 * CAPH);          // this wave's lists
-    unsigned short *own_list = my_list + (l31 * 2 + h) * CAPH;               // this lane's private part
-    const unsigned short *row_list = my_list + l31 * 2 * CAPH;
-    float *zz_s = wave_f + wave_u * 96;                                      // exact ||z||^2 per row
-    int *job_s = reinterpret_cast<int *>(zz_s + 32);                         // refine batch: (row<<16)|code
-    float *res_s = zz_s + 64;                                                // refine batch: distances
     const int ntile = K32 >> 5;
     const uint4 *ap0 = Eimg + (size_t)h * K32 + l31;
     const float *np0 = neh + 4 * h;
 
-    // one 32-code x 32-row screen tile: acc = -||e||^2/2 + bf16(e) . bf16(z)
-    auto screen_tile = [&](int ct, const bf16x8(&zb)[NQ], f32x16 &acc) {
-        const float *np = np0 + ct * 32;
-        uint4 a[NQ];
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) a[q] = ap0[(size_t)q * 2 * K32 + ct * 32];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const f32x4 e4 = *reinterpret_cast<const f32x4 *>(np + 8 * g);
-            acc[4 * g] = e4.x; acc[4 * g + 1] = e4.y; acc[4 * g + 2] = e4.z; acc[4 * g + 3] = e4.w;
-        }
-#pragma unroll
-        for (int q = 0; q < NQ; ++q)
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q]), zb[q], acc, 0, 0, 0);
-    };
     auto tile_max = [](const f32x16 &acc) -> float {
         const float m0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), m1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
         const float m2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), m3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
         const float m4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
         return fmaxf(fmaxf(fmaxf(m0, m1), m2), fmaxf(fmaxf(m3, m4), acc[15]));
     };
-    // this lane's half row (channels [32h, 32h+32)) as fp32, straight from memory (L2-hot on re-reads)
+    // this lane's half row (channels [32h, 32h+32)) as fp32
     auto load_half = [&](size_t zbase, size_t img0, unsigned voff, float(&zf)[HALF]) {
         if (ROWMAJOR) {
 #pragma unroll
@@ -109,277 +92,347 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
         }
     };
 
-    // per row block: this lane's row and addressing (ROWMAJOR: half row base; NCHW: channel 0 of the row)
-    long long r0 = 0, row = 0, rc = 0;
-    bool valid = false;
-    size_t zbase = 0, img0 = 0;
-    unsigned voff = 0;
-    auto setup = [&](long long rb) {
-        r0 = rb * 256 + wave_u * 32;
-        row = r0 + l31;
-        valid = row < N;
-        rc = valid ? row : N - 1;
+    // ---- per-tile state (t = 0, 1; every index below is a compile-time constant after unrolling) ---------------
+    long long r0[TPW], row[TPW], rc[TPW];
+    bool valid[TPW], bad[TPW], refine[TPW];
+    size_t zbase[TPW], img0[TPW];
+    unsigned voff[TPW];
+    float zf[TPW][HALF], thr[TPW], zz[TPW];
+    int ncand[TPW], n0[TPW], kbest[TPW];
+    auto setup = [&](long long sb, int t) {
+        r0[t] = (sb * 8 + wave_u) * (32 * TPW) + 32 * t;
+        row[t] = r0[t] + l31;
+        valid[t] = row[t] < N;
+        rc[t] = valid[t] ? row[t] : N - 1;
+        img0[t] = 0; voff[t] = 0;
         if (ROWMAJOR) {
-            zbase = (size_t)rc * D + HALF * h;
+            zbase[t] = (size_t)rc[t] * D + HALF * h;
         } else {
-            const long long b0 = (r0 < N ? r0 : N - 1) / HW;
-            const long long b = rc / HW;
-            const int hw = (int)(rc - b * HW);
-            zbase = (size_t)b * D * HW + hw;
-            img0 = (size_t)b0 * D * HW;
-            voff = (unsigned)((((b - b0) * D + HALF * h) * HW + hw) * 4);
+            const long long b0 = (r0[t] < N ? r0[t] : N - 1) / HW;
+            const long long b = rc[t] / HW;
+            const int hw = (int)(rc[t] - b * HW);
+            zbase[t] = (size_t)b * D * HW + hw;
+            img0[t] = (size_t)b0 * D * HW;
+            voff[t] = (unsigned)((((b - b0) * D + HALF * h) * HW + hw) * 4);
         }
     };
-    // The half row stays in registers from its load to the epilogue (one HBM read per element).  The first
-    // block's rows are requested before the codebook image is copied to LDS, so the two latencies overlap.
-    float zf[HALF];
-    setup(blockIdx.x);
-    load_half(zbase, img0, voff, zf);
+    auto lists_of = [&](int t) -> unsigned short * { return cand_list + (wave_u * TPW + t) * (32 * 2 * CAPH); };
+    auto fbuf_of = [&](int t) -> float * { return wave_f + (wave_u * TPW + t) * 96; };
+
+    // the first iteration's rows are requested before the codebook image is copied to LDS
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        setup(blockIdx.x, t);
+        load_half(zbase[t], img0[t], voff[t], zf[t]);
+    }
     for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
     for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
     for (int k = tid; k < K; k += 512) hist_s[k] = 0;
     __syncthreads();
 
     double dacc = 0.0;
-    for (long long rb = blockIdx.x; rb < nblocks; rb += gridDim.x) {
-        if (rb != (long long)blockIdx.x) {
-            setup(rb);
-            load_half(zbase, img0, voff, zf);
-        }
-        // ---- approximate ||z||^2 and the bf16 B operands --------------------------------------------
-        bf16x8 zb[NQ];
-        float zs = 0.0f;
+    for (long long sb = blockIdx.x; sb < nblocks; sb += gridDim.x) {
+        if (sb != (long long)blockIdx.x) {
 #pragma unroll
-        for (int c = 0; c < HALF; ++c) zs = __builtin_fmaf(zf[c], zf[c], zs);
-#pragma unroll
-        for (int q = 0; q < NQ; ++q) {
-            uint4 pk;
-            pk.x = cvt_pk_bf16(zf[8 * q], zf[8 * q + 1]);
-            pk.y = cvt_pk_bf16(zf[8 * q + 2], zf[8 * q + 3]);
-            pk.z = cvt_pk_bf16(zf[8 * q + 4], zf[8 * q + 5]);
-            pk.w = cvt_pk_bf16(zf[8 * q + 6], zf[8 * q + 7]);
-            zb[q] = __builtin_bit_cast(bf16x8, pk);
+            for (int t = 0; t < TPW; ++t) {
+                setup(sb, t);
+                load_half(zbase[t], img0[t], voff[t], zf[t]);
+            }
         }
-        zs += __shfl_xor(zs, 32);
-        bool bad = valid && (cb_bad || !(zs < 1.0e38f));
-        const float zn = __builtin_sqrtf(zs) * 1.0001f;
-        const float delta0 = 2.0f * ((0.00396f + 8.0e-6f) * zn * Emax + 2.0e-6f * EEmax + 1.2e-7f * (zs * 1.0001f + EEmax));
+        // ================= screen: convert, sweep 1, sweep 2 -- both row tiles share every codebook operand read ===
+        bf16x8 zb[TPW][NQ];
+        float delta0[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            float zs = 0.0f;
+#pragma unroll
+            for (int c = 0; c < HALF; ++c) zs = __builtin_fmaf(zf[t][c], zf[t][c], zs);
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) {
+                uint4 pk;
+                pk.x = cvt_pk_bf16(zf[t][8 * q], zf[t][8 * q + 1]);
+                pk.y = cvt_pk_bf16(zf[t][8 * q + 2], zf[t][8 * q + 3]);
+                pk.z = cvt_pk_bf16(zf[t][8 * q + 4], zf[t][8 * q + 5]);
+                pk.w = cvt_pk_bf16(zf[t][8 * q + 6], zf[t][8 * q + 7]);
+                zb[t][q] = __builtin_bit_cast(bf16x8, pk);
+            }
+            zs += __shfl_xor(zs, 32);
+            bad[t] = valid[t] && (cb_bad || !(zs < 1.0e38f));
+            const float zn = __builtin_sqrtf(zs) * 1.0001f;
+            delta0[t] = 2.0f * ((0.00396f + 8.0e-6f) * zn * Emax + 2.0e-6f * EEmax + 1.2e-7f * (zs * 1.0001f + EEmax));
+        }
+        // one 32-code tile against both row tiles: the A operand (codes) and -||e||^2/2 are read from LDS once
+        auto screen_pair = [&](int ct, f32x16(&acc)[TPW]) {
+            const float *np = np0 + ct * 32;
+            uint4 a[NQ];
+#pragma unroll
+            for (int q = 0; q < NQ; ++q) a[q] = ap0[(size_t)q * 2 * K32 + ct * 32];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 e4 = *reinterpret_cast<const f32x4 *>(np + 8 * g);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    acc[t][4 * g] = e4.x; acc[t][4 * g + 1] = e4.y; acc[t][4 * g + 2] = e4.z; acc[t][4 * g + 3] = e4.w;
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[q]), zb[t][q], acc[t], 0, 0, 0);
+        };
 
-        // ---- sweep 1: row maximum of the screen (two independent tiles in flight) ---------------------
-        float best = -__builtin_inff();
+        // ---- sweep 1: row maxima of the screen (two code tiles x two row tiles in flight) -------------------------
+        float best[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) best[t] = -__builtin_inff();
         {
             int ct = 0;
             for (; ct + 1 < ntile; ct += 2) {
-                f32x16 accA, accB;
-                screen_tile(ct, zb, accA);
-                screen_tile(ct + 1, zb, accB);
-                best = fmaxf(best, fmaxf(tile_max(accA), tile_max(accB)));
+                f32x16 accA[TPW], accB[TPW];
+                screen_pair(ct, accA);
+                screen_pair(ct + 1, accB);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) best[t] = fmaxf(best[t], fmaxf(tile_max(accA[t]), tile_max(accB[t])));
             }
             if (ct < ntile) {
-                f32x16 accA;
-                screen_tile(ct, zb, accA);
-                best = fmaxf(best, tile_max(accA));
+                f32x16 accA[TPW];
+                screen_pair(ct, accA);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) best[t] = fmaxf(best[t], tile_max(accA[t]));
             }
         }
-        best = fmaxf(best, __shfl_xor(best, 32));
-        const float thr = best - (delta0 + 4.0e-7f * __builtin_fabsf(best));
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            best[t] = fmaxf(best[t], __shfl_xor(best[t], 32));
+            thr[t] = best[t] - (delta0[t] + 4.0e-7f * __builtin_fabsf(best[t]));
+        }
 
         // ---- sweep 2: collect every code the bound cannot exclude.  Per element one subtract and one
         //      v_alignbit shift the sign of (acc - thr) into a 32-bit miss mask covering two code tiles; only
         //      lanes with a hit decode it.  Up to CAPH codes per lane half stay packed in four registers. ----
-        int cnt = 0;
-        unsigned cl[CAPH / 2];
+        int cnt[TPW];
+        unsigned cl[TPW][CAPH / 2];
 #pragma unroll
-        for (int i = 0; i < CAPH / 2; ++i) cl[i] = 0;
-        auto miss_mask = [&](unsigned m, const f32x16 &acc) -> unsigned {
+        for (int t = 0; t < TPW; ++t) {
+            cnt[t] = 0;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r] - thr), 31);
+            for (int i = 0; i < CAPH / 2; ++i) cl[t][i] = 0;
+        }
+        auto miss_mask = [&](unsigned m, const f32x16 &acc, float th) -> unsigned {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = __builtin_amdgcn_alignbit(m, __float_as_uint(acc[r] - th), 31);
             return m;
         };
         // hits: bit 31-r = element r of tile ct, bit 15-r = element r of tile ct+1
-        auto extract = [&](int ct, unsigned hits) {
+        auto extract = [&](int ct, unsigned hits, int &cn, unsigned(&c4)[CAPH / 2]) {
             if (__builtin_amdgcn_ballot_w64(hits != 0)) {
                 while (hits) {
                     const int b = 31 - __builtin_clz(hits);
                     hits &= ~(1u << b);
                     const int r = (31 - b) & 15;
                     const unsigned code = (unsigned)((ct + (b < 16 ? 1 : 0)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
-                    if (cnt < CAPH) {
+                    if (cn < CAPH) {
 #pragma unroll
-                        for (int i = CAPH / 2 - 1; i > 0; --i) cl[i] = (cl[i] << 16) | (cl[i - 1] >> 16);
-                        cl[0] = (cl[0] << 16) | code;
+                        for (int i = CAPH / 2 - 1; i > 0; --i) c4[i] = (c4[i] << 16) | (c4[i - 1] >> 16);
+                        c4[0] = (c4[0] << 16) | code;
                     }
-                    ++cnt;
+                    ++cn;
                 }
             }
         };
         {
             int ct = 0;
             for (; ct + 1 < ntile; ct += 2) {
-                f32x16 accA, accB;
-                screen_tile(ct, zb, accA);
-                screen_tile(ct + 1, zb, accB);
-                extract(ct, ~miss_mask(miss_mask(0u, accA), accB));
+                f32x16 accA[TPW], accB[TPW];
+                screen_pair(ct, accA);
+                screen_pair(ct + 1, accB);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    extract(ct, ~miss_mask(miss_mask(0u, accA[t], thr[t]), accB[t], thr[t]), cnt[t], cl[t]);
             }
             if (ct < ntile) {
-                f32x16 accA;
-                screen_tile(ct, zb, accA);
-                extract(ct, ~(miss_mask(0u, accA) << 16) & 0xffff0000u);
+                f32x16 accA[TPW];
+                screen_pair(ct, accA);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    extract(ct, ~(miss_mask(0u, accA[t], thr[t]) << 16) & 0xffff0000u, cnt[t], cl[t]);
             }
         }
         // publish the packed lists (newest first) for the refine stage
-        if (cnt > 0) {
-            u32x4 w;
-            w.x = cl[0]; w.y = cl[1]; w.z = cl[2]; w.w = cl[3];
-            *reinterpret_cast<u32x4 *>(own_list) = w;
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            unsigned short *own_list = lists_of(t) + (l31 * 2 + h) * CAPH;
+            if (cnt[t] > 0) {
+                u32x4 w;
+                w.x = cl[t][0]; w.y = cl[t][1]; w.z = cl[t][2]; w.w = cl[t][3];
+                *reinterpret_cast<u32x4 *>(own_list) = w;
+            }
         }
         __builtin_amdgcn_wave_barrier();
-        const int cnt_o = __shfl_xor(cnt, 32);
-        const int n0 = h ? cnt_o : cnt, n1 = h ? cnt : cnt_o;         // counts of half 0 / half 1
-        const int ncand = n0 + n1;
-        auto cand_at = [&](int j) -> int { return j < n0 ? row_list[j] : row_list[CAPH + (j - n0)]; };
-        if (valid && (ncand < 1 || n0 > CAPH || n1 > CAPH)) bad = true;   // NaN screens / overflow: scalar path
-        int k = (ncand > 0 && !bad) ? cand_at(0) : 0;
-        const bool refine = valid && !bad && ncand > 1;
-
-        float zz = 0.0f;
-        if (__builtin_amdgcn_ballot_w64(refine || bad)) {
-            // ---- ||z||^2 in ATen's order (8-lane vectors x 4-way ILP).  Lane halves hold channels
-            //      [0,32) and [32,64): swap so each lane owns matching (c, c+32) pairs, then chain. ----
-            float P[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float slo = zf[i] * zf[i], shi = zf[16 + i] * zf[16 + i];
-                const float recv = __shfl_xor(h ? slo : shi, 32);
-                const float lo = h ? recv : slo;           // channel 16h + i       (first  32)
-                const float hi = h ? shi : recv;           // channel 32 + 16h + i  (second 32)
-                P[i] = lo + hi;                            // P_q[t], q = 2h + i/8, t = i%8
-            }
-            float fin = 0.0f;
-#pragma unroll
-            for (int t = 0; t < 8; ++t) {
-                const float s01 = P[t] + P[8 + t];                 // lane h=0: P0+P1
-                const float from0 = __shfl_xor(s01, 32);           // lane h=1 receives P0+P1
-                const float A = (from0 + P[t]) + P[8 + t];         // valid on h=1: ((P0+P1)+P2)+P3
-                fin = fin + A;
-            }
-            const float other = __shfl_xor(fin, 32);
-            zz = h ? fin : other;
-            if (h == 0) zz_s[l31] = zz;
+        for (int t = 0; t < TPW; ++t) {
+            const int cnt_o = __shfl_xor(cnt[t], 32);
+            n0[t] = h ? cnt_o : cnt[t];
+            const int n1 = h ? cnt[t] : cnt_o;                    // counts of half 0 / half 1
+            ncand[t] = n0[t] + n1;
+            if (valid[t] && (ncand[t] < 1 || n0[t] > CAPH || n1 > CAPH)) bad[t] = true;   // NaN screens / overflow
+            const unsigned short *row_list = lists_of(t) + l31 * 2 * CAPH;
+            kbest[t] = (ncand[t] > 0 && !bad[t]) ? (0 < n0[t] ? row_list[0] : row_list[CAPH]) : 0;
+            refine[t] = valid[t] && !bad[t] && ncand[t] > 1;
         }
 
-        if (__builtin_amdgcn_ballot_w64(refine)) {
-            // ---- exact reference distances, compacted: every (row, candidate) pair of the tile is a
-            //      job; jobs are dealt 32 at a time to the 32 lane pairs, so rows with many candidates
-            //      do not serialise the wave.  job = (row << 16) | code ---------------------------------
-            const int nj = (h == 0 && refine) ? ncand : 0;
-            int incl = nj;                                          // inclusive scan over lanes 0..31
+        // ================= exact part: ||z||^2 in ATen's order, refine, scalar fallback (per tile) ==============
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const int up = __shfl_up(incl, o);
-                if (l31 >= o) incl += up;
+        for (int t = 0; t < TPW; ++t) {
+            const unsigned short *row_list = lists_of(t) + l31 * 2 * CAPH;
+            auto cand_at = [&](int j) -> int { return j < n0[t] ? row_list[j] : row_list[CAPH + (j - n0[t])]; };
+            float *zz_s = fbuf_of(t);                              // exact ||z||^2 per row
+            int *job_s = reinterpret_cast<int *>(zz_s + 32);      // refine batch: (row<<16)|code
+            float *res_s = zz_s + 64;                              // refine batch: distances
+            zz[t] = 0.0f;
+            if (__builtin_amdgcn_ballot_w64(refine[t] || bad[t])) {
+                // lane halves hold channels [0,32) and [32,64): swap so each lane owns matching (c, c+32) pairs
+                float P[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float slo = zf[t][i] * zf[t][i], shi = zf[t][16 + i] * zf[t][16 + i];
+                    const float recv = __shfl_xor(h ? slo : shi, 32);
+                    const float lo = h ? recv : slo;           // channel 16h + i       (first  32)
+                    const float hi = h ? shi : recv;           // channel 32 + 16h + i  (second 32)
+                    P[i] = lo + hi;                            // P_q[t], q = 2h + i/8, t = i%8
+                }
+                float fin = 0.0f;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const float s01 = P[u] + P[8 + u];                 // lane h=0: P0+P1
+                    const float from0 = __shfl_xor(s01, 32);           // lane h=1 receives P0+P1
+                    const float A = (from0 + P[u]) + P[8 + u];         // valid on h=1: ((P0+P1)+P2)+P3
+                    fin = fin + A;
+                }
+                const float other = __shfl_xor(fin, 32);
+                zz[t] = h ? fin : other;
+                if (h == 0) zz_s[l31] = zz[t];
             }
-            const int total = __shfl(incl, 31);
-            int off = incl - nj;
-            off = __shfl(off, l31);                                 // both halves know the row's offset
-            float bd = __builtin_inff();
-            int bk = 0x7fffffff;
-            for (int base = 0; base < total; base += 32) {
-                if (h == 0 && refine) {
-                    for (int j = 0; j < ncand; ++j) {
-                        const int slot = off + j - base;
-                        if (slot >= 0 && slot < 32) job_s[slot] = (l31 << 16) | cand_at(j);
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-                const bool act = base + l31 < total;
-                const int job = act ? job_s[l31] : 0;
-                const int jr = job >> 16, jk = job & 0xffff;
-                // the job's row half comes from its owner lane's registers (ds_bpermute), the code half from L2
-                int src = (jr + 32 * h) << 2;
-                const float *e = cb + (size_t)jk * D + HALF * h;
-                float ef[HALF];
+
+            if (__builtin_amdgcn_ballot_w64(refine[t])) {
+                // ---- exact reference distances, compacted: every (row, candidate) pair of the tile is a
+                //      job; jobs are dealt 32 at a time to the 32 lane pairs.  job = (row << 16) | code ----
+                const int nj = (h == 0 && refine[t]) ? ncand[t] : 0;
+                int incl = nj;                                          // inclusive scan over lanes 0..31
 #pragma unroll
-                for (int q = 0; q < HALF / 4; ++q) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(e + 4 * q);
-                    ef[4 * q] = v.x; ef[4 * q + 1] = v.y; ef[4 * q + 2] = v.z; ef[4 * q + 3] = v.w;
+                for (int o = 1; o < 32; o <<= 1) {
+                    const int up = __shfl_up(incl, o);
+                    if (l31 >= o) incl += up;
                 }
-                float p = 0.0f;                                       // channels 0..31, valid on h=0
-#pragma unroll
-                for (int c = 0; c < HALF; ++c)
-                    p = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[c]))), ef[c], p);
-                float m = __shfl_xor(p, 32);                          // h=1 continues lane h=0's chain
-                asm volatile("" : "+v"(src));                         // fetch again rather than hold 32 more registers
-#pragma unroll
-                for (int c = 0; c < HALF; ++c)
-                    m = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[c]))), ef[c], m);
-                if (h == 1 && act) {                                  // full 64-term chain lives on h=1
-                    const float t = zz_s[jr] + ee_g[jk];
-                    const float u2 = 2.0f * m;
-                    res_s[l31] = t - u2;
-                }
-                __builtin_amdgcn_wave_barrier();
-                if (refine) {
-                    for (int j = 0; j < ncand; ++j) {
-                        const int slot = off + j - base;
-                        if (slot >= 0 && slot < 32) {
-                            const float d = res_s[slot];
-                            const int kc = cand_at(j);
-                            const bool better = d < bd || (d == bd && kc < bk);
-                            bd = better ? d : bd;
-                            bk = better ? kc : bk;
+                const int total = __shfl(incl, 31);
+                int off = incl - nj;
+                off = __shfl(off, l31);                                 // both halves know the row's offset
+                float bd = __builtin_inff();
+                int bk = 0x7fffffff;
+                for (int base = 0; base < total; base += 32) {
+                    if (h == 0 && refine[t]) {
+                        for (int j = 0; j < ncand[t]; ++j) {
+                            const int slot = off + j - base;
+                            if (slot >= 0 && slot < 32) job_s[slot] = (l31 << 16) | cand_at(j);
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
+                    const bool act = base + l31 < total;
+                    const int job = act ? job_s[l31] : 0;
+                    const int jr = job >> 16, jk = job & 0xffff;
+                    // the job's row half comes from its owner lane's registers (ds_bpermute), the code half from L2
+                    int src = (jr + 32 * h) << 2;
+                    const float *e = cb + (size_t)jk * D + HALF * h;
+                    float ef[HALF];
+#pragma unroll
+                    for (int q = 0; q < HALF / 4; ++q) {
+                        const f32x4 v = *reinterpret_cast<const f32x4 *>(e + 4 * q);
+                        ef[4 * q] = v.x; ef[4 * q + 1] = v.y; ef[4 * q + 2] = v.z; ef[4 * q + 3] = v.w;
+                    }
+                    float p = 0.0f;                                       // channels 0..31, valid on h=0
+#pragma unroll
+                    for (int c = 0; c < HALF; ++c)
+                        p = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[t][c]))), ef[c], p);
+                    float m = __shfl_xor(p, 32);                          // h=1 continues lane h=0's chain
+                    asm volatile("" : "+v"(src));                         // fetch again rather than hold 32 more registers
+#pragma unroll
+                    for (int c = 0; c < HALF; ++c)
+                        m = __builtin_fmaf(__int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(zf[t][c]))), ef[c], m);
+                    if (h == 1 && act) {                                  // full 64-term chain lives on h=1
+                        const float tt = zz_s[jr] + ee_g[jk];
+                        const float u2 = 2.0f * m;
+                        res_s[l31] = tt - u2;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    if (refine[t]) {
+                        for (int j = 0; j < ncand[t]; ++j) {
+                            const int slot = off + j - base;
+                            if (slot >= 0 && slot < 32) {
+                                const float d = res_s[slot];
+                                const int kc = cand_at(j);
+                                const bool better = d < bd || (d == bd && kc < bk);
+                                bd = better ? d : bd;
+                                bk = better ? kc : bk;
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
+                if (refine[t]) kbest[t] = bk;
             }
-            if (refine) k = bk;
-        }
-        if (__builtin_amdgcn_ballot_w64(bad)) {
-            int ks = 0;
-            if (bad && h == 0)
-                ks = vq_slow_argmin<D, ROWMAJOR>(z, ROWMAJOR ? (size_t)rc * D : zbase, ROWMAJOR ? 1 : (size_t)HW,
-                                                 cb, ee_g, K, zz);
-            ks = __shfl(ks, l31);
-            if (bad) k = ks;
+            if (__builtin_amdgcn_ballot_w64(bad[t])) {
+                int ks = 0;
+                if (bad[t] && h == 0)
+                    ks = vq_slow_argmin<D, ROWMAJOR>(z, ROWMAJOR ? (size_t)rc[t] * D : zbase[t], ROWMAJOR ? 1 : (size_t)HW,
+                                                     cb, ee_g, K, zz[t]);
+                ks = __shfl(ks, l31);
+                if (bad[t]) kbest[t] = ks;
+            }
         }
 
-        // ---- epilogue: gather e_k, z + (e_k - z), squared error, index, histogram ---------------------
-        {
-            const float *e = cb + (size_t)k * D + HALF * h;
+        // ================= epilogue: both gathers in flight, then z + (e_k - z), squared error, index, histogram =
+        f32x4 ev[TPW][HALF / 4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const float *e = cb + (size_t)kbest[t] * D + HALF * h;
+#pragma unroll
+            for (int q = 0; q < HALF / 4; ++q) ev[t][q] = *reinterpret_cast<const f32x4 *>(e + 4 * q);
+        }
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
             float sq = 0.0f;
 #pragma unroll
             for (int q = 0; q < HALF / 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4 *>(e + 4 * q);
-                const float ev[4] = {v.x, v.y, v.z, v.w};
+                const float e4[4] = {ev[t][q].x, ev[t][q].y, ev[t][q].z, ev[t][q].w};
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const float diff = ev[i] - zf[4 * q + i];
+                    const float diff = e4[i] - zf[t][4 * q + i];
                     sq = sq + diff * diff;
-                    zf[4 * q + i] = zf[4 * q + i] + diff;
+                    zf[t][4 * q + i] = zf[t][4 * q + i] + diff;
                 }
             }
-            if (valid) {
+            if (valid[t]) {
                 dacc += (double)sq;
                 if (zq) {
                     if (ROWMAJOR) {
 #pragma unroll
                         for (int q = 0; q < HALF / 4; ++q) {
                             f32x4 v;
-                            v.x = zf[4 * q]; v.y = zf[4 * q + 1]; v.z = zf[4 * q + 2]; v.w = zf[4 * q + 3];
-                            *reinterpret_cast<f32x4 *>(zq + zbase + 4 * q) = v;
+                            v.x = zf[t][4 * q]; v.y = zf[t][4 * q + 1]; v.z = zf[t][4 * q + 2]; v.w = zf[t][4 * q + 3];
+                            *reinterpret_cast<f32x4 *>(zq + zbase[t] + 4 * q) = v;
                         }
                     } else {
-                        const auto rs = make_rsrc(zq + img0);
+                        const auto rs = make_rsrc(zq + img0[t]);
 #pragma unroll
                         for (int c = 0; c < HALF; ++c)
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zf[c]), rs, voff,
+                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zf[t][c]), rs, voff[t],
                                                                   (unsigned)c * HW * 4u, 0);
                     }
                 }
                 if (h == 0) {
-                    idx[row] = k;
-                    atomicAdd(&hist_s[k], 1);
+                    idx[row[t]] = kbest[t];
+                    atomicAdd(&hist_s[kbest[t]], 1);
                 }
             }
         }
@@ -404,9 +457,9 @@ __global__ __launch_bounds__(512, 4) void vq_filter_kernel_d64(
 int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
                          float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out) {
     const VqPlan p = vq_plan(K, 64);
-    const long long nblocks = (N + 255) / 256;
+    const long long nblocks = (N + 256 * kVqTilesPerWave - 1) / (256 * kVqTilesPerWave);   // 512-row super-blocks
     const int cus = num_cus();
-    const int per_cu = p.filter_lds_bytes * 2 <= (size_t)kLdsBytes ? 2 : 1;
+    const int per_cu = 1;                                  // 256-VGPR waves: one 512-thread workgroup per CU
     long long grid = nblocks < (long long)cus * per_cu ? nblocks : (long long)cus * per_cu;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
     *grid_out = (int)grid;
