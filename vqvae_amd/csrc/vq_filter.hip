@@ -44,7 +44,7 @@ __device__ __forceinline__ unsigned cvt_pk_bf16(float lo, float hi) {
 // with both epilogue gathers issued before either is consumed -- so one tile's memory round trips hide under the
 // other tile's matrix / vector work.  One 512-thread workgroup per CU (the 256-VGPR budget holds both tiles' rows
 // in registers from load to store; the codebook image is staged once per CU).
-template <bool ROWMAJOR>
+template <bool ROWMAJOR, bool STAGE>
 __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img16,
     const float *__restrict__ neh_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
@@ -59,10 +59,13 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
     unsigned short *cand_list = reinterpret_cast<unsigned short *>(hist_s + K + (K & 1));   // [8][TPW][32][2][CAPH]
     float *wave_f = reinterpret_cast<float *>(cand_list + 8 * TPW * 32 * 2 * CAPH);          // [8][TPW][96]
     double *red = reinterpret_cast<double *>(wave_f + 8 * TPW * 96);
+    // STAGE: a wave-private 32 x 68-float tile through which rows enter and leave with fully coalesced 1-KiB
+    // instructions (row-major input only; the row-per-lane-pair pattern touches 64 lines per instruction)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    float *stage_w = reinterpret_cast<float *>(red + 8) + (size_t)wave_u * (32 * 68);
     const int cb_bad = flags[0];
     const float EEmax = __int_as_float(flags[1]) * 1.0001f;
     const float Emax = __builtin_sqrtf(EEmax) * 1.0001f;
@@ -90,6 +93,53 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
             for (int c = 0; c < HALF; ++c)
                 zf[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, voff, (unsigned)c * HW * 4u, 0));
         }
+    };
+
+    // coalesced tile I/O through the staging tile: instruction i moves rows 4i..4i+3 (lane L: row 4i + L/16,
+    // floats 4*(L%16)..+3); fragments are rows l31, floats [32h, 32h+32)
+    auto load_tile_staged = [&](long long r0t, float(&zf)[HALF]) {
+        const float *base = z + (size_t)r0t * D;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rr = 4 * i + (lane >> 4);
+            f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (r0t + rr < N) v = *reinterpret_cast<const f32x4 *>(base + (size_t)(i * 64 + lane) * 4);
+            zf[4 * i] = v.x; zf[4 * i + 1] = v.y; zf[4 * i + 2] = v.z; zf[4 * i + 3] = v.w;
+        }
+    };
+    auto stage_to_fragments = [&](float(&zf)[HALF]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f32x4 v; v.x = zf[4 * i]; v.y = zf[4 * i + 1]; v.z = zf[4 * i + 2]; v.w = zf[4 * i + 3];
+            *reinterpret_cast<f32x4 *>(stage_w + (4 * i + (lane >> 4)) * 68 + 4 * (lane & 15)) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage_w + l31 * 68 + 32 * h + 4 * q);
+            zf[4 * q] = v.x; zf[4 * q + 1] = v.y; zf[4 * q + 2] = v.z; zf[4 * q + 3] = v.w;
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+    auto store_tile_staged = [&](long long r0t, const float(&zf)[HALF]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            f32x4 v; v.x = zf[4 * q]; v.y = zf[4 * q + 1]; v.z = zf[4 * q + 2]; v.w = zf[4 * q + 3];
+            *reinterpret_cast<f32x4 *>(stage_w + l31 * 68 + 32 * h + 4 * q) = v;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        float *base = zq + (size_t)r0t * D;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int rr = 4 * i + (lane >> 4);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(stage_w + rr * 68 + 4 * (lane & 15));
+            if (r0t + rr < N) *reinterpret_cast<f32x4 *>(base + (size_t)(i * 64 + lane) * 4) = v;
+        }
+        __builtin_amdgcn_wave_barrier();
     };
 
     // ---- per-tile state (t = 0, 1; every index below is a compile-time constant after unrolling) ---------------
@@ -123,7 +173,8 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
 #pragma unroll
     for (int t = 0; t < TPW; ++t) {
         setup(blockIdx.x, t);
-        load_half(zbase[t], img0[t], voff[t], zf[t]);
+        if (ROWMAJOR && STAGE) load_tile_staged(r0[t], zf[t]);
+        else load_half(zbase[t], img0[t], voff[t], zf[t]);
     }
     for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
     for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
@@ -136,8 +187,13 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
 #pragma unroll
             for (int t = 0; t < TPW; ++t) {
                 setup(sb, t);
-                load_half(zbase[t], img0[t], voff[t], zf[t]);
+                if (ROWMAJOR && STAGE) load_tile_staged(r0[t], zf[t]);
+                else load_half(zbase[t], img0[t], voff[t], zf[t]);
             }
+        }
+        if (ROWMAJOR && STAGE) {                              // coalesced layout -> one half row per lane
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) stage_to_fragments(zf[t]);
         }
         // ================= screen: convert, sweep 1, sweep 2 -- both row tiles share every codebook operand read ===
         bf16x8 zb[TPW][NQ];
@@ -415,7 +471,9 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
             if (valid[t]) {
                 dacc += (double)sq;
                 if (zq) {
-                    if (ROWMAJOR) {
+                    if (ROWMAJOR && STAGE) {
+                        // handled below for the whole tile (wave-uniform)
+                    } else if (ROWMAJOR) {
 #pragma unroll
                         for (int q = 0; q < HALF / 4; ++q) {
                             f32x4 v;
@@ -435,6 +493,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
                     atomicAdd(&hist_s[kbest[t]], 1);
                 }
             }
+            if (ROWMAJOR && STAGE && zq) store_tile_staged(r0[t], zf[t]);
         }
     }
 
@@ -468,19 +527,23 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
     const uint4 *img16 = reinterpret_cast<const uint4 *>(ws + p.off_img16);
     const float *neh = reinterpret_cast<const float *>(ws + p.off_neh);
     double *partials = reinterpret_cast<double *>(ws + p.off_partials);
-#define VQF_LAUNCH(RM_)                                                                              \
+    // staged (fully coalesced) row I/O needs 8 x 32 x 68 floats more LDS: row-major input, codebook image small enough
+    const size_t stage_bytes = (size_t)8 * 32 * 68 * sizeof(float);
+    const bool stage = rowmajor && p.filter_lds_bytes + stage_bytes <= (size_t)kLdsBytes;
+    const size_t lds = p.filter_lds_bytes + (stage ? stage_bytes : 0);
+#define VQF_LAUNCH(RM_, ST_)                                                                         \
     do {                                                                                             \
-        auto kfn = vq_filter_kernel_d64<RM_>;                                                        \
+        auto kfn = vq_filter_kernel_d64<RM_, ST_>;                                                   \
         static bool attr_set = false;                                                                \
         if (!attr_set) {                                                                             \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);        \
             attr_set = true;                                                                         \
         }                                                                                            \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), p.filter_lds_bytes, st, z, cb, img16, neh, ee, \
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds, st, z, cb, img16, neh, ee,     \
                            wflags, N, HW, K, p.K32, nblocks, zq, idx, hist, partials);               \
     } while (0)
-    if (rowmajor) VQF_LAUNCH(true); else VQF_LAUNCH(false);
+    if (stage) VQF_LAUNCH(true, true); else if (rowmajor) VQF_LAUNCH(true, false); else VQF_LAUNCH(false, false);
 #undef VQF_LAUNCH
     return (int)hipGetLastError();
 }
