@@ -178,12 +178,13 @@ VQVAE_API int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed
 
 /* Last decoder layer, nn.ConvTranspose2d(Cin,Cout,k=4,s=2,p=1) (models/decoder.py:34-35), reading
  * row-major (B,H,W,Cin) and writing the NCHW image (B,Cout,2H,2W).  Cout <= 4, Cin % 4 == 0,
- * Cin <= 256.  Runs as GEMM (pixels x Cin x 16*Cout on the MFMA) + in-LDS col2im.                 */
+ * Cin <= 256.  Runs as GEMM (pixels x Cin x 16*Cout on the MFMA) + in-LDS col2im.  flags: 0, or
+ * VQVAE_CONV_EXACT_FP32 for the fp32 MFMA instead of the split-bf16 products.                      */
 VQVAE_API size_t vqvae_convt_out_packed_bytes(int Cin, int Cout);
 VQVAE_API int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed,
                                        vqvae_stream_t stream);
 VQVAE_API int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float *bias,
-                                          int64_t B, int H, int W, int Cin, int Cout,
+                                          int64_t B, int H, int W, int Cin, int Cout, int flags,
                                           float *y_nchw, vqvae_stream_t stream);
 
 /* Batched transpose x[batch][R][C] -> y[batch][C][R]: (B,C,HW) <-> (B,HW,C) layout changes for

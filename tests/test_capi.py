@@ -80,7 +80,7 @@ def test_conv_and_training_argument_errors_without_gpu():
     assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 128, 32, 0, a, None) == -3         # in place
     assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 31, 32, 3, 64, 0, a, None) == -3
     assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 32, 32, 2, 64, 0, a, None) == -3           # Cin not in {1,3,4}
-    assert L.vqvae_convt_out_forward_f32(a, a, a, 1, 16, 16, 64, 5, a, None) == -3            # Cout > 4
+    assert L.vqvae_convt_out_forward_f32(a, a, a, 1, 16, 16, 64, 5, 0, a, None) == -3            # Cout > 4
     assert L.vqvae_vq_backward_workspace_bytes(2048, 512, 64) > 2048 * 16
     assert L.vqvae_vq_backward_workspace_bytes(2048, 20000, 64) == 0
     assert L.vqvae_vq_backward_f32(a, a, None, None, None, 1, 64, 8, 8, 512, 0.25, 0, a, a, a, 1 << 30, None) == -1

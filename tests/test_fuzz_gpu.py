@@ -162,7 +162,7 @@ def test_first_and_last_layer_random_shapes_vs_torch_cpu(seed):
                           lambda wt, buf: L.vqvae_convt_out_pack_f32(wt.data_ptr(), Ci, Co, buf.data_ptr(), None))
     xh = torch.empty((B, Co, 2 * h, 2 * w), device=dev())
     td = t.to(dev()).permute(0, 2, 3, 1).contiguous()
-    _lib.check(L.vqvae_convt_out_forward_f32(td.data_ptr(), p4.data_ptr(), dd.bias.data_ptr(), B, h, w, Ci, Co,
+    _lib.check(L.vqvae_convt_out_forward_f32(td.data_ptr(), p4.data_ptr(), dd.bias.data_ptr(), B, h, w, Ci, Co, 0,
                                              xh.data_ptr(), st))
     np.testing.assert_allclose(xh.cpu().numpy(), ref2.numpy(), atol=1e-5, rtol=1e-4,
                                err_msg=f"convT_out {Ci}->{Co} B={B} {h}x{w}")

@@ -60,7 +60,7 @@ d4 = dec.inverse_conv_stack[4]
 p4 = conv_hip._packed(d4, ("convt_out",), d4.weight, lambda: L.vqvae_convt_out_packed_bytes(64, 3),
                       lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), 64, 3, buf.data_ptr(), None))
 xh = torch.empty(B, 3, 32, 32, device=dev)
-us = timeit(lambda: _lib.check(L.vqvae_convt_out_forward_f32(y0.data_ptr(), p4.data_ptr(), d4.bias.data_ptr(), B, 16, 16, 64, 3,
+us = timeit(lambda: _lib.check(L.vqvae_convt_out_forward_f32(y0.data_ptr(), p4.data_ptr(), d4.bias.data_ptr(), B, 16, 16, 64, 3, 0,
                                                              xh.data_ptr(), torch.cuda.current_stream().cuda_stream)))
 tot += us
 print(f"{'convT_out 4x4s2 64->3':22s} {us:7.1f} us  {(B * 256 * 64 * 4 + B * 3072 * 4) / us / 1e3:6.0f} GB/s")

@@ -37,7 +37,7 @@ SIGNATURES = {
     "vqvae_conv_in_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vqvae_convt_out_packed_bytes": (_sz, [_i32, _i32]),
     "vqvae_convt_out_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),
-    "vqvae_convt_out_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_convt_out_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vqvae_transpose_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "vqvae_vq_backward_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vqvae_vq_backward_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,

@@ -145,7 +145,7 @@ class ConvTOutFn(torch.autograd.Function):
         p4 = conv_hip._packed(mod, ("convt_out",), weight, lambda: L.vqvae_convt_out_packed_bytes(C, Cout),
                               lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), C, Cout, buf.data_ptr(), _sp(w)))
         x_hat = torch.empty((B, Cout, 2 * H, 2 * W), dtype=torch.float32, device=t.device)
-        _lib.check(L.vqvae_convt_out_forward_f32(t.data_ptr(), p4.data_ptr(), bias.detach().data_ptr(), B, H, W, C, Cout,
+        _lib.check(L.vqvae_convt_out_forward_f32(t.data_ptr(), p4.data_ptr(), bias.detach().data_ptr(), B, H, W, C, Cout, 0,
                                                  x_hat.data_ptr(), _sp(t)))
         ctx.save_for_backward(t, weight.detach())
         ctx.mod = mod

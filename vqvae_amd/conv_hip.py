@@ -172,5 +172,5 @@ def decoder_forward(dec, z_q, rowmajor_in):
                  lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), C2, Cout, buf.data_ptr(), _sp(w)))
     x_hat = torch.empty((B, Cout, 2 * H2, 2 * W2), dtype=torch.float32, device=a2.device)
     _lib.check(L.vqvae_convt_out_forward_f32(a2.data_ptr(), p4.data_ptr(), d4.bias.detach().data_ptr(), B, H2, W2,
-                                             C2, Cout, x_hat.data_ptr(), _sp(a2)))                     # :34-35
+                                             C2, Cout, 0, x_hat.data_ptr(), _sp(a2)))                     # :34-35
     return x_hat

@@ -1556,7 +1556,9 @@ __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float *__restri
 // A workgroup owns a 16x16 region of input pixels (a 14x14 interior + 1-pixel halo, or the whole
 // image when it is at most 16 wide/high), keeps T for the region in LDS and writes the interior's
 // 2x upsampled outputs with coalesced NCHW stores.
-template <int NT>
+// BF3: products from exact three-term bf16 splits on the bf16 matrix cores (weights split at pack time, image
+// [chunk][n_tile][term][k-step][half][n] x 16 B; activations split in registers) instead of the fp32 MFMA.
+template <int NT, bool BF3>
 __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ wimg,
                                                         const float *__restrict__ bias,
@@ -1567,8 +1569,9 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     const int STRIDE = 16 * Cout + 1;              // T row: the 16*Cout used columns (odd stride: conflict-free)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cpt = (Cin + 31) / 32;
-    float *Ws = smem;                               // [cpt][NT][1024]
-    float *Ts = smem + (size_t)cpt * NT * 1024;     // [256][STRIDE]
+    constexpr int WCH = BF3 ? 1536 : 1024;          // floats per (chunk, n-tile) of the weight image
+    float *Ws = smem;                               // [cpt][NT][WCH]
+    float *Ts = smem + (size_t)cpt * NT * WCH;      // [256][STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
 
@@ -1579,7 +1582,7 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     const int y0 = ty * TH, x0 = tx * TW;
     const int ry = y0 - halo_y, rx = x0 - halo_x;
 
-    for (int i = tid; i < cpt * NT * 256; i += 256)
+    for (int i = tid; i < cpt * NT * (WCH / 4); i += 256)
         reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
 
     f32x16 acc[MT][NT];
@@ -1612,6 +1615,24 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
             }
     };
     auto mma = [&](int c, const f32x4(&a)[MT][4]) {
+        if (BF3) {
+            const u32x4 *wb = reinterpret_cast<const u32x4 *>(Ws + (size_t)c * NT * WCH);
+            u32x4 S1[MT][2], S2[MT][2], S3[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                split8(a[mt][0], a[mt][1], S1[mt][0], S2[mt][0], S3[mt][0]);
+                split8(a[mt][2], a[mt][3], S1[mt][1], S2[mt][1], S3[mt][1]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4 *bp = wb + nt * 384 + (t * 2 + h) * 32 + l31;
+                    prod6x2(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bp[0], bp[128], bp[256], acc[0][nt],
+                            acc[1][nt]);
+                }
+            return;
+        }
         const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws + (size_t)c * NT * 1024);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -1706,6 +1727,31 @@ __global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__rest
         const int ci = chunk * 32 + 16 * h + 4 * j + i, col = nt * 32 + n;
         const int tap = col / Cout, co = col - tap * Cout;
         img[e] = (ci < Cin && tap < 16) ? w[((size_t)ci * Cout + co) * 16 + tap] : 0.0f;
+    }
+}
+
+// split-bf16 image of the same weights: [chunk][n_tile][term 3][k-step 2][half 2][n 32] x 8 bf16 (cf. conv_pack_bf3)
+__global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__restrict__ w, unsigned short *__restrict__ img,
+                                                                 int Cin, int Cout, int ntile) {
+    const int cpt = (Cin + 31) / 32;
+    const int total = cpt * ntile * 1024;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e & 7, n = (e >> 3) & 31, hh = (e >> 8) & 1, t = (e >> 9) & 1;
+        const int r = e >> 10;
+        const int nt = r % ntile, chunk = r / ntile;
+        const int ci = chunk * 32 + 16 * hh + 8 * t + i, col = nt * 32 + n;
+        const int tap = col / Cout, co = col - tap * Cout;
+        const float v = (ci < Cin && tap < 16) ? w[((size_t)ci * Cout + co) * 16 + tap] : 0.0f;
+        const unsigned short b1 = f32_to_bf16_rne(v);
+        const float r1 = v - __uint_as_float((unsigned)b1 << 16);
+        const unsigned short b2 = f32_to_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
+        const unsigned short b3 = f32_to_bf16_rne(r2);
+        const size_t base = (size_t)(chunk * ntile + nt) * 3072;
+        const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
+        img[base + pos] = b1;
+        img[base + 1024 + pos] = b2;
+        img[base + 2048 + pos] = b3;
     }
 }
 
@@ -1997,19 +2043,24 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
 size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
     if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;
     const int ntile = (16 * Cout + 31) / 32;
-    return (size_t)((Cin + 31) / 32) * ntile * 1024 * sizeof(float);
+    // [fp32 B-operand image][split-bf16 image]
+    return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
 }
 
 int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
     if (!w || !packed) return VQVAE_ERR_NULL;
     if (vqvae_convt_out_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
+    const int ntile_p = (16 * Cout + 31) / 32;
     hipLaunchKernelGGL(convt_out_pack_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed,
-                       Cin, Cout, (16 * Cout + 31) / 32);
+                       Cin, Cout, ntile_p);
+    hipLaunchKernelGGL(convt_out_pack_bf3_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w,
+                       reinterpret_cast<unsigned short *>(packed + (size_t)((Cin + 31) / 32) * ntile_p * 1024), Cin, Cout,
+                       ntile_p);
     return (int)hipGetLastError();
 }
 
 int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
-                                int Cin, int Cout, float *y_nchw, vqvae_stream_t stream) {
+                                int Cin, int Cout, int flags, float *y_nchw, vqvae_stream_t stream) {
     if (!x || !packed || !y_nchw) return VQVAE_ERR_NULL;
     if (B < 1 || H < 1 || W < 1) return VQVAE_ERR_SHAPE;
     if (vqvae_convt_out_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
@@ -2020,19 +2071,21 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
     const long long ntiles = B * (long long)tiles_y * tiles_x;
     if (ntiles > INT32_MAX) return VQVAE_ERR_OVERFLOW;
     const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
-    const size_t lds = ((size_t)cpt * ntile * 1024 + 256 * (16 * Cout + 1)) * sizeof(float);
+    const bool bf3 = !(flags & VQVAE_CONV_EXACT_FP32);     // default: split-bf16 products (image behind the fp32 one)
+    const size_t lds = ((size_t)cpt * ntile * (bf3 ? 1536 : 1024) + 256 * (16 * Cout + 1)) * sizeof(float);
+    const float *wimg = bf3 ? packed + (size_t)cpt * ntile * 1024 : packed;
     prof_begin(VQVAE_PROF_CONV_OUT, st);
-    if (ntile == 1) {
-        auto k = convt_out_kernel<1>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, packed, bias, y_nchw, (int)B, H, W, Cin,
-                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);
-    } else {
-        auto k = convt_out_kernel<2>;
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, packed, bias, y_nchw, (int)B, H, W, Cin,
-                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);
-    }
+#define CTO_LAUNCH(NT_, BF_)                                                                                          \
+    do {                                                                                                              \
+        auto k = convt_out_kernel<NT_, BF_>;                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
+                                  kLdsBytes);                                                                         \
+        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, wimg, bias, y_nchw, (int)B, H, W, Cin,   \
+                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);                                           \
+    } while (0)
+    if (ntile == 1) { if (bf3) CTO_LAUNCH(1, true); else CTO_LAUNCH(1, false); }
+    else { if (bf3) CTO_LAUNCH(2, true); else CTO_LAUNCH(2, false); }
+#undef CTO_LAUNCH
     prof_end(VQVAE_PROF_CONV_OUT, st);
     return (int)hipGetLastError();
 }
