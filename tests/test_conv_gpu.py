@@ -158,11 +158,12 @@ def test_convt_out_vs_torch_cpu():
         xr = rows(x.to(dev()))
         p = conv_hip._packed(md, ("convt_out",), md.weight, lambda: L.vqvae_convt_out_packed_bytes(Cin, Cout),
                              lambda w, buf: L.vqvae_convt_out_pack_f32(w.data_ptr(), Cin, Cout, buf.data_ptr(), None))
-        y = torch.empty((B, Cout, 2 * H, 2 * W), device=dev())
-        _lib.check(L.vqvae_convt_out_forward_f32(xr.data_ptr(), p.data_ptr(), md.bias.data_ptr(), B, H, W, Cin, Cout, 0,
-                                                 y.data_ptr(), torch.cuda.current_stream().cuda_stream))
-        torch.cuda.synchronize()
-        close(y.cpu().numpy(), ref.numpy())
+        for flags in (0, 4):                       # split-bf16 products (default) and VQVAE_CONV_EXACT_FP32
+            y = torch.empty((B, Cout, 2 * H, 2 * W), device=dev())
+            _lib.check(L.vqvae_convt_out_forward_f32(xr.data_ptr(), p.data_ptr(), md.bias.data_ptr(), B, H, W, Cin, Cout,
+                                                     flags, y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            close(y.cpu().numpy(), ref.numpy())
 
 
 def test_transpose_roundtrip():

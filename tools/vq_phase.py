@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Fused VQ kernel at BASELINE config-3 size: kernel time, agreement with the exhaustive kernel and -- for a
+-DVQ_TIMING build (tools/build_variant.py) -- the per-phase wall-clock breakdown averaged over all waves."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from vqvae_amd import _lib
+if os.environ.get("VQVAE_BENCH_LIB"):
+    _lib.LIB_PATH = os.environ["VQVAE_BENCH_LIB"]
+from vqvae_amd import functional as F
+
+dev = torch.device("cuda:0"); g = torch.Generator().manual_seed(0)
+K, D = 512, 64
+N = int(os.environ.get("VQ_ROWS", 262144))
+cb = ((torch.rand(K, D, generator=g) * 2 - 1) / K).to(dev)
+z = (torch.randn(N // 64, 8, 8, D, generator=g) * 0.066).to(dev)
+ws = F.vq_workspace(K, D, dev)
+out = F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws)
+ref = F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=F.vq_workspace(K, D, dev), exact_sweep=True)
+same = all(torch.equal(a, b) for a, b in zip(out, ref) if isinstance(a, torch.Tensor))
+for _ in range(3):
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+_lib.profile_enable(True)
+for _ in range(30):
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+kms, kn = _lib.profile_collect('vq_main')
+_lib.profile_enable(False)
+us = kms / max(kn, 1) * 1e3
+print(f"[{os.path.basename(_lib.LIB_PATH)}] N={N} kernel {us:.2f} us  {N * 520 / us / 1e6:.3f} TB/s  frac {N * 520 / us / 1e6 / 8:.3f}  "
+      f"outputs == exhaustive kernel: {same}")
+if os.environ.get("VQ_TIMING"):
+    off = 256
+    off = (off + K * 4 + 255) // 256 * 256
+    off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8
+    slots = ws[off:off + 64 * 64].view(torch.int64)
+    slots.zero_()
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+    torch.cuda.synchronize()
+    names = ["prologue (codebook copy, first requests)", "rows landed", "convert + sweep 1", "sweep 2", "exact part",
+             "epilogue", "loop exit", "tail: loss partial + histogram flush (x8)"]
+    t = slots.view(64, 8).sum(0).cpu().tolist()
+    for n, v in zip(names, t):
+        print(f"   {n:42s} {v / 512 * 0.01:8.2f} us per wave (sum over its blocks, first 64 workgroups)")
+    print(f"   {'total':42s} {sum(t) / 512 * 0.01:8.2f} us")

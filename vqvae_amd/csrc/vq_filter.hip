@@ -67,6 +67,21 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     float *stage_w = reinterpret_cast<float *>(red + 8) + (size_t)wave_u * (32 * 68);
     const int cb_bad = flags[0];
+#ifdef VQ_TIMING
+    // debug build (tools/build_variant.py NAME -DVQ_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
+    // ticks) over the waves of the first 64 workgroups, collected in LDS and written to the spare tail of `partials`
+    unsigned *tsum = reinterpret_cast<unsigned *>(red);       // the loss scratch is not used before the loop ends
+    if (tid < 8) tsum[tid] = 0;
+    unsigned long long tprev = wall_clock64();
+#define VQ_STAMP(slot)                                                       \
+    do {                                                                     \
+        const unsigned long long tnow = wall_clock64();                      \
+        if (lane == 0) atomicAdd(&tsum[slot], (unsigned)(tnow - tprev));     \
+        tprev = tnow;                                                        \
+    } while (0)
+#else
+#define VQ_STAMP(slot) do {} while (0)
+#endif
     const float EEmax = __int_as_float(flags[1]) * 1.0001f;
     const float Emax = __builtin_sqrtf(EEmax) * 1.0001f;
     const int ntile = K32 >> 5;
@@ -176,10 +191,31 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
         if (ROWMAJOR && STAGE) load_tile_staged(r0[t], zf[t]);
         else load_half(zbase[t], img0[t], voff[t], zf[t]);
     }
-    for (int i = tid; i < NQ * 2 * K32; i += 512) Eimg[i] = img16[i];
+    // codebook image -> LDS, eight 16-byte requests in flight per thread (one at a time costs a full L2 round trip
+    // each; the empty asm pins "all requests, then all stores" -- the compiler otherwise sinks each load to its store)
+    {
+        const u32x4 *src16 = reinterpret_cast<const u32x4 *>(img16);
+        u32x4 *dst16 = reinterpret_cast<u32x4 *>(Eimg);
+        for (int i0 = 0; i0 < NQ * 2 * K32; i0 += 8 * 512) {
+            u32x4 v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 512 + tid;
+                v[j] = src16[i < NQ * 2 * K32 ? i : 0];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * 512 + tid;
+                if (i < NQ * 2 * K32) dst16[i] = v[j];
+            }
+        }
+    }
     for (int i = tid; i < K32; i += 512) neh[i] = neh_g[i];
     for (int k = tid; k < K; k += 512) hist_s[k] = 0;
     __syncthreads();
+    VQ_STAMP(0);                                               // codebook copy + first row requests
 
     double dacc = 0.0;
     for (long long sb = blockIdx.x; sb < nblocks; sb += gridDim.x) {
@@ -195,6 +231,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
 #pragma unroll
             for (int t = 0; t < TPW; ++t) stage_to_fragments(zf[t]);
         }
+        VQ_STAMP(1);                                           // rows landed (load wait + transpose)
         // ================= screen: convert, sweep 1, sweep 2 -- both row tiles share every codebook operand read ===
         bf16x8 zb[TPW][NQ];
         float delta0[TPW];
@@ -258,6 +295,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
                 for (int t = 0; t < TPW; ++t) best[t] = fmaxf(best[t], tile_max(accA[t]));
             }
         }
+        VQ_STAMP(2);                                           // convert + sweep 1
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
             best[t] = fmaxf(best[t], __shfl_xor(best[t], 32));
@@ -315,6 +353,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
                     extract(ct, ~(miss_mask(0u, accA[t], thr[t]) << 16) & 0xffff0000u, cnt[t], cl[t]);
             }
         }
+        VQ_STAMP(3);                                           // sweep 2
         // publish the packed lists (newest first) for the refine stage
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
@@ -447,6 +486,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
             }
         }
 
+        VQ_STAMP(4);                                           // exact part
         // ================= epilogue: both gathers in flight, then z + (e_k - z), squared error, index, histogram =
         f32x4 ev[TPW][HALF / 4];
 #pragma unroll
@@ -495,7 +535,15 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
             }
             if (ROWMAJOR && STAGE && zq) store_tile_staged(r0[t], zf[t]);
         }
+        VQ_STAMP(5);                                           // epilogue (gathers, z_q staging, store issue)
     }
+    VQ_STAMP(6);
+#ifdef VQ_TIMING
+    __syncthreads();
+    if (tid < 8 && blockIdx.x < 64) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + tid] = tsum[tid];
+    __syncthreads();
+    const unsigned long long ttail0 = wall_clock64();
+#endif
 
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
@@ -511,6 +559,11 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
         const int c = hist_s[k];
         if (c) atomicAdd(&hist[k], c);
     }
+#ifdef VQ_TIMING
+    __builtin_amdgcn_s_waitcnt(0);                             // the flush has been acknowledged
+    if (tid == 0 && blockIdx.x < 64)
+        reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + 7] = (wall_clock64() - ttail0) * 8;
+#endif
 }
 
 int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
