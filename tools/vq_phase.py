@@ -28,7 +28,19 @@ _lib.profile_enable(False)
 us = kms / max(kn, 1) * 1e3
 print(f"[{os.path.basename(_lib.LIB_PATH)}] N={N} kernel {us:.2f} us  {N * 520 / us / 1e6:.3f} TB/s  frac {N * 520 / us / 1e6 / 8:.3f}  "
       f"outputs == exhaustive kernel: {same}")
-if os.environ.get("VQ_TIMING"):
+if os.environ.get("VQ_TIMING") == "2":
+    off = 256
+    off = (off + K * 4 + 255) // 256 * 256
+    off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8
+    slots = ws[off:off + 64 * 64].view(torch.int64)
+    slots.zero_()
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+    torch.cuda.synchronize()
+    t = slots.view(64, 8).cpu()
+    cyc, wall = t[:, 0].double(), t[:, 1].double()
+    print(f"   shader clock over the kernel: {(cyc / (wall * 10e-9)).mean() / 1e9:.3f} GHz  (wave 0 of 64 workgroups; "
+          f"{wall.mean() * 0.01:.1f} us per wave)")
+elif os.environ.get("VQ_TIMING"):
     off = 256
     off = (off + K * 4 + 255) // 256 * 256
     off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8

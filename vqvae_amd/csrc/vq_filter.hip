@@ -67,8 +67,12 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     float *stage_w = reinterpret_cast<float *>(red + 8) + (size_t)wave_u * (32 * 68);
     const int cb_bad = flags[0];
-#ifdef VQ_TIMING
-    // debug build (tools/build_variant.py NAME -DVQ_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
+#if defined(VQ_TIMING) && VQ_TIMING == 2
+    // debug build: shader-clock (s_memtime) vs 100 MHz wall clock over the whole wave -> the clock the kernel ran at
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+#define VQ_STAMP(slot) do {} while (0)
+#elif defined(VQ_TIMING)
+    // debug build (tools/build_variant.py NAME -DVQ_TIMING=1, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
     // ticks) over the waves of the first 64 workgroups, collected in LDS and written to the spare tail of `partials`
     unsigned *tsum = reinterpret_cast<unsigned *>(red);       // the loss scratch is not used before the loop ends
     if (tid < 8) tsum[tid] = 0;
@@ -538,7 +542,13 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
         VQ_STAMP(5);                                           // epilogue (gathers, z_q staging, store issue)
     }
     VQ_STAMP(6);
-#ifdef VQ_TIMING
+#if defined(VQ_TIMING) && VQ_TIMING == 2
+    if (tid == 0 && blockIdx.x < 64) {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(partials + 512) + blockIdx.x * 8;
+        o[0] = __builtin_readcyclecounter() - c0;
+        o[1] = wall_clock64() - w0;
+    }
+#elif defined(VQ_TIMING)
     __syncthreads();
     if (tid < 8 && blockIdx.x < 64) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + tid] = tsum[tid];
     __syncthreads();
@@ -559,7 +569,7 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
         const int c = hist_s[k];
         if (c) atomicAdd(&hist[k], c);
     }
-#ifdef VQ_TIMING
+#if defined(VQ_TIMING) && VQ_TIMING == 1
     __builtin_amdgcn_s_waitcnt(0);                             // the flush has been acknowledged
     if (tid == 0 && blockIdx.x < 64)
         reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + 7] = (wall_clock64() - ttail0) * 8;
