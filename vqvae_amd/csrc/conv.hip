@@ -598,8 +598,9 @@ template <int NT, bool S2D>
 __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
                                                                 const u32x4 *__restrict__ wimg,
                                                                 const float *__restrict__ bias,
-                                                                float *__restrict__ out, ConvGeom g) {
-    constexpr int MT = 2, PX = 64, PLANE = (PX + 1) * 2;        // u32x4 per (k-step, term) plane: [pixel + zero][half]
+                                                                float *__restrict__ out, ConvGeom g, int ny) {
+    constexpr int MT = 2, PX = 64, PLANE = (PX + 1) * 2;        // u32x4 per (k-step, term) plane: [half][pixel + zero]
+    constexpr int HP = PX + 1;                                   // (consecutive lanes = consecutive 16 B: no bank conflicts)
     constexpr int TILE4 = 2 * 3 * PLANE;                         // [k-step 2][term 3][PLANE]
     constexpr int CH4 = NT * 384;
     __shared__ u32x4 Bs[2][CH4];
@@ -607,14 +608,29 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
-    const int phase = blockIdx.y % g.nphase, nb = blockIdx.y / g.nphase;
+    // 1-D grid of (image group bx) x (phase / n-block by) workgroups.  The ny workgroups that read the same four
+    // images are adjacent slots of ONE XCD's dispatch sequence (workgroup i goes to XCD i % 8), so the re-reads of
+    // an image by its other output phases / n-blocks hit that XCD's L2 instead of going back to the fabric.
+    unsigned bx, by;
+    {
+        const unsigned id = blockIdx.x, nxb = gridDim.x / (unsigned)ny;
+        if ((nxb & 7u) == 0) {
+            const unsigned slot = id >> 3;
+            by = slot % (unsigned)ny;
+            bx = (slot / (unsigned)ny) * 8 + (id & 7u);
+        } else {
+            by = id % (unsigned)ny;
+            bx = id / (unsigned)ny;
+        }
+    }
+    const int phase = by % g.nphase, nb = by / g.nphase;
     const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
     const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt, nchunk = ntaps * cpt;
 
-    if (lane < 12) As[(lane >> 1) * PLANE + PX * 2 + (lane & 1)] = u32x4{0, 0, 0, 0};      // padding pixels
+    if (lane < 12) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};     // padding pixels
 
-    const long long img = (long long)blockIdx.x * 4 + wave;
+    const long long img = (long long)bx * 4 + wave;
     const bool img_ok = img < g.B;
     // this lane's pixel row (S2D: the top-left pixel of this lane's 2x2 input block)
     const float *src = S2D ? in + (((size_t)(img_ok ? img : 0) * 16 + 2 * (lane >> 3)) * 16 + 2 * (lane & 7)) * g.Cin
@@ -671,16 +687,16 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = relu4(raw[j]);
         }
-        u32x4 *dst = As + lane * 2;
+        u32x4 *dst = As + lane;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
                 u32x4 t1, t2, t3;
                 split8(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], t1, t2, t3);
-                dst[(t * 3 + 0) * PLANE + hh] = t1;
-                dst[(t * 3 + 1) * PLANE + hh] = t2;
-                dst[(t * 3 + 2) * PLANE + hh] = t3;
+                dst[(t * 3 + 0) * PLANE + hh * HP] = t1;
+                dst[(t * 3 + 1) * PLANE + hh * HP] = t2;
+                dst[(t * 3 + 2) * PLANE + hh * HP] = t3;
             }
     };
 
@@ -723,7 +739,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int p = ((tapok[mt] >> okbit) & 1u) ? spx[mt] + shift : PX;
-                const u32x4 *ap = As + (t * 3) * PLANE + p * 2 + h;
+                const u32x4 *ap = As + (t * 3) * PLANE + h * HP + p;
                 A[mt][0] = __builtin_bit_cast(bf16x8, ap[0]);
                 A[mt][1] = __builtin_bit_cast(bf16x8, ap[PLANE]);
                 A[mt][2] = __builtin_bit_cast(bf16x8, ap[2 * PLANE]);
@@ -982,7 +998,8 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                                                                const u32x4 *__restrict__ w1img,
                                                                const u32x4 *__restrict__ w2img,
                                                                float *__restrict__ out, int B, int C, int flags) {
-    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][pixel + zero][2]
+    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][half][pixel + zero]
+    constexpr int HP = PX + 1;                                     // (consecutive lanes = consecutive 16 B: no bank conflicts)
     static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
     __shared__ u32x4 W2s[NT2 * 384];
     __shared__ u32x4 As_all[4 * TILE4];
@@ -993,7 +1010,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     const int cpt = C >> 5, nslice = C >> 4;
 
     for (int i = tid; i < NT2 * 384; i += 256) W2s[i] = w2img[i];
-    if (lane < 6) As[(lane >> 1) * ((PX + 1) * 2) + PX * 2 + (lane & 1)] = u32x4{0, 0, 0, 0};   // padding pixel
+    if (lane < 6) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
 
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
@@ -1056,10 +1073,10 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
             split8(raw[2], raw[3], t1b, t2b, t3b);
             if (sl + 1 < nslice) load_raw(sl + 1, raw);
             __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
-            u32x4 *dst = As + lane * 2;
-            dst[0] = t1a; dst[1] = t1b;
-            dst[(PX + 1) * 2] = t2a; dst[(PX + 1) * 2 + 1] = t2b;
-            dst[(PX + 1) * 4] = t3a; dst[(PX + 1) * 4 + 1] = t3b;
+            u32x4 *dst = As + lane;
+            dst[0] = t1a; dst[HP] = t1b;
+            dst[HP * 2] = t2a; dst[HP * 3] = t2b;
+            dst[HP * 4] = t3a; dst[HP * 5] = t3b;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
         }
@@ -1073,8 +1090,8 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
-                const u32x4 *ap = As + p * 2 + h;
-                S[mt][0] = ap[0]; S[mt][1] = ap[(PX + 1) * 2]; S[mt][2] = ap[(PX + 1) * 4];
+                const u32x4 *ap = As + h * HP + p;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2]; S[mt][2] = ap[HP * 4];
             }
             prod6x2(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
                     acc1[1]);
@@ -1904,12 +1921,12 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
         const unsigned gx = (unsigned)((M + 127) / 128);
         if (g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0)
             // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps
-            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false>), dim3((unsigned)((B + 3) / 4), g.nphase * (g.ntile / 2)),
-                               dim3(256), 0, st, x, img3, bias, y, g);
+            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false>), dim3((unsigned)((B + 3) / 4) * g.nphase * (g.ntile / 2)),
+                               dim3(256), 0, st, x, img3, bias, y, g, g.nphase * (g.ntile / 2));
         else if (kind == VQVAE_CONV_4x4_S2 && g.Hin == 16 && g.Win == 16 && Cin % 32 == 0 && g.ntile % 2 == 0)
             // 16x16 -> 8x8: the same kernel over 2x2 input blocks, weights in the s2d chunk order (third image)
-            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true>), dim3((unsigned)((B + 3) / 4), g.ntile / 2), dim3(256), 0,
-                               st, x, img3 + packed_bf3_bytes(g) / sizeof(u32x4), bias, y, g);
+            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true>), dim3((unsigned)((B + 3) / 4) * (g.ntile / 2)), dim3(256), 0,
+                               st, x, img3 + packed_bf3_bytes(g) / sizeof(u32x4), bias, y, g, g.ntile / 2);
         else if (g.ntile % 4 == 0)
             hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
                                img3, bias, y, g);
