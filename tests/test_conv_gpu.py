@@ -143,6 +143,27 @@ def test_residual_stack_quirks_vs_torch_cpu(C, Rh, n, B, H, W):
     close(y1.cpu().numpy(), ref1.numpy())
 
 
+@pytest.mark.parametrize("C,B", [(128, 2051), (64, 2049)])
+def test_residual_layer_large_batch(C, B):
+    """Fused residual layer on a large, odd batch of 8x8 maps (partial last workgroup): a sample of images against the
+    CPU restatement, and every image against the same kernel run on 1024-image slices (same bits)."""
+    from oracle import torch_port
+    from vqvae_amd import conv_hip
+    from vqvae_amd.modules import ResidualStack
+    torch.manual_seed(C)
+    rs = ResidualStack(C, C, 32, 1)
+    x = torch.randn(B, C, 8, 8)
+    w1, w2 = rs.stack[0].res_block[1].weight.detach(), rs.stack[0].res_block[3].weight.detach()
+    pick = [0, 1, 2, 7, 1000, B - 2, B - 1]
+    ref = torch_port.residual_stack(x[pick].clone(), w1, w2, 1).numpy()
+    rsd = rs.to(dev())
+    t = conv_hip.nchw_to_rows(x.to(dev()))
+    y = conv_hip.res_layer(t, rsd.stack[0], 1 | 2)                      # relu_in | relu_out == a 1-layer stack
+    close(conv_hip.rows_to_nchw(y[pick]).cpu().numpy(), ref)
+    halves = [conv_hip.res_layer(t[i:i + 1024].contiguous(), rsd.stack[0], 1 | 2) for i in range(0, B, 1024)]
+    assert torch.equal(torch.cat(halves), y), "results must not depend on how the batch is sliced"
+
+
 def test_convt_out_vs_torch_cpu():
     from vqvae_amd import _lib, conv_hip
     torch.manual_seed(9)
