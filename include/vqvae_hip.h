@@ -168,7 +168,8 @@ VQVAE_API int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1
                                           int Rh, int flags, float *y, vqvae_stream_t stream);
 
 /* First encoder conv, nn.Conv2d(Cin,Cout,k=4,s=2,p=1) (models/encoder.py:29-31), reading the NCHW
- * image x (B,Cin,H,W) and writing row-major (B,H/2,W/2,Cout).  Cin in {1,3,4}, Cout <= 128.      */
+ * image x (B,Cin,H,W) and writing row-major (B,H/2,W/2,Cout).  Cin in {1,3,4}, Cout <= 128.
+ * flags: VQVAE_CONV_RELU_OUT, VQVAE_CONV_EXACT_FP32 (fp32 MFMA instead of the split-bf16 products). */
 VQVAE_API size_t vqvae_conv_in_packed_bytes(int Cin, int Cout);
 VQVAE_API int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed,
                                      vqvae_stream_t stream);

@@ -102,11 +102,12 @@ def test_conv_in_vs_torch_cpu(Cin, Cout, B, H, W):
     xd = x.to(dev())
     p0 = conv_hip._packed(c0, ("conv_in",), c0.weight, lambda: L.vqvae_conv_in_packed_bytes(Cin, Cout),
                           lambda w, buf: L.vqvae_conv_in_pack_f32(w.data_ptr(), Cin, Cout, buf.data_ptr(), None))
-    y = torch.empty((B, H // 2, W // 2, Cout), device=dev())
-    _lib.check(L.vqvae_conv_in_forward_f32(xd.data_ptr(), p0.data_ptr(), c0.bias.data_ptr(), B, H, W, Cin, Cout, 2,
-                                           y.data_ptr(), torch.cuda.current_stream().cuda_stream))
-    torch.cuda.synchronize()
-    close(nchw(y).cpu().numpy(), ref.numpy())
+    for flags in (2, 2 | 4):                       # RELU_OUT with split-bf16 products (default) / the fp32 MFMA
+        y = torch.empty((B, H // 2, W // 2, Cout), device=dev())
+        _lib.check(L.vqvae_conv_in_forward_f32(xd.data_ptr(), p0.data_ptr(), c0.bias.data_ptr(), B, H, W, Cin, Cout,
+                                               flags, y.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        torch.cuda.synchronize()
+        close(nchw(y).cpu().numpy(), ref.numpy())
 
 
 @pytest.mark.parametrize("C,Rh,n,B,H,W", [(128, 32, 2, 3, 8, 8), (64, 16, 3, 2, 4, 6), (32, 8, 1, 2, 5, 5)])

@@ -1428,16 +1428,21 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
 // 256 | Hg*Wg: 32x32 and 256x256 images): the 2R+2 input rows the band needs are staged once in LDS with
 // coalesced 16-byte loads and a zero border, and the 8*CIN gathers per pixel become LDS reads without
 // bounds checks (the plain kernel issues them as predicated 4-byte global loads).
-template <int CIN, int NT>
+// BF3: the 8*CIN-deep reduction runs as CIN k-steps of exact three-term bf16 splits on the bf16 matrix cores
+// (weights split at pack time: [n_tile][k-step][term][half][n] x 16 B; the gathered pixels are split in
+// registers) instead of 4*CIN fp32 MFMAs -- 2.7x less matrix time, which is what this otherwise memory-bound
+// layer was waiting on.
+template <int CIN, int NT, bool BF3>
 __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ wimg,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int B, int H, int W,
                                                            int Cout, int flags) {
     constexpr int MT = 2, S = CIN * 8, JG = (S + 3) / 4;
+    constexpr int WF = BF3 ? NT * CIN * 768 : NT * JG * 256;     // floats of the weight image
     extern __shared__ __attribute__((aligned(16))) float smem_ci[];
-    float *Ws = smem_ci;                                   // [NT * JG * 256]
-    float *Xs = smem_ci + NT * JG * 256;                   // [CIN][2R + 2][W + 8], column ix at 4 + ix
+    float *Ws = smem_ci;                                   // [WF]
+    float *Xs = smem_ci + WF;                              // [CIN][2R + 2][W + 8], column ix at 4 + ix
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int Hg = H / 2, Wg = W / 2;
@@ -1446,7 +1451,7 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
     const long long b = band / (Hg / R);
     const int gy0 = (int)(band - b * (Hg / R)) * R;
     const int iy0 = 2 * gy0 - 1;
-    for (int i = tid; i < NT * JG * 64; i += 256)
+    for (int i = tid; i < WF / 4; i += 256)
         reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
     const int w4 = W / 4;
     for (int i = tid; i < CIN * NR * w4; i += 256) {
@@ -1486,20 +1491,38 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-    const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws);
+    if constexpr (BF3) {
+        const u32x4 *wb = reinterpret_cast<const u32x4 *>(Ws);
 #pragma unroll
-    for (int j = 0; j < JG; ++j) {
-        f32x4 b4[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) b4[nt] = ws[((nt * JG + j) * 2 + h) * 32 + l31];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int t = 0; t < CIN; ++t) {                    // k-step t: this lane half's values 8t .. 8t+7
+            u32x4 s1[MT], s2[MT], s3[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
+                split8(f32x4{a[mt][8 * t], a[mt][8 * t + 1], a[mt][8 * t + 2], a[mt][8 * t + 3]},
+                       f32x4{a[mt][8 * t + 4], a[mt][8 * t + 5], a[mt][8 * t + 6], a[mt][8 * t + 7]}, s1[mt], s2[mt],
+                       s3[mt]);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][4 * j + i], b4[nt][i],
-                                                                       acc[mt][nt], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 *bp = wb + ((nt * CIN + t) * 3) * 64 + h * 32 + l31;
+                prod6x2(s1[0], s2[0], s3[0], s1[1], s2[1], s3[1], bp[0], bp[64], bp[128], acc[0][nt], acc[1][nt]);
+            }
+        }
+    } else {
+        const f32x4 *ws = reinterpret_cast<const f32x4 *>(Ws);
+#pragma unroll
+        for (int j = 0; j < JG; ++j) {
+            f32x4 b4[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) b4[nt] = ws[((nt * JG + j) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mt][4 * j + i], b4[nt][i],
+                                                                           acc[mt][nt], 0, 0, 0);
+        }
     }
     const bool relu_out = flags & kFlagReluOut;
     const long long wbase = band * 256 + wave * (32 * MT);
@@ -1561,6 +1584,29 @@ __global__ __launch_bounds__(256) void conv_in_pack_kernel(const float *__restri
             v = w[((co * CIN + ci) * 4 + ky) * 4 + kx];
         }
         img[e] = v;
+    }
+}
+
+// split-bf16 image of the first layer's weights: [n_tile][k-step CIN][term 3][half 2][n 32] x 8 bf16; k-step t, half hh,
+// slot i holds reduction index s = 8t + i of that half, i.e. (ci = t, ky = i >> 1, kx = 2 hh + (i & 1))
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_pack_bf3_kernel(const float *__restrict__ w, unsigned short *__restrict__ img,
+                                                               int Cout, int ntile) {
+    const int total = ntile * CIN * 512;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int i = e & 7, n = (e >> 3) & 31, hh = (e >> 8) & 1;
+        const int r = e >> 9, t = r % CIN, nt = r / CIN;
+        const int co = nt * 32 + n, ky = i >> 1, kx = 2 * hh + (i & 1);
+        const float v = co < Cout ? w[((co * CIN + t) * 4 + ky) * 4 + kx] : 0.0f;
+        const unsigned short b1 = f32_to_bf16_rne(v);
+        const float r1 = v - __uint_as_float((unsigned)b1 << 16);
+        const unsigned short b2 = f32_to_bf16_rne(r1);
+        const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
+        const unsigned short b3 = f32_to_bf16_rne(r2);
+        const size_t base = (size_t)((nt * CIN + t) * 3) * 512 + (size_t)(hh * 32 + n) * 8 + i;
+        img[base] = b1;
+        img[base + 512] = b2;
+        img[base + 1024] = b3;
     }
 }
 
@@ -1997,7 +2043,8 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
 size_t vqvae_conv_in_packed_bytes(int Cin, int Cout) {
     if (!(Cin == 1 || Cin == 3 || Cin == 4) || Cout < 1 || Cout > 128) return 0;
     const int S = Cin * 8, JG = (S + 3) / 4;
-    return (size_t)((Cout + 31) / 32) * JG * 256 * sizeof(float);
+    // [fp32 B-operand image][split-bf16 image]
+    return (size_t)((Cout + 31) / 32) * ((size_t)JG * 256 + (size_t)Cin * 768) * sizeof(float);
 }
 
 int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -2009,6 +2056,12 @@ int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqv
         case 1: hipLaunchKernelGGL((conv_in_pack_kernel<1>), dim3(16), dim3(256), 0, st, w, packed, Cout, ntile); break;
         case 3: hipLaunchKernelGGL((conv_in_pack_kernel<3>), dim3(16), dim3(256), 0, st, w, packed, Cout, ntile); break;
         case 4: hipLaunchKernelGGL((conv_in_pack_kernel<4>), dim3(16), dim3(256), 0, st, w, packed, Cout, ntile); break;
+    }
+    unsigned short *img3 = reinterpret_cast<unsigned short *>(packed + (size_t)ntile * ((Cin * 8 + 3) / 4) * 256);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL((conv_in_pack_bf3_kernel<1>), dim3(16), dim3(256), 0, st, w, img3, Cout, ntile); break;
+        case 3: hipLaunchKernelGGL((conv_in_pack_bf3_kernel<3>), dim3(16), dim3(256), 0, st, w, img3, Cout, ntile); break;
+        case 4: hipLaunchKernelGGL((conv_in_pack_bf3_kernel<4>), dim3(16), dim3(256), 0, st, w, img3, Cout, ntile); break;
     }
     return (int)hipGetLastError();
 }
@@ -2028,13 +2081,19 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
     const bool rows = Wg <= 256 && 256 % Wg == 0 && ((long long)Hg * Wg) % 256 == 0 && W % 4 == 0 &&
                       ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     const int jg = (Cin * 8 + 3) / 4;
-    size_t rows_lds = rows ? ((size_t)ntile * jg * 256 + (size_t)Cin * (2 * (256 / Wg) + 2) * (W + 8)) * sizeof(float) : 0;
+    const bool bf3 = !(flags & VQVAE_CONV_EXACT_FP32);     // split-bf16 products unless the fp32 MFMA is asked for
+    const float *packed3 = packed + (size_t)ntile * jg * 256;
+    size_t rows_lds = rows ? ((size_t)ntile * (bf3 ? Cin * 768 : jg * 256) + (size_t)Cin * (2 * (256 / Wg) + 2) * (W + 8)) *
+                                 sizeof(float) : 0;
     if (rows_lds < 4 * 32 * 36 * sizeof(float)) rows_lds = 4 * 32 * 36 * sizeof(float);   // the epilogue's output tiles
 #define CI_LAUNCH(CIN_, NT_)                                                                                       \
     do {                                                                                                           \
-        if (rows && rows_lds <= 64 * 1024)                                                                         \
-            hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_>), dim3(gx), dim3(256), rows_lds, st, x_nchw, packed, \
-                               bias, y, (int)B, H, W, Cout, flags);                                                \
+        if (rows && rows_lds <= 64 * 1024 && bf3)                                                                  \
+            hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, true>), dim3(gx), dim3(256), rows_lds, st, x_nchw,  \
+                               packed3, bias, y, (int)B, H, W, Cout, flags);                                       \
+        else if (rows && rows_lds <= 64 * 1024)                                                                    \
+            hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, false>), dim3(gx), dim3(256), rows_lds, st, x_nchw, \
+                               packed, bias, y, (int)B, H, W, Cout, flags);                                        \
         else                                                                                                       \
             hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
                                (int)B, H, W, Cout, flags);                                                         \
