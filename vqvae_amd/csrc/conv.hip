@@ -67,23 +67,22 @@ __device__ __forceinline__ f32x4 relu4(f32x4 v) {
 }
 
 // Epilogue helper: move one 32-pixel x 32-channel accumulator tile (this wave's) through a wave-private
-// 32 x 36-float LDS tile so that every lane ends up with 8 consecutive channels of one pixel, and finish it
-// there with 16-byte accesses.  fin(p, n, a, b): pixel row p of the tile (0..31), first channel n, the two
-// float4 of accumulator values.  Dword stores straight from the accumulator layout cost ~6x more per byte.
+// 32 x 32-float LDS tile so that lane L of pass k holds channels 4 (L % 8) .. +3 of pixel L / 8 + 8 k, and finish
+// it there with 16-byte accesses: each instruction then covers eight pixels x 128 contiguous bytes (whole cache
+// lines; both the LDS write in accumulator layout and the linear 16-byte read-back are conflict-free).
+// fin(p, n, v, k): pixel row p of the tile (0..31), first channel n, four accumulator values, pass k (0..3).
+// Dword stores straight from the accumulator layout cost ~6x more per byte.
 template <typename Fin>
 __device__ __forceinline__ void tile_epilogue(float *tile, const float (&v)[16], int lane, int nbase, Fin fin) {
     const int l31 = lane & 31, h = lane >> 5;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 36 + l31] = v[r];
+    for (int r = 0; r < 16; ++r) tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v[r];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    const int g8 = (lane & 3) * 8;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        const int p = (lane >> 2) + 16 * u;
-        const f32x4 a = *reinterpret_cast<const f32x4 *>(tile + p * 36 + g8);
-        const f32x4 b = *reinterpret_cast<const f32x4 *>(tile + p * 36 + g8 + 4);
-        fin(p, nbase + g8, a, b);
+    for (int k = 0; k < 4; ++k) {
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+        fin((lane >> 3) + 8 * k, nbase + 4 * (lane & 7), q, k);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -796,15 +795,13 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
                     v[r] = acc[mt][nt][r] + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                 }
-                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, f32x4 b) {
+                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
                     const int px = 32 * mt + p;
                     const int gy = px >> 3, gx = px & 7;
                     const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
                                            g.opx[phase]) * (long long)g.Cout;
-                    if (n < g.Cout) {                          // Cout % 8 == 0: an 8-channel group is all in or all out
+                    if (n < g.Cout)                            // Cout % 8 == 0: a 4-channel group is all in or all out
                         *reinterpret_cast<f32x4 *>(out + off + n) = a;
-                        *reinterpret_cast<f32x4 *>(out + off + n + 4) = b;
-                    }
                 });
             }
     } else if (img_ok) {
@@ -1146,14 +1143,18 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) v[r] = acc2[mt][r];
-                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, f32x4 b4) {
-                    const long long o = (wbase + mt * 32 + p) * C + n;
-                    f32x4 u0 = *reinterpret_cast<const f32x4 *>(in + o), u1 = *reinterpret_cast<const f32x4 *>(in + o + 4);
-                    if (relu_in) { u0 = relu4(u0); u1 = relu4(u1); }
-                    f32x4 y0 = u0 + a4, y1 = u1 + b4;
-                    if (relu_out) { y0 = relu4(y0); y1 = relu4(y1); }
-                    *reinterpret_cast<f32x4 *>(out + o) = y0;
-                    *reinterpret_cast<f32x4 *>(out + o + 4) = y1;
+                // the four skip values of this lane are requested before the tile goes through LDS
+                f32x4 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    u[k] = *reinterpret_cast<const f32x4 *>(in + (wbase + mt * 32 + (lane >> 3) + 8 * k) * C + nt * 32 +
+                                                            4 * (lane & 7));
+                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int k) {
+                    f32x4 u0 = u[k];
+                    if (relu_in) u0 = relu4(u0);
+                    f32x4 y0 = u0 + a4;
+                    if (relu_out) y0 = relu4(y0);
+                    *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = y0;
                 });
             }
         }
@@ -1542,12 +1543,8 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
                     v[r] = acc[mt][nt][r] + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                 }
-                tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, f32x4 b4) {
-                    if (n < Cout) {
-                        float *o = out + (wbase + mt * 32 + p) * Cout + n;
-                        *reinterpret_cast<f32x4 *>(o) = a4;
-                        *reinterpret_cast<f32x4 *>(o + 4) = b4;
-                    }
+                tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
+                    if (n < Cout) *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * Cout + n) = a4;
                 });
             }
         return;
