@@ -1752,15 +1752,45 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         return s;
     };
     if ((OW & 3) == 0 && (Wo & 3) == 0 && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)) {
-        // four consecutive ox per thread: one 16-byte store per quad
+        // four consecutive ox per thread: one 16-byte store per quad.  The quad (ox = 4 xq .. 4 xq + 3, ox even first)
+        // reads input columns ixc - 1 .. ixc + 2 of two input rows; per output the taps are added in gather()'s
+        // order (ky, then kx), with the index arithmetic hoisted out of the sixteen LDS reads.
         const int qw = OW >> 2, nquad = Cout * OH * qw;
+        const bool pow2 = ((qw & (qw - 1)) | (OH & (OH - 1))) == 0;
+        const int lq = 31 - __builtin_clz(qw), lh = 31 - __builtin_clz(OH);
         for (int e = tid; e < nquad; e += 256) {
-            const int xq = e % qw;
-            const int q = e / qw;
-            const int oyl = q % OH, co = q / OH;
+            int xq, oyl, co;
+            if (pow2) { xq = e & (qw - 1); oyl = (e >> lq) & (OH - 1); co = e >> (lq + lh); }
+            else { xq = e % qw; const int q = e / qw; oyl = q % OH; co = q / OH; }
             const int oy = 2 * y0 + oyl, ox = 2 * x0 + 4 * xq;
+            const float bsv = bias ? bias[co] : 0.0f;
+            const int ky0 = (oy + 1) & 1;
+            const int iyA = (oy + 1 - ky0) >> 1, iyB = iyA - 1;            // rows of ky = ky0 and ky0 + 2
+            const bool vA = iyA < H, vB = iyB >= 0;
+            const float *TA = Ts + ((vA ? iyA - ry : 0) * 16 - rx) * STRIDE + (ky0 * 4) * Cout + co;
+            const float *TB = Ts + ((vB ? iyB - ry : 0) * 16 - rx) * STRIDE + ((ky0 + 2) * 4) * Cout + co;
+            const int ixc = ox >> 1;
+            const bool vm = ixc - 1 >= 0, v1 = ixc + 1 < W, v2 = ixc + 2 < W;
+            const int om = (vm ? ixc - 1 : ixc) * STRIDE, o0 = ixc * STRIDE, o1 = (v1 ? ixc + 1 : ixc) * STRIDE,
+                      o2 = (v2 ? ixc + 2 : ixc) * STRIDE;
+            // one output: row A taps (kx0 at column ca, kx0 + 2 at column cb), then row B taps
+            auto one = [&](int kx0, int ca, bool va, int cb, bool vb) -> float {
+                float acc = bsv;
+                if (vA) {
+                    if (va) acc += TA[ca + kx0 * Cout];
+                    if (vb) acc += TA[cb + (kx0 + 2) * Cout];
+                }
+                if (vB) {
+                    if (va) acc += TB[ca + kx0 * Cout];
+                    if (vb) acc += TB[cb + (kx0 + 2) * Cout];
+                }
+                return acc;
+            };
             f32x4 v;
-            v.x = gather(co, oy, ox); v.y = gather(co, oy, ox + 1); v.z = gather(co, oy, ox + 2); v.w = gather(co, oy, ox + 3);
+            v.x = one(1, o0, true, om, vm);
+            v.y = one(0, o1, v1, o0, true);
+            v.z = one(1, o1, v1, o0, true);
+            v.w = one(0, o2, v2, o1, v1);
             *reinterpret_cast<f32x4 *>(out + ((b * Cout + co) * Ho + oy) * (long long)Wo + ox) = v;
         }
     } else {
