@@ -593,8 +593,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 // S2D: the 4x4 stride-2 conv on a 16x16 map, read as a conv over the 8x8 grid of 2x2 input blocks: a chunk is
 // (sub-position (py,px) of the block, 32-channel slice) and meets four block offsets ("virtual taps"), so every
 // input element is still split once and used four times (weights in the s2d chunk order, conv_pack_bf3_kernel).
-template <int NT, bool S2D>
-__global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
+template <int NT, bool S2D, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
                                                                 const u32x4 *__restrict__ wimg,
                                                                 const float *__restrict__ bias,
                                                                 float *__restrict__ out, ConvGeom g, int ny) {
@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
     constexpr int TILE4 = 2 * 3 * PLANE;                         // [k-step 2][term 3][PLANE]
     constexpr int CH4 = NT * 384;
     __shared__ u32x4 Bs[2][CH4];
-    __shared__ u32x4 As_all[4 * TILE4];
+    __shared__ u32x4 As_all[NW * TILE4];                        // NW waves = NW images per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -629,7 +629,7 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
 
     if (lane < 12) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};     // padding pixels
 
-    const long long img = (long long)bx * 4 + wave;
+    const long long img = (long long)bx * NW + wave;
     const bool img_ok = img < g.B;
     // this lane's pixel row (S2D: the top-left pixel of this lane's 2x2 input block)
     const float *src = S2D ? in + (((size_t)(img_ok ? img : 0) * 16 + 2 * (lane >> 3)) * 16 + 2 * (lane & 7)) * g.Cin
@@ -659,16 +659,17 @@ __global__ __launch_bounds__(256, 2) void conv_tile8_bf3_kernel(const float *__r
 
     const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 384;
     const size_t wchunk = (size_t)g.ntile * 384;
-    constexpr int NBQ = CH4 / 256;                     // NT in {2, 4}: 3 or 6 u32x4 per thread
+    constexpr int NBQ = CH4 / (NW * 64);               // u32x4 of the weight chunk per thread
+    static_assert(CH4 % (NW * 64) == 0, "weight chunk must divide over the workgroup");
     u32x4 b_nxt[NBQ];
     auto load_b = [&](int c) {
         const u32x4 *p = wbase + (size_t)c * wchunk;
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) b_nxt[q] = p[tid + 256 * q];
+        for (int q = 0; q < NBQ; ++q) b_nxt[q] = p[tid + NW * 64 * q];
     };
     auto store_b = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + 256 * q] = b_nxt[q];
+        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + NW * 64 * q] = b_nxt[q];
     };
     f32x4 raw[8];
     auto load_raw = [&](int cc) {
@@ -1992,14 +1993,27 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
         // default: split-bf16 products on the bf16 matrix cores (fp32-grade accuracy, ~2.7x the rate)
         const u32x4 *img3 = reinterpret_cast<const u32x4 *>(packed + packed_floats(g));
         const unsigned gx = (unsigned)((M + 127) / 128);
-        if (g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0)
-            // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps
-            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false>), dim3((unsigned)((B + 3) / 4) * g.nphase * (g.ntile / 2)),
-                               dim3(256), 0, st, x, img3, bias, y, g, g.nphase * (g.ntile / 2));
-        else if (kind == VQVAE_CONV_4x4_S2 && g.Hin == 16 && g.Win == 16 && Cin % 32 == 0 && g.ntile % 2 == 0)
-            // 16x16 -> 8x8: the same kernel over 2x2 input blocks, weights in the s2d chunk order (third image)
-            hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true>), dim3((unsigned)((B + 3) / 4) * (g.ntile / 2)), dim3(256), 0,
-                               st, x, img3 + packed_bf3_bytes(g) / sizeof(u32x4), bias, y, g, g.ntile / 2);
+        const bool tile8 = g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0;
+        // 16x16 -> 8x8 (4x4 s2): the same kernel over 2x2 input blocks, weights in the s2d chunk order (third image)
+        const bool S2D_ = !tile8 && kind == VQVAE_CONV_4x4_S2 && g.Hin == 16 && g.Win == 16 && Cin % 32 == 0 && g.ntile % 2 == 0;
+        if (tile8 || S2D_)
+        {
+            // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps.  With four
+            // output tiles per wave (all 128 channels: the image is read and split once) the workgroup has eight
+            // waves, so that its weight chunks (2 x 24 KiB) and eight operand tiles still fit one CU's LDS.
+            static const int nt4 = [] { const char *e = getenv("VQVAE_TILE8_NT4"); return e ? atoi(e) : 1; }();
+            const bool wide = nt4 && g.ntile % 4 == 0;
+            const int ny = (S2D_ ? 1 : g.nphase) * (g.ntile / (wide ? 4 : 2));
+            const unsigned gxt = (unsigned)((B + (wide ? 7 : 3)) / (wide ? 8 : 4)) * ny;
+            const u32x4 *wsel = S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3;
+            if (wide) {
+                if (S2D_) hipLaunchKernelGGL((conv_tile8_bf3_kernel<4, true, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny);
+                else hipLaunchKernelGGL((conv_tile8_bf3_kernel<4, false, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny);
+            } else {
+                if (S2D_) hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true, 4>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny);
+                else hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false, 4>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny);
+            }
+        }
         else if (g.ntile % 4 == 0)
             hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
                                img3, bias, y, g);
