@@ -192,7 +192,8 @@ def main():
         # the convs dominate the step time: their matrix-pipe roofline next to the quantizer's HBM one.
         # MAC*2 per image at 32x32: enc 4x4s2 16.8 M + enc 3x3 18.9 M + 1x1 1.05 M + dec convT3x3
         # 9.4 M + dec convT4x4s2 16.8 M + 4 residual layers 21.0 M = 83.9 MF on the split-bf16 path (6 bf16 MFMA
-        # term products per fp32 product); the first/last layers (3.1 MF) run on the fp32 MFMA
+        # term products per fp32 product); the first/last layers (3.1 MF, also split-bf16) are memory-bound and
+        # reported under "kernels" only
         roofline_conv = None
         if workload == "c3" and "conv_igemm" in extra and "res_layer" in extra:
             t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
@@ -200,11 +201,16 @@ def main():
             roofline_conv = {
                 "kernel": "conv_tile8_bf3_kernel + res_tile8_bf3_kernel (9 launches per step, split-bf16 products)",
                 "bound": "mfma", "achieved": round(bf16_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(bf16_tf / 2500.0, 4), "traffic": None,
+                "frac": round(bf16_tf / 2500.0, 4),
+                # HBM-side bytes per step of these nine launches from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+                # offline at B=4096: 815.7 kB per image = 1.31x the 622.6 kB algorithmic; profiles/r01_c3_hbm_traffic_v8.txt)
+                "traffic": int(B * 815.7e3),
                 "fp32_equivalent_tflops": round(bf16_tf / 6, 1), "ms_per_step": round(t_conv * 1e3, 4),
                 "note": "achieved = bf16 MFMA flop issued (6 term products per fp32 product) / live HIP-event time of "
                         "those kernels; the matrix pipe sustains ~1900 TF with random operands "
-                        "(tools/ubench/mfma_bf16_peak.hip), 2500 TF is the dense spec peak",
+                        "(tools/ubench/mfma_bf16_peak.hip), 2500 TF is the dense spec peak at 2.4 GHz; PMC: the chip "
+                        "holds ~2.0 GHz under this load and the pipe is 59-60% busy in the conv kernels, 43% in the "
+                        "residual layers (profiles/r01_c3_pmc_util_v7.txt)",
             }
         line = {
             "metric": METRIC, "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",
