@@ -1,38 +1,72 @@
 #!/usr/bin/env python3
-"""bench.py -- images/sec of the VQ-VAE forward (32x32x3, K=512, D=64) on N MI355X.
+"""bench.py -- images/sec of the VQ-VAE forward on N MI355X (BASELINE.json's metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3|c2|c4|c5] [--batch B]
 
-One process per GPU (the driver launches N>1 through torch.distributed.run).  The
-batch shards embarrassingly: every rank runs the same per-GPU batch on its own
-replica of the weights (weak scaling), there is no data-path collective; RCCL is
-used only for the barrier and the max-over-ranks of the elapsed time.
+One process per GPU.  `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-executes this file under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (so the plain command
+produces an N-rank line); launched by a driver that already set RANK / WORLD_SIZE it runs as that rank, and
+WORLD_SIZE != --gpus is an error.  The batch shards embarrassingly: every rank runs the same per-GPU batch on its own
+replica of the weights (weak scaling), there is no data-path collective; RCCL carries only the barrier and the
+max-over-ranks of the elapsed time.
 
 A "step" is one `VQVAE.forward(x)` over one synthetic batch already resident in HBM:
-  c3 (default)  BASELINE config 3: full HIP path (Encoder + VQ + Decoder kernels), B=4096/GPU
-  c2            BASELINE config 2: HIP VectorQuantizer, torch convs unchanged,      B=1024/GPU
+  c3 (default)  BASELINE config 3: full HIP path (Encoder + VQ + Decoder kernels), 32x32x3,  K=512,  D=64,  B=4096/GPU
+  c2            BASELINE config 2: HIP VectorQuantizer, torch (MIOpen) convs,       32x32x3,  K=512,  D=64,  B=1024/GPU
+  c4            BASELINE config 4: full HIP path,                                   224x224x3, K=1024, D=64,  B=512/GPU
+  c5            BASELINE config 5: full HIP path, per-GPU shard of B=8192 over 8,   256x256x3, K=8192, D=128, B=1024/GPU
+There is no fallback between workloads: a missing kernel library or extension is an error.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the fused VectorQuantizer kernel
-(timed live with HIP events on the launch stream, vqvae_profile_* hooks, in extra
-steps after the timed region); `cpu_baseline` is the reference's algorithm on the
-host cores (oracle/torch_port.py, same ATen ops as the reference, bounded sample).
+Timing: W warm-up steps, then R repeats of EXACTLY K steps, each repeat bracketed by barrier + synchronize on both
+sides and reduced with MAX over ranks; R is chosen so that the timed work is at least ~1 s (never fewer than 5
+repeats).  `value` / `ms_per_step` come from the MEDIAN repeat; min / max are reported beside it.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the fused VectorQuantizer kernel, timed live with HIP events on the
+launch stream (vqvae_profile_* hooks) in extra steps after the timed region -- the event pairs add a little
+overhead, so the per-kernel figures sum to slightly more than one un-instrumented step.  `roofline.traffic` is
+HBM bytes per launch from rocprofv3 PMC passes recorded in the file named by `traffic_source` (null when no
+such file is committed for the workload); it is never a constant in this script.  `cpu_baseline` is the reference's
+algorithm on the host cores (oracle/torch_port.py, same ATen ops as the reference, bounded sample).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
+HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_ACHIEVABLE_GBPS = 6290.0
+MFMA_16BIT_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
+MFMA_F32_PEAK_TFLOPS = 157.3      # exact-fp32 MFMA = vector rate
 
-METRIC = "images/sec VQ-VAE forward (32x32x3, K=512, D=64)"
-HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-MFMA_F32_PEAK_TFLOPS = 157.3  # exact-fp32 MFMA = vector rate
+# name -> (description, per-GPU batch, H = W, K, D, conv backend)
+WORKLOADS = {
+    "c3": ("BASELINE config 3: full HIP path (Encoder+VQ+Decoder), 32x32x3, K=512, D=64", 4096, 32, 512, 64, "hip"),
+    "c2": ("BASELINE config 2: HIP VectorQuantizer kernel, torch (MIOpen) convs unchanged, 32x32x3, K=512, D=64",
+           1024, 32, 512, 64, "torch"),
+    "c4": ("BASELINE config 4: full HIP path, 224x224x3 -> 56x56 latent, K=1024, D=64", 512, 224, 1024, 64, "hip"),
+    "c5": ("BASELINE config 5: full HIP path, per-GPU shard (1024 images) of the 8192-image batch, 256x256x3, "
+           "K=8192, D=128", 1024, 256, 8192, 128, "hip"),
+}
+
+
+def conv_flops_per_image(H, W, D, h_dim=128, res_h=32, n_res=2):
+    """2*MAC of every conv / conv-transpose / residual layer between the first and the last."""
+    h2, h4 = (H // 2) * (W // 2), (H // 4) * (W // 4)
+    enc2 = 2 * h4 * (h_dim // 2) * 16 * h_dim                  # 4x4 s2, 64 -> 128
+    enc4 = 2 * h4 * h_dim * 9 * h_dim                          # 3x3, 128 -> 128
+    res = n_res * 2 * h4 * (h_dim * 9 * res_h + res_h * h_dim)  # per stack
+    pre = 2 * h4 * h_dim * D
+    dec0 = 2 * h4 * D * 9 * h_dim
+    dec2 = 2 * h2 * h_dim * 4 * (h_dim // 2)                   # convT 4x4 s2 = 4 phases x 2x2 taps
+    return enc2 + enc4 + 2 * res + pre + dec0 + dec2
 
 
 def parse():
@@ -40,18 +74,40 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="auto", choices=["auto", "c3", "c2"])
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on the timed work (sets the repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control-flow check without a GPU (gloo, a stub CPU step): exercises the rank spawn, the "
+                         "barriers, the max-reduce and the JSON line; its numbers are NOT measurements")
     return ap.parse_args()
 
 
-def cpu_baseline(seconds: float):
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def respawn(args):
+    """`python bench.py --gpus N` from a plain shell: become N ranks (one per GPU) under torch.distributed.run."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(seconds: float, torch):
     """Reference algorithm on the host: same ATen CPU ops in the same order as the reference
-    (oracle/torch_port.py), main.py defaults, eval + no_grad, on a bounded sample.  A few thread
-    counts are tried briefly (big hosts thrash on 32-image batches) and the best is reported with
-    the thread count that produced it."""
+    (oracle/torch_port.py), main.py defaults (32x32x3, K=512, D=64), eval + no_grad, on a bounded sample.  A few
+    thread counts are tried briefly (big hosts thrash on 32-image batches) and the best is reported with the
+    thread count that produced it."""
     from oracle import torch_port
     sd = torch_port.init_state_dict()
     ncpu = os.cpu_count() or 1
@@ -84,21 +140,48 @@ def cpu_baseline(seconds: float):
                       f", {ncpu} logical cpus); ~{per:.1f}s per (threads,batch) point, img/s: " + " ".join(detail)}
 
 
+def pmc_traffic(workload: str):
+    """HBM bytes per row / per image from the committed rocprofv3 PMC summary for this workload, or None.
+    The file is written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled on
+    gfx950, as MI355X_MICROARCH.md prescribes)."""
+    path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        d["_path"] = os.path.relpath(path, ROOT)
+        return d
+    except (OSError, ValueError):
+        return None
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(respawn(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a MI355X: the HIP path has no CPU fallback")
-    # dry-run switches for a 1-GPU box (exercise the N>1 control flow without N GPUs): all ranks on device 0
-    # and gloo for the barrier / max-reduce.  The driver's real runs use neither.
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
+                         "(or drop the launcher and let --gpus spawn them)")
+
+    import torch
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a MI355X: the HIP path has no CPU fallback (use --dry-run for the control-flow check)")
+    # VQVAE_BENCH_SHARE_GPU=1: all ranks on device 0 (N>1 control flow on a 1-GPU box); never used by the driver
     share_gpu = os.environ.get("VQVAE_BENCH_SHARE_GPU") == "1"
-    backend = os.environ.get("VQVAE_BENCH_DIST_BACKEND", "nccl")
+    backend = "gloo" if dry else os.environ.get("VQVAE_BENCH_DIST_BACKEND", "nccl")
     if share_gpu:
         local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dev = torch.device("cpu")
+    if not dry:
+        if local >= torch.cuda.device_count():
+            raise SystemExit(f"rank {rank}: LOCAL_RANK {local} but only {torch.cuda.device_count()} GPU(s) visible")
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
@@ -108,131 +191,151 @@ def main():
         else:
             dist_mod.init_process_group(backend, rank=rank, world_size=world)
         dist = dist_mod
-    n_gpus = world
 
-    from vqvae_amd import _lib, conv
-    from vqvae_amd.modules import VQVAE
-    _lib.load()                                    # fail loudly if the HIP library is missing
+    def sync():
+        if not dry:
+            torch.cuda.synchronize()
 
-    workload = args.workload
-    if workload == "auto":
-        try:
-            from vqvae_amd import conv_hip  # noqa: F401
-            workload = "c3"
-        except ImportError:
-            workload = "c2"
-    conv.set_conv_backend("hip" if workload == "c3" else "torch")
-    B = args.batch or (4096 if workload == "c3" else 1024)
-    K, D, H, W = 512, 64, 32, 32
+    desc, B0, HW, K, D, conv_backend = WORKLOADS[args.workload]
+    B = args.batch or B0
+    H = W = HW
+    if dry:
+        B, H, W = 8, 32, 32
+        conv = torch.nn.Conv2d(3, 8, 3, padding=1)
 
-    torch.manual_seed(0)                           # same weights on every rank (replicas)
-    model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+        def step():                                   # stub: control flow only
+            with torch.no_grad():
+                return None, conv(x), None
+        _lib = None
+    else:
+        from vqvae_amd import _lib, conv as conv_mod
+        from vqvae_amd.modules import VQVAE
+        _lib.load()                                    # fail loudly if the HIP library is missing
+        if conv_backend == "hip":
+            from vqvae_amd import conv_hip  # noqa: F401   (an ImportError here is an error, not a smaller workload)
+        conv_mod.set_conv_backend(conv_backend)
+        torch.manual_seed(0)                           # same weights on every rank (replicas)
+        model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+
+        def step():
+            with torch.no_grad():
+                return model(x)
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(B, 3, H, W, generator=g).to(dev)   # synthetic, resident in HBM before timing
 
-    def step():
-        with torch.no_grad():
-            return model(x)
+    def timed_repeat():
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
+        el = time.perf_counter() - t0
+        if dist:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
 
     for _ in range(args.warmup):
         step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    first, out = timed_repeat()
+    # every rank must run the same number of repeats: derive it from the max-reduced first repeat
+    repeats = max(5, min(200, int(args.min_seconds / max(first, 1e-6)) + 1))
+    if dry:
+        repeats = 5
+    times = [first]
+    for _ in range(repeats - 1):
+        el, out = timed_repeat()
+        times.append(el)
     assert torch.isfinite(out[1]).all()
+    srt = sorted(times)
+    elapsed = srt[len(srt) // 2]                       # median repeat
 
-    # ---- per-kernel time of the fused VQ kernel, extra steps outside the timed region ----
-    _lib.profile_enable(True)
-    nprof = min(args.steps, 50)
-    for _ in range(nprof):
-        step()
-    vq_ms, vq_n = _lib.profile_collect("vq_main")
-    extra = {}
-    for name in ("conv_igemm", "res_layer", "conv_in", "conv_out"):
-        ms, n = _lib.profile_collect(name)
-        if n:
-            extra[name] = {"ms_per_step": round(ms / nprof, 4), "launches_per_step": n // nprof}
-    _lib.profile_enable(False)
+    # ---- per-kernel time of the fused VQ kernel (and the conv groups), extra steps outside the timed region ----
+    extra, vq_ms, vq_n, nprof = {}, 0.0, 0, min(args.steps, 50)
+    if not dry:
+        _lib.profile_enable(True)
+        for _ in range(nprof):
+            step()
+        vq_ms, vq_n = _lib.profile_collect("vq_main")
+        for name in ("conv_igemm", "res_layer", "conv_in", "conv_out"):
+            ms, n = _lib.profile_collect(name)
+            if n:
+                extra[name] = {"ms_per_step": round(ms / nprof, 4), "launches_per_step": n // nprof}
+        _lib.profile_enable(False)
 
     if rank == 0:
-        rows = B * (H // 4) * (W // 4)
-        t_vq = vq_ms / max(vq_n, 1) * 1e-3            # seconds per launch
-        alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
-        achieved = alg_bytes / t_vq / 1e9
-        flops = 2.0 * rows * K * D
-        roofline = {
-            "kernel": "vq_filter_kernel_d64 (fused VQ: bf16-MFMA screen with a rigorous bound + exact fp32 "
-                      "refine of the surviving codes; bit-exact indices)",
-            "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4),
-            # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x2 gfx950 correction + WRITE_SIZE),
-            # measured offline on a 4.19 M-row stream: 520.7 B/row (profiles/r01_vq_hbm_traffic.txt)
-            "traffic": rows * 521,
-            "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
-            "alg_bytes_per_row": 8 * D + 8,
-            "screen_tflops_bf16": round(2 * flops / t_vq / 1e12, 1),
-            "hbm_achievable_frac": round(achieved / 6290.0, 4),
-            "note": "algorithmic bytes = rows x (8D+8): read z_e, write z_q, write int64 idx; the screen "
-                    "sweeps the codebook twice on the bf16 matrix cores (2 x 2KD flop/row); an exhaustive "
-                    "exact-fp32 sweep (VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic",
-        }
-        # the convs dominate the step time: their matrix-pipe roofline next to the quantizer's HBM one.
-        # MAC*2 per image at 32x32: enc 4x4s2 16.8 M + enc 3x3 18.9 M + 1x1 1.05 M + dec convT3x3
-        # 9.4 M + dec convT4x4s2 16.8 M + 4 residual layers 21.0 M = 83.9 MF on the split-bf16 path (6 bf16 MFMA
-        # term products per fp32 product); the first/last layers (3.1 MF, also split-bf16) are memory-bound and
-        # reported under "kernels" only
-        roofline_conv = None
-        if workload == "c3" and "conv_igemm" in extra and "res_layer" in extra:
-            t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
-            bf16_tf = B * 83.9e6 * 6 / t_conv / 1e12
-            roofline_conv = {
-                "kernel": "conv_tile8_bf3_kernel + res_tile8_bf3_kernel (9 launches per step, split-bf16 products)",
-                "bound": "mfma", "achieved": round(bf16_tf, 1), "peak": 2500.0, "unit": "TFLOP/s",
-                "frac": round(bf16_tf / 2500.0, 4),
-                # HBM-side bytes per step of these nine launches from rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-                # offline at B=4096: 815.7 kB per image = 1.31x the 622.6 kB algorithmic; profiles/r01_c3_hbm_traffic_v8.txt)
-                "traffic": int(B * 815.7e3),
-                "fp32_equivalent_tflops": round(bf16_tf / 6, 1), "ms_per_step": round(t_conv * 1e3, 4),
-                "note": "achieved = bf16 MFMA flop issued (6 term products per fp32 product) / live HIP-event time of "
-                        "those kernels; the matrix pipe sustains ~1900 TF with random operands "
-                        "(tools/ubench/mfma_bf16_peak.hip), 2500 TF is the dense spec peak at 2.4 GHz; PMC: the chip "
-                        "holds ~2.0 GHz under this load and the pipe is 59-60% busy in the conv kernels, 43% in the "
-                        "residual layers (profiles/r01_c3_pmc_util_v7.txt)",
-            }
+        n_gpus = world
         line = {
-            "metric": METRIC, "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",
+            "metric": "images/sec VQ-VAE forward (32x32x3, K=512, D=64)" if args.workload in ("c2", "c3") else
+                      f"images/sec VQ-VAE forward ({H}x{W}x3, K={K}, D={D})",
+            "value": round(B * n_gpus * args.steps / elapsed, 1), "unit": "images/s",
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            # fp32 in/out and fp32 accumulation everywhere; conv products are formed from exact
-            # three-term bf16 splits of the fp32 operands (error <= 3*2^-24 per product, fp32-grade;
-            # VQVAE_CONV_EXACT_FP32 selects the plain fp32-MFMA kernels); quantizer indices bit-exact
+            # fp32 in/out and fp32 accumulation everywhere; conv products are formed from exact three-term bf16
+            # splits of the fp32 operands (error <= 3*2^-24 per product, fp32-grade; VQVAE_CONV_EXACT_FP32 selects the
+            # plain fp32-MFMA kernels); quantizer indices bit-exact
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": {"c3": "BASELINE config 3: full HIP path (Encoder+VQ+Decoder), "
-                                          "32x32x3, K=512, D=64",
-                                    "c2": "BASELINE config 2: HIP VectorQuantizer kernel, torch (MIOpen) "
-                                          "convs unchanged, 32x32x3, K=512, D=64"}[workload],
-                       "per_gpu_batch": B, "global_batch": B * n_gpus, "image": [3, H, W],
+            "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * n_gpus, "image": [3, H, W],
                        "K": K, "D": D, "parallelism": f"batch-sharded replicas x{n_gpus}, no collective"},
-            "roofline": roofline,
-            "roofline_conv": roofline_conv,
-            "kernels": extra,
+            "timing": {"repeats": len(times), "steps_per_repeat": args.steps, "statistic": "median repeat",
+                       "ms_per_step_min": round(srt[0] / args.steps * 1e3, 4),
+                       "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 4),
+                       "timed_seconds_total": round(sum(times), 3)},
         }
-        if n_gpus == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        if dry:
+            line["dry_run"] = True
+            line["data"] = "dry-run stub (no kernels ran; not a measurement)"
+        else:
+            rows = B * (H // 4) * (W // 4)
+            pmc = pmc_traffic(args.workload)
+            if vq_n:
+                t_vq = vq_ms / vq_n * 1e-3                     # seconds per launch
+                alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
+                achieved = alg_bytes / t_vq / 1e9
+                line["roofline"] = {
+                    "kernel": _lib.vq_kernel_name(K, D) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
+                              "fp32 refine of the surviving codes; bit-exact indices)",
+                    "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": int(pmc["vq_bytes_per_row"] * rows) if pmc and "vq_bytes_per_row" in pmc else None,
+                    "traffic_source": pmc["_path"] if pmc and "vq_bytes_per_row" in pmc else None,
+                    "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
+                    "alg_bytes_per_row": 8 * D + 8,
+                    "screen_tflops_16bit": round(2.0 * rows * K * D * _lib.vq_sweeps(K, D) / t_vq / 1e12, 1),
+                    "hbm_achievable_frac": round(achieved / HBM_ACHIEVABLE_GBPS, 4),
+                    "note": "algorithmic bytes = rows x (8D+8): read z_e, write z_q, write int64 idx; avg_kernel_us is "
+                            "the live HIP-event average over the instrumented steps; an exhaustive exact-fp32 sweep "
+                            "(VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic at K=512, D=64",
+                }
+            if conv_backend == "hip" and "conv_igemm" in extra and "res_layer" in extra:
+                t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
+                alg_tf = B * conv_flops_per_image(H, W, D) / t_conv / 1e12
+                line["roofline_conv"] = {
+                    "kernel": "conv / conv-transpose / fused residual-layer kernels between the first and the last layer "
+                              "(split-bf16 products: 6 bf16 MFMA term products per fp32 product)",
+                    "bound": "mfma", "achieved": round(6 * alg_tf, 1), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(6 * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4),
+                    "achieved_algorithmic_tflops": round(alg_tf, 1),
+                    "frac_of_split_bf16_ceiling": round(alg_tf / (MFMA_16BIT_PEAK_TFLOPS / 6), 4),
+                    "frac_of_fp32_mfma_peak": round(alg_tf / MFMA_F32_PEAK_TFLOPS, 4),
+                    "traffic": int(pmc["conv_bytes_per_image"] * B) if pmc and "conv_bytes_per_image" in pmc else None,
+                    "traffic_source": pmc["_path"] if pmc and "conv_bytes_per_image" in pmc else None,
+                    "flops_per_image": conv_flops_per_image(H, W, D), "ms_per_step": round(t_conv * 1e3, 4),
+                    "note": "achieved = bf16 MFMA flop ISSUED (6 term products per fp32 product) / live HIP-event time; "
+                            "achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
+                            "would be credited with): its ceiling on this path is 2500/6 = 417 TF",
+                }
+            line["kernels"] = extra
+            if n_gpus == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, torch)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

@@ -76,7 +76,15 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
                                         and workspace): skip the prepare kernel        */
 
 #define VQVAE_VQ_EXACT_SWEEP    0x4  /* force the exhaustive exact-fp32 MFMA sweep instead of the
-                                        bf16-screened + exactly-refined kernel (identical outputs) */
+                                        16-bit-screened + exactly-refined kernels (identical outputs) */
+#define VQVAE_VQ_BF16_FILTER    0x8  /* use round 1's two-sweep bf16 filter kernel where the default would be the
+                                        single-sweep fp16 kernel (identical outputs; A/B timing and tests) */
+
+/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_sweep_kernel_d64", "vq_filter_kernel_d64",
+ * "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix cores per row
+ * (0 for the exact-fp32 kernel).  For reporting (bench.py). */
+VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);
+VQVAE_API int vqvae_vq_screen_sweeps(int K, int D, int flags);
 
 /* Bytes of workspace vqvae_vq_forward_f32 needs for n_rows = B*H*W latent rows. */
 VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);

@@ -18,13 +18,13 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact)
+                                            exact_sweep=exact, bf16_filter=bf16_filter)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -32,14 +32,15 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False):
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("exact", [False, True], ids=["filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
-def test_vq_matches_reference_golden(name, rowmajor, exact, golden_vq):
-    """Both kernels -- the bf16-screened + exactly-refined one (default where it applies: D=64) and
-    the exhaustive fp32-MFMA sweep -- must reproduce the reference bit for bit."""
+def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
+    """All three kernels -- the single-sweep fp16-screened one (default for row-major D=64 rows), round 1's
+    two-sweep bf16 filter (default for NCHW D=64 rows) and the exhaustive fp32-MFMA sweep -- must reproduce
+    the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
-    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=exact)
+    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -72,8 +73,9 @@ def test_vq_matches_oracle_fresh(K, D, B, H, W, scale):
     cb = ((torch.rand(K, D, generator=g) * 2 - 1) / K) if scale < 1 else torch.randn(K, D, generator=g)
     z = torch.randn(B, D, H, W, generator=g) * scale
     ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
-    for rowmajor, exact in ((False, False), (True, False), (False, True), (True, True)):
-        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, exact=exact)
+    for rowmajor, exact, bf in ((False, False, False), (True, False, False), (True, False, True), (False, True, False),
+                                (True, True, False)):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, exact=exact, bf16_filter=bf)
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
@@ -101,8 +103,8 @@ def test_vq_filter_adversarial_near_ties():
     zr[6::17] *= 1e-4
     z = zr.view(6, 8, 8, D).permute(0, 3, 1, 2).contiguous()
     ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
-    for rowmajor in (False, True):
-        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor)
+    for rowmajor, bf in ((False, False), (True, False), (True, True)):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, bf16_filter=bf)
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
@@ -123,11 +125,39 @@ def test_vq_aligned_rounding_adversarial(p, seed):
     z = torch.from_numpy(np.ascontiguousarray(zr.reshape(n // 64, 8, 8, d).transpose(0, 3, 1, 2)))
     cbt = torch.from_numpy(cb)
     ref = c_oracle.vq_forward(z.numpy(), cb, 0.25)
-    for rowmajor, exact in ((True, False), (False, False), (True, True)):
-        loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, rowmajor, exact=exact)
+    for rowmajor, exact, bf in ((True, False, False), (True, False, True), (False, False, False), (True, True, False)):
+        loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, rowmajor, exact=exact, bf16_filter=bf)
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
+
+
+@pytest.mark.parametrize("shrink", [1.0, 0.5, -0.25])
+def test_vq_near_ties_within_one_lane_half(shrink):
+    """Two near-tied codes that the single-sweep kernel tracks in the SAME lane (same half of a 32-code tile
+    group, different tiles), with positive, negative and mixed-sign screen scores.  Their keys share every
+    upper bit, so the order of the low (code) bits decides -- the end-of-tile fix-up must not reorder them
+    (a round-2 bug: with negative scores the later tile's key overtook the earlier one, med3 then duplicated
+    it and the true argmin was never refined)."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(5)
+    K, D = 512, 64
+    cb = torch.randn(K, D, generator=g)
+    rows = []
+    for i in range(512):
+        ta, tb = torch.randint(0, 16, (2,), generator=g).tolist()
+        half = int(torch.randint(0, 2, (1,), generator=g))
+        ia = [j for j in range(32) if ((j >> 2) & 1) == half]
+        ka = ta * 32 + ia[int(torch.randint(0, 16, (1,), generator=g))]
+        kb = tb * 32 + ia[int(torch.randint(0, 16, (1,), generator=g))]
+        mid = 0.5 * (cb[ka] + cb[kb])
+        rows.append(shrink * mid + torch.randn(D, generator=g) * (1e-4 if i % 2 else 1e-6))
+    z = torch.stack(rows).view(8, 8, 8, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    for rowmajor, bf in ((True, False), (True, True), (False, False)):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, bf16_filter=bf)
+        np.testing.assert_array_equal(idx, ref["idx"])
+        assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
 def test_vq_nonfinite_codebook_forces_slow_path():

@@ -23,6 +23,8 @@ SIGNATURES = {
     "vqvae_strerror": (C.c_char_p, [_i32]),
     "vqvae_profile_enable": (_i32, [_i32]),
     "vqvae_profile_collect": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "vqvae_vq_kernel_name": (C.c_char_p, [_i32, _i32, _i32]),
+    "vqvae_vq_screen_sweeps": (_i32, [_i32, _i32, _i32]),
     "vqvae_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vqvae_vq_forward_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -85,6 +87,15 @@ def load():
 def check(code: int):
     if code != 0:
         raise VqvaeHipError(f"libvqvae_hip: {load().vqvae_strerror(code).decode()} (code {code})")
+
+
+def vq_kernel_name(K: int, D: int, flags: int = 0x1) -> str:
+    """kernel vqvae_vq_forward_f32 launches for this shape (default flags: row-major rows, the fused path's layout)"""
+    return load().vqvae_vq_kernel_name(K, D, flags).decode()
+
+
+def vq_sweeps(K: int, D: int, flags: int = 0x1) -> int:
+    return load().vqvae_vq_screen_sweeps(K, D, flags)
 
 
 PROF_IDS = {"vq_main": 0, "conv_igemm": 1, "res_layer": 2, "conv_in": 3, "conv_out": 4}

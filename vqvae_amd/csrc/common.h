@@ -39,7 +39,7 @@ struct VqPlan {
     int KC;           // codes per LDS chunk (multiple of 32)
     int nchunks;      // ceil(K / KC)
     int K_pad;        // nchunks * KC
-    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, total;
+    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, off_imgh, off_seeds, total;
     size_t lds_bytes;
     // filter-and-refine kernel (bf16 screening): usable when the whole bf16 image fits LDS
     bool filter_ok;
@@ -70,7 +70,9 @@ inline VqPlan vq_plan(int K, int D) {
     p.K32 = (K + 31) / 32 * 32;
     p.off_img16 = align_up(p.off_partials + sizeof(double) * kVqMaxGrid, 256);
     p.off_neh = align_up(p.off_img16 + (size_t)p.K32 * D * 2, 256);
-    p.total = align_up(p.off_neh + (size_t)p.K32 * 4, 256);
+    p.off_imgh = align_up(p.off_neh + (size_t)p.K32 * 4, 256);        // fp16 image + seeds of the single-sweep kernel
+    p.off_seeds = align_up(p.off_imgh + (size_t)p.K32 * D * 2, 256);
+    p.total = align_up(p.off_seeds + (size_t)p.K32 * 4, 256);
     // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
     p.filter_lds_bytes = (size_t)p.K32 * D * 2 + (size_t)p.K32 * 4 + (size_t)K * 4 +
                          kVqTilesPerWave * (8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4) + 256 + 8;
@@ -81,5 +83,11 @@ inline VqPlan vq_plan(int K, int D) {
 // vq_filter.hip: bf16-screened, exactly-refined VectorQuantizer kernel (same outputs as the exact one)
 int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
                          float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out);
+
+// vq_sweep.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel (D = 64, row-major rows)
+bool vq_sweep_ok(int K, int D);
+void launch_vq_prepare16(const float *cb, int K, char *ws, hipStream_t st);
+int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
+                        char *ws, hipStream_t st, int *grid_out);
 
 }  // namespace vqvae

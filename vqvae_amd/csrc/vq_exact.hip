@@ -66,8 +66,12 @@ __global__ __launch_bounds__(64) void vq_prepare_kernel(const float *__restrict_
         for (int c = 0; c < D; ++c) sq[c] = e[c] * e[c];
         n2 = aten_sqsum_full<D>(sq);
         if (!(n2 < 1.0e38f)) atomicOr(flags, 1);
-        // statistics for the screening bound: max ||e||^2 (non-negative floats order like ints)
+        // statistics for the screening bounds: max ||e||^2 and max |e_kc| (non-negative floats order like ints)
         atomicMax(flags + 1, __float_as_int(n2));
+        float am = 0.0f;
+#pragma unroll
+        for (int c = 0; c < D; ++c) am = fmaxf(am, __builtin_fabsf(e[c]));
+        atomicMax(flags + 2, __float_as_int(am));
     }
     ee[k] = n2;
     if (k < K32) {
@@ -445,9 +449,20 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
                            p.K_pad, ee, img, wflags, p.K32,
                            reinterpret_cast<unsigned short *>(ws + p.off_img16),
                            reinterpret_cast<float *>(ws + p.off_neh));
+        if (vq_sweep_ok(K, D)) launch_vq_prepare16(cb, K, ws, st);
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
     if constexpr (D == 64) {
+        if (rowmajor && vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
+            int fgrid = 0;
+            prof_begin(VQVAE_PROF_VQ_MAIN, st);
+            const int rc = launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid);
+            prof_end(VQVAE_PROF_VQ_MAIN, st);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
+                               beta, loss, ppl);
+            return (int)hipGetLastError();
+        }
         if (p.filter_ok && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
@@ -500,6 +515,20 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
 using namespace vqvae;
 
 extern "C" {
+
+const char *vqvae_vq_kernel_name(int K, int D, int flags) {
+    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return "unsupported";
+    if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
+        if ((flags & VQVAE_VQ_ROWMAJOR) && vq_sweep_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_sweep_kernel_d64";
+        if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
+    }
+    return "vq_exact_kernel";
+}
+
+int vqvae_vq_screen_sweeps(int K, int D, int flags) {
+    const char *n = vqvae_vq_kernel_name(K, D, flags);
+    return n[3] == 's' ? 1 : (n[3] == 'f' ? 2 : 0);
+}
 
 size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D) {
     (void)n_rows;

@@ -12,6 +12,7 @@ from . import _lib
 VQ_ROWMAJOR = 0x1
 VQ_CODEBOOK_PREPARED = 0x2
 VQ_EXACT_SWEEP = 0x4
+VQ_BF16_FILTER = 0x8
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -35,13 +36,14 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
-               exact_sweep: bool = False):
+               exact_sweep: bool = False, bf16_filter: bool = False):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
     z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
     Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
-    exact_sweep=True forces the exhaustive fp32-MFMA kernel instead of the bf16-screened one
-    (both produce identical bits; the flag exists for testing and A/B timing).
+    exact_sweep=True forces the exhaustive fp32-MFMA kernel, bf16_filter=True round 1's two-sweep bf16 filter
+    kernel, instead of the default (single-sweep fp16 screen for row-major D=64 rows); all three produce
+    identical bits, the flags exist for testing and A/B timing.
     """
     _check_dev("z_e", z_e)
     _check_dev("codebook", codebook)
@@ -68,7 +70,7 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         hist = torch.empty((K,), dtype=torch.int32, device=dev)
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
-            (VQ_EXACT_SWEEP if exact_sweep else 0)
+            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0)
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
