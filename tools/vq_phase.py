@@ -28,7 +28,21 @@ _lib.profile_enable(False)
 us = kms / max(kn, 1) * 1e3
 print(f"[{os.path.basename(_lib.LIB_PATH)}] N={N} kernel {us:.2f} us  {N * 520 / us / 1e6:.3f} TB/s  frac {N * 520 / us / 1e6 / 8:.3f}  "
       f"outputs == exhaustive kernel: {same}")
-if os.environ.get("VQ_TIMING") == "2":
+if os.environ.get("VQ_TIMING") == "span":
+    # -DVQ_SWEEP_TIMING=2 build: per-workgroup [start, end] on the chip-wide 100 MHz clock
+    off = 256
+    off = (off + K * 4 + 255) // 256 * 256
+    off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8
+    slots = ws[off:off + 256 * 16].view(torch.int64)
+    slots.zero_()
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+    torch.cuda.synchronize()
+    t = slots.view(256, 2).cpu().double() * 0.01
+    t0 = t[:, 0].min()
+    st, en = t[:, 0] - t0, t[:, 1] - t0
+    print(f"   workgroup starts: 0 .. {st.max():.2f} us (mean {st.mean():.2f});  ends: {en.min():.2f} .. {en.max():.2f} us (mean {en.mean():.2f});"
+          f"  durations: mean {(en - st).mean():.2f}, min {(en - st).min():.2f}, max {(en - st).max():.2f} us")
+elif os.environ.get("VQ_TIMING") == "2":
     off = 256
     off = (off + K * 4 + 255) // 256 * 256
     off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8
@@ -48,9 +62,16 @@ elif os.environ.get("VQ_TIMING"):
     slots.zero_()
     F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
     torch.cuda.synchronize()
-    names = ["prologue (codebook copy, first requests)", "rows landed", "convert + sweep 1", "sweep 2", "exact part",
-             "epilogue", "loop exit", "tail: loss partial + histogram flush (x8)"]
-    t = slots.view(64, 8).sum(0).cpu().tolist()
+    names = ["prologue (codebook copy, first requests)", "rows landed + fp16 conversion", "sweep", "merge + classify", "exact part",
+             "epilogue", "loop exit", "-"]
+    if os.environ.get("VQ_TIMING") == "old":
+        names = ["prologue (codebook copy, first requests)", "rows landed", "convert + sweep 1", "sweep 2", "exact part",
+                 "epilogue", "loop exit", "tail: loss partial + histogram flush (x8)"]
+    per_block = slots.view(64, 8).cpu()
+    mx = per_block[:, 7].double() * 0.01
+    print(f"   slowest wave of a workgroup: mean {mx.mean():.2f} us, max {mx.max():.2f} us, min {mx.min():.2f} us (first 64 workgroups)")
+    t = per_block.sum(0).tolist()
+    t[7] = 0
     for n, v in zip(names, t):
         print(f"   {n:42s} {v / 512 * 0.01:8.2f} us per wave (sum over its blocks, first 64 workgroups)")
     print(f"   {'total':42s} {sum(t) / 512 * 0.01:8.2f} us")

@@ -108,15 +108,29 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     float *seeds = reinterpret_cast<float *>(Eimg + (size_t)ntile * 256);               // [ntile][2][16]
     int *hist_s = reinterpret_cast<int *>(seeds + (size_t)ntile * 32);                  // [K]
     double *red = reinterpret_cast<double *>(hist_s + K + (K & 1));                     // [NW]
-    unsigned char *wave_base = reinterpret_cast<unsigned char *>(red + NW);             // per wave: 4 KiB fp16 tile + 256 B
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(red + NW);             // per wave: 8 KiB (the pair's fp16 rows, later fp32 row slots) + 1.25 KiB task tables
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int j16 = lane & 15, g4 = lane >> 4;                 // coalesced layout: 16 lanes per row, 4 rows per instruction
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char *tile_s = wave_base + (size_t)wave_u * (4096 + 256);
-    int *kb_s = reinterpret_cast<int *>(tile_s + 4096);        // [32] refined indices of the tile in hand
-    float *zz_s = reinterpret_cast<float *>(tile_s + 4096 + 128);   // [32] exact ||z||^2 of its flagged rows
+    unsigned char *tile_s = wave_base + (size_t)wave_u * (8192 + 1280);
 
+#ifdef VQ_SWEEP_TIMING
+    // debug build (tools/build_variant.py NAME -DVQ_SWEEP_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
+    // ticks) over the waves of the first 64 workgroups, collected in LDS and written to the spare tail of `partials`
+    unsigned *tsum = reinterpret_cast<unsigned *>(red);       // the loss scratch is not used before the loop ends
+    if (tid < 8) tsum[tid] = 0;
+    unsigned long long tprev = wall_clock64();
+    const unsigned long long tstart = tprev;
+#define VQ_STAMP(slot)                                                       \
+    do {                                                                     \
+        const unsigned long long tnow = wall_clock64();                      \
+        if (lane == 0) atomicAdd(&tsum[slot], (unsigned)(tnow - tprev));     \
+        tprev = tnow;                                                        \
+    } while (0)
+#else
+#define VQ_STAMP(slot) do {} while (0)
+#endif
     const int cb_bad = flags[0];
     const int a_e = flags[5];
     const float A = __builtin_ldexpf(1.0f, a_e);
@@ -128,7 +142,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 
     // ---- row I/O: F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the pair (1 KiB contiguous per instruction) ----
     // rows past the end read row N-1 again (their results are never stored), so the loads need no branches
-    auto load_pair = [&](long long p, f32x4(&F)[2][8]) {
+    auto load_pair = [&](long long p, f32x4(&F)[2][8], int g4, int j16) {
         const long long r0 = p * 64 + g4;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -143,26 +157,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     const long long pstride = (long long)gridDim.x * NW;
     long long p = (long long)blockIdx.x * NW + wave_u;
     f32x4 F[2][8], Fn[2][8];
-    if (p < npairs) load_pair(p, F);
+    if (p < npairs) load_pair(p, F, lane >> 4, lane & 15);
 
     // codebook image and seeds -> LDS (eight 16-byte requests in flight per thread)
     {
         const u32x4 *src16 = reinterpret_cast<const u32x4 *>(img_g);
         u32x4 *dst16 = reinterpret_cast<u32x4 *>(Eimg);
         const int n16 = ntile * 256;
+        // every workgroup reads the same 64 KiB: each starts at its own offset so the CUs do not queue on the same lines
+        const int rot = (int)((blockIdx.x * 97u) % (unsigned)ntile) * 256;
         for (int i0 = 0; i0 < n16; i0 += 8 * NW * 64) {
             u32x4 v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = i0 + j * NW * 64 + tid;
-                v[j] = src16[i < n16 ? i : 0];
+                v[j] = src16[i < n16 ? (i + rot) % n16 : 0];
             }
 #pragma unroll
             for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int i = i0 + j * NW * 64 + tid;
-                if (i < n16) dst16[i] = v[j];
+                if (i < n16) dst16[(i + rot) % n16] = v[j];
             }
         }
     }
@@ -170,8 +186,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     for (int k = tid; k < K; k += NW * 64) hist_s[k] = 0;
     __syncthreads();
 
-    const uint4 *ap0 = Eimg + h * 32 + l31;
-    const float *sp0 = seeds + h * 16;
+    VQ_STAMP(0);                                               // codebook image copy + first row requests
     const float inf = __builtin_inff();
     // low key bits: [ntile - tile : 5 or 6][half (fresh flag during the sweep) : 1][r : 4]
     const unsigned keymask = ntile <= 31 ? 0xfffffc00u : 0xfffff800u;
@@ -181,6 +196,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 
     for (; p < npairs; p += pstride) {
         const long long r0 = p * 64;
+        // lane-derived indices are made opaque once per iteration: hipcc otherwise hoists ~40 per-lane address values out
+        // of this loop, spills them and reloads them from scratch inside it (cdna_hip_programming.md, "lane-constant
+        // address hoisted to kernel entry")
+        int lane_v = tid & 63;
+        asm volatile("" : "+v"(lane_v));
+        const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5, j16 = lane_v & 15, g4 = lane_v >> 4;
+        const uint4 *ap0 = Eimg + h * 32 + l31;
+        const float *sp0 = seeds + h * 16;
 
         // ================= fp32 rows -> fp16 B operands (through the wave's LDS tile), |z^|^2 ==========================
         f16x8 zb[2][4];
@@ -196,14 +219,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                 u32x2 w;
                 w.x = __builtin_bit_cast(unsigned, lo);
                 w.y = __builtin_bit_cast(unsigned, hi);
-                *reinterpret_cast<u32x2 *>(tile_s + row * 128 + ((((j16 >> 1) ^ (row >> 1)) & 7) << 4) + ((j16 & 1) << 3)) = w;
+                *reinterpret_cast<u32x2 *>(tile_s + t * 4096 + row * 128 + ((((j16 >> 1) ^ (row >> 1)) & 7) << 4) + ((j16 & 1) << 3)) = w;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __builtin_amdgcn_wave_barrier();
             float s = 0.0f;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4));
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4));
                 zb[t][q] = __builtin_bit_cast(f16x8, v);
                 s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), s, false);
                 s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), s, false);
@@ -215,20 +238,33 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             zn2[t] = s + __uint_as_float(h ? sw[0] : sw[1]);
         }
 
+        VQ_STAMP(1);                                           // rows landed, fp16 conversion
         // ================= the sweep: 4 MFMAs per (code tile, row tile), top-3 keys per lane ==========================
         float m1[2], m2[2], m3[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { m1[t] = -inf; m2[t] = -inf; m3[t] = -inf; }
-        for (int ct = 0; ct < ntile; ++ct) {
-            uint4 a[4];
+        // max(m1, key) is written med3(m1, key, +inf) with an OPAQUE +inf: given the literal, hipcc turns it into v_max
+        // plus a canonicalising v_max of the integer-built key -- a fifth VALU op per element in a VALU-bound loop
+        float pinf = inf;
+        asm volatile("" : "+v"(pinf));
+        // Operands of tile ct+1 are requested right behind the MFMAs of tile ct and land under its ~130 VALU ops; two
+        // operand sets ping-pong through a loop unrolled by two, so nothing is copied.
+        auto fetch = [&](int ct, u32x4(&a)[4], f32x16 &seed) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) a[q] = ap0[ct * 256 + q * 64];
-            f32x16 seed;
+            for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
                 seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
             }
+        };
+        // Fresh keys (low field 16 | r) get their tile at the end of the tile: m += (m & 16) (2 f - 1) turns the field into
+        // (f << 5) | r with f = ntile - tile.  Storing ntile - tile (not tile) keeps the order of two keys with EQUAL upper
+        // bits the same before and after the fix-up -- a fresh key's field (16..31) is below every older key's (>= 32),
+        // and so is (ntile - tile) << 5 against any earlier tile's -- so med3 / max always see a consistently ordered
+        // triple.  (Adding the tile number itself reorders near-tied NEGATIVE scores of one lane, after which med3
+        // duplicates one key and drops the other.)
+        auto cell = [&](int ct, const u32x4(&a)[4], const f32x16 &seed, u32x4(&an)[4], f32x16 &seedn) {
             f32x16 acc[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -237,36 +273,52 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                 for (int q = 1; q < 4; ++q)
                     acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[t][q], acc[t], 0, 0, 0);
             }
-            // Fresh keys (low field 16 | r) get their tile at the end of the tile: m += (m & 16) (2 f - 1) turns the field
-            // into (f << 5) | r with f = ntile - tile.  Storing ntile - tile (not tile) keeps the order of two keys with
-            // EQUAL upper bits the same before and after the fix-up -- a fresh key's field (16..31) is below every older
-            // key's (>= 32), and so is (ntile - tile) << 5 against any earlier tile's -- so med3 / max always see a
-            // consistently ordered triple.  (Adding the tile number itself reorders near-tied NEGATIVE scores of one
-            // lane, after which med3 duplicates one key and drops the other.)
+            fetch(ct + 1 < ntile ? ct + 1 : ct, an, seedn);
             const unsigned fix = (unsigned)(2 * (ntile - ct) - 1);
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float key = __uint_as_float((__float_as_uint(acc[t][r]) & keymask) | (unsigned)(r | 16));
+#if defined(VQ_KNOB) && VQ_KNOB == 2          // knock-out builds (timing only, wrong results): 1 = no m3, 2 = one op per element
+                    m1[t] = __builtin_amdgcn_fmed3f(m1[t], acc[t][r], pinf);
+                    continue;
+#endif
+#if !defined(VQ_KNOB) || VQ_KNOB != 1
                     m3[t] = __builtin_amdgcn_fmed3f(m2[t], m3[t], key);
+#endif
                     m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], key);
-                    m1[t] = __builtin_amdgcn_fmed3f(m1[t], key, inf);
+                    m1[t] = __builtin_amdgcn_fmed3f(m1[t], key, pinf);
                 }
                 unsigned b1 = __float_as_uint(m1[t]), b2 = __float_as_uint(m2[t]), b3 = __float_as_uint(m3[t]);
-                b1 += (b1 & 16u) * fix;
-                b2 += (b2 & 16u) * fix;
-                b3 += (b3 & 16u) * fix;
+                b1 += __umul24(b1 & 16u, fix);
+                b2 += __umul24(b2 & 16u, fix);
+                b3 += __umul24(b3 & 16u, fix);
                 m1[t] = __uint_as_float(b1);
                 m2[t] = __uint_as_float(b2);
                 m3[t] = __uint_as_float(b3);
             }
+            // the prefetched operands are first "used" here: their loads cannot sink below, their wait cannot rise above
+            asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]));
+        };
+        {
+            u32x4 aA[4], aB[4];
+            f32x16 sA, sB;
+            fetch(0, aA, sA);
+            int ct = 0;
+            for (; ct + 1 < ntile; ct += 2) {
+                cell(ct, aA, sA, aB, sB);
+                cell(ct + 1, aB, sB, aA, sA);
+            }
+            if (ct < ntile) cell(ct, aA, sA, aB, sB);
         }
 
+        VQ_STAMP(2);                                           // sweep
         // ================= merge the two lane halves of every row, classify ===========================================
         int kbest[2];
         bool valid[2], bad[2], pairf[2], hardf[2];
         int c2[2];
+        float thr[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const long long row = r0 + 32 * t + l31;
@@ -296,6 +348,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             const float delta = (2.0f * eps + 2.0f * xi + trunc) * 1.001f;
             bad[t] = valid[t] && (cb_bad || !(zs < 1.0e30f) || !(v1 > -1.0e37f) || !(delta < 1.0e37f));
             const bool amb2 = !(v1 - v2 >= delta), amb3 = !(v1 - v3 >= delta);
+            thr[t] = v1 - delta;
             pairf[t] = valid[t] && !bad[t] && amb2 && !amb3 && kbest[t] >= 0 && kbest[t] < K && c2[t] >= 0 && c2[t] < K;
             hardf[t] = valid[t] && !bad[t] && amb2 && !pairf[t];
 #ifdef VQ_SWEEP_DEBUG   // debug build (tools/build_variant.py dbg -DVQ_SWEEP_DEBUG): the screen's view of every row INSTEAD of z_q
@@ -309,96 +362,202 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             if (c2[t] < 0 || c2[t] >= K) c2[t] = 0;
         }
 
-        // ================= exact part (rows the screen left open): ||z||^2 in ATen's order and, for two-candidate rows,
-        //                   both reference distances, by a 16-lane group per row on the rows in their load layout ==========
+        // Codebook rows for the epilogue are requested NOW with the screen's index (final for every row the screen
+        // decided, ~95 %), together with the exact part's own gathers: one memory round trip per iteration instead of
+        // three in series (each costs ~2 us under load).  Two-candidate rows are finished by their task group below.
+        f32x4 ev[2][8];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const bool flagged = pairf[t] || hardf[t] || bad[t];
-            const unsigned fmask = (unsigned)__builtin_amdgcn_ballot_w64(flagged);       // bits 0..31 = rows (both halves agree)
-            if (fmask) {
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    if ((fmask >> (4 * i)) & 0xfu) {
-                        const int rr = 4 * i + g4;                                        // this group's row
-                        const bool act = __shfl((int)pairf[t], rr) != 0;
-                        const int ka = __shfl(kbest[t], rr), kb2 = __shfl(c2[t], rr);
+            for (int i = 0; i < 8; ++i) {
+                const int kr = __shfl(kbest[t], 4 * i + g4);
+                ev[t][i] = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
+            }
+        unsigned long long done_mask = 0ull, late_mask = 0ull;   // rows finished by a task group / rows that need a late gather
+        VQ_STAMP(3);                                           // merge + classify
+        // ================= exact part (rows the screen left open) =========================================================
+        // An open row becomes a TASK (row, code a, code b); four tasks run per pass, one per 16-lane group, on the row's
+        // fp32 data (copied from its owner lanes into the wave's LDS tile): ||z||^2 in ATen's summation order and the two
+        // c-ordered fmaf chains, all with DPP row operations, then d = fl(fl(zz + ee_k) - 2 m).  Each row finally takes
+        // the lexicographic (d, k) minimum over its tasks = torch.argmin's first-index rule.
+        //   two-candidate rows: one task (row, c1, c2)
+        //   rows with three or more candidates: the tile's screen is run again with the row's now-known threshold
+        //       v1 - DELTA and every code at or above it becomes a task (same accumulators as in the sweep)
+        //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
+        {
+            // lane L of the wave speaks for row L of the pair (tile L >> 5, row L & 31)
+            const bool o_pair = h ? pairf[1] : pairf[0], o_hard = h ? hardf[1] : hardf[0];
+            bool o_bad = h ? bad[1] : bad[0];
+            const int o_k1 = h ? kbest[1] : kbest[0], o_k2 = h ? c2[1] : c2[0];
+#if defined(VQ_KNOB) && VQ_KNOB == 3          // knock-out: no exact part
+            const unsigned long long fm = 0ull;
+#else
+            const unsigned long long fm = __builtin_amdgcn_ballot_w64(o_pair || o_hard || o_bad);
+#endif
+            if (fm) {
+                unsigned char *zrow_s = tile_s;                                          // [16 row slots][64] fp32 (over the fp16 rows, after the rescan)
+                unsigned *task_s = reinterpret_cast<unsigned *>(tile_s + 8192);          // [64] row | a << 6 | b << 19
+                float *res_s = reinterpret_cast<float *>(tile_s + 8192 + 256);           // [64][2] distances
+                float *zz_s = reinterpret_cast<float *>(tile_s + 8192 + 768);            // [64] ||z||^2 per row of the pair
+                int *cnt_s = reinterpret_cast<int *>(tile_s + 8192 + 1024);              // counter of the rescan's tasks
+                const unsigned long long lowmask = (1ull << lane) - 1ull;
+                const unsigned long long tm = __builtin_amdgcn_ballot_w64(o_pair || o_bad);
+                const int ndirect = __builtin_popcountll(tm);
+                __builtin_amdgcn_wave_barrier();
+                if (o_pair || o_bad)
+                    task_s[__builtin_popcountll(tm & lowmask)] = (unsigned)lane | ((unsigned)(o_bad ? 0 : o_k1) << 6) | ((unsigned)(o_bad ? 0 : o_k2) << 19);
+                int ntasks = ndirect;
+                const unsigned long long hmask = __builtin_amdgcn_ballot_w64(o_hard);
+                if (hmask) {
+                    // rows with >= 3 candidates: the tile's screen again, hits (acc >= v1 - DELTA) become tasks
+                    if (lane == 0) cnt_s[0] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        if ((unsigned)(hmask >> (32 * t))) {
+                            for (int ct = 0; ct < ntile; ++ct) {
+                                f32x16 acc;
+#pragma unroll
+                                for (int g = 0; g < 4; ++g) {
+                                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
+                                    acc[4 * g] = e4.x; acc[4 * g + 1] = e4.y; acc[4 * g + 2] = e4.z; acc[4 * g + 3] = e4.w;
+                                }
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const u32x4 bq = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4));
+                                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ap0[ct * 256 + q * 64]), __builtin_bit_cast(f16x8, bq), acc, 0, 0, 0);
+                                }
+                                bool anyhit = false;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) anyhit = anyhit || (acc[r] >= thr[t]);
+                                if (__builtin_amdgcn_ballot_w64(anyhit && hardf[t])) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) {
+                                        const int code = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                        if (hardf[t] && acc[r] >= thr[t] && code < K) {
+                                            const int sl = ndirect + atomicAdd(&cnt_s[0], 1);
+                                            if (sl < 64) task_s[sl] = (unsigned)(32 * t + l31) | ((unsigned)code << 6) | ((unsigned)code << 19);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    ntasks = ndirect + cnt_s[0];
+                }
+                if (ntasks > 64) {                      // pathological tie counts: every open row takes the scalar path;
+                    o_bad = o_bad || o_pair || o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
+                    __builtin_amdgcn_wave_barrier();
+                    if (o_bad) task_s[__builtin_popcountll(fm & lowmask)] = (unsigned)lane;
+                    ntasks = __builtin_popcountll(fm);
+                }
+                const unsigned long long pm = __builtin_amdgcn_ballot_w64(o_pair && !o_bad);   // rows their task group finishes
+                done_mask = pm;
+                late_mask = fm & ~pm;
+                const int nrows = __builtin_popcountll(fm);
+                for (int rd = 0; rd * 16 < nrows; ++rd) {
+                    // copy this round's rows (ranks 16 rd .. 16 rd + 15 among the flagged rows) into the row slots
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            if ((fm >> (32 * t + 4 * i)) & 0xfull) {
+                                const int rr = 32 * t + 4 * i + g4;
+                                const int rank = __builtin_popcountll(fm & ((1ull << rr) - 1ull));
+                                if (((fm >> rr) & 1ull) && (rank >> 4) == rd)
+                                    *reinterpret_cast<f32x4 *>(zrow_s + (rank & 15) * 256 + 16 * j16) = F[t][i];
+                            }
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                    for (int base = 0; base < ntasks; base += 4) {
+                        const int jj = base + g4;
+                        const unsigned task = task_s[jj < ntasks ? jj : 0];
+                        const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
                         const f32x4 ea = *reinterpret_cast<const f32x4 *>(cb + (size_t)ka * D + 4 * j16);
                         const f32x4 eb = *reinterpret_cast<const f32x4 *>(cb + (size_t)kb2 * D + 4 * j16);
-                        const f32x4 zv = F[t][i];
-                        // ||z||^2 in ATen's order: vectors of 8 lanes x 4-way ILP (lane j16 holds elements 4 j16 .. +3):
-                        // P = v_q + v_{q+4} (lane j + lane j+8), A = ((P0 + P1) + P2) + P3 (lanes b, b+2, b+4, b+6),
-                        // then the eight A's summed in order (lane 0: A0..A3, lane 1: A4..A7)
-                        float P[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
+                        const float eea = ee_g[ka], eeb = ee_g[kb2];
+                        const int rank = __builtin_popcountll(fm & ((1ull << rr) - 1ull));
+                        const bool mine = jj < ntasks && (rank >> 4) == rd;
+                        const f32x4 zv = *reinterpret_cast<const f32x4 *>(zrow_s + (rank & 15) * 256 + 16 * j16);
+                        // ||z||^2 in ATen's order (lane j16 holds elements 4 j16 .. +3): P = v_q + v_{q+4} (lane j + lane j+8),
+                        // A = ((P0 + P1) + P2) + P3 (lanes b, b+2, b+4, b+6), then A0..A7 in order (lane 0, then lane 1)
                         float Aq[4];
+                        const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            P[e] = P[e] + __shfl(P[e], (j16 + 8) & 15, 16);              // valid on lanes 0..7
-                            const float p1 = __shfl(P[e], (j16 + 2) & 15, 16), p2 = __shfl(P[e], (j16 + 4) & 15, 16);
-                            const float p3 = __shfl(P[e], (j16 + 6) & 15, 16);
-                            Aq[e] = ((P[e] + p1) + p2) + p3;                             // valid on lanes 0, 1
+                            const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
+                            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
+                            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
+                            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
+                            Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
                         }
-                        const float fin = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];    // lane 0: A0..A3
-                        const float f0 = __shfl(fin, 0, 16);
-                        const float fin1 = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];     // lane 1: + A4..A7
-                        const float zz = __shfl(fin1, 1, 16);
+                        const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
+                        const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
+                        const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
                         // c-ordered fmaf chains: lane j continues lane j-1's partial sum (row_shr:1, 0 enters lane 0)
                         float ma = 0.0f, mb = 0.0f;
 #pragma unroll
                         for (int sidx = 0; sidx < 16; ++sidx) {
-                            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, false));
-                            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, false));
+                            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
+                            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
                             ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
                             mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
                         }
-                        if (j16 == 15) {                                                 // lane 15 of the group holds both full chains
+                        const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
+                        const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
+                        const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
+                        if (j16 == 1 && mine) {
+                            res_s[2 * jj] = da;
+                            res_s[2 * jj + 1] = db;
                             zz_s[rr] = zz;
-                            if (act) {
-                                const float da = (zz + ee_g[ka]) - 2.0f * ma;
-                                const float db = (zz + ee_g[kb2]) - 2.0f * mb;
-                                const bool take_b = db < da || (db == da && kb2 < ka);
-                                kb_s[rr] = take_b ? kb2 : ka;
+                        }
+                        // a two-candidate row has this one task: its group holds the row and both code rows, so it
+                        // writes the row's z_q and squared error right here (the epilogue skips the row)
+                        const bool finish = mine && jj < ndirect && ((pm >> rr) & 1ull);
+                        if (__builtin_amdgcn_ballot_w64(finish)) {
+                            const bool take_b = __shfl((int)(db < da || (db == da && kb2 < ka)), 1, 16) != 0;
+                            const f32x4 ew = take_b ? eb : ea;
+                            const float d0 = ew.x - zv.x, d1 = ew.y - zv.y, d2 = ew.z - zv.z, d3 = ew.w - zv.w;
+                            f32x4 o;
+                            o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
+                            if (finish) {
+                                dacc += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
+#ifndef VQ_SWEEP_DEBUG
+                                if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)(r0 + rr) * D + 4 * j16) = o;
+#endif
                             }
                         }
                     }
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 __builtin_amdgcn_wave_barrier();
-                if (pairf[t]) kbest[t] = kb_s[l31];
-                // rows the screen cannot narrow to two codes: every code exactly, the whole wave per row
-                unsigned hm = (unsigned)__builtin_amdgcn_ballot_w64(hardf[t] && h == 0);
-                while (hm) {
-                    const int rr = __builtin_ctz(hm);
-                    hm &= hm - 1;
-                    long long grow = r0 + 32 * t + rr;
-                    const float *zr = z + (size_t)grow * D;                               // wave-uniform
-                    const float zz = zz_s[rr];
+                int o_best = o_k1;
+                if ((o_pair || o_hard) && !o_bad) {
                     float bd = inf;
                     int bk = 0x7fffffff;
-                    for (int k = lane; k < K; k += 64) {
-                        const float *e = cb + (size_t)k * D;
-                        float m = 0.0f;
-                        for (int c = 0; c < D; c += 4) {
-                            const f32x4 zc = *reinterpret_cast<const f32x4 *>(zr + c);
-                            const f32x4 ec = *reinterpret_cast<const f32x4 *>(e + c);
-                            m = __builtin_fmaf(zc.w, ec.w, __builtin_fmaf(zc.z, ec.z, __builtin_fmaf(zc.y, ec.y, __builtin_fmaf(zc.x, ec.x, m))));
+                    for (int jj = 0; jj < ntasks; ++jj) {
+                        const unsigned task = task_s[jj];
+                        if ((int)(task & 63u) == lane) {
+                            const float da = res_s[2 * jj], db = res_s[2 * jj + 1];
+                            const int ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
+                            if (da < bd || (da == bd && ka < bk)) { bd = da; bk = ka; }
+                            if (db < bd || (db == bd && kb2 < bk)) { bd = db; bk = kb2; }
                         }
-                        const float d = (zz + ee_g[k]) - 2.0f * m;
-                        if (d < bd || (d == bd && k < bk)) { bd = d; bk = k; }
                     }
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float od = __shfl_xor(bd, o);
-                        const int ok = __shfl_xor(bk, o);
-                        if (od < bd || (od == bd && ok < bk)) { bd = od; bk = ok; }
-                    }
-                    if (l31 == rr) kbest[t] = bk == 0x7fffffff ? 0 : bk;
+                    if (bk != 0x7fffffff) o_best = bk; else o_bad = true;            // no task came back (cannot happen): scalar path
                 }
-                // non-finite rows / unusable codebooks: torch.argmin semantics (NaN is minimal, first index wins), one lane per row
-                if (bad[t] && h == 0) {
-                    const float *zr = z + (size_t)(r0 + 32 * t + l31) * D;
-                    const float zz = zz_s[l31];
+                if (o_bad) {
+                    // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
+                    const long long grow = r0 + lane;
+                    const float *zr = z + (size_t)(grow < N ? grow : N - 1) * D;
+                    const float zz = zz_s[lane];                                      // every open row had a task
                     int best = 0;
-                    if (zz == zz) {                                                       // NaN ||z||^2: every distance is NaN -> index 0
+                    if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
                         float bd = 0.0f;
                         for (int k = 0; k < K; ++k) {
                             float m = 0.0f;
@@ -408,29 +567,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                             if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
                         }
                     }
-                    kb_s[l31] = best;
+                    o_best = best;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if (bad[t]) kbest[t] = kb_s[l31];
+                const int k0n = __shfl(o_best, l31), k1n = __shfl(o_best, 32 + l31);
+                if (pairf[0] || hardf[0] || bad[0]) kbest[0] = k0n;
+                if (pairf[1] || hardf[1] || bad[1]) kbest[1] = k1n;
                 __builtin_amdgcn_wave_barrier();
             }
         }
 
+        VQ_STAMP(4);                                           // exact part
         // the next pair's rows are requested here: both row buffers do not fit 256 registers next to the sweep's operands
         // and accumulators or the exact part's temporaries; the loads fly under the epilogue and the partner wave's sweep
-        if (PREFETCH && p + pstride < npairs) load_pair(p + pstride, Fn);
+        if (PREFETCH && p + pstride < npairs) load_pair(p + pstride, Fn, g4, j16);
 
-        // ================= epilogue: gather e_k, z + (e_k - z), squared error, index, histogram =========================
+        // ================= epilogue: z + (e_k - z), squared error, index, histogram ======================================
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            asm volatile("" ::: "memory");          // one tile's gathers at a time (both at once spill the prefetched rows)
-            f32x4 ev[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kr = __shfl(kbest[t], 4 * i + g4);
-                ev[i] = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
-            }
 #ifdef VQ_SWEEP_DEBUG
             float *obase = nullptr;
 #else
@@ -438,12 +591,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #endif
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
+                const int rr = 32 * t + 4 * i + g4;
+                f32x4 e = ev[t][i];
+                if ((late_mask >> (32 * t + 4 * i)) & 0xfull) {      // rows decided by several tasks / the scalar path (rare)
+                    const int kr = __shfl(kbest[t], 4 * i + g4);
+                    if ((late_mask >> rr) & 1ull) e = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
+                }
                 const f32x4 zv = F[t][i];
                 f32x4 o;
-                const float d0 = ev[i].x - zv.x, d1 = ev[i].y - zv.y, d2 = ev[i].z - zv.z, d3 = ev[i].w - zv.w;
+                const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
                 o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
                 const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-                if (r0 + 32 * t + 4 * i + g4 < N) {
+                if (r0 + rr < N && !((done_mask >> rr) & 1ull)) {
                     dacc += (double)sq;
                     if (obase) *reinterpret_cast<f32x4 *>(obase + (size_t)((t * 8 + i) * 64 + lane) * 4) = o;
                 }
@@ -453,6 +612,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                 atomicAdd(&hist_s[kbest[t]], 1);
             }
         }
+        VQ_STAMP(5);                                           // epilogue
         if (PREFETCH) {
             if (p + pstride < npairs) {
 #pragma unroll
@@ -461,10 +621,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                     for (int i = 0; i < 8; ++i) F[t][i] = Fn[t][i];
             }
         } else if (p + pstride < npairs) {
-            load_pair(p + pstride, F);
+            load_pair(p + pstride, F, g4, j16);
         }
     }
 
+#if defined(VQ_SWEEP_TIMING) && VQ_SWEEP_TIMING == 2
+    // per-workgroup span on the chip-wide 100 MHz clock: [512 + 2 b] = first wave's start, [513 + 2 b] = last wave's end
+    {
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(partials + 512);
+        if (blockIdx.x < 256) {
+            if (tid == 0) o[2 * blockIdx.x] = tstart;
+            __syncthreads();
+            if (tid == 0) o[2 * blockIdx.x + 1] = wall_clock64();
+        }
+    }
+#elif defined(VQ_SWEEP_TIMING)
+    VQ_STAMP(6);
+    if (lane == 0) atomicMax(&tsum[7], (unsigned)(wall_clock64() - tstart));     // slowest wave of the workgroup
+    __syncthreads();
+    if (tid < 8 && blockIdx.x < 64) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + tid] = tsum[tid];
+    __syncthreads();
+#endif
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
     __syncthreads();
@@ -483,7 +660,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 
 size_t vq_sweep_lds_bytes(int K, int nw) {
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)(K + (K & 1)) * 4 + (size_t)nw * 8 + (size_t)nw * (4096 + 256);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)(K + (K & 1)) * 4 + (size_t)nw * 8 + (size_t)nw * (8192 + 1280);
 }
 
 bool vq_sweep_ok(int K, int D) {
