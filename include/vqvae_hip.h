@@ -80,7 +80,10 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
 #define VQVAE_VQ_BF16_FILTER    0x8  /* use round 1's two-sweep bf16 filter kernel where the default would be the
                                         single-sweep fp16 kernel (identical outputs; A/B timing and tests) */
 
-/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_sweep_kernel_d64", "vq_filter_kernel_d64",
+#define VQVAE_VQ_PRODUCER_CONSUMER 0x10 /* use the producer / consumer form of the fp16 kernel (sweeper + I/O wave per SIMD) where the
+                                        default is its single-role form (identical outputs; A/B timing and tests) */
+
+/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_pc_kernel_d64", "vq_sweep_kernel_d64", "vq_filter_kernel_d64",
  * "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix cores per row
  * (0 for the exact-fp32 kernel).  For reporting (bench.py). */
 VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);

@@ -18,13 +18,13 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, producer_consumer=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact, bf16_filter=bf16_filter)
+                                            exact_sweep=exact, bf16_filter=bf16_filter, producer_consumer=producer_consumer)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -32,7 +32,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "producer_consumer", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -40,7 +40,8 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     two-sweep bf16 filter (default for NCHW D=64 rows) and the exhaustive fp32-MFMA sweep -- must reproduce
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
-    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter")
+    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter",
+                                    producer_consumer=kernel == "producer_consumer")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]

@@ -54,6 +54,20 @@ elif os.environ.get("VQ_TIMING") == "2":
     cyc, wall = t[:, 0].double(), t[:, 1].double()
     print(f"   shader clock over the kernel: {(cyc / (wall * 10e-9)).mean() / 1e9:.3f} GHz  (wave 0 of 64 workgroups; "
           f"{wall.mean() * 0.01:.1f} us per wave)")
+elif os.environ.get("VQ_TIMING") == "pc":
+    off = 256
+    off = (off + K * 4 + 255) // 256 * 256
+    off = (off + K * D * 4 + 255) // 256 * 256 + 512 * 8
+    slots = ws[off:off + 64 * 64].view(torch.int64)
+    slots.zero_()
+    F.vq_forward(z, cb, 0.25, rowmajor=True, workspace=ws, prepared=True)
+    torch.cuda.synchronize()
+    names = ["prologue (all 8 waves, /2)", "sweeper: waiting for tiles", "sweeper: sweep + merge + publish", "I/O: convert + publish",
+             "I/O: waiting for the verdict", "I/O: (rest of) gathers + exact part", "I/O: epilogue", "I/O: rows landing + loop", "exit",
+             "  I/O: verdict read + tile-0 gathers issued", "  I/O: direct task list", "  I/O: rescan", "  I/O: row copy", "  I/O: task passes", "-", "-"]
+    t = slots.view(32, 16).sum(0).cpu().tolist()
+    for n, v in zip(names, t):
+        print(f"   {n:46s} {v / 128 * 0.01:8.2f} us per wave of that role (sum over its 4 pairs, first 32 workgroups)")
 elif os.environ.get("VQ_TIMING"):
     off = 256
     off = (off + K * 4 + 255) // 256 * 256
@@ -64,6 +78,9 @@ elif os.environ.get("VQ_TIMING"):
     torch.cuda.synchronize()
     names = ["prologue (codebook copy, first requests)", "rows landed + fp16 conversion", "sweep", "merge + classify", "exact part",
              "epilogue", "loop exit", "-"]
+    if os.environ.get("VQ_TIMING") == "pc":
+        names = ["prologue (all 8 waves; x2 roles)", "sweeper: waiting for tiles", "sweeper: sweep + merge + publish", "I/O: convert + publish",
+                 "I/O: waiting for the verdict", "I/O: gathers + exact part", "I/O: epilogue", "I/O: rows landing + loop"]
     if os.environ.get("VQ_TIMING") == "old":
         names = ["prologue (codebook copy, first requests)", "rows landed", "convert + sweep 1", "sweep 2", "exact part",
                  "epilogue", "loop exit", "tail: loss partial + histogram flush (x8)"]
@@ -73,5 +90,5 @@ elif os.environ.get("VQ_TIMING"):
     t = per_block.sum(0).tolist()
     t[7] = 0
     for n, v in zip(names, t):
-        print(f"   {n:42s} {v / 512 * 0.01:8.2f} us per wave (sum over its blocks, first 64 workgroups)")
+        print(f"   {n:42s} {v / (256 if os.environ.get('VQ_TIMING') == 'pc' else 512) * 0.01:8.2f} us per wave (sum over its blocks, first 64 workgroups)")
     print(f"   {'total':42s} {sum(t) / 512 * 0.01:8.2f} us")

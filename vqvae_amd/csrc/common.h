@@ -86,6 +86,9 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 
 // vq_sweep.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel (D = 64, row-major rows)
 bool vq_sweep_ok(int K, int D);
+bool vq_pc_ok(int K, int D);
+int launch_vq_pc_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
+                     char *ws, hipStream_t st, int *grid_out);
 void launch_vq_prepare16(const float *cb, int K, char *ws, hipStream_t st);
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out);

@@ -13,6 +13,7 @@ VQ_ROWMAJOR = 0x1
 VQ_CODEBOOK_PREPARED = 0x2
 VQ_EXACT_SWEEP = 0x4
 VQ_BF16_FILTER = 0x8
+VQ_PRODUCER_CONSUMER = 0x10
 
 
 def _stream_ptr(t: torch.Tensor) -> int:
@@ -36,7 +37,7 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
-               exact_sweep: bool = False, bf16_filter: bool = False):
+               exact_sweep: bool = False, bf16_filter: bool = False, producer_consumer: bool = False):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
     z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
@@ -70,7 +71,8 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         hist = torch.empty((K,), dtype=torch.int32, device=dev)
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
-            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0)
+            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0) | \
+            (VQ_PRODUCER_CONSUMER if producer_consumer else 0)
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
