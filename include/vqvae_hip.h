@@ -125,7 +125,10 @@ VQVAE_API int vqvae_vq_onehot_f32(const int64_t *idx, int64_t N, int K, float *o
                         vqvae_stream_t stream);
 
 /* indices -> z_q (B,D,H,W): the one-hot @ embedding.weight -> view -> permute
- * sequence of the notebook's generate_samples (visualization.ipynb:358-365).  */
+ * sequence of the notebook's generate_samples (visualization.ipynb:358-365).
+ * An index outside [0, K) never reads the codebook: its D elements become NaN
+ * (the reference raises; a launch cannot -- validate on the host if the indices
+ * are not your own, as the Python front end does).                             */
 VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codebook,
                                 int64_t B, int D, int H, int W, int K,
                                 float *z_q, vqvae_stream_t stream);

@@ -133,20 +133,46 @@ def test_forward_only_and_no_cpu_fallback():
     assert out[1].shape == x.shape
 
 
-def test_large_batch_config3_properties():
-    """BASELINE config-3 size (B=4096): shard-additivity -- the forward of a batch equals the
-    forwards of its halves for x_hat (independent images), and hist-derived scalars combine."""
+def test_large_batch_config3_sampled_vs_reference_port():
+    """BASELINE config-3 size (B=4096) against the reference's algorithm: every 64th image (64 images) is run through
+    oracle/torch_port.py (bitwise the imported reference, tests/test_oracle.py) and compared stage by stage --
+    z_e atol 2e-6, indices exact except provable near-ties (counted), x_hat atol 1e-5 + rtol 1e-4 on images without a
+    flip.  Also shard-additivity of x_hat (independent images)."""
+    from oracle import torch_port
+    from vqvae_amd import conv, conv_hip
+    conv.set_conv_backend("hip")
     m, _ = build("kat1")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     m = m.to(dev())
     g = torch.Generator().manual_seed(5)
-    x = torch.randn(4096, 3, 32, 32, generator=g).to(dev())
+    x = torch.randn(4096, 3, 32, 32, generator=g)
+    xd = x.to(dev())
     with torch.no_grad():
-        loss, x_hat, ppl = m(x)
-        l0, xh0, p0 = m(x[:2048])
-        l1, xh1, p1 = m(x[2048:])
+        loss, x_hat, ppl = m(xd)
+        z_e = conv_hip.encoder_forward(m.encoder, xd, m.pre_quantization_conv)          # (B, 8, 8, D)
+        idx = m.encode(xd).view(4096, 64)
+        l0, xh0, p0 = m(xd[:2048])
+        l1, xh1, p1 = m(xd[2048:])
     assert torch.equal(x_hat[:2048], xh0) and torch.equal(x_hat[2048:], xh1)
     np.testing.assert_allclose(loss.item(), 0.5 * (l0.item() + l1.item()), rtol=1e-5)
-    assert torch.isfinite(x_hat).all()
+    sel = torch.arange(0, 4096, 64)
+    with torch.no_grad():
+        z_e_ref = torch_port.encode(sd, x[sel].clone(), 2)                                  # (64, D, 8, 8)
+        cbk = sd["vector_quantization.embedding.weight"]
+        _, z_q_ref, _, _, idx_ref = torch_port.quantize(z_e_ref, cbk, 0.25)
+        x_hat_ref = torch_port.decode(sd, z_q_ref.clone(), 2)
+    np.testing.assert_allclose(z_e[sel].permute(0, 3, 1, 2).cpu().numpy(), z_e_ref.numpy(), atol=2e-6, rtol=0)
+    got = idx[sel].cpu().numpy().reshape(-1)
+    want = idx_ref.numpy().reshape(-1)
+    flips = np.nonzero(got != want)[0]
+    assert len(flips) <= 4, f"{len(flips)} index flips in 4096 sampled rows"
+    zf = z_e_ref.permute(0, 2, 3, 1).reshape(-1, 64).double().numpy()
+    e = cbk.double().numpy()
+    for r in flips:                                                    # every flip must be a near-tie in fp64
+        d = (zf[r] ** 2).sum() + (e ** 2).sum(1) - 2 * e @ zf[r]
+        assert abs(d[got[r]] - d[want[r]]) <= 8 * 2.0 ** -24 * ((zf[r] ** 2).sum() + (e[want[r]] ** 2).sum()) * 4
+    clean = np.setdiff1d(np.arange(64), np.unique(flips // 64))
+    np.testing.assert_allclose(x_hat[sel][clean].cpu().numpy(), x_hat_ref[clean].numpy(), atol=1e-5, rtol=1e-4)
 
 
 # BASELINE configs 4 and 5 (and an odd-sized one) at batch 1-2: the generic (non-tile) conv kernels, the

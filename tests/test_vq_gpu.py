@@ -161,6 +161,37 @@ def test_vq_near_ties_within_one_lane_half(shrink):
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
+def _oracle_vq_chunked(z, cb, beta, n_chunks=64, workers=32):
+    """C oracle over image chunks in a thread pool (rows are independent; ctypes releases the GIL)."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle
+    zs = np.array_split(z.numpy(), n_chunks, axis=0)
+    cbn = cb.numpy()
+    with ThreadPoolExecutor(max_workers=workers) as ex:
+        outs = list(ex.map(lambda a: c_oracle.vq_forward(np.ascontiguousarray(a), cbn, beta), zs))
+    return np.concatenate([o["idx"] for o in outs]), np.concatenate([o["z_q"] for o in outs])
+
+
+@pytest.mark.parametrize("B,H,W", [(4096, 8, 8), (2100, 7, 9)], ids=["config3_262144rows", "ragged_132300rows"])
+def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
+    """BASELINE config-3 size against the ORACLE (not against the kernels themselves): 262 144 rows of the benchmark
+    distribution, and a ragged row count above 131 072 (rows % 64 != 0, several pairs per wave) -- indices and z_q
+    bit for bit from the default kernel, its producer/consumer form and round 1's bf16 filter."""
+    g = torch.Generator().manual_seed(2024 + B)
+    K, D = 512, 64
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, H, W, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
+    for kw in ({}, {"producer_consumer": True}, {"bf16_filter": True}):
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
+        np.testing.assert_array_equal(idx, ref_idx)
+        assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+        np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, False)          # NCHW boundary layout
+    np.testing.assert_array_equal(idx, ref_idx)
+    assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+
+
 def test_vq_nonfinite_codebook_forces_slow_path():
     """A codebook norm that is not < 1e38 routes EVERY row through the scalar torch.argmin path."""
     from oracle import c_oracle
@@ -224,6 +255,54 @@ def test_onehot_and_decode_indices():
     oh = F.vq_onehot(idx, 100)
     ref = torch.zeros(105, 100, device=dev).scatter_(1, idx, 1)
     assert torch.equal(oh, ref)
+
+
+def test_decode_indices_rejects_out_of_range_indices():
+    """an index outside [0, K) must never read past the codebook.  The front end raises like the
+    reference's embedding lookup; the C entry point itself writes NaN for that element."""
+    from vqvae_amd import functional as F, _lib
+    dev = _dev()
+    cb = torch.randn(100, 64, device=dev)
+    idx = torch.randint(0, 100, (2 * 4 * 4, 1), device=dev)
+    idx[5] = 100
+    with pytest.raises(IndexError):
+        F.vq_decode_indices(idx, cb, 2, 4, 4)
+    idx[5] = -1
+    with pytest.raises(IndexError):
+        F.vq_decode_indices(idx, cb, 2, 4, 4)
+    out = torch.zeros(2, 64, 4, 4, device=dev)
+    idx[5] = 1 << 40
+    _lib.check(_lib.load().vqvae_vq_decode_indices_f32(idx.data_ptr(), cb.data_ptr(), 2, 64, 4, 4, 100, out.data_ptr(),
+                                                       torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    o = out.permute(0, 2, 3, 1).reshape(-1, 64)
+    assert torch.isnan(o[5]).all() and torch.isfinite(o[torch.arange(32, device=dev) != 5]).all()
+    idx[5] = 7
+    assert torch.equal(F.vq_decode_indices(idx, cb, 2, 4, 4).permute(0, 2, 3, 1).reshape(-1, 64), cb[idx.view(-1)])
+
+
+def test_codebook_cache_invalidation():
+    """The prepared codebook image is keyed on (data_ptr, _version): a write through `.data` needs invalidate();
+    in-place ops, load_state_dict and .to() are picked up automatically."""
+    from vqvae_amd.modules import VectorQuantizer
+    torch.manual_seed(1)
+    vq = VectorQuantizer(64, 64, 0.25).to(_dev())
+    z = torch.randn(2, 64, 4, 4, device=_dev())
+    with torch.no_grad():
+        a = vq(z)[4].clone()
+        new = torch.randn(64, 64, device=_dev())
+        vq.embedding.weight.data.copy_(new)              # does not bump _version
+        vq.invalidate()
+        b = vq(z)[4].clone()
+        ref = torch.cdist(z.permute(0, 2, 3, 1).reshape(-1, 64), new).argmin(1, keepdim=True)
+        assert torch.equal(b, ref) and not torch.equal(a, b)
+        vq.embedding.weight.mul_(-1.0)                   # in-place op: picked up through _version
+        c = vq(z)[4]
+        assert torch.equal(c, torch.cdist(z.permute(0, 2, 3, 1).reshape(-1, 64), -new).argmin(1, keepdim=True))
+        sd = {"embedding.weight": new.clone()}
+        vq.load_state_dict(sd)
+        vq.invalidate()
+        assert torch.equal(vq(z)[4], b)
 
 
 def test_module_interface_matches_reference_signature():

@@ -41,6 +41,11 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
     return buf
 
 
+def invalidate(mod):
+    """Forget the packed-weight images cached on `mod` (see modules.VQVAE.invalidate_caches)."""
+    mod.__dict__.pop("_vqvae_amd_packed", None)
+
+
 def _pack_conv(mod, kind, weight, Cin, Cout):
     L = _lib.load()
     return _packed(mod, ("conv", kind), weight,

@@ -16,16 +16,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kLdsBytes = 160 * 1024;  // per CU on gfx950
 
+// CU count of the CURRENT device (cached per device id: one process may drive several GPUs)
 inline int num_cus() {
-    static int n = 0;
-    if (n == 0) {
-        int dev = 0;
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (n[dev] == 0) {
         hipDeviceProp_t p;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess)
-            n = p.multiProcessorCount;
-        if (n <= 0) n = 256;
+        int c = 0;
+        if (hipGetDeviceProperties(&p, dev) == hipSuccess) c = p.multiProcessorCount;
+        n[dev] = c > 0 ? c : 256;          // benign race: every thread computes the same value
     }
-    return n;
+    return n[dev];
 }
 
 // profiling hooks (capi.hip); no-ops unless vqvae_profile_enable(1)

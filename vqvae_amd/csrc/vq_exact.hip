@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void vq_onehot_kernel(const long long *__restr
 
 __global__ __launch_bounds__(256) void vq_decode_indices_kernel(const long long *__restrict__ idx,
                                                                 const float *__restrict__ cb,
-                                                                long long total, int D, int HW,
+                                                                long long total, int D, int HW, int K,
                                                                 float *__restrict__ zq) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total;
          i += (long long)gridDim.x * 256) {
@@ -425,7 +425,10 @@ __global__ __launch_bounds__(256) void vq_decode_indices_kernel(const long long 
         const long long bc = i / HW;
         const int c = (int)(bc % D);
         const long long b = bc / D;
-        zq[i] = cb[(size_t)idx[b * HW + hw] * D + c];
+        // an index outside [0, K) never reads the codebook: the element becomes NaN (the reference's embedding
+        // lookup raises there; the Python front end does too, before the launch)
+        const long long k = idx[b * HW + hw];
+        zq[i] = (k >= 0 && k < K) ? cb[(size_t)k * D + c] : __builtin_nanf("");
     }
 }
 
@@ -488,12 +491,9 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
 #define VQ_LAUNCH(RT_, RM_)                                                                        \
     do {                                                                                           \
         auto kfn = vq_exact_kernel<D, RT_, RM_>;                                                   \
-        static bool attr_set = false;                                                              \
-        if (!attr_set) {                                                                           \
+        /* per device, so set on every launch (a process may drive several GPUs) */                   \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                             \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);            \
-            attr_set = true;                                                                       \
-        }                                                                                          \
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), p.lds_bytes, st, z, cb, img, ee,  \
                            wflags, N, HW, K, p.KC, p.nchunks, nblocks, zq, idx, hist, partials);   \
     } while (0)
@@ -586,7 +586,7 @@ int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codebook, int64
     if (grid > 256 * 16) grid = 256 * 16;
     hipLaunchKernelGGL(vq_decode_indices_kernel, dim3((unsigned)grid), dim3(256), 0,
                        static_cast<hipStream_t>(stream), reinterpret_cast<const long long *>(idx),
-                       codebook, total, D, H * W, z_q);
+                       codebook, total, D, H * W, K, z_q);
     return (int)hipGetLastError();
 }
 

@@ -605,12 +605,9 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 #define VQF_LAUNCH(RM_, ST_)                                                                         \
     do {                                                                                             \
         auto kfn = vq_filter_kernel_d64<RM_, ST_>;                                                   \
-        static bool attr_set = false;                                                                \
-        if (!attr_set) {                                                                             \
+        /* per device, so set on every launch (a process may drive several GPUs) */                   \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),                           \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);        \
-            attr_set = true;                                                                         \
-        }                                                                                            \
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), lds, st, z, cb, img16, neh, ee,     \
                            wflags, N, HW, K, p.K32, nblocks, zq, idx, hist, partials);               \
     } while (0)

@@ -198,6 +198,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     __syncthreads();
 
     VQ_STAMP(0);                                               // codebook image copy + first row requests
+#ifdef VQ_SKEW       // experiment: hold back the second wave of every SIMD by ~VQ_SKEW x 0.6 us to de-phase the pair
+    if (wave_u >= NW / 2) {
+        for (int i = 0; i < VQ_SKEW; ++i) __builtin_amdgcn_s_sleep(20);
+    }
+#endif
     const float inf = __builtin_inff();
     // low key bits: [ntile - tile : 5 or 6][half (fresh flag during the sweep) : 1][r : 4]
     const unsigned keymask = ntile <= 31 ? 0xfffffc00u : 0xfffff800u;

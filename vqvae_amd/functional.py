@@ -102,6 +102,12 @@ def vq_decode_indices(idx: torch.Tensor, codebook: torch.Tensor, B: int, H: int,
     K, D = codebook.shape
     if idx.numel() != B * H * W:
         raise ValueError("idx must hold B*H*W indices")
+    # the reference's embedding lookup raises on an out-of-range index; the kernel cannot (it writes NaN), so the
+    # check is done here -- one host sync, skipped while a graph is being captured
+    if not torch.cuda.is_current_stream_capturing():
+        lo, hi = int(idx.min()), int(idx.max())
+        if lo < 0 or hi >= K:
+            raise IndexError(f"index out of range in decode_indices: [{lo}, {hi}] not within [0, {K})")
     out = torch.empty((B, D, H, W), dtype=torch.float32, device=idx.device)
     with torch.cuda.device(idx.device):
         _lib.check(_lib.load().vqvae_vq_decode_indices_f32(idx.data_ptr(), codebook.data_ptr(), B, D, H, W, K,

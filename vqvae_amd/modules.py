@@ -56,27 +56,40 @@ class VectorQuantizer(nn.Module):
         self._ws = None
         self._ws_key = None
 
+    def invalidate(self):
+        """Forget the prepared codebook image.  The cache is keyed on (data_ptr, _version, device), which in-place ops
+        and optimizers bump; writes through `.data` (`weight.data.copy_()`, EMA updates) do NOT -- call this after
+        such a write.  `load_state_dict` and `.to()/.cuda()` call it for you."""
+        self._ws_key = None
+
     def _workspace(self):
-        """Per-module workspace holding the codebook's LDS image; re-prepared only
-        when the embedding tensor changes (in-place update bumps `_version`)."""
+        """-> (workspace, prepared, key): per-module workspace holding the codebook's LDS images; re-prepared only when
+        the embedding tensor changes.  The caller stores `key` once the launch has succeeded."""
         w = self.embedding.weight
         key = (w.data_ptr(), w._version, w.device)
-        prepared = self._ws is not None and self._ws_key == key
         if self._ws is None or self._ws.device != w.device:
             self._ws = F_hip.vq_workspace(self.n_e, self.e_dim, w.device)
-            prepared = False
-        self._ws_key = key
-        return self._ws, prepared
+            self._ws_key = None
+        return self._ws, self._ws_key == key, key
 
     def quantize(self, z, *, rowmajor=False, want_zq=True):
         """-> (loss, z_q, perplexity, min_encoding_indices, hist); no one-hot."""
         w = self.embedding.weight
-        ws, prepared = self._workspace()
+        ws, prepared, key = self._workspace()
+        if not prepared:
+            self._ws_key = None                                  # a failed launch must not leave a stale "prepared" image
         if torch.is_grad_enabled() and (z.requires_grad or w.requires_grad):
             from .training import VQStraightThrough          # HIP forward + HIP backward
-            return VQStraightThrough.apply(z, w, self.beta, rowmajor, ws, prepared)
-        return F_hip.vq_forward(z, w.detach(), self.beta, rowmajor=rowmajor, workspace=ws,
-                                prepared=prepared, want_zq=want_zq)
+            out = VQStraightThrough.apply(z, w, self.beta, rowmajor, ws, prepared)
+        else:
+            out = F_hip.vq_forward(z, w.detach(), self.beta, rowmajor=rowmajor, workspace=ws,
+                                   prepared=prepared, want_zq=want_zq)
+        self._ws_key = key
+        return out
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate()
+        return super()._apply(fn, *args, **kwargs)
 
     def forward(self, z):
         loss, z_q, perplexity, idx, _ = self.quantize(z)
@@ -178,6 +191,16 @@ class VQVAE(nn.Module):
             self.img_to_embedding_map = {i: [] for i in range(n_embeddings)}
         else:
             self.img_to_embedding_map = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_caches())
+
+    def invalidate_caches(self):
+        """Drop the prepared codebook image and every packed-weight image (they are keyed on the parameters'
+        data_ptr / _version, which writes through `.data` do not change; `load_state_dict` calls this)."""
+        from . import conv_hip
+        for mod in self.modules():
+            conv_hip.invalidate(mod)
+            if isinstance(mod, VectorQuantizer):
+                mod.invalidate()
 
     def forward(self, x, verbose=False):
         from . import conv as C_hip
