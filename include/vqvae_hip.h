@@ -280,6 +280,66 @@ VQVAE_API int vqvae_gated_activation_f32(const float *t1, const float *t2, const
                                          int HW, int dim, float *out, vqvae_stream_t stream);
 VQVAE_API int vqvae_add_f32(const float *a, const float *b, int64_t n, float *out, vqvae_stream_t stream);
 
+/* ------------------------------------------------------------------- whole path
+ * models/vqvae.py:29-44 as ONE call: Encoder (models/encoder.py:28-43) -> pre_quantization_conv (models/vqvae.py:33)
+ * -> VectorQuantizer (models/quantizer.py:45-76) -> Decoder (models/decoder.py:27-39).  The caller owns every buffer:
+ * the packed weights (built once per weight version with vqvae_weights_pack_f32), the activation workspace
+ * (vqvae_workspace_bytes) and, optionally, a persistent quantizer workspace that keeps the prepared codebook images
+ * across calls.  Nothing is allocated or synchronised; every kernel goes to `stream`.                                 */
+typedef struct VqvaeDims {          /* VQVAE(h_dim, res_h_dim, n_res_layers, n_embeddings, embedding_dim, beta), vqvae.py:11-12 */
+    int h_dim, res_h_dim, n_res_layers, n_embeddings, embedding_dim, in_ch;
+    float beta;
+} VqvaeDims;
+
+typedef struct VqvaeRawWeights {    /* device pointers to the parameters in torch's layouts; names = state_dict keys */
+    const float *enc0_w, *enc0_b;           /* encoder.conv_stack.0  (h/2, in_ch, 4, 4), (h/2)                      */
+    const float *enc2_w, *enc2_b;           /* encoder.conv_stack.2  (h, h/2, 4, 4), (h)                            */
+    const float *enc4_w, *enc4_b;           /* encoder.conv_stack.4  (h, h, 3, 3), (h)                              */
+    const float *enc_res_w1, *enc_res_w2;   /* encoder.conv_stack.5.stack.0.res_block.{1,3}  (Rh, h, 3, 3), (h, Rh, 1, 1) */
+    const float *pre_w, *pre_b;             /* pre_quantization_conv (D, h, 1, 1), (D)                              */
+    const float *codebook;                  /* vector_quantization.embedding.weight (K, D)                          */
+    const float *dec0_w, *dec0_b;           /* decoder.inverse_conv_stack.0  (D, h, 3, 3), (h)   [ConvTranspose2d]  */
+    const float *dec_res_w1, *dec_res_w2;   /* decoder.inverse_conv_stack.1.stack.0.res_block.{1,3}                 */
+    const float *dec2_w, *dec2_b;           /* decoder.inverse_conv_stack.2  (h, h/2, 4, 4), (h/2)                  */
+    const float *dec4_w, *dec4_b;           /* decoder.inverse_conv_stack.4  (h/2, in_ch, 4, 4), (in_ch)            */
+} VqvaeRawWeights;
+
+typedef struct VqvaeWeights {       /* what the whole-path entry points consume: packed images + biases + codebook */
+    VqvaeDims dims;
+    const float *enc0, *enc0_b, *enc2, *enc2_b, *enc4, *enc4_b, *enc_res_w1, *enc_res_w2, *pre, *pre_b, *codebook;
+    const float *dec0, *dec0_b, *dec_res_w1, *dec_res_w2, *dec2, *dec2_b, *dec4, *dec4_b;
+} VqvaeWeights;
+
+/* Bytes of the one buffer that holds every packed weight image (0: unsupported dims). */
+VQVAE_API size_t vqvae_weights_packed_bytes(const VqvaeDims *dims);
+/* Packs every layer into `packed` and fills `out` (its bias / codebook pointers alias `raw`'s: keep those alive). */
+VQVAE_API int vqvae_weights_pack_f32(const VqvaeDims *dims, const VqvaeRawWeights *raw, void *packed, size_t packed_bytes,
+                                     VqvaeWeights *out, vqvae_stream_t stream);
+/* Bytes of activation workspace for a (B, in_ch, H, W) batch (H, W multiples of 4; 0: unsupported). */
+VQVAE_API size_t vqvae_workspace_bytes(const VqvaeDims *dims, int64_t B, int H, int W);
+
+/* ResidualStack.forward (models/residual.py:47-51): n_layers applications of the SAME layer, then F.relu if
+ * VQVAE_CONV_RELU_OUT; VQVAE_CONV_RELU_IN applies the first layer's in-place ReLU on read.  x, y, tmp row-major
+ * (B,H,W,C); the result is in y; tmp (same size) is needed when n_layers > 1; x is not modified.                    */
+VQVAE_API int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const float *x, int64_t B, int H, int W,
+                                 int C, int Rh, int n_layers, int flags, float *y, float *tmp, vqvae_stream_t stream);
+
+/* Encoder + pre_quantization_conv: x (B,in_ch,H,W) NCHW -> z_e (B,H/4,W/4,D) ROW-MAJOR (the layout vqvae_vq_forward_f32
+ * takes with VQVAE_VQ_ROWMAJOR).  workspace: at least the two activation buffers of vqvae_workspace_bytes.          */
+VQVAE_API int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e,
+                                void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* Decoder: z_q (B,h,w,D) row-major -> x_hat (B,in_ch,4h,4w) NCHW. */
+VQVAE_API int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h, int w_, float *x_hat,
+                                void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* VQVAE.forward: x -> (embedding_loss, x_hat, perplexity) (models/vqvae.py:44); idx (B*H/4*W/4 int64) is optional.
+ * vq_flags: VQVAE_VQ_CODEBOOK_PREPARED (only meaningful with a persistent vq_workspace of vqvae_vq_workspace_bytes),
+ * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _PRODUCER_CONSUMER.  vq_workspace may be NULL (then the codebook images are
+ * rebuilt inside `workspace` on every call).                                                                         */
+VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags,
+                                float *x_hat, float *loss, float *perplexity, int64_t *idx, void *workspace,
+                                size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
+                                vqvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

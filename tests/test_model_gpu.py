@@ -175,6 +175,52 @@ def test_large_batch_config3_sampled_vs_reference_port():
     np.testing.assert_allclose(x_hat[sel][clean].cpu().numpy(), x_hat_ref[clean].numpy(), atol=1e-5, rtol=1e-4)
 
 
+@pytest.mark.parametrize("name", ["kat1", "small"])
+def test_whole_path_c_entry_points_match_layerwise(name):
+    """vqvae_encoder_f32 / vqvae_decoder_f32 / vqvae_resstack_f32 / vqvae_forward_f32 (the whole-path C ABI of
+    SURVEY.md 8b) sequence the same kernels as the layer-by-layer Python composition: outputs must be bitwise equal."""
+    from vqvae_amd import _lib, conv, conv_hip, functional as F
+    conv.set_conv_backend("hip")
+    L = _lib.load()
+    m, x = build(name)
+    m = m.to(dev())
+    xd = x.to(dev()).contiguous()
+    B, _, H, W = xd.shape
+    st = torch.cuda.current_stream().cuda_stream
+    with torch.no_grad():
+        z_e_ref = conv_hip.encoder_forward(m.encoder, xd, m.pre_quantization_conv)               # (B,h,w,D)
+        loss_ref, z_q_ref, ppl_ref, idx_ref, _ = m.vector_quantization.quantize(z_e_ref, rowmajor=True)
+        x_hat_ref = conv_hip.decoder_forward(m.decoder, z_q_ref, rowmajor_in=True)
+        cw, _keep = m._c_weights()
+        nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+        assert nws > 0
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+        z_e = torch.empty_like(z_e_ref)
+        _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, H, W, z_e.data_ptr(), ws.data_ptr(), nws, st))
+        assert torch.equal(z_e, z_e_ref)
+        x_hat = torch.empty_like(xd)
+        _lib.check(L.vqvae_decoder_f32(cw, z_q_ref.data_ptr(), B, H // 4, W // 4, x_hat.data_ptr(), ws.data_ptr(), nws, st))
+        assert torch.equal(x_hat, x_hat_ref)
+        # residual stack on its own: relu-in + final relu (= ResidualStack.forward on a fresh tensor)
+        stack = m.encoder.conv_stack[5]
+        t = torch.randn(B, H // 4, W // 4, cw.dims.h_dim, device=dev())
+        want = conv_hip._res_stack_rows(t, list(stack.stack), True, True)
+        y, tmp = torch.empty_like(t), torch.empty_like(t)
+        _lib.check(L.vqvae_resstack_f32(cw.enc_res_w1, cw.enc_res_w2, t.data_ptr(), B, H // 4, W // 4, cw.dims.h_dim,
+                                        cw.dims.res_h_dim, cw.dims.n_res_layers, 3, y.data_ptr(), tmp.data_ptr(), st))
+        assert torch.equal(y, want)
+        # the whole forward, through the module (one ctypes call) and with indices
+        loss, xh, ppl, idx = m._forward_c(xd, want_idx=True)
+        assert torch.equal(xh, x_hat_ref) and torch.equal(idx, idx_ref)
+        assert loss.item() == loss_ref.item() and ppl.item() == ppl_ref.item()
+        out = m(xd)
+        assert torch.equal(out[1], x_hat_ref)
+        # error conventions: a workspace that is too small, unsupported image size
+        assert L.vqvae_forward_f32(cw, xd.data_ptr(), B, H, W, 0, xh.data_ptr(), loss.data_ptr(), ppl.data_ptr(), None,
+                                   ws.data_ptr(), 1024, None, 0, st) == -4
+        assert L.vqvae_workspace_bytes(cw.dims, B, 30, 32) == 0
+
+
 # BASELINE configs 4 and 5 (and an odd-sized one) at batch 1-2: the generic (non-tile) conv kernels, the
 # chunked-codebook exact VQ kernel and the halo-tiled last layer, stage by stage against the live CPU oracle
 # (oracle/torch_port.py issues the reference's ATen ops).  Each stage is fed the ORACLE's input bits so a

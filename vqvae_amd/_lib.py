@@ -17,6 +17,27 @@ LIB_PATH = os.path.join(_HERE, "libvqvae_hip.so")
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
 
+class VqvaeDims(C.Structure):
+    _fields_ = [("h_dim", _i32), ("res_h_dim", _i32), ("n_res_layers", _i32), ("n_embeddings", _i32),
+                ("embedding_dim", _i32), ("in_ch", _i32), ("beta", _f32)]
+
+
+_RAW_FIELDS = ["enc0_w", "enc0_b", "enc2_w", "enc2_b", "enc4_w", "enc4_b", "enc_res_w1", "enc_res_w2", "pre_w", "pre_b",
+               "codebook", "dec0_w", "dec0_b", "dec_res_w1", "dec_res_w2", "dec2_w", "dec2_b", "dec4_w", "dec4_b"]
+_PACKED_FIELDS = ["enc0", "enc0_b", "enc2", "enc2_b", "enc4", "enc4_b", "enc_res_w1", "enc_res_w2", "pre", "pre_b", "codebook",
+                  "dec0", "dec0_b", "dec_res_w1", "dec_res_w2", "dec2", "dec2_b", "dec4", "dec4_b"]
+
+
+class VqvaeRawWeights(C.Structure):
+    _fields_ = [(n, _vp) for n in _RAW_FIELDS]
+
+
+class VqvaeWeights(C.Structure):
+    _fields_ = [("dims", VqvaeDims)] + [(n, _vp) for n in _PACKED_FIELDS]
+
+
+_dimsp, _rawp, _wp = C.POINTER(VqvaeDims), C.POINTER(VqvaeRawWeights), C.POINTER(VqvaeWeights)
+
 # name -> (restype, argtypes); mirrors include/vqvae_hip.h one to one
 SIGNATURES = {
     "vqvae_abi_version": (_i32, []),
@@ -53,6 +74,13 @@ SIGNATURES = {
     "vqvae_bias_grad_workspace_bytes": (_sz, [_i32]),
     "vqvae_bias_grad_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
+    "vqvae_weights_packed_bytes": (_sz, [_dimsp]),
+    "vqvae_weights_pack_f32": (_i32, [_dimsp, _rawp, _vp, _sz, _wp, _vp]),
+    "vqvae_workspace_bytes": (_sz, [_dimsp, _i64, _i32, _i32]),
+    "vqvae_resstack_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "vqvae_encoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqvae_decoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqvae_forward_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_gather_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "vqvae_im2col_rows_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vqvae_gated_activation_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),

@@ -1,0 +1,237 @@
+// Whole-path entry points of the C ABI (include/vqvae_hip.h): models/vqvae.py:29-44 = Encoder (models/encoder.py:28-43)
+// -> pre_quantization_conv (models/vqvae.py:33) -> VectorQuantizer (models/quantizer.py:45-76) -> Decoder
+// (models/decoder.py:27-39) as ONE call over caller-owned buffers.  These functions only sequence the per-layer entry
+// points of this library on the caller's stream and carve the caller's workspace; they allocate nothing and never
+// synchronise.  A C / C++ caller needs nothing from the Python package.
+#include "common.h"
+
+namespace vqvae {
+namespace {
+
+struct Carve {
+    char *p;
+    size_t left;
+    bool ok = true;
+    float *f32(size_t n) { return reinterpret_cast<float *>(raw(n * sizeof(float))); }
+    void *raw(size_t bytes) {
+        bytes = align_up(bytes, 256);
+        if (bytes > left) { ok = false; return nullptr; }
+        void *r = p;
+        p += bytes;
+        left -= bytes;
+        return r;
+    }
+};
+
+bool dims_ok(const VqvaeDims *d) {
+    return d && d->h_dim >= 8 && d->h_dim % 8 == 0 && d->res_h_dim >= 1 && d->n_res_layers >= 0 && d->n_embeddings >= 1 &&
+           d->embedding_dim >= 1 && (d->in_ch == 1 || d->in_ch == 3 || d->in_ch == 4);
+}
+
+// elements of the largest row-major activation between two layers, and of one latent map
+size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
+    const size_t half = (size_t)B * (H / 2) * (W / 2) * (d->h_dim / 2);
+    const size_t quarter = (size_t)B * (H / 4) * (W / 4) * d->h_dim;
+    return half > quarter ? half : quarter;
+}
+
+int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
+              bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out) {
+    // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
+    // the producer applies it; buffers alternate so that the result of the LAST layer lands in y
+    const float *cur = x;
+    *out = x;
+    for (int i = 0; i < n_layers; ++i) {
+        int flags = (i == 0 && first_relu_in) ? VQVAE_CONV_RELU_IN : 0;
+        if (i < n_layers - 1 || final_relu) flags |= VQVAE_CONV_RELU_OUT;
+        float *dst = ((n_layers - 1 - i) % 2 == 0) ? y : tmp;
+        const int rc = vqvae_res_layer_forward_f32(cur, w1, w2, B, H, W, C, Rh, flags, dst, st);
+        if (rc != 0) return rc;
+        cur = dst;
+    }
+    *out = cur;
+    return 0;
+}
+
+}  // namespace
+}  // namespace vqvae
+
+using namespace vqvae;
+
+extern "C" {
+
+size_t vqvae_weights_packed_bytes(const VqvaeDims *d) {
+    if (!dims_ok(d)) return 0;
+    const int h = d->h_dim, D = d->embedding_dim, Rh = d->res_h_dim;
+    size_t n = 0;
+    const size_t parts[] = {
+        vqvae_conv_in_packed_bytes(d->in_ch, h / 2), vqvae_conv_packed_bytes(VQVAE_CONV_4x4_S2, h / 2, h),
+        vqvae_conv_packed_bytes(VQVAE_CONV_3x3_S1, h, h), vqvae_conv_packed_bytes(VQVAE_CONV_3x3_S1, h, Rh),
+        vqvae_conv_packed_bytes(VQVAE_CONV_1x1, Rh, h), vqvae_conv_packed_bytes(VQVAE_CONV_1x1, h, D),
+        vqvae_conv_packed_bytes(VQVAE_CONVT_3x3_S1, D, h), vqvae_conv_packed_bytes(VQVAE_CONV_3x3_S1, h, Rh),
+        vqvae_conv_packed_bytes(VQVAE_CONV_1x1, Rh, h), vqvae_conv_packed_bytes(VQVAE_CONVT_4x4_S2, h, h / 2),
+        vqvae_convt_out_packed_bytes(h / 2, d->in_ch)};
+    for (size_t b : parts) {
+        if (b == 0) return 0;
+        n += align_up(b, 256);
+    }
+    return n;
+}
+
+int vqvae_weights_pack_f32(const VqvaeDims *d, const VqvaeRawWeights *raw, void *packed, size_t packed_bytes,
+                           VqvaeWeights *out, vqvae_stream_t stream) {
+    if (!d || !raw || !packed || !out) return VQVAE_ERR_NULL;
+    const size_t need = vqvae_weights_packed_bytes(d);
+    if (need == 0) return VQVAE_ERR_UNSUPPORTED;
+    if (packed_bytes < need) return VQVAE_ERR_WORKSPACE;
+    const float *req[] = {raw->enc0_w, raw->enc0_b, raw->enc2_w, raw->enc2_b, raw->enc4_w, raw->enc4_b, raw->enc_res_w1,
+                          raw->enc_res_w2, raw->pre_w, raw->pre_b, raw->codebook, raw->dec0_w, raw->dec0_b, raw->dec_res_w1,
+                          raw->dec_res_w2, raw->dec2_w, raw->dec2_b, raw->dec4_w, raw->dec4_b};
+    for (const float *q : req)
+        if (!q) return VQVAE_ERR_NULL;
+    const int h = d->h_dim, D = d->embedding_dim, Rh = d->res_h_dim;
+    Carve c{static_cast<char *>(packed), packed_bytes};
+    int rc;
+#define PACK_CONV(dst, kind, w, Cin, Cout)                                                          \
+    do {                                                                                            \
+        float *buf = static_cast<float *>(c.raw(vqvae_conv_packed_bytes(kind, Cin, Cout)));         \
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;                                                      \
+        if ((rc = vqvae_conv_pack_f32(kind, w, Cin, Cout, buf, stream)) != 0) return rc;            \
+        out->dst = buf;                                                                             \
+    } while (0)
+    {
+        float *buf = static_cast<float *>(c.raw(vqvae_conv_in_packed_bytes(d->in_ch, h / 2)));
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;
+        if ((rc = vqvae_conv_in_pack_f32(raw->enc0_w, d->in_ch, h / 2, buf, stream)) != 0) return rc;
+        out->enc0 = buf;
+    }
+    PACK_CONV(enc2, VQVAE_CONV_4x4_S2, raw->enc2_w, h / 2, h);
+    PACK_CONV(enc4, VQVAE_CONV_3x3_S1, raw->enc4_w, h, h);
+    PACK_CONV(enc_res_w1, VQVAE_CONV_3x3_S1, raw->enc_res_w1, h, Rh);
+    PACK_CONV(enc_res_w2, VQVAE_CONV_1x1, raw->enc_res_w2, Rh, h);
+    PACK_CONV(pre, VQVAE_CONV_1x1, raw->pre_w, h, D);
+    PACK_CONV(dec0, VQVAE_CONVT_3x3_S1, raw->dec0_w, D, h);
+    PACK_CONV(dec_res_w1, VQVAE_CONV_3x3_S1, raw->dec_res_w1, h, Rh);
+    PACK_CONV(dec_res_w2, VQVAE_CONV_1x1, raw->dec_res_w2, Rh, h);
+    PACK_CONV(dec2, VQVAE_CONVT_4x4_S2, raw->dec2_w, h, h / 2);
+#undef PACK_CONV
+    {
+        float *buf = static_cast<float *>(c.raw(vqvae_convt_out_packed_bytes(h / 2, d->in_ch)));
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;
+        if ((rc = vqvae_convt_out_pack_f32(raw->dec4_w, h / 2, d->in_ch, buf, stream)) != 0) return rc;
+        out->dec4 = buf;
+    }
+    out->dims = *d;
+    out->enc0_b = raw->enc0_b; out->enc2_b = raw->enc2_b; out->enc4_b = raw->enc4_b; out->pre_b = raw->pre_b;
+    out->dec0_b = raw->dec0_b; out->dec2_b = raw->dec2_b; out->dec4_b = raw->dec4_b;
+    out->codebook = raw->codebook;
+    return VQVAE_OK;
+}
+
+size_t vqvae_workspace_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
+    if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return 0;
+    const size_t vq = vqvae_vq_workspace_bytes(B * (int64_t)(H / 4) * (W / 4), d->n_embeddings, d->embedding_dim);
+    if (vq == 0) return 0;
+    const size_t act = align_up(act_elems(d, B, H, W) * sizeof(float), 256);
+    const size_t lat = align_up((size_t)B * (H / 4) * (W / 4) * d->embedding_dim * sizeof(float), 256);
+    const size_t rows = (size_t)B * (H / 4) * (W / 4);
+    return 2 * act + 2 * lat + align_up(rows * sizeof(int64_t), 256) + align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) +
+           align_up(vq, 256) + 256;
+}
+
+int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const float *x, int64_t B, int H, int W, int C,
+                       int Rh, int n_layers, int flags, float *y, float *tmp, vqvae_stream_t stream) {
+    if (!packed_w1 || !packed_w2 || !x || !y) return VQVAE_ERR_NULL;
+    if (n_layers > 1 && !tmp) return VQVAE_ERR_NULL;
+    if (n_layers < 1) return VQVAE_ERR_SHAPE;
+    const float *res = nullptr;
+    return res_stack(packed_w1, packed_w2, x, B, H, W, C, Rh, n_layers, flags & VQVAE_CONV_RELU_IN, flags & VQVAE_CONV_RELU_OUT,
+                     y, tmp, static_cast<hipStream_t>(stream), &res);
+}
+
+int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
+                      size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return VQVAE_ERR_SHAPE;
+    Carve c{static_cast<char *>(workspace), workspace_bytes};
+    const size_t act = act_elems(d, B, H, W);
+    float *a = c.f32(act), *b = c.f32(act);
+    if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int h = d->h_dim;
+    int rc;
+    // encoder.py:29-31, :32-34, :35-36 (+ the residual stack's first in-place ReLU, residual.py:19)
+    if ((rc = vqvae_conv_in_forward_f32(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
+    if ((rc = vqvae_conv_forward_f32(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st)) != 0) return rc;
+    if ((rc = vqvae_conv_forward_f32(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
+    const float *t = a;
+    if (d->n_res_layers > 0) {                                                                  // encoder.py:37-38
+        // the first layer must not write into its own input (a): with an even layer count the result comes back to a
+        float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
+        if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t)) != 0)
+            return rc;
+    }
+    // n_res_layers == 0: F.relu of an already ReLU'd tensor is the identity
+    return vqvae_conv_forward_f32(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st);   // vqvae.py:33
+}
+
+int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
+                      size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
+    Carve c{static_cast<char *>(workspace), workspace_bytes};
+    const size_t act = act_elems(d, B, 4 * h4, 4 * w4);
+    float *a = c.f32(act), *b = c.f32(act);
+    if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int h = d->h_dim;
+    int rc;
+    // decoder.py:28-29 (+ the stack's first in-place ReLU), :30, :31-33, :34-35
+    if ((rc = vqvae_conv_forward_f32(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
+    const float *t = a;
+    if (d->n_res_layers > 0) {
+        float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
+        if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t)) != 0) return rc;
+    }
+    float *u = (t == a) ? b : a;
+    if ((rc = vqvae_conv_forward_f32(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st)) != 0) return rc;
+    return vqvae_convt_out_forward_f32(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st);
+}
+
+int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, float *x_hat,
+                      float *loss, float *perplexity, int64_t *idx, void *workspace, size_t workspace_bytes,
+                      void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !x || !x_hat || !loss || !perplexity || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    const size_t need = vqvae_workspace_bytes(d, B, H, W);
+    if (need == 0) return VQVAE_ERR_UNSUPPORTED;
+    if (workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
+    Carve c{static_cast<char *>(workspace), workspace_bytes};
+    const size_t act = act_elems(d, B, H, W);
+    const size_t rows = (size_t)B * (H / 4) * (W / 4);
+    void *acts = c.raw(2 * align_up(act * sizeof(float), 256));
+    float *z_e = c.f32(rows * d->embedding_dim), *z_q = c.f32(rows * d->embedding_dim);
+    int64_t *idx_ws = static_cast<int64_t *>(c.raw(rows * sizeof(int64_t)));
+    int32_t *hist = static_cast<int32_t *>(c.raw((size_t)d->n_embeddings * sizeof(int32_t)));
+    const size_t vqb = vqvae_vq_workspace_bytes((int64_t)rows, d->n_embeddings, d->embedding_dim);
+    void *vqws = vq_workspace;
+    size_t vqws_bytes = vq_workspace_bytes;
+    if (!vqws) {                                       // no persistent codebook workspace: use (and re-prepare) ours
+        vqws = c.raw(vqb);
+        vqws_bytes = vqb;
+        vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
+    }
+    if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256);
+    int rc;
+    if ((rc = vqvae_encoder_f32(w, x, B, H, W, z_e, acts, acts_bytes, stream)) != 0) return rc;                 // vqvae.py:31-33
+    if ((rc = vqvae_vq_forward_f32(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
+                                   (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
+                                                VQVAE_VQ_PRODUCER_CONSUMER)) | VQVAE_VQ_ROWMAJOR,
+                                   z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream)) != 0) return rc;   // :34
+    return vqvae_decoder_f32(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, stream);                           // :36
+}
+
+}  // extern "C"

@@ -197,10 +197,93 @@ class VQVAE(nn.Module):
         """Drop the prepared codebook image and every packed-weight image (they are keyed on the parameters'
         data_ptr / _version, which writes through `.data` do not change; `load_state_dict` calls this)."""
         from . import conv_hip
+        self.__dict__.pop("_c_weights_cache", None)
         for mod in self.modules():
             conv_hip.invalidate(mod)
             if isinstance(mod, VectorQuantizer):
                 mod.invalidate()
+
+    # ---- whole-path C ABI (include/vqvae_hip.h: vqvae_forward_f32) ------------------------------------------------
+    _RAW = {"enc0_w": "encoder.conv_stack.0.weight", "enc0_b": "encoder.conv_stack.0.bias",
+            "enc2_w": "encoder.conv_stack.2.weight", "enc2_b": "encoder.conv_stack.2.bias",
+            "enc4_w": "encoder.conv_stack.4.weight", "enc4_b": "encoder.conv_stack.4.bias",
+            "enc_res_w1": "encoder.conv_stack.5.stack.0.res_block.1.weight",
+            "enc_res_w2": "encoder.conv_stack.5.stack.0.res_block.3.weight",
+            "pre_w": "pre_quantization_conv.weight", "pre_b": "pre_quantization_conv.bias",
+            "codebook": "vector_quantization.embedding.weight",
+            "dec0_w": "decoder.inverse_conv_stack.0.weight", "dec0_b": "decoder.inverse_conv_stack.0.bias",
+            "dec_res_w1": "decoder.inverse_conv_stack.1.stack.0.res_block.1.weight",
+            "dec_res_w2": "decoder.inverse_conv_stack.1.stack.0.res_block.3.weight",
+            "dec2_w": "decoder.inverse_conv_stack.2.weight", "dec2_b": "decoder.inverse_conv_stack.2.bias",
+            "dec4_w": "decoder.inverse_conv_stack.4.weight", "dec4_b": "decoder.inverse_conv_stack.4.bias"}
+
+    def _c_weights(self):
+        """-> (VqvaeWeights, keep-alive tensors): every layer packed once per weight version into ONE buffer by
+        vqvae_weights_pack_f32; rebuilt when any parameter's (data_ptr, _version) changes or invalidate_caches() ran."""
+        from . import _lib
+        params = dict(self.named_parameters(remove_duplicate=False))
+        n_res = self.encoder.conv_stack[5].n_res_layers
+        tensors = {}
+        for f, k in self._RAW.items():
+            if k not in params:                       # n_res_layers == 0: no residual weights; the stack is skipped
+                tensors[f] = params["encoder.conv_stack.4.weight"]
+            else:
+                tensors[f] = params[k]
+        key = tuple((t.data_ptr(), t._version) for t in tensors.values()) + (str(tensors["enc0_w"].device),)
+        hit = self.__dict__.get("_c_weights_cache")
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        L = _lib.load()
+        w0 = tensors["enc0_w"]
+        dims = _lib.VqvaeDims(self.encoder.conv_stack[4].weight.shape[0], tensors["enc_res_w1"].shape[0] if n_res else 1,
+                              n_res, self.vector_quantization.n_e, self.vector_quantization.e_dim, w0.shape[1],
+                              float(self.vector_quantization.beta))
+        nbytes = L.vqvae_weights_packed_bytes(dims)
+        if nbytes == 0:
+            raise VqvaeHipError("model dimensions not supported by the gfx950 whole-path entry points")
+        keep = {f: t.detach().contiguous() for f, t in tensors.items()}
+        raw = _lib.VqvaeRawWeights(**{f: t.data_ptr() for f, t in keep.items()})
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=w0.device)
+        cw = _lib.VqvaeWeights()
+        with torch.cuda.device(w0.device):
+            _lib.check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, cw,
+                                                torch.cuda.current_stream(w0.device).cuda_stream))
+        self.__dict__["_c_weights_cache"] = (key, cw, (keep, packed))
+        return cw, (keep, packed)
+
+    def _forward_c(self, x, want_idx=False):
+        """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32)."""
+        from . import _lib
+        L = _lib.load()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        cw, _keep = self._c_weights()
+        if Cin != cw.dims.in_ch or H % 4 or W % 4:
+            raise ValueError(f"expected (B, {cw.dims.in_ch}, 4k, 4m) images, got {tuple(x.shape)}")
+        dev = x.device
+        with torch.cuda.device(dev):
+            nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+            if nws == 0:
+                raise VqvaeHipError(f"shape {tuple(x.shape)} not supported by the gfx950 whole-path entry points")
+            wkey = (nws, str(dev))
+            hit = self.__dict__.get("_c_ws_cache")
+            if hit is None or hit[0] != wkey:                 # one activation workspace per (shape, device), reused
+                hit = (wkey, torch.empty(nws, dtype=torch.uint8, device=dev))
+                self.__dict__["_c_ws_cache"] = hit
+            ws = hit[1]
+            vq = self.vector_quantization
+            vws, prepared, key = vq._workspace()
+            if not prepared:
+                vq._ws_key = None
+            x_hat = torch.empty_like(x)
+            scal = torch.empty(2, dtype=torch.float32, device=dev)
+            idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev) if want_idx else None
+            _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, F_hip.VQ_CODEBOOK_PREPARED if prepared else 0,
+                                           x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
+                                           idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
+                                           torch.cuda.current_stream(dev).cuda_stream))
+            vq._ws_key = key
+        return (scal[0], x_hat, scal[1]) + ((idx,) if want_idx else ())
 
     def forward(self, x, verbose=False):
         from . import conv as C_hip
@@ -215,6 +298,8 @@ class VQVAE(nn.Module):
             x_hat = A_hip.decoder_forward_train(self.decoder, z_q)
             return embedding_loss, x_hat, perplexity
         _require_forward_only(x, *self.parameters())
+        if C_hip.get_conv_backend() == "hip" and not verbose and x.is_cuda and x.dtype == torch.float32:
+            return self._forward_c(x)                 # one ctypes call: vqvae_forward_f32
         # encoder + 1x1 pre-quantisation conv, activations kept row-major (B,H,W,C)
         z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
         embedding_loss, z_q, perplexity, _, _ = self.vector_quantization.quantize(z_e, rowmajor=True)
