@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""HBM-side bytes per VQ row / per image from rocprofv3 PMC passes -> profiles/hbm_traffic_<workload>.json (read by bench.py).
+
+    python tools/pmc_traffic.py WORKLOAD B BENCH_FETCH_DIR BENCH_WRITE_DIR VQ_FETCH_DIR VQ_WRITE_DIR VQ_ROWS OUT.json
+
+Method (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE in SEPARATE passes, kernel-trace only; counters are
+KiB per dispatch; FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of 16-B/lane streaming reads at 64 B --
+calibrated on a 1 GiB copy in round 1, profiles/r01_vq_hbm_traffic.txt); WRITE_SIZE is taken as is.  Infinity-Cache hits
+are counted, so these are fabric-side bytes (an upper bound on HBM bytes).  The VQ figure comes from a stream far beyond
+the 256 MiB Infinity Cache (tools/vq_traffic.py), the conv figure from the bench workload itself."""
+import collections, csv, glob, json, sys
+
+
+def per_kernel(d):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def main():
+    wl, B = sys.argv[1], int(sys.argv[2])
+    bf, bw, vf, vw = (per_kernel(p) for p in sys.argv[3:7])
+    vq_rows, out = int(sys.argv[7]), sys.argv[8]
+    is_vq = lambda k: "vq_" in k and "kernel_d64" in k or "vq_exact_kernel" in k
+    vqk = [k for k in vf if is_vq(k)]
+    assert vqk, list(vf)
+    k = max(vqk, key=lambda n: vf[n][0])
+    vq_read, vq_write = 2 * vf[k][0] * 1024, vw[k][0] * 1024
+    res = {"workload": wl, "per_gpu_batch": B,
+           "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate kernel-trace passes; bytes = 2 x FETCH_SIZE KiB "
+                     "(gfx950 correction for wide coalesced reads) + WRITE_SIZE KiB; fabric-side (Infinity-Cache hits counted)",
+           "vq_kernel": k[:60], "vq_rows_measured": vq_rows,
+           "vq_read_bytes_per_row": round(vq_read / vq_rows, 2), "vq_write_bytes_per_row": round(vq_write / vq_rows, 2),
+           "vq_bytes_per_row": round((vq_read + vq_write) / vq_rows, 2)}
+    # conv kernels of one bench step: per-dispatch average x dispatches per step (steps = dispatches of the VQ kernel)
+    bvq = [n for n in bf if is_vq(n)]
+    steps = max(bf[n][1] for n in bvq) if bvq else 1
+    conv, table = 0.0, {}
+    for n in sorted(bf):
+        rd, cnt = bf[n]
+        wr = bw.get(n, (0.0, 0))[0]
+        per_step = cnt / steps
+        byts = (2 * rd + wr) * 1024 * per_step
+        table[n[:70]] = {"launches_per_step": round(per_step, 2), "read_KiB_x2": round(2 * rd), "write_KiB": round(wr)}
+        if any(t in n for t in ("conv_tile8", "res_tile8", "res_layer", "conv_igemm")):
+            conv += byts
+    res["conv_bytes_per_image"] = round(conv / B, 1)
+    res["per_kernel_KiB_per_dispatch"] = table
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_KiB_per_dispatch"}))
+
+
+if __name__ == "__main__":
+    main()
