@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (loads libamdhip64 first)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvqvae_hip.so")
+LIB_PATH = os.environ.get("VQVAE_HIP_LIB_OVERRIDE") or os.path.join(_HERE, "libvqvae_hip.so")   # override: A/B tools only
 
 _i64, _i32, _f32, _vp, _sz = C.c_int64, C.c_int, C.c_float, C.c_void_p, C.c_size_t
 

@@ -151,23 +151,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     const float EEh = 0.5f * EEmax * A, EEa = EEmax * A;
 
     // ---- row I/O: F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the pair (1 KiB contiguous per instruction) ----
-    // rows past the end read row N-1 again (their results are never stored), so the loads need no branches
-    auto load_pair = [&](long long p, f32x4(&F)[2][8], int g4, int j16) {
-        const long long r0 = p * 64 + g4;
+    // a buffer descriptor over the pair's 16 KiB clipped at the end of z: rows past the end read zeros (their results are
+    // never stored), one 32-bit lane offset serves all 16 loads -- no per-load 64-bit index math or clamps
+    auto load_pair = [&](long long p, f32x4(&F)[2][8], int lane) {
+        const long long left = (N - p * 64) * (D * 4);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z + (size_t)p * 64 * D), 0,
+                                                          (unsigned)(left < 16384 ? left : 16384), 0x00020000);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                long long row = r0 + 32 * t + 4 * i;
-                row = row < N ? row : N - 1;
-                F[t][i] = *reinterpret_cast<const f32x4 *>(z + (size_t)row * D + 4 * j16);
-            }
+            for (int i = 0; i < 8; ++i)
+                F[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, (unsigned)(t * 8 + i) * 1024u, 0));
     };
 
     const long long pstride = (long long)gridDim.x * NW;
     long long p = (long long)blockIdx.x * NW + wave_u;
     f32x4 F[2][8];
-    if (p < npairs) load_pair(p, F, lane >> 4, lane & 15);
+    if (p < npairs) load_pair(p, F, lane);
 
     // codebook image and seeds -> LDS (eight 16-byte requests in flight per thread)
     {
@@ -610,6 +610,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #else
         const unsigned pm[2] = {(unsigned)__builtin_amdgcn_ballot_w64(pairf[0]), (unsigned)__builtin_amdgcn_ballot_w64(pairf[1])};
 #endif
+        const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
         f32x4 ev[2][8];
         f32x4 pool[4];
         int npool = 0;
@@ -621,12 +622,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #if defined(VQ_KNOB) && VQ_KNOB == 8
                 ev[t][i] = F[t][i] * (float)(kr + 1);
 #else
-                ev[t][i] = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
+                ev[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr * (D * 4) + (unsigned)j16 * 16u, 0, 0));
 #endif
                 if ((pm[t] >> (4 * i)) & 0xfu) {
                     if (npool < 4) {
                         const int kr2 = __shfl(c2[t], 4 * i + g4);
-                        const f32x4 e2 = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr2 * D + 4 * j16);
+                        const f32x4 e2 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr2 * (D * 4) + (unsigned)j16 * 16u, 0, 0));
                         if (npool == 0) pool[0] = e2; else if (npool == 1) pool[1] = e2; else if (npool == 2) pool[2] = e2; else pool[3] = e2;
                     }
                     ++npool;
@@ -638,11 +639,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
         {
             int slot = 0;
 #ifdef VQ_SWEEP_DEBUG
-            float *obase = nullptr;
+            const bool store_zq = false;
 #else
-            float *obase = zq ? zq + (size_t)p * 64 * D : nullptr;
+            const bool store_zq = zq != nullptr;
 #endif
             const int nleft = (int)(N - r0 < 64 ? N - r0 : 64);         // rows of this pair that exist
+            // the descriptor covers exactly the pair's existing rows: stores of rows past the end are dropped by the hardware
+            const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq ? zq + (size_t)p * 64 * D : const_cast<float *>(z), 0,
+                                                                 store_zq ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
+            float sacc = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -692,16 +697,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                     const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
                     o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
                     const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-                    if (rr < nleft) {
-                        dacc += (double)sq;
-#if defined(VQ_KNOB) && VQ_KNOB == 7
-                        if (obase && o.x == 12345.678f) *reinterpret_cast<f32x4 *>(obase + (size_t)((t * 8 + i) * 64 + lane) * 4) = o;
-#else
-                        if (obase) *reinterpret_cast<f32x4 *>(obase + (size_t)((t * 8 + i) * 64 + lane) * 4) = o;
-#endif
-                    }
+                    sacc += rr < nleft ? sq : 0.0f;              // fp32 over the pair's 16 groups, one fp64 add per pair
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zq_rs, (unsigned)lane * 16u, (unsigned)(t * 8 + i) * 1024u, 0);
                 }
             }
+            dacc += (double)sacc;
             lds_order_wave();
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
@@ -719,7 +719,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             if (lane == 0) q = atomicAdd(ticket_s, 1);
             q = __builtin_amdgcn_readfirstlane(q);
             p = (long long)(q / NW) * pstride + (long long)blockIdx.x * NW + (q % NW);
-            if (p < npairs) load_pair(p, F, g4, j16);
+            if (p < npairs) load_pair(p, F, lane);
         }
     }
 
