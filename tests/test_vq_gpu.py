@@ -64,6 +64,8 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     (512, 64, 33, 8, 8, 1.0),        # ragged row blocks
     (1024, 64, 2, 56, 56, 0.066),    # config-4 shape: two LDS chunks, 3136-row images
     (8192, 128, 1, 32, 32, 0.066),   # config-5 shape: 37 chunks
+    (1000, 128, 3, 7, 9, 1.0),       # streamed kernel: K % 32 != 0, 189 rows (one ragged block)
+    (700, 64, 5, 9, 13, 1.0),        # streamed kernel, D = 64: 585 rows
     (512, 32, 7, 9, 5, 1.0),
     (300, 256, 2, 6, 6, 1.0),
     (1, 64, 2, 4, 4, 1.0),           # single code
@@ -190,6 +192,81 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     loss, zq, ppl, idx, hist = _run(z, cb, 0.25, False)          # NCHW boundary layout
     np.testing.assert_array_equal(idx, ref_idx)
     assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+
+
+def test_vq_stream_kernel_is_the_default_for_large_codebooks():
+    from vqvae_amd import _lib
+    assert _lib.vq_kernel_name(512, 64) == "vq_sweep_kernel_d64"
+    for K, D in ((640, 64), (1024, 64), (16384, 64), (64, 128), (8192, 128)):
+        assert _lib.vq_kernel_name(K, D) == "vq_stream_sweep_kernel", (K, D)
+        assert _lib.vq_sweeps(K, D) == 1
+    assert _lib.vq_kernel_name(8192, 128, 0x1 | 0x4) == "vq_exact_kernel"      # VQVAE_VQ_EXACT_SWEEP
+    assert _lib.vq_kernel_name(8192, 256) == "vq_exact_kernel"
+
+
+@pytest.mark.parametrize("K,D,p,seed", [(640, 64, 11, 0), (1024, 64, 11, 1), (1024, 64, 11, 2), (2048, 128, 11, 3),
+                                        (8192, 128, 11, 4), (96, 128, 11, 5), (3000, 64, 8, 6)])
+def test_vq_stream_aligned_rounding_adversarial(K, D, p, seed):
+    """tests/adversarial.py through the streamed-codebook kernel (vq_chunk.hip): several LDS chunks, several key
+    epochs, D = 128, a K that is not a multiple of 32 -- every row bit for bit against the oracle."""
+    from oracle import c_oracle
+    from tests import adversarial as A
+    zr, cb, _ = A.make_problem(p, K=K, D=D, n_rows=256, seed=seed)
+    z = torch.from_numpy(np.ascontiguousarray(zr.reshape(4, 8, 8, D).transpose(0, 3, 1, 2)))
+    ref = c_oracle.vq_forward(z.numpy(), cb, 0.25)
+    for exact in (False, True):
+        loss, zq, ppl, idx, hist = _run(z, torch.from_numpy(cb), 0.25, True, exact=exact)
+        np.testing.assert_array_equal(idx, ref["idx"])
+        assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
+        np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
+        np.testing.assert_array_equal(hist, ref["hist"])
+
+
+@pytest.mark.parametrize("K,D", [(1024, 64), (1500, 128)])
+def test_vq_stream_near_ties_duplicates_and_nonfinite_rows(K, D):
+    """Everything the streamed kernel's task lists exist for: midpoints between codes of different key epochs (pair
+    tasks), > 3 exact duplicates and near-duplicates (hard tasks), rows with NaN / Inf / beyond fp16's range (hard
+    tasks with torch.argmin semantics), huge dynamic range in the codebook."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(K + D)
+    cb = torch.randn(K, D, generator=g)
+    cb[40:60] = cb[700]                                     # duplicates across epochs: first index must win
+    cb[900:] *= torch.logspace(-2, 2, K - 900).unsqueeze(1)
+    n = 1024
+    ka = torch.randint(0, K, (n,), generator=g)
+    kb = torch.randint(0, K, (n,), generator=g)
+    zr = 0.5 * (cb[ka] + cb[kb]) + torch.randn(n, D, generator=g) * 1e-6
+    zr[::5] = cb[ka[::5]] + torch.randn(len(ka[::5]), D, generator=g) * 1e-3
+    zr[3::16] = cb[700]
+    zr[7, 5] = float("nan")
+    zr[64 + 9, 0] = float("inf")
+    zr[200, 3] = -float("inf")
+    zr[300] = 7.0e4                                         # finite, but not representable in fp16
+    zr[301] = 1.0e-7                                        # fp16 subnormal / zero
+    zr[302] = 0.0
+    z = zr.view(n // 64, 8, 8, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True)
+    np.testing.assert_array_equal(idx, ref["idx"])
+    assert np.array_equal(np.isnan(zq), np.isnan(ref["z_q"]))
+    m = ~np.isnan(zq)
+    assert np.array_equal(zq[m].view(np.uint32), ref["z_q"][m].view(np.uint32))
+    np.testing.assert_array_equal(hist, ref["hist"])
+
+
+def test_vq_stream_two_slabs_ragged_vs_oracle():
+    """More rows than one slab of the streamed kernel (2^18): 262 144 + 1 280 rows, K = 640."""
+    g = torch.Generator().manual_seed(99)
+    K, D, B, H, W = 640, 64, 4116, 8, 8                      # 263 424 rows
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, H, W, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True)
+    np.testing.assert_array_equal(idx, ref_idx)
+    assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+    np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
+    a = _run(z, cb, 0.25, True)
+    assert a[0].tobytes() == loss.tobytes() and a[2].tobytes() == ppl.tobytes()        # run-to-run bitwise
 
 
 def test_vq_nonfinite_codebook_forces_slow_path():

@@ -41,7 +41,7 @@ struct VqPlan {
     int KC;           // codes per LDS chunk (multiple of 32)
     int nchunks;      // ceil(K / KC)
     int K_pad;        // nchunks * KC
-    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, off_imgh, off_seeds, total;
+    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, off_imgh, off_seeds, off_chunk, total;
     size_t lds_bytes;
     // filter-and-refine kernel (bf16 screening): usable when the whole bf16 image fits LDS
     bool filter_ok;
@@ -51,6 +51,11 @@ struct VqPlan {
 constexpr int kVqCandCap = 8;   // per lane half (16 per row), unsigned short entries   // candidate list capacity per row in the filter kernel
 constexpr int kVqTilesPerWave = 2;   // 32-row tiles a wave of the filter kernel walks per iteration
 constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many workgroups
+constexpr int kVqSlabRows = 1 << 18; // rows per pass of the streamed-codebook kernels (vq_chunk.hip): bounds their scratch
+
+bool vq_sweep_ok(int K, int D);
+bool vq_chunk_ok(int K, int D);
+size_t vq_chunk_scratch_bytes(int D);
 
 inline VqPlan vq_plan(int K, int D) {
     VqPlan p;
@@ -73,8 +78,11 @@ inline VqPlan vq_plan(int K, int D) {
     p.off_img16 = align_up(p.off_partials + sizeof(double) * kVqMaxGrid, 256);
     p.off_neh = align_up(p.off_img16 + (size_t)p.K32 * D * 2, 256);
     p.off_imgh = align_up(p.off_neh + (size_t)p.K32 * 4, 256);        // fp16 image + seeds of the single-sweep kernel
-    p.off_seeds = align_up(p.off_imgh + (size_t)p.K32 * D * 2, 256);
-    p.total = align_up(p.off_seeds + (size_t)p.K32 * 4, 256);
+    // (+ 512 codes / 4 KiB of padding: the streamed-codebook kernel copies whole chunks)
+    p.off_seeds = align_up(p.off_imgh + (size_t)(p.K32 + 512) * D * 2, 256);
+    p.off_chunk = align_up(p.off_seeds + (size_t)p.K32 * 4 + 4096, 256);
+    // row scratch of the streamed-codebook kernels: only where they are the default path
+    p.total = p.off_chunk + ((vq_chunk_ok(K, D) && !vq_sweep_ok(K, D)) ? vq_chunk_scratch_bytes(D) : 0);
     // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
     p.filter_lds_bytes = (size_t)p.K32 * D * 2 + (size_t)p.K32 * 4 + (size_t)K * 4 +
                          kVqTilesPerWave * (8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4) + 256 + 8;
@@ -87,11 +95,13 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
                          float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out);
 
 // vq_sweep.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel (D = 64, row-major rows)
-bool vq_sweep_ok(int K, int D);
 bool vq_pc_ok(int K, int D);
 int launch_vq_pc_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                      char *ws, hipStream_t st, int *grid_out);
-void launch_vq_prepare16(const float *cb, int K, char *ws, hipStream_t st);
+void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);
+// vq_chunk.hip: the same screen with the codebook image streamed through LDS (D = 64 / 128, any K <= 16384)
+int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,
+                      char *ws, hipStream_t st, int *grid_out);
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out);
 

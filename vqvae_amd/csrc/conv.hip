@@ -2002,8 +2002,7 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
             // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps.  With four
             // output tiles per wave (all 128 channels: the image is read and split once) the workgroup has eight
             // waves, so that its weight chunks (2 x 24 KiB) and eight operand tiles still fit one CU's LDS.
-            static const int nt4 = [] { const char *e = getenv("VQVAE_TILE8_NT4"); return e ? atoi(e) : 1; }();
-            const bool wide = nt4 && g.ntile % 4 == 0;
+            const bool wide = g.ntile % 4 == 0;
             const int ny = (S2D_ ? 1 : g.nphase) * (g.ntile / (wide ? 4 : 2));
             const unsigned gxt = (unsigned)((B + (wide ? 7 : 3)) / (wide ? 8 : 4)) * ny;
             const u32x4 *wsel = S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3;

@@ -452,7 +452,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
                            p.K_pad, ee, img, wflags, p.K32,
                            reinterpret_cast<unsigned short *>(ws + p.off_img16),
                            reinterpret_cast<float *>(ws + p.off_neh));
-        if (vq_sweep_ok(K, D)) launch_vq_prepare16(cb, K, ws, st);
+        if (vq_sweep_ok(K, D) || vq_chunk_ok(K, D)) launch_vq_prepare16(cb, K, D, ws, st);
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
     if constexpr (D == 64) {
@@ -468,6 +468,21 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
                                beta, loss, ppl);
             return (int)hipGetLastError();
         }
+    }
+    if constexpr (D == 64 || D == 128) {
+        // larger codebooks / D = 128: the same fp16 screen with the codebook image streamed through LDS (vq_chunk.hip)
+        if (rowmajor && vq_chunk_ok(K, D) && !vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
+            int fgrid = 0;
+            prof_begin(VQVAE_PROF_VQ_MAIN, st);
+            const int rc = launch_vq_chunked(z, cb, N, K, D, zq, idx, hist, ws, st, &fgrid);
+            prof_end(VQVAE_PROF_VQ_MAIN, st);
+            if (rc != 0) return rc;
+            hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
+                               beta, loss, ppl);
+            return (int)hipGetLastError();
+        }
+    }
+    if constexpr (D == 64) {
         if (p.filter_ok && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
@@ -523,8 +538,11 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_sweep_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER))
             return (vq_pc_ok(K, D) && (flags & VQVAE_VQ_PRODUCER_CONSUMER)) ? "vq_pc_kernel_d64" : "vq_sweep_kernel_d64";
+        if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
         if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
     }
+    if (D == 128 && (flags & VQVAE_VQ_ROWMAJOR) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)) && vq_chunk_ok(K, D))
+        return "vq_stream_sweep_kernel";
     return "vq_exact_kernel";
 }
 

@@ -58,6 +58,7 @@ constexpr float kPadSeed = -3.0e38f;          // padded codes: finite (a key mus
 // Prepare, second stage (after vq_prepare_kernel wrote ee[] and the max |e| / max ee statistics): fp16 A-operand image
 // [tile][q][half][32 codes] x 16 B of the scaled codebook, seeds -A ee_k / 2 in accumulator-register order
 // [tile][half][16], and the statistics of the bound.  One thread per (padded) code.
+template <int D>
 __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restrict__ cb, const float *__restrict__ ee,
                                                           int K, int K32, int *__restrict__ flags,
                                                           unsigned short *__restrict__ img, float *__restrict__ seeds) {
@@ -75,10 +76,10 @@ __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restric
     if (k == 0) flags[5] = a_e;
     const int ct = k >> 5, i = k & 31;
     float eh2 = 0.0f, de2 = 0.0f;
-    for (int c8 = 0; c8 < 8; ++c8) {                       // chunk c8 = (q, half): channels 8 c8 .. 8 c8 + 7
+    for (int c8 = 0; c8 < D / 8; ++c8) {                   // chunk c8 = (q, half): channels 8 c8 .. 8 c8 + 7
         unsigned short v[8];
         for (int j = 0; j < 8; ++j) {
-            const float es = k < K ? cb[(size_t)k * 64 + 8 * c8 + j] * A : 0.0f;
+            const float es = k < K ? cb[(size_t)k * D + 8 * c8 + j] * A : 0.0f;
             const _Float16 hv = (_Float16)es;                // round to nearest even
             const float hf = (float)hv;
             const float d = es - hf;                       // exact
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restric
             de2 = __builtin_fmaf(d, d, de2);
             v[j] = __builtin_bit_cast(unsigned short, hv);
         }
-        unsigned short *dst = img + ((size_t)(ct * 8 + c8) * 32 + i) * 8;
+        unsigned short *dst = img + ((size_t)(ct * (D / 8) + c8) * 32 + i) * 8;
         for (int j = 0; j < 8; ++j) dst[j] = v[j];
     }
     float seed = kPadSeed;
@@ -1436,11 +1437,14 @@ bool vq_sweep_ok(int K, int D) {
     return D == 64 && K <= 1024 && vq_sweep_lds_bytes(K, 8) <= (size_t)kLdsBytes;
 }
 
-void launch_vq_prepare16(const float *cb, int K, char *ws, hipStream_t st) {
-    const VqPlan p = vq_plan(K, 64);
-    hipLaunchKernelGGL(vq_prepare16_kernel, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb,
-                       reinterpret_cast<const float *>(ws + p.off_ee), K, p.K32, reinterpret_cast<int *>(ws + p.off_flags),
-                       reinterpret_cast<unsigned short *>(ws + p.off_imgh), reinterpret_cast<float *>(ws + p.off_seeds));
+void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st) {
+    const VqPlan p = vq_plan(K, D);
+    const float *ee = reinterpret_cast<const float *>(ws + p.off_ee);
+    int *fl = reinterpret_cast<int *>(ws + p.off_flags);
+    unsigned short *img = reinterpret_cast<unsigned short *>(ws + p.off_imgh);
+    float *seeds = reinterpret_cast<float *>(ws + p.off_seeds);
+    if (D == 64) hipLaunchKernelGGL(vq_prepare16_kernel<64>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds);
+    else hipLaunchKernelGGL(vq_prepare16_kernel<128>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds);
 }
 
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
