@@ -83,13 +83,15 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
 #define VQVAE_VQ_PRODUCER_CONSUMER 0x10 /* use the producer / consumer form of the fp16 kernel (sweeper + I/O wave per SIMD) where the
                                         default is its single-role form (identical outputs; A/B timing and tests) */
 
-/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_pc_kernel_d64", "vq_sweep_kernel_d64", "vq_filter_kernel_d64",
- * "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix cores per row
- * (0 for the exact-fp32 kernel).  For reporting (bench.py). */
+/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_pc_kernel_d64", "vq_sweep_kernel_d64" (codebook image
+ * resident in LDS: D = 64, K <= ~600), "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
+ * "vq_filter_kernel_d64", "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix
+ * cores per row (0 for the exact-fp32 kernel).  For reporting (bench.py). */
 VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);
 VQVAE_API int vqvae_vq_screen_sweeps(int K, int D, int flags);
 
-/* Bytes of workspace vqvae_vq_forward_f32 needs for n_rows = B*H*W latent rows. */
+/* Bytes of workspace vqvae_vq_forward_f32 needs (any number of rows: the streamed-codebook kernels work through the rows
+ * in slabs of 2^18, so their scratch -- 39 MB at D = 64, 72 MB at D = 128 -- does not grow with n_rows). */
 VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);
 
 /*
