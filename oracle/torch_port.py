@@ -6,7 +6,7 @@ same ATen ops in the same order as the reference modules, so that on the host it
 runs on it is bitwise what the reference would compute there.  It is used
   * as the multi-core CPU baseline timed by bench.py (`cpu_baseline.kind="port"`;
     the Python reference itself cannot travel to the GPU box), and
-  * as a second checker next to the C oracle (tests/test_oracle_vs_reference.py
+  * as a second checker next to the C oracle (tests/test_oracle.py
     proves it bitwise-equal to the imported reference in the build container).
 Nothing under vqvae_amd/ imports it.
 

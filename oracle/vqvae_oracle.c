@@ -15,7 +15,7 @@
  * delegates its arithmetic to PyTorch/ATen CPU kernels; where the rounding
  * ORDER of those kernels matters for bit-exactness (the quantizer's distance
  * matrix) the order is restated here and is verified bit-for-bit against live
- * torch by tests/test_oracle_vs_torch.py:
+ * torch by tests/test_oracle.py:
  *
  *   torch.matmul(z, E.t())          == k-ordered fmaf chain, acc starts at 0
  *                                      (valid for D <= 256 on this build)
