@@ -158,6 +158,8 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
 #define VQVAE_CONV_RELU_IN  0x1 /* apply ReLU to the input as it is read (the in-place nn.ReLU(True)
                                    in front of a conv, residual.py:19,22)                          */
 #define VQVAE_CONV_RELU_OUT 0x2 /* ReLU on the result (encoder.py:31,34, decoder.py:33)           */
+#define VQVAE_CONV_BF16_SPLIT 0x8 /* use round 1's three-term bf16 products (6 per fp32 product) where the default on 8x8
+                                    maps is the two-term fp16 scheme (3 per product, same error bound; A/B and tests) */
 #define VQVAE_CONV_EXACT_FP32 0x4 /* use the exact-fp32 MFMA kernels (157 TF peak) instead of the default
                                    split-bf16 ones: every fp32 operand is split exactly into three bf16 terms
                                    and the six significant term products run on the bf16 matrix cores with

@@ -363,9 +363,84 @@ __device__ __forceinline__ void prod6x2(const u32x4 &s1, const u32x4 &s2, const 
 #undef BF
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Two-term fp16 products (round 2; the 8x8-map kernels).  fp16 carries 11 significand bits + a signed remainder:
+// x = h1 + h2 with |x - h1 - h2| <= 2^-24 |x| (h1 = fp16(x), h2 = fp16(x - h1), the difference is exact in fp32), so
+//     x*w ~ h1 g1 + h1 g2 + h2 g1                                   (dropped h2 g2 <= 2^-24 |xw|)
+// has the SAME error bound as the six-product three-term bf16 scheme above (3 * 2^-24 relative per product) at HALF
+// the matrix work.  What bf16 gave for free and fp16 does not is range: operands are scaled by exact powers of two
+// -- weights once per layer at pack time (largest |w| -> [2^14, 2^15)), activations once per IMAGE by the wave that
+// owns the image (largest |x| of the image -> [2^14, 2^15)) -- and the accumulator is scaled back in the epilogue.
+// Elements more than 2^17 below the image's maximum lose RELATIVE precision (their h2 is a fp16 subnormal, absolute
+// error 2^-25 in scaled units = 2^-40 of the maximum), which is invisible next to the fp32 accumulation itself.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void split2_h(float a, float b, unsigned &p1, unsigned &p2) {
+    const f16x2 h = {(_Float16)a, (_Float16)b};                      // v_cvt_pk_f16_f32, round to nearest even
+    const f16x2 r = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    p1 = __builtin_bit_cast(unsigned, h);
+    p2 = __builtin_bit_cast(unsigned, r);
+}
+// split 8 consecutive fp32 channels (two float4), pre-multiplied by the image's scale, into two fp16x8 terms
+__device__ __forceinline__ void split8_h(const f32x4 &u, const f32x4 &v, float sc, u32x4 &t1, u32x4 &t2) {
+    unsigned a1, a2, b1, b2, c1, c2, d1, d2;
+    split2_h(u.x * sc, u.y * sc, a1, a2);
+    split2_h(u.z * sc, u.w * sc, b1, b2);
+    split2_h(v.x * sc, v.y * sc, c1, c2);
+    split2_h(v.z * sc, v.w * sc, d1, d2);
+    t1 = u32x4{a1, b1, c1, d1};
+    t2 = u32x4{a2, b2, c2, d2};
+}
+// the three significant term products of one 16-deep step for two pixel tiles, smallest terms first
+__device__ __forceinline__ void prod3x2(const u32x4 &s1, const u32x4 &s2, const u32x4 &t1, const u32x4 &t2,
+                                        const u32x4 &w1, const u32x4 &w2, f32x16 &accA, f32x16 &accB) {
+#define HF(v) __builtin_bit_cast(f16x8, v)
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(s2), HF(w1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(t2), HF(w1), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(s1), HF(w2), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(t1), HF(w2), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(s1), HF(w1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(t1), HF(w1), accB, 0, 0, 0);
+#undef HF
+}
+// largest value of the wave -> the power of two that puts it into [2^14, 2^15) (0 for an all-zero or non-finite image)
+__device__ __forceinline__ int wave_scale_exp(float m) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    int e = 15;
+    if (m > 0.0f && m < 3.0e38f) (void)__builtin_frexpf(m, &e);
+    e = 15 - e;
+    e = e > 100 ? 100 : (e < -100 ? -100 : e);
+    return __builtin_amdgcn_readfirstlane(e);
+}
+
+// Weight scale of a layer: header {int kw} in front of its two-term fp16 image (one block).
+__global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, long long n, int *__restrict__ hdr) {
+    __shared__ float red[256];
+    float m = 0.0f;
+    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(w[i]));
+    red[threadIdx.x] = m;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 15;
+        const float mm = red[0];
+        if (mm > 0.0f && mm < 3.0e38f) (void)__builtin_frexpf(mm, &e);
+        e = 15 - e;
+        hdr[0] = e > 100 ? 100 : (e < -100 ? -100 : e);
+    }
+}
+
+// H2 = false: three bf16 terms per element; H2 = true: two fp16 terms of w * 2^kw (kw from conv_wscale_kernel)
+template <bool H2>
 __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restrict__ w,
                                                             unsigned short *__restrict__ img, ConvGeom g,
-                                                            long long total) {
+                                                            long long total, const int *__restrict__ hdr) {
+    const float wsc = H2 ? __builtin_ldexpf(1.0f, hdr[0]) : 1.0f;
     // one thread per (phase, chunk, ntile, step, half, n, i) element; writes the three term images
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         const int i = e & 7, n = (e >> 3) & 31, hh = (e >> 8) & 1, t = (e >> 9) & 1;
@@ -394,17 +469,26 @@ __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restr
         if (ci < g.Cin && co < g.Cout)
             v = g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx]
                              : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
-        const unsigned short b1 = f32_to_bf16_rne(v);
-        const float r1 = v - __uint_as_float((unsigned)b1 << 16);
-        const unsigned short b2 = f32_to_bf16_rne(r1);
-        const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
-        const unsigned short b3 = f32_to_bf16_rne(r2);
-        // image: [(phase*nchunk + chunk)*ntile + nt][term][t][hh][n][i]
-        const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 3072;
         const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
-        img[base + pos] = b1;
-        img[base + 1024 + pos] = b2;
-        img[base + 2048 + pos] = b3;
+        if (H2) {
+            const float vs = v * wsc;
+            const _Float16 g1 = (_Float16)vs;
+            const _Float16 g2 = (_Float16)(vs - (float)g1);
+            const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 2048;
+            img[base + pos] = __builtin_bit_cast(unsigned short, g1);
+            img[base + 1024 + pos] = __builtin_bit_cast(unsigned short, g2);
+        } else {
+            const unsigned short b1 = f32_to_bf16_rne(v);
+            const float r1 = v - __uint_as_float((unsigned)b1 << 16);
+            const unsigned short b2 = f32_to_bf16_rne(r1);
+            const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
+            const unsigned short b3 = f32_to_bf16_rne(r2);
+            // image: [(phase*nchunk + chunk)*ntile + nt][term][t][hh][n][i]
+            const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 3072;
+            img[base + pos] = b1;
+            img[base + 1024 + pos] = b2;
+            img[base + 2048 + pos] = b3;
+        }
     }
 }
 
@@ -598,16 +682,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 // S2D: the 4x4 stride-2 conv on a 16x16 map, read as a conv over the 8x8 grid of 2x2 input blocks: a chunk is
 // (sub-position (py,px) of the block, 32-channel slice) and meets four block offsets ("virtual taps"), so every
 // input element is still split once and used four times (weights in the s2d chunk order, conv_pack_bf3_kernel).
-template <int NT, bool S2D, int NW>
+// H2: two-term fp16 products with per-image activation scale and per-layer weight scale (see split8_h) instead of the
+// three-term bf16 products; whdr = the weight image's header {kw}.
+template <int NT, bool S2D, int NW, int WB = 2, bool H2 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
                                                                 const u32x4 *__restrict__ wimg,
                                                                 const float *__restrict__ bias,
-                                                                float *__restrict__ out, ConvGeom g, int ny) {
+                                                                float *__restrict__ out, ConvGeom g, int ny, const int *__restrict__ whdr) {
     constexpr int MT = 2, PX = 64, PLANE = (PX + 1) * 2;        // u32x4 per (k-step, term) plane: [half][pixel + zero]
     constexpr int HP = PX + 1;                                   // (consecutive lanes = consecutive 16 B: no bank conflicts)
-    constexpr int TILE4 = 2 * 3 * PLANE;                         // [k-step 2][term 3][PLANE]
-    constexpr int CH4 = NT * 384;
-    __shared__ u32x4 Bs[2][CH4];
+    constexpr int TERMS = H2 ? 2 : 3;
+    constexpr int TILE4 = 2 * TERMS * PLANE;                     // [k-step 2][term][PLANE]
+    constexpr int CH4 = NT * 128 * TERMS;
+    __shared__ u32x4 Bs[WB][CH4];                               // WB = 1: one weight buffer, two barriers per iteration (two workgroups per CU)
     __shared__ u32x4 As_all[NW * TILE4];                        // NW waves = NW images per workgroup
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -632,7 +719,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
     const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt, nchunk = ntaps * cpt;
 
-    if (lane < 12) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};     // padding pixels
+    if (lane < 4 * TERMS) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};     // padding pixels
 
     const long long img = (long long)bx * NW + wave;
     const bool img_ok = img < g.B;
@@ -662,8 +749,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         tapok[mt] = m;
     }
 
-    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 384;
-    const size_t wchunk = (size_t)g.ntile * 384;
+    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * (128 * TERMS);
+    const size_t wchunk = (size_t)g.ntile * (128 * TERMS);
     constexpr int NBQ = CH4 / (NW * 64);               // u32x4 of the weight chunk per thread
     static_assert(CH4 % (NW * 64) == 0, "weight chunk must divide over the workgroup");
     u32x4 b_nxt[NBQ];
@@ -676,6 +763,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 #pragma unroll
         for (int q = 0; q < NBQ; ++q) Bs[buf][tid + NW * 64 * q] = b_nxt[q];
     };
+    float xscale = 1.0f, descale = 1.0f;             // H2: image scale 2^kx, accumulator scale 2^-(kx + kw)
     f32x4 raw[8];
     auto load_raw = [&](int cc) {
         const float *q = src + 32 * cc;
@@ -697,11 +785,18 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                u32x4 t1, t2, t3;
-                split8(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], t1, t2, t3);
-                dst[(t * 3 + 0) * PLANE + hh * HP] = t1;
-                dst[(t * 3 + 1) * PLANE + hh * HP] = t2;
-                dst[(t * 3 + 2) * PLANE + hh * HP] = t3;
+                if constexpr (H2) {
+                    u32x4 t1, t2;
+                    split8_h(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], xscale, t1, t2);
+                    dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
+                    dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
+                } else {
+                    u32x4 t1, t2, t3;
+                    split8(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], t1, t2, t3);
+                    dst[(t * 3 + 0) * PLANE + hh * HP] = t1;
+                    dst[(t * 3 + 1) * PLANE + hh * HP] = t2;
+                    dst[(t * 3 + 2) * PLANE + hh * HP] = t3;
+                }
             }
     };
 
@@ -712,6 +807,23 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+
+    if constexpr (H2) {
+        // the image's largest |x| (after the input ReLU) -> its power-of-two scale; the image is read again below (L2)
+        float m = 0.0f;
+        for (int c2 = 0; c2 < cpt; ++c2) {
+            load_raw(c2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                f32x4 v = raw[j];
+                if (relu_in) v = relu4(v);
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+            }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        descale = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+    }
 
     // iteration it = cc * ntaps + tap  ->  weight chunk tap * cpt + cc
     const int niter = nchunk;
@@ -728,7 +840,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
             if (cc + 1 < cpt) load_raw(cc + 1);
         }
         __syncthreads();                                   // weights of this iteration + (tap 0) the fresh tile
-        const u32x4 *bs = Bs[it & 1];
+        const u32x4 *bs = Bs[WB == 2 ? (it & 1) : 0];
         int shift, okbit;
         if (S2D) {
             const int sub = cc / g.cpt;
@@ -740,6 +852,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if constexpr (H2) {
+                u32x4 A1[MT], A2[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int p = ((tapok[mt] >> okbit) & 1u) ? spx[mt] + shift : PX;
+                    const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
+                    A1[mt] = ap[0];
+                    A2[mt] = ap[PLANE];
+                }
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4 *bp = bs + nt * 256 + (t * 2 + h) * 32 + l31;
+                    prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], acc[0][nt], acc[1][nt]);
+                }
+                continue;
+            }
             bf16x8 A[MT][3];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -774,7 +902,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         int ntap = tap + 1, ncc = cc;
         if (ntap == ntaps) { ntap = 0; ++ncc; }
         if (it + 1 < niter) {
-            store_b((it + 1) & 1);
+            if (WB == 1) __syncthreads();                  // single buffer: every wave is done reading this iteration's weights
+            store_b(WB == 2 ? ((it + 1) & 1) : 0);
             int t2 = ntap + 1, c2 = ncc;
             if (t2 == ntaps) { t2 = 0; ++c2; }
             if (it + 2 < niter) load_b(S2D ? c2 * 4 + t2 : t2 * cpt + c2);
@@ -798,7 +927,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    v[r] = acc[mt][nt][r] + bv[nt];
+                    v[r] = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                 }
                 tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
@@ -823,7 +952,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = (nb * NT + nt) * 32 + l31;
                     if (n < g.Cout) {
-                        float v = acc[mt][nt][r] + bv[nt];
+                        float v = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
                         if (relu_out) v = fmaxf(v, 0.0f);
                         out[off + n] = v;
                     }
@@ -995,15 +1124,19 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 // Compared with res_layer_bf3_kernel (A re-loaded from L2 and re-split for each of the 9 taps) this cuts
 // the L1/TA traffic and the split VALU work of the 3x3 GEMM 9x; no workgroup barrier in the reduction.
 // The hidden tile and the 1x1 GEMM / skip / ReLU epilogue are the same as in res_layer_bf3_kernel.
-template <int NT2>
+// H2: two-term fp16 products (split8_h): per-image scale for x, a second one for the hidden tile, per-layer weight scales
+// in the headers hdr1 / hdr2 of the two weight images.
+template <int NT2, bool H2 = false>
 __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__restrict__ in,
                                                                const u32x4 *__restrict__ w1img,
                                                                const u32x4 *__restrict__ w2img,
-                                                               float *__restrict__ out, int B, int C, int flags) {
-    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][half][pixel + zero]
+                                                               float *__restrict__ out, int B, int C, int flags,
+                                                               const int *__restrict__ hdr1, const int *__restrict__ hdr2) {
+    constexpr int TERMS = H2 ? 2 : 3;
+    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][half][pixel + zero] (sized for 3 terms: the hidden tile aliases it)
     constexpr int HP = PX + 1;                                     // (consecutive lanes = consecutive 16 B: no bank conflicts)
     static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
-    __shared__ u32x4 W2s[NT2 * 384];
+    __shared__ u32x4 W2s[NT2 * 128 * TERMS];
     __shared__ u32x4 As_all[4 * TILE4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -1011,7 +1144,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
     const int cpt = C >> 5, nslice = C >> 4;
 
-    for (int i = tid; i < NT2 * 384; i += 256) W2s[i] = w2img[i];
+    for (int i = tid; i < NT2 * 128 * TERMS; i += 256) W2s[i] = w2img[i];
     if (lane < 6) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
 
     const long long img = (long long)blockIdx.x * 4 + wave;
@@ -1053,12 +1186,29 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     // conv_pack_bf3 layout: chunk = tap*cpt + slice/2, k-step = slice & 1
     const u32x4 *w1v = w1img + h * 32 + l31;
     auto load_w = [&](int tap, int sl, u32x4(&bw)[3]) {
-        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 384 + (sl & 1) * 64;
-        bw[0] = p[0]; bw[1] = p[128]; bw[2] = p[256];
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * (128 * TERMS) + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+        if constexpr (!H2) bw[2] = p[256];
     };
 
     f32x4 raw[4];
     u32x4 bw[2][3];
+    float xscale = 1.0f, d1 = 1.0f;                  // H2: image scale 2^kx, GEMM1 accumulator scale 2^-(kx + kw1)
+    if constexpr (H2) {
+        float m = 0.0f;
+        for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl, raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = raw[j];
+                if (relu_in) v = relu4(v);
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+            }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+    }
     load_raw(0, raw);
     load_w(0, 0, bw[0]);
     // one 16-channel slice; PAR = slice parity (nine taps per slice flip which weight register set is "current")
@@ -1071,14 +1221,19 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                 for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
             }
             u32x4 t1a, t2a, t3a, t1b, t2b, t3b;
-            split8(raw[0], raw[1], t1a, t2a, t3a);
-            split8(raw[2], raw[3], t1b, t2b, t3b);
+            if constexpr (H2) {
+                split8_h(raw[0], raw[1], xscale, t1a, t2a);
+                split8_h(raw[2], raw[3], xscale, t1b, t2b);
+            } else {
+                split8(raw[0], raw[1], t1a, t2a, t3a);
+                split8(raw[2], raw[3], t1b, t2b, t3b);
+            }
             if (sl + 1 < nslice) load_raw(sl + 1, raw);
             __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
             u32x4 *dst = As + lane;
             dst[0] = t1a; dst[HP] = t1b;
             dst[HP * 2] = t2a; dst[HP * 3] = t2b;
-            dst[HP * 4] = t3a; dst[HP * 5] = t3b;
+            if constexpr (!H2) { dst[HP * 4] = t3a; dst[HP * 5] = t3b; }
             lds_order_wave();
         }
 #pragma unroll
@@ -1092,10 +1247,14 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
             for (int mt = 0; mt < MT; ++mt) {
                 const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
                 const u32x4 *ap = As + h * HP + p;
-                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2]; S[mt][2] = ap[HP * 4];
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+                if constexpr (!H2) S[mt][2] = ap[HP * 4];
             }
-            prod6x2(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
-                    acc1[1]);
+            if constexpr (H2)
+                prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+            else
+                prod6x2(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
+                        acc1[1]);
         }
     };
     for (int sl = 0; sl < nslice; sl += 2) {                  // C % 32 == 0: an even number of slices
@@ -1107,7 +1266,21 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33), one m-tile at a time in the
     // (now free) operand tile
     float *Hs = reinterpret_cast<float *>(As);
-    u32x4 H1[MT][2], H2[MT][2], H3[MT][2];
+    u32x4 H1[MT][2], Hb[MT][2], H3[MT][2];
+    float hscale = 1.0f, d2 = 1.0f;                  // H2: hidden-tile scale 2^kh, GEMM2 accumulator scale 2^-(kh + kw2)
+    if constexpr (H2) {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
+                m = fmaxf(m, acc1[mt][r]);
+            }
+        const int kh = wave_scale_exp(m);
+        hscale = __builtin_ldexpf(1.0f, kh);
+        d2 = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -1119,9 +1292,14 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
         float a2[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
-        split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], H2[mt][0], H3[mt][0]);
-        split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], H2[mt][1],
-               H3[mt][1]);
+        if constexpr (H2) {
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+        } else {
+            split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], Hb[mt][0], H3[mt][0]);
+            split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], Hb[mt][1],
+                   H3[mt][1]);
+        }
         __builtin_amdgcn_wave_barrier();
     }
 
@@ -1135,9 +1313,13 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
             for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
-            const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
-            prod6x2(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            const u32x4 *bp = W2s + nt * (128 * TERMS) + (t * 2 + h) * 32 + l31;
+            if constexpr (H2) {
+                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+            } else {
+                const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+                prod6x2(H1[0][t], Hb[0][t], H3[0][t], H1[1][t], Hb[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            }
         }
         if (img_ok) {
             // skip connection, activation and store in the staged layout: 16-byte loads and stores
@@ -1145,7 +1327,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
             for (int mt = 0; mt < MT; ++mt) {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc2[mt][r];
+                for (int r = 0; r < 16; ++r) v[r] = H2 ? acc2[mt][r] * d2 : acc2[mt][r];
                 // the four skip values of this lane are requested before the tile goes through LDS
                 f32x4 u[4];
 #pragma unroll
@@ -1940,6 +2122,15 @@ static size_t packed_floats(const ConvGeom &g) {
 static size_t packed_bf3_bytes(const ConvGeom &g) {
     return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 3072 * sizeof(unsigned short);
 }
+// two-term fp16 image: 2 terms x 32x32 fp16 per (phase, chunk, n_tile) = 4 KiB, behind a 256-byte header {int kw}
+constexpr size_t kH2Header = 256;
+static size_t packed_h2_bytes(const ConvGeom &g) {
+    return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 2048 * sizeof(unsigned short);
+}
+// byte offset of the header from the start of a layer's packed weights
+static size_t packed_h2_offset(const ConvGeom &g, int kind) {
+    return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
+}
 
 }  // namespace vqvae
 
@@ -1951,7 +2142,8 @@ size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout) {
     ConvGeom g;
     if (Cin < 1 || Cout < 1 || make_geom(kind, 1, 4, 4, Cin, Cout, 0, g) != VQVAE_OK) return 0;
     // [fp32 B-operand image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]
-    return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
+    // [header {kw}][two-term fp16 image][4x4 s2 only: the same in space-to-depth chunk order]
+    return packed_h2_offset(g, kind) + kH2Header + packed_h2_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
 }
 
 int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -1967,12 +2159,22 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
                        packed, g, total);
     // split-bf16 image right behind it (1024 bf16 elements per term per (phase, chunk, n_tile))
     const long long total3 = total;
-    hipLaunchKernelGGL(conv_pack_bf3_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       reinterpret_cast<unsigned short *>(packed + total), g, total3);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv_pack_bf3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned short *>(packed + total), g, total3, (const int *)nullptr);
+    // two-term fp16 image of w * 2^kw behind its header
+    char *h2 = reinterpret_cast<char *>(packed) + packed_h2_offset(g, kind);
+    int *hdr = reinterpret_cast<int *>(h2);
+    hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * g.kk, hdr);
+    hipLaunchKernelGGL(conv_pack_bf3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned short *>(h2 + kH2Header), g, total3, hdr);
     if (kind == VQVAE_CONV_4x4_S2) {
         g.s2d = 1;
-        hipLaunchKernelGGL(conv_pack_bf3_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                           reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2, g, total3);
+        hipLaunchKernelGGL(conv_pack_bf3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, w,
+                           reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2, g, total3,
+                           (const int *)nullptr);
+        hipLaunchKernelGGL(conv_pack_bf3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, w,
+                           reinterpret_cast<unsigned short *>(h2 + kH2Header + packed_h2_bytes(g)), g, total3, hdr);
     }
     return (int)hipGetLastError();
 }
@@ -2005,14 +2207,22 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
             const bool wide = g.ntile % 4 == 0;
             const int ny = (S2D_ ? 1 : g.nphase) * (g.ntile / (wide ? 4 : 2));
             const unsigned gxt = (unsigned)((B + (wide ? 7 : 3)) / (wide ? 8 : 4)) * ny;
-            const u32x4 *wsel = S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3;
+            const bool h2 = !(flags & VQVAE_CONV_BF16_SPLIT);
+            const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
+            const int *whdr = reinterpret_cast<const int *>(h2base);
+            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + kH2Header + (S2D_ ? packed_h2_bytes(g) : 0))
+                                   : (S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3);
+#define TILE8_LAUNCH(NT_, S2D__, NW_, H2_, THREADS_)                                                                   \
+    hipLaunchKernelGGL((conv_tile8_bf3_kernel<NT_, S2D__, NW_, 2, H2_>), dim3(gxt), dim3(THREADS_), 0, st, x, wsel, bias, y, \
+                       g, ny, whdr)
             if (wide) {
-                if (S2D_) hipLaunchKernelGGL((conv_tile8_bf3_kernel<4, true, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny);
-                else hipLaunchKernelGGL((conv_tile8_bf3_kernel<4, false, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny);
+                if (S2D_) { if (h2) TILE8_LAUNCH(4, true, 8, true, 512); else TILE8_LAUNCH(4, true, 8, false, 512); }
+                else      { if (h2) TILE8_LAUNCH(4, false, 8, true, 512); else TILE8_LAUNCH(4, false, 8, false, 512); }
             } else {
-                if (S2D_) hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, true, 4>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny);
-                else hipLaunchKernelGGL((conv_tile8_bf3_kernel<2, false, 4>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny);
+                if (S2D_) { if (h2) TILE8_LAUNCH(2, true, 4, true, 256); else TILE8_LAUNCH(2, true, 4, false, 256); }
+                else      { if (h2) TILE8_LAUNCH(2, false, 4, true, 256); else TILE8_LAUNCH(2, false, 4, false, 256); }
             }
+#undef TILE8_LAUNCH
         }
         else if (g.ntile % 4 == 0)
             hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
@@ -2060,10 +2270,21 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
         if (H == 8 && W == 8) {
             // whole 8x8 images per wave: operands split once and kept in LDS for all nine taps
             const unsigned gt = (unsigned)((B + 3) / 4);
-            switch (C / 32) {
-                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
-                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
-                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags); break;
+            if (!(flags & VQVAE_CONV_BF16_SPLIT)) {
+                // two-term fp16 images: [header {kw}][image] behind the bf16 ones (vqvae_conv_pack_f32)
+                const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+                const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+                const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+                const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+                switch (C / 32) {
+                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
+                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
+                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
+                }
+            } else switch (C / 32) {
+                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
+                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
+                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
             }
         } else switch (C / 32) {
             case 1: hipLaunchKernelGGL((res_layer_bf3_kernel<1>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
