@@ -105,4 +105,13 @@ int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out);
 
+// conv.hip: the per-layer entry points with the per-image activation maxima of the two-term fp16 product path
+// (arrays of B ints, -1 = not provided; NULL = none): written by a producing layer, read by the consuming one.
+int conv_forward_impl(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
+                      int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
+int res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
+                           int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
+int conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
+                         int Cout, int flags, float *y, hipStream_t stream, int *out_amax);
+
 }  // namespace vqvae

@@ -415,6 +415,15 @@ __device__ __forceinline__ int wave_scale_exp(float m) {
     return __builtin_amdgcn_readfirstlane(e);
 }
 
+// Producer side of the per-image activation scale: the wave's largest |output| of image `img` goes to out_amax[img]
+// (non-negative floats order like signed ints; the array starts at -1 = "not provided").  A consumer that finds a value
+// there skips its own pass over the image.
+__device__ __forceinline__ void publish_amax(int *out_amax, long long img, float om, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmaxf(om, __shfl_xor(om, o));
+    if (lane == 0) atomicMax(out_amax + img, __float_as_int(om));
+}
+
 // Weight scale of a layer: header {int kw} in front of its two-term fp16 image (one block).
 __global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, long long n, int *__restrict__ hdr) {
     __shared__ float red[256];
@@ -688,7 +697,8 @@ template <int NT, bool S2D, int NW, int WB = 2, bool H2 = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float *__restrict__ in,
                                                                 const u32x4 *__restrict__ wimg,
                                                                 const float *__restrict__ bias,
-                                                                float *__restrict__ out, ConvGeom g, int ny, const int *__restrict__ whdr) {
+                                                                float *__restrict__ out, ConvGeom g, int ny, const int *__restrict__ whdr,
+                                                                const int *__restrict__ in_amax, int *__restrict__ out_amax) {
     constexpr int MT = 2, PX = 64, PLANE = (PX + 1) * 2;        // u32x4 per (k-step, term) plane: [half][pixel + zero]
     constexpr int HP = PX + 1;                                   // (consecutive lanes = consecutive 16 B: no bank conflicts)
     constexpr int TERMS = H2 ? 2 : 3;
@@ -811,7 +821,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
     if constexpr (H2) {
         // the image's largest |x| (after the input ReLU) -> its power-of-two scale; the image is read again below (L2)
         float m = 0.0f;
-        for (int c2 = 0; c2 < cpt; ++c2) {
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;        // the producer's maximum of this image, if any
+        if (given >= 0) m = __int_as_float(given);
+        else for (int c2 = 0; c2 < cpt; ++c2) {
             load_raw(c2);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -917,6 +929,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
     }
+    float omax = 0.0f;
     if (img_ok && (g.Cout & 7) == 0) {
         // the operand tile is free now (wave-private): stage the outputs through it, 16-byte stores
         float *tile = reinterpret_cast<float *>(As);
@@ -929,6 +942,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 for (int r = 0; r < 16; ++r) {
                     v[r] = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                    omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
                 tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
                     const int px = 32 * mt + p;
@@ -954,11 +968,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                     if (n < g.Cout) {
                         float v = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
                         if (relu_out) v = fmaxf(v, 0.0f);
+                        omax = fmaxf(omax, __builtin_fabsf(v));
                         out[off + n] = v;
                     }
                 }
             }
     }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1131,7 +1147,8 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                                                                const u32x4 *__restrict__ w1img,
                                                                const u32x4 *__restrict__ w2img,
                                                                float *__restrict__ out, int B, int C, int flags,
-                                                               const int *__restrict__ hdr1, const int *__restrict__ hdr2) {
+                                                               const int *__restrict__ hdr1, const int *__restrict__ hdr2,
+                                                               const int *__restrict__ in_amax, int *__restrict__ out_amax) {
     constexpr int TERMS = H2 ? 2 : 3;
     constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][half][pixel + zero] (sized for 3 terms: the hidden tile aliases it)
     constexpr int HP = PX + 1;                                     // (consecutive lanes = consecutive 16 B: no bank conflicts)
@@ -1196,7 +1213,9 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     float xscale = 1.0f, d1 = 1.0f;                  // H2: image scale 2^kx, GEMM1 accumulator scale 2^-(kx + kw1)
     if constexpr (H2) {
         float m = 0.0f;
-        for (int sl = 0; sl < nslice; ++sl) {
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;        // the producer's maximum of this image, if any
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
             load_raw(sl, raw);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -1304,6 +1323,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     }
 
     const long long wbase = img * PX;
+    float omax = 0.0f;
 #pragma unroll
     for (int nt = 0; nt < NT2; ++nt) {
         f32x16 acc2[MT];
@@ -1339,11 +1359,13 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
                     if (relu_in) u0 = relu4(u0);
                     f32x4 y0 = u0 + a4;
                     if (relu_out) y0 = relu4(y0);
+                    omax = fmaxf(omax, fmaxf(fmaxf(__builtin_fabsf(y0.x), __builtin_fabsf(y0.y)), fmaxf(__builtin_fabsf(y0.z), __builtin_fabsf(y0.w))));
                     *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = y0;
                 });
             }
         }
     }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -1622,7 +1644,7 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
                                                            const float *__restrict__ wimg,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int B, int H, int W,
-                                                           int Cout, int flags) {
+                                                           int Cout, int flags, int *__restrict__ out_amax) {
     constexpr int MT = 2, S = CIN * 8, JG = (S + 3) / 4;
     constexpr int WF = BF3 ? NT * CIN * 768 : NT * JG * 256;     // floats of the weight image
     extern __shared__ __attribute__((aligned(16))) float smem_ci[];
@@ -1711,6 +1733,7 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
     }
     const bool relu_out = flags & kFlagReluOut;
     const long long wbase = band * 256 + wave * (32 * MT);
+    float omax = 0.0f;
     float bv[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) bv[nt] = (bias && nt * 32 + l31 < Cout) ? bias[nt * 32 + l31] : 0.0f;
@@ -1726,11 +1749,13 @@ __global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restri
                 for (int r = 0; r < 16; ++r) {
                     v[r] = acc[mt][nt][r] + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                    if (nt * 32 + l31 < Cout) omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
                 tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
                     if (n < Cout) *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * Cout + n) = a4;
                 });
             }
+        if (out_amax) publish_amax(out_amax, b, omax, lane);       // the band's 256 pixels belong to image b
         return;
     }
 #pragma unroll
@@ -2181,6 +2206,14 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
 
 int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B,
                            int H, int W, int Cin, int Cout, int flags, float *y, vqvae_stream_t stream) {
+    return vqvae::conv_forward_impl(kind, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+}  // extern "C"
+
+// in_amax / out_amax: per-image activation maxima handed from layer to layer inside the whole-path entry points
+// (model.hip); NULL from the per-layer C entry points, where the consuming kernel measures its image itself.
+int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
+                             int Cin, int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax) {
     if (!x || !packed || !y) return VQVAE_ERR_NULL;
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return VQVAE_ERR_SHAPE;
     if (Cin % 4) return VQVAE_ERR_UNSUPPORTED;          // float4 activation loads
@@ -2214,7 +2247,7 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
                                    : (S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3);
 #define TILE8_LAUNCH(NT_, S2D__, NW_, H2_, THREADS_)                                                                   \
     hipLaunchKernelGGL((conv_tile8_bf3_kernel<NT_, S2D__, NW_, 2, H2_>), dim3(gxt), dim3(THREADS_), 0, st, x, wsel, bias, y, \
-                       g, ny, whdr)
+                       g, ny, whdr, in_amax, out_amax)
             if (wide) {
                 if (S2D_) { if (h2) TILE8_LAUNCH(4, true, 8, true, 512); else TILE8_LAUNCH(4, true, 8, false, 512); }
                 else      { if (h2) TILE8_LAUNCH(4, false, 8, true, 512); else TILE8_LAUNCH(4, false, 8, false, 512); }
@@ -2251,8 +2284,16 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
     return (int)hipGetLastError();
 }
 
+extern "C" {
+
 int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B,
                                 int H, int W, int C, int Rh, int flags, float *y, vqvae_stream_t stream) {
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+}  // extern "C"
+
+int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
+                                  int C, int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax) {
     if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
     if (B < 1 || H < 1 || W < 1 || C < 1 || Rh < 1) return VQVAE_ERR_SHAPE;
     if (Rh > 32 || C % 4 || !(C == 32 || C == 64 || C == 128)) return VQVAE_ERR_UNSUPPORTED;
@@ -2277,14 +2318,14 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
                 const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
                 const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
                 switch (C / 32) {
-                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
-                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
-                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2); break;
+                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
                 }
             } else switch (C / 32) {
-                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
-                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
-                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr); break;
+                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
+                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
+                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
             }
         } else switch (C / 32) {
             case 1: hipLaunchKernelGGL((res_layer_bf3_kernel<1>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
@@ -2301,6 +2342,8 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();
 }
+
+extern "C" {
 
 size_t vqvae_conv_in_packed_bytes(int Cin, int Cout) {
     if (!(Cin == 1 || Cin == 3 || Cin == 4) || Cout < 1 || Cout > 128) return 0;
@@ -2330,6 +2373,12 @@ int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqv
 
 int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H,
                               int W, int Cin, int Cout, int flags, float *y, vqvae_stream_t stream) {
+    return vqvae::conv_in_forward_impl(x_nchw, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr);
+}
+}  // extern "C"
+
+int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W,
+                                int Cin, int Cout, int flags, float *y, hipStream_t stream, int *out_amax) {
     if (!x_nchw || !packed || !y) return VQVAE_ERR_NULL;
     if (B < 1 || H < 2 || W < 2) return VQVAE_ERR_SHAPE;
     if (H % 2 || W % 2 || vqvae_conv_in_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
@@ -2352,10 +2401,10 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
     do {                                                                                                           \
         if (rows && rows_lds <= 64 * 1024 && bf3)                                                                  \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, true>), dim3(gx), dim3(256), rows_lds, st, x_nchw,  \
-                               packed3, bias, y, (int)B, H, W, Cout, flags);                                       \
+                               packed3, bias, y, (int)B, H, W, Cout, flags, out_amax);                             \
         else if (rows && rows_lds <= 64 * 1024)                                                                    \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, false>), dim3(gx), dim3(256), rows_lds, st, x_nchw, \
-                               packed, bias, y, (int)B, H, W, Cout, flags);                                        \
+                               packed, bias, y, (int)B, H, W, Cout, flags, out_amax);                              \
         else                                                                                                       \
             hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
                                (int)B, H, W, Cout, flags);                                                         \
@@ -2377,6 +2426,8 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
     prof_end(VQVAE_PROF_CONV_IN, st);
     return (int)hipGetLastError();
 }
+
+extern "C" {
 
 size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
     if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;

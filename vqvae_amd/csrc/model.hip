@@ -35,8 +35,9 @@ size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
     return half > quarter ? half : quarter;
 }
 
+// amax: NULL, or (n_layers + 1) arrays of B ints (-1 = not provided): [0] belongs to x, [i + 1] to layer i's output
 int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
-              bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out) {
+              bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr) {
     // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
     // the producer applies it; buffers alternate so that the result of the LAST layer lands in y
     const float *cur = x;
@@ -45,13 +46,18 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
         int flags = (i == 0 && first_relu_in) ? VQVAE_CONV_RELU_IN : 0;
         if (i < n_layers - 1 || final_relu) flags |= VQVAE_CONV_RELU_OUT;
         float *dst = ((n_layers - 1 - i) % 2 == 0) ? y : tmp;
-        const int rc = vqvae_res_layer_forward_f32(cur, w1, w2, B, H, W, C, Rh, flags, dst, st);
+        const int rc = res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, amax ? amax + (size_t)i * B : nullptr,
+                                              amax ? amax + (size_t)(i + 1) * B : nullptr);
         if (rc != 0) return rc;
         cur = dst;
     }
     *out = cur;
     return 0;
 }
+
+// per-image activation maxima handed from layer to layer (two-term fp16 product path): one array of B ints per
+// inter-layer activation of the encoder (conv_in, enc2, enc4, n residual layers) or the decoder (dec0, n residual layers)
+size_t amax_bytes(const VqvaeDims *d, int64_t B) { return align_up((size_t)(3 + d->n_res_layers) * B * sizeof(int), 256); }
 
 }  // namespace
 }  // namespace vqvae
@@ -135,8 +141,8 @@ size_t vqvae_workspace_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
     const size_t act = align_up(act_elems(d, B, H, W) * sizeof(float), 256);
     const size_t lat = align_up((size_t)B * (H / 4) * (W / 4) * d->embedding_dim * sizeof(float), 256);
     const size_t rows = (size_t)B * (H / 4) * (W / 4);
-    return 2 * act + 2 * lat + align_up(rows * sizeof(int64_t), 256) + align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) +
-           align_up(vq, 256) + 256;
+    return 2 * act + amax_bytes(d, B) + 2 * lat + align_up(rows * sizeof(int64_t), 256) +
+           align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) + align_up(vq, 256) + 256;
 }
 
 int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const float *x, int64_t B, int H, int W, int C,
@@ -159,21 +165,28 @@ int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // optional: the per-image maxima (a workspace of the documented size has room; without them every consumer measures
+    // its own image)
+    int *am = static_cast<int *>(c.raw(amax_bytes(d, B)));
+    if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    int *am0 = am, *am1 = am ? am + B : nullptr, *am2 = am ? am + 2 * B : nullptr;     // conv_in, enc2, enc4 (+ residual layers)
     const int h = d->h_dim;
     int rc;
     // encoder.py:29-31, :32-34, :35-36 (+ the residual stack's first in-place ReLU, residual.py:19)
-    if ((rc = vqvae_conv_in_forward_f32(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
-    if ((rc = vqvae_conv_forward_f32(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st)) != 0) return rc;
-    if ((rc = vqvae_conv_forward_f32(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
+    if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st, am0)) != 0) return rc;
+    if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st, am0, am1)) != 0) return rc;
+    if ((rc = conv_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT, a, st, am1, am2)) != 0) return rc;
     const float *t = a;
+    const int *amt = am2;
     if (d->n_res_layers > 0) {                                                                  // encoder.py:37-38
         // the first layer must not write into its own input (a): with an even layer count the result comes back to a
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
-        if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t)) != 0)
+        if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am2)) != 0)
             return rc;
+        if (am2) amt = am2 + (size_t)d->n_res_layers * B;
     }
     // n_res_layers == 0: F.relu of an already ReLU'd tensor is the identity
-    return vqvae_conv_forward_f32(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st);   // vqvae.py:33
+    return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st, amt, nullptr);   // vqvae.py:33
 }
 
 int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
@@ -186,17 +199,21 @@ int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    int *am = static_cast<int *>(c.raw(amax_bytes(d, B)));                    // optional, see vqvae_encoder_f32
+    if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
     const int h = d->h_dim;
     int rc;
     // decoder.py:28-29 (+ the stack's first in-place ReLU), :30, :31-33, :34-35
-    if ((rc = vqvae_conv_forward_f32(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st)) != 0) return rc;
+    if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, nullptr, am)) != 0) return rc;
     const float *t = a;
+    const int *amt = am;
     if (d->n_res_layers > 0) {
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
-        if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t)) != 0) return rc;
+        if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am)) != 0) return rc;
+        if (am) amt = am + (size_t)d->n_res_layers * B;
     }
     float *u = (t == a) ? b : a;
-    if ((rc = vqvae_conv_forward_f32(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st)) != 0) return rc;
+    if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st, amt, nullptr)) != 0) return rc;
     return vqvae_convt_out_forward_f32(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st);
 }
 
@@ -211,7 +228,7 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     Carve c{static_cast<char *>(workspace), workspace_bytes};
     const size_t act = act_elems(d, B, H, W);
     const size_t rows = (size_t)B * (H / 4) * (W / 4);
-    void *acts = c.raw(2 * align_up(act * sizeof(float), 256));
+    void *acts = c.raw(2 * align_up(act * sizeof(float), 256) + amax_bytes(d, B));
     float *z_e = c.f32(rows * d->embedding_dim), *z_q = c.f32(rows * d->embedding_dim);
     int64_t *idx_ws = static_cast<int64_t *>(c.raw(rows * sizeof(int64_t)));
     int32_t *hist = static_cast<int32_t *>(c.raw((size_t)d->n_embeddings * sizeof(int32_t)));
@@ -224,7 +241,7 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
     }
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
-    const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256);
+    const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256) + amax_bytes(d, B);
     int rc;
     if ((rc = vqvae_encoder_f32(w, x, B, H, W, z_e, acts, acts_bytes, stream)) != 0) return rc;                 // vqvae.py:31-33
     if ((rc = vqvae_vq_forward_f32(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
