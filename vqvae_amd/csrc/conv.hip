@@ -1640,7 +1640,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
 // registers) instead of 4*CIN fp32 MFMAs -- 2.7x less matrix time, which is what this otherwise memory-bound
 // layer was waiting on.
 template <int CIN, int NT, bool BF3>
-__global__ __launch_bounds__(256) void conv_in_rows_kernel(const float *__restrict__ x,
+__global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__restrict__ x,
                                                            const float *__restrict__ wimg,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int B, int H, int W,
