@@ -318,20 +318,26 @@ def main():
             if conv_backend == "hip" and "conv_igemm" in extra and "res_layer" in extra:
                 t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
                 alg_tf = B * conv_flops_per_image(H, W, D) / t_conv / 1e12
+                # 16-bit MFMA term products per fp32 multiply-add on this workload's maps (3 = two-term fp16 on 8x8 maps,
+                # 6 = three-term bf16 on larger ones), asked of the library for the 3x3 layer at the latent resolution
+                terms = _lib.load().vqvae_conv_term_products(1, H // 4, W // 4, 128, 128, 0) or 6
+                scheme = ("two-term fp16 products: 3 fp16 MFMA term products per fp32 product" if terms == 3 else
+                          "three-term bf16 products: 6 bf16 MFMA term products per fp32 product")
                 line["roofline_conv"] = {
                     "kernel": "conv / conv-transpose / fused residual-layer kernels between the first and the last layer "
-                              "(split-bf16 products: 6 bf16 MFMA term products per fp32 product)",
-                    "bound": "mfma", "achieved": round(6 * alg_tf, 1), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(6 * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4),
+                              f"({scheme})",
+                    "bound": "mfma", "achieved": round(terms * alg_tf, 1), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(terms * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4),
+                    "term_products_per_mac": terms,
                     "achieved_algorithmic_tflops": round(alg_tf, 1),
-                    "frac_of_split_bf16_ceiling": round(alg_tf / (MFMA_16BIT_PEAK_TFLOPS / 6), 4),
+                    "frac_of_split_ceiling": round(alg_tf / (MFMA_16BIT_PEAK_TFLOPS / terms), 4),
                     "frac_of_fp32_mfma_peak": round(alg_tf / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": int(pmc["conv_bytes_per_image"] * B) if pmc and "conv_bytes_per_image" in pmc else None,
                     "traffic_source": pmc["_path"] if pmc and "conv_bytes_per_image" in pmc else None,
                     "flops_per_image": conv_flops_per_image(H, W, D), "ms_per_step": round(t_conv * 1e3, 4),
-                    "note": "achieved = bf16 MFMA flop ISSUED (6 term products per fp32 product) / live HIP-event time; "
-                            "achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
-                            "would be credited with): its ceiling on this path is 2500/6 = 417 TF",
+                    "note": f"achieved = 16-bit MFMA flop ISSUED ({terms} term products per fp32 product) / live HIP-event "
+                            "time; achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
+                            f"would be credited with): its ceiling on this path is 2500/{terms} = {2500 // terms} TF",
                 }
             line["kernels"] = extra
             if n_gpus == 1 and not args.no_cpu_baseline:

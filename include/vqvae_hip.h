@@ -171,6 +171,10 @@ VQVAE_API int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, f
 /* y = conv(x) + bias [ReLU]; x (B,H,W,Cin) row-major, y (B,Hout,Wout,Cout) row-major; bias may be
  * NULL.  Cin must be a multiple of 4.  Replaces one nn.Conv2d / nn.ConvTranspose2d call.
  * packed: [fp32 image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]. */
+/* How many 16-bit MFMA term products vqvae_conv_forward_f32 issues per fp32 multiply-add for this layer shape: 3 (two-term
+ * fp16, 8x8 maps), 6 (three-term bf16), 1 (VQVAE_CONV_EXACT_FP32), 0 = unsupported shape.  For reporting (bench.py). */
+VQVAE_API int vqvae_conv_term_products(int kind, int H, int W, int Cin, int Cout, int flags);
+
 VQVAE_API int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias,
                                      int64_t B, int H, int W, int Cin, int Cout, int flags,
                                      float *y, vqvae_stream_t stream);

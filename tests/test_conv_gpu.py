@@ -50,12 +50,13 @@ CONV_CASES = [
 KIND = {"conv4x4s2": 0, "conv3x3": 1, "conv1x1": 2, "convT3x3": 3, "convT4x4s2": 4}
 
 
-@pytest.mark.parametrize("exact", [False, True], ids=["splitbf16", "fp32mfma"])
+@pytest.mark.parametrize("exact", [0, 4, 8], ids=["default", "fp32mfma", "bf16split"])
 @pytest.mark.parametrize("relu_in,relu_out", [(False, False), (True, True)])
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: f"{c[0]}-{c[3]}to{c[4]}-{c[5]}x{c[6]}")
 def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out, exact):
-    """Both product paths: the default split-bf16 one (three exact bf16 terms per operand, six term
-    products on the bf16 matrix cores, fp32 accumulate) and the exact-fp32 MFMA one (flag 0x4)."""
+    """All product paths: the default (two-term fp16 products with per-image / per-layer power-of-two scales on 8x8 maps,
+    three-term bf16 products elsewhere; fp32 accumulate), the three-term bf16 one everywhere (flag 0x8) and the
+    exact-fp32 MFMA one (flag 0x4)."""
     from vqvae_amd import conv_hip
     name, ctor, B, Cin, Cout, H, W = case
     torch.manual_seed(hash(name) % 1000 + Cin + Cout)
@@ -67,10 +68,73 @@ def test_conv_layer_vs_torch_cpu(case, relu_in, relu_out, exact):
             ref = torch.relu(ref)
     md = ctor(Cin, Cout).to(dev())
     md.load_state_dict(m.state_dict())
-    flags = (1 if relu_in else 0) | (2 if relu_out else 0) | (4 if exact else 0)
+    flags = (1 if relu_in else 0) | (2 if relu_out else 0) | exact
     y = conv_hip.conv(KIND[name], rows(x.to(dev())), md, md.weight, md.bias, Cin, Cout, flags)
     torch.cuda.synchronize()
     close(nchw(y).cpu().numpy(), ref.numpy())
+
+
+@pytest.mark.parametrize("kind,ctor,Cin,Cout,H,W", [
+    ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1), 128, 128, 8, 8),
+    ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1), 64, 128, 16, 16),
+    ("convT4x4s2", lambda ci, co: nn.ConvTranspose2d(ci, co, 4, 2, 1), 128, 64, 8, 8),
+    ("conv1x1", lambda ci, co: nn.Conv2d(ci, co, 1, 1), 128, 64, 8, 8),
+])
+@pytest.mark.parametrize("wscale", [1.0, 3.0e-5, 7.0e3])
+def test_fp16_two_term_scaling_extremes(kind, ctor, Cin, Cout, H, W, wscale):
+    """The two-term fp16 path lives on exact power-of-two scales: one per image for the activations, one per layer for
+    the weights.  Images of one batch 12 orders of magnitude apart (each far outside fp16's own range), an all-zero
+    image, weights scaled far below / above fp16's normal range: every image must still match torch's fp32 conv to the
+    usual tolerance RELATIVE TO ITS OWN magnitude."""
+    from vqvae_amd import conv_hip
+    torch.manual_seed(Cin + Cout + H)
+    m = ctor(Cin, Cout)
+    with torch.no_grad():
+        m.weight.mul_(wscale)
+        m.bias.zero_()
+    mags = [1.0, 1.0e-6, 3.0e5, 0.0, 2.5e-3, 6.0e4, 1.0e6, 40.0]
+    x = torch.randn(len(mags), Cin, H, W) * torch.tensor(mags).view(-1, 1, 1, 1)
+    with torch.no_grad():
+        ref = m(x)
+    md = ctor(Cin, Cout).to(dev())
+    md.load_state_dict(m.state_dict())
+    y = nchw(conv_hip.conv(KIND[kind], rows(x.to(dev())), md, md.weight, md.bias, Cin, Cout, 0)).cpu().numpy()
+    for i, mag in enumerate(mags):
+        r = ref[i].numpy()
+        np.testing.assert_allclose(y[i], r, atol=1e-5 * max(np.abs(r).max(), 1e-30), rtol=RTOL, err_msg=f"image {i} (x{mag})")
+    assert np.all(y[3] == 0.0)
+
+
+@pytest.mark.parametrize("mag", [1.0, 1.0e-5, 2.0e4])
+def test_fp16_two_term_residual_layer_scales(mag):
+    """Fused residual layer on the two-term fp16 path: x, the hidden tile and both weight tensors each get their own
+    scale; compare with torch per image, images of different magnitude in one batch."""
+    from vqvae_amd import conv_hip
+    from vqvae_amd.modules import ResidualLayer
+    torch.manual_seed(11)
+    layer = ResidualLayer(128, 128, 32)
+    mags = torch.tensor([mag, 1.0, mag * 300.0, 0.0, mag * 1e-3]).view(-1, 1, 1, 1)
+    x = torch.randn(5, 128, 8, 8) * mags
+    with torch.no_grad():                                 # models/residual.py:27-29 with its in-place ReLU: relu(x) + block
+        xr = torch.relu(x)
+        ref = xr + F.conv2d(torch.relu(F.conv2d(xr, layer.res_block[1].weight, padding=1)), layer.res_block[3].weight)
+    ld = ResidualLayer(128, 128, 32).to(dev())
+    ld.load_state_dict(layer.state_dict())
+    for flags in (1, 1 | 8):                              # RELU_IN; the same with the three-term bf16 products
+        y = nchw(conv_hip.res_layer(rows(x.to(dev())), ld, flags)).cpu().numpy()
+        for i in range(5):
+            r = ref[i].numpy()
+            np.testing.assert_allclose(y[i], r, atol=1e-5 * max(np.abs(r).max(), 1e-30), rtol=RTOL, err_msg=f"image {i}")
+
+
+def test_conv_term_products_query():
+    from vqvae_amd import _lib
+    L = _lib.load()
+    assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 0) == 3         # 8x8 map: two-term fp16
+    assert L.vqvae_conv_term_products(0, 16, 16, 64, 128, 0) == 3        # 4x4 s2 on a 16x16 map (tile kernel)
+    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0) == 6       # larger maps: three-term bf16
+    assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 8) == 6         # VQVAE_CONV_BF16_SPLIT
+    assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 4) == 1         # VQVAE_CONV_EXACT_FP32
 
 
 def test_conv_vs_c_oracle():

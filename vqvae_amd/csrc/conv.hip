@@ -2204,6 +2204,15 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
     return (int)hipGetLastError();
 }
 
+int vqvae_conv_term_products(int kind, int H, int W, int Cin, int Cout, int flags) {
+    ConvGeom g;
+    if (Cin < 1 || Cout < 1 || H < 1 || W < 1 || make_geom(kind, 1, H, W, Cin, Cout, flags, g) != VQVAE_OK) return 0;
+    if (flags & VQVAE_CONV_EXACT_FP32) return 1;
+    const bool tile8 = g.Hin == 8 && g.Win == 8 && g.istride == 1 && g.Hg == 8 && g.Wg == 8 && Cin % 32 == 0 && g.ntile % 2 == 0;
+    const bool s2d = !tile8 && kind == VQVAE_CONV_4x4_S2 && g.Hin == 16 && g.Win == 16 && Cin % 32 == 0 && g.ntile % 2 == 0;
+    return ((tile8 || s2d) && !(flags & VQVAE_CONV_BF16_SPLIT)) ? 3 : 6;
+}
+
 int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B,
                            int H, int W, int Cin, int Cout, int flags, float *y, vqvae_stream_t stream) {
     return vqvae::conv_forward_impl(kind, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
