@@ -1143,14 +1143,17 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 // H2: two-term fp16 products (split8_h): per-image scale for x, a second one for the hidden tile, per-layer weight scales
 // in the headers hdr1 / hdr2 of the two weight images.
 template <int NT2, bool H2 = false>
-__global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const float *__restrict__ in,
                                                                const u32x4 *__restrict__ w1img,
                                                                const u32x4 *__restrict__ w2img,
                                                                float *__restrict__ out, int B, int C, int flags,
                                                                const int *__restrict__ hdr1, const int *__restrict__ hdr2,
                                                                const int *__restrict__ in_amax, int *__restrict__ out_amax) {
     constexpr int TERMS = H2 ? 2 : 3;
-    constexpr int MT = 2, PX = 64, TILE4 = 3 * (PX + 1) * 2;      // u32x4 per wave tile: [term][half][pixel + zero] (sized for 3 terms: the hidden tile aliases it)
+    // u32x4 per wave tile: [term][half][pixel + zero], at least the 32 x 33 floats of the hidden tile that aliases it.
+    // H2: 4.1 KiB per wave + 16 KiB of W2 = 33 KiB per workgroup -> four workgroups (16 waves) per CU, and the 1024
+    // workgroups of a B = 4096 layer are all resident at once (no second, part-filled round)
+    constexpr int MT = 2, PX = 64, TILE4 = H2 ? 264 : 3 * (PX + 1) * 2;
     constexpr int HP = PX + 1;                                     // (consecutive lanes = consecutive 16 B: no bank conflicts)
     static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
     __shared__ u32x4 W2s[NT2 * 128 * TERMS];
@@ -1162,7 +1165,7 @@ __global__ __launch_bounds__(256, 3) void res_tile8_bf3_kernel(const float *__re
     const int cpt = C >> 5, nslice = C >> 4;
 
     for (int i = tid; i < NT2 * 128 * TERMS; i += 256) W2s[i] = w2img[i];
-    if (lane < 6) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
+    if (lane < 2 * TERMS) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
 
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
