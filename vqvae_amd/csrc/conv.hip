@@ -876,6 +876,10 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const u32x4 *bp = bs + nt * 256 + (t * 2 + h) * 32 + l31;
+#if defined(TILE8_KNOB) && TILE8_KNOB == 1      // timing-only knock-outs (wrong results): 1 = no MFMAs (operands still read)
+                    asm volatile("" :: "v"(A1[0]), "v"(A2[0]), "v"(A1[1]), "v"(A2[1]), "v"(bp[0]), "v"(bp[128]));
+                    continue;
+#endif
                     prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], acc[0][nt], acc[1][nt]);
                 }
                 continue;
@@ -913,6 +917,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         // then fetch the iteration after that
         int ntap = tap + 1, ncc = cc;
         if (ntap == ntaps) { ntap = 0; ++ncc; }
+#if defined(TILE8_KNOB) && TILE8_KNOB == 2      // 2 = weights loaded once (no weight stream through global -> LDS after the first two chunks)
+        if (it >= 1) { tap = ntap; cc = ncc; continue; }
+#endif
         if (it + 1 < niter) {
             if (WB == 1) __syncthreads();                  // single buffer: every wave is done reading this iteration's weights
             store_b(WB == 2 ? ((it + 1) & 1) : 0);
