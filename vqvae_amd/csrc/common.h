@@ -111,6 +111,9 @@ int conv_forward_impl(int kind, const float *x, const float *packed, const float
                       int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
 int res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                            int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
+bool res_pair_supported(int H, int W, int C, int Rh, int flags);
+int res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
+                          int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
 int conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
                          int Cout, int flags, float *y, hipStream_t stream, int *out_amax);
 

@@ -1379,6 +1379,278 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 }
 
 // ---------------------------------------------------------------------------
+// TWO residual layers of a stack in one kernel (models/residual.py:47-51: the layers of a stack share their weights), 8x8
+// maps, two-term fp16 products.  One wave owns one image; the first layer's output never leaves the chip:
+//   layer 1:  as res_tile8_bf3_kernel<., true>, but the skip relu(x) is added in the ACCUMULATOR layout (dword loads, 128
+//             contiguous bytes per pixel row) and y1' = relu(relu(x) + W2 h1) -- the ReLU is the second layer's in-place
+//             one -- stays in 128 registers per lane, Y[m-tile][n-tile][16];
+//   layer 2:  per 32-channel chunk Y goes accumulator layout -> [pixel][channel] through the wave's LDS tile (the hidden
+//             tile's path), is split with the image's scale (maximum taken from the registers) and parked as the 3x3 GEMM's
+//             operands; the skip of the second 1x1 GEMM comes straight from Y.
+// HBM-side traffic per pair of layers: x read twice (reduction + skip), y2 written once -- 3 maps instead of 6.
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w1img,
+                                                              const u32x4 *__restrict__ w2img, float *__restrict__ out,
+                                                              int B, int C, int flags, const int *__restrict__ hdr1,
+                                                              const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                              int *__restrict__ out_amax) {
+    constexpr int MT = 2, PX = 64, TILE4 = 264, HP = PX + 1;
+    __shared__ u32x4 W2s[NT2 * 256];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    float *Hs = reinterpret_cast<float *>(As);
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+    if (lane < 4) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
+
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+    const float *src = in + (size_t)(img_ok ? img : 0) * PX * C + (size_t)lane * C;   // this lane's pixel row
+    const int kw1 = hdr1[0], kw2 = hdr2[0];
+
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        }
+        tapok[mt] = m;
+    }
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[2]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+    };
+    // nine taps of one parked 16-channel slice into acc1; PAR = which weight register set is current at tap 0
+    u32x4 bw[2][2];
+    f32x16 acc1[MT];
+    auto taps = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+            u32x4 S[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + h * HP + p;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+            }
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+        }
+    };
+    // hidden tile: relu, scale, accumulator layout -> A operands of the 1x1 GEMM; returns that GEMM's accumulator scale
+    u32x4 H1[MT][2], Hb[MT][2];
+    auto hidden = [&](float d1) -> float {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
+                m = fmaxf(m, acc1[mt][r]);
+            }
+        const int kh = wave_scale_exp(m);
+        const float hscale = __builtin_ldexpf(1.0f, kh);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc1[mt][r];
+            lds_order_wave();
+            float a2[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return __builtin_ldexpf(1.0f, -(kh + kw2));
+    };
+    auto gemm2 = [&](int nt, f32x16(&acc2)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+            prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+        }
+    };
+
+    // =========================================== layer 1 ===========================================
+    auto load_raw = [&](int sl, f32x4(&r)[4]) {
+        const float *q = src + 32 * (sl >> 1) + 8 * (sl & 1);
+        r[0] = *reinterpret_cast<const f32x4 *>(q);
+        r[1] = *reinterpret_cast<const f32x4 *>(q + 4);
+        r[2] = *reinterpret_cast<const f32x4 *>(q + 16);
+        r[3] = *reinterpret_cast<const f32x4 *>(q + 20);
+    };
+    f32x4 raw[4];
+    float xscale, d1;
+    {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl, raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = raw[j];
+                if (relu_in) v = relu4(v);
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+            }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+    load_raw(0, raw);
+    load_w(0, 0, bw[0]);
+    auto slice1 = [&](int sl, auto PAR) {
+        if (relu_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
+        }
+        u32x4 t1a, t2a, t1b, t2b;
+        split8_h(raw[0], raw[1], xscale, t1a, t2a);
+        split8_h(raw[2], raw[3], xscale, t1b, t2b);
+        if (sl + 1 < nslice) load_raw(sl + 1, raw);
+        __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+        u32x4 *dst = As + lane;
+        dst[0] = t1a; dst[HP] = t1b;
+        dst[HP * 2] = t2a; dst[HP * 3] = t2b;
+        lds_order_wave();
+        taps(sl, PAR);
+    };
+    for (int sl = 0; sl < nslice; sl += 2) {
+        slice1(sl, std::integral_constant<int, 0>{});
+        slice1(sl + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+    float Y[MT][NT2][16];
+    {
+        const float d2 = hidden(d1);
+        const float *xb = in + (size_t)(img_ok ? img : 0) * PX * C;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16 acc2[MT];
+            // the skip values in accumulator layout: element r of m-tile mt = pixel 32 mt + (r&3) + 8 (r>>2) + 4 h, channel
+            // 32 nt + l31 (the first m-tile's are requested before the GEMM, the second's behind it: 16 live registers)
+            float u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = xb[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * C + nt * 32 + l31];
+            gemm2(nt, acc2);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float u0 = relu_in ? fmaxf(u[r], 0.0f) : u[r];
+                    Y[mt][nt][r] = fmaxf(u0 + acc2[mt][r] * d2, 0.0f);       // + the second layer's in-place ReLU
+                }
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) u[r] = xb[(size_t)(32 * (mt + 1) + (r & 3) + 8 * (r >> 2) + 4 * h) * C + nt * 32 + l31];
+                }
+            }
+        }
+    }
+
+    // =========================================== layer 2 ===========================================
+    {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, Y[mt][nt][r]);
+        const int kx = wave_scale_exp(m);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+    load_w(0, 0, bw[0]);
+#pragma unroll
+    for (int c = 0; c < NT2; ++c) {
+        // chunk c of Y: accumulator layout -> lane (pixel l31 of tile mt, half h) holds channels 32 c + 16 h + [0, 16); the
+        // transposition runs once per 16-channel slice (eight of the sixteen values each time: LDS traffic is cheaper
+        // than sixteen more live registers next to Y)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 t1[MT], t2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_wave_barrier();          // the previous slice's taps / the previous tile's reads are behind us
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                lds_order_wave();
+                float a2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xscale, t1[mt], t2[mt]);
+            }
+            __builtin_amdgcn_wave_barrier();              // scratch reads are done
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                As[(0 * 2 + h) * HP + 32 * mt + l31] = t1[mt];
+                As[(1 * 2 + h) * HP + 32 * mt + l31] = t2[mt];
+            }
+            if (lane < 4) As[lane * HP + PX] = u32x4{0, 0, 0, 0};      // the padding pixel was under the transposition scratch
+            lds_order_wave();
+            if (s2 == 0) taps(2 * c, std::integral_constant<int, 0>{});
+            else taps(2 * c + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    {
+        const float d2 = hidden(d1);
+        const long long wbase = img * PX;
+        float omax = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16 acc2[MT];
+            gemm2(nt, acc2);
+            if (img_ok) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        v[r] = Y[mt][nt][r] + acc2[mt][r] * d2;
+                        if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                        omax = fmaxf(omax, __builtin_fabsf(v[r]));
+                    }
+                    tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
+                        *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
+                    });
+                }
+            }
+        }
+        if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
@@ -2357,6 +2629,35 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
             case 2: hipLaunchKernelGGL((res_layer_kernel<2>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
             case 4: hipLaunchKernelGGL((res_layer_kernel<4>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
         }
+    }
+    prof_end(VQVAE_PROF_RES_LAYER, st);
+    return (int)hipGetLastError();
+}
+
+// Two layers of a residual stack (shared weights) in one launch: 8x8 maps on the two-term fp16 path only.  x == y is
+// allowed (every wave reads its image completely before it writes it).  Returns VQVAE_ERR_UNSUPPORTED when the caller
+// has to run the two layers separately.
+bool vqvae::res_pair_supported(int H, int W, int C, int Rh, int flags) {
+    return H == 8 && W == 8 && Rh >= 1 && Rh <= 32 && (C == 32 || C == 64 || C == 128) &&
+           !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32));
+}
+
+int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
+                                 int C, int Rh, int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax) {
+    if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
+    if (B < 1 || !res_pair_supported(H, W, C, Rh, flags)) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    const int cpt = (C + 31) / 32;
+    const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+    const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+    const unsigned gt = (unsigned)((B + 3) / 4);
+    prof_begin(VQVAE_PROF_RES_LAYER, st);
+    switch (C / 32) {
+        case 1: hipLaunchKernelGGL((res_pair8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+        case 2: hipLaunchKernelGGL((res_pair8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+        case 4: hipLaunchKernelGGL((res_pair8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

@@ -39,17 +39,28 @@ size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
 int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
               bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr) {
     // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
-    // the producer applies it; buffers alternate so that the result of the LAST layer lands in y
+    // the producer applies it.  Layers run in PAIRS where the fused two-layer kernel applies (8x8 maps, two-term fp16
+    // products; the intermediate map stays on chip), a trailing odd layer alone; buffers alternate so that the result of
+    // the LAST step lands in y.  A pair may write over its own input (tmp == x in the encoder / decoder), a single layer
+    // never has to.
     const float *cur = x;
     *out = x;
-    for (int i = 0; i < n_layers; ++i) {
+    const bool pairs = n_layers >= 2 && res_pair_supported(H, W, C, Rh, 0);
+    const int nsteps = pairs ? n_layers / 2 + (n_layers & 1) : n_layers;
+    int i = 0;
+    for (int j = 0; j < nsteps; ++j) {
+        const bool pair = pairs && i + 1 < n_layers;
+        const int last = pair ? i + 1 : i;
         int flags = (i == 0 && first_relu_in) ? VQVAE_CONV_RELU_IN : 0;
-        if (i < n_layers - 1 || final_relu) flags |= VQVAE_CONV_RELU_OUT;
-        float *dst = ((n_layers - 1 - i) % 2 == 0) ? y : tmp;
-        const int rc = res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, amax ? amax + (size_t)i * B : nullptr,
-                                              amax ? amax + (size_t)(i + 1) * B : nullptr);
+        if (last < n_layers - 1 || final_relu) flags |= VQVAE_CONV_RELU_OUT;
+        float *dst = ((nsteps - 1 - j) % 2 == 0) ? y : tmp;
+        const int *ain = amax ? amax + (size_t)i * B : nullptr;
+        int *aout = amax ? amax + (size_t)(last + 1) * B : nullptr;
+        const int rc = pair ? res_pair_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout)
+                            : res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout);
         if (rc != 0) return rc;
         cur = dst;
+        i = last + 1;
     }
     *out = cur;
     return 0;
