@@ -178,7 +178,10 @@ def test_large_batch_config3_sampled_vs_reference_port():
 @pytest.mark.parametrize("name", ["kat1", "small"])
 def test_whole_path_c_entry_points_match_layerwise(name):
     """vqvae_encoder_f32 / vqvae_decoder_f32 / vqvae_resstack_f32 / vqvae_forward_f32 (the whole-path C ABI of
-    SURVEY.md 8b) sequence the same kernels as the layer-by-layer Python composition: outputs must be bitwise equal."""
+    SURVEY.md 8b) against the layer-by-layer Python composition.  On 8x8 latent maps both run the same kernels on the
+    same per-image scales: outputs must be BITWISE equal (this also pins the fused residual pairs to the separate
+    layers).  On other map sizes the whole path hands the per-image maxima from layer to layer and uses the two-term
+    fp16 products where the per-layer entry points use the three-term bf16 ones: equal to the fp32 tolerance tiers."""
     from vqvae_amd import _lib, conv, conv_hip, functional as F
     conv.set_conv_backend("hip")
     L = _lib.load()
@@ -187,6 +190,14 @@ def test_whole_path_c_entry_points_match_layerwise(name):
     xd = x.to(dev()).contiguous()
     B, _, H, W = xd.shape
     st = torch.cuda.current_stream().cuda_stream
+    tile = H // 4 == 8 and W // 4 == 8
+
+    def same(a, b, atol, rtol):
+        if tile:
+            assert torch.equal(a, b)
+        else:
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=atol, rtol=rtol)
+
     with torch.no_grad():
         z_e_ref = conv_hip.encoder_forward(m.encoder, xd, m.pre_quantization_conv)               # (B,h,w,D)
         loss_ref, z_q_ref, ppl_ref, idx_ref, _ = m.vector_quantization.quantize(z_e_ref, rowmajor=True)
@@ -197,10 +208,10 @@ def test_whole_path_c_entry_points_match_layerwise(name):
         ws = torch.empty(nws, dtype=torch.uint8, device=dev())
         z_e = torch.empty_like(z_e_ref)
         _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, H, W, z_e.data_ptr(), ws.data_ptr(), nws, st))
-        assert torch.equal(z_e, z_e_ref)
+        same(z_e, z_e_ref, 2e-6, 0)
         x_hat = torch.empty_like(xd)
         _lib.check(L.vqvae_decoder_f32(cw, z_q_ref.data_ptr(), B, H // 4, W // 4, x_hat.data_ptr(), ws.data_ptr(), nws, st))
-        assert torch.equal(x_hat, x_hat_ref)
+        same(x_hat, x_hat_ref, 1e-5, 1e-4)
         # residual stack on its own: relu-in + final relu (= ResidualStack.forward on a fresh tensor)
         stack = m.encoder.conv_stack[5]
         t = torch.randn(B, H // 4, W // 4, cw.dims.h_dim, device=dev())
@@ -208,13 +219,20 @@ def test_whole_path_c_entry_points_match_layerwise(name):
         y, tmp = torch.empty_like(t), torch.empty_like(t)
         _lib.check(L.vqvae_resstack_f32(cw.enc_res_w1, cw.enc_res_w2, t.data_ptr(), B, H // 4, W // 4, cw.dims.h_dim,
                                         cw.dims.res_h_dim, cw.dims.n_res_layers, 3, y.data_ptr(), tmp.data_ptr(), st))
-        assert torch.equal(y, want)
+        same(y, want, 1e-5, 1e-4)
         # the whole forward, through the module (one ctypes call) and with indices
         loss, xh, ppl, idx = m._forward_c(xd, want_idx=True)
-        assert torch.equal(xh, x_hat_ref) and torch.equal(idx, idx_ref)
-        assert loss.item() == loss_ref.item() and ppl.item() == ppl_ref.item()
+        if tile:
+            assert torch.equal(xh, x_hat_ref) and torch.equal(idx, idx_ref)
+            assert loss.item() == loss_ref.item() and ppl.item() == ppl_ref.item()
+        else:
+            # z_e differs in its last bits: an index may flip on a near-tie; images without a flip must agree
+            flips = (idx.view(B, -1) != idx_ref.view(B, -1)).any(1).cpu()
+            assert flips.float().mean() <= 0.25
+            np.testing.assert_allclose(xh[~flips].cpu().numpy(), x_hat_ref[~flips].cpu().numpy(), atol=1e-5, rtol=1e-4)
+            np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-4)
         out = m(xd)
-        assert torch.equal(out[1], x_hat_ref)
+        assert torch.equal(out[1], xh)
         # error conventions: a workspace that is too small, unsupported image size
         assert L.vqvae_forward_f32(cw, xd.data_ptr(), B, H, W, 0, xh.data_ptr(), loss.data_ptr(), ppl.data_ptr(), None,
                                    ws.data_ptr(), 1024, None, 0, st) == -4
@@ -259,6 +277,59 @@ def test_large_and_odd_shapes_stagewise_vs_oracle(name):
         np.testing.assert_allclose(ppl.item(), ppl_ref.item(), rtol=1e-5)
         x_hat = md.decoder(z_q_ref.to(dev()))
         np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.numpy(), atol=1e-5, rtol=1e-4)
+        # the whole-path C entry points on the same inputs (generic maps: two-term fp16 products on per-image maxima
+        # handed from layer to layer, streamed-codebook quantizer) against the oracle
+        from vqvae_amd import _lib
+        L = _lib.load()
+        cw, _keep = md._c_weights()
+        nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+        st = torch.cuda.current_stream().cuda_stream
+        xd = x.to(dev()).contiguous()
+        z_e_c = torch.empty(B, H // 4, W // 4, D, device=dev())
+        _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, H, W, z_e_c.data_ptr(), ws.data_ptr(), nws, st))
+        np.testing.assert_allclose(z_e_c.permute(0, 3, 1, 2).cpu().numpy(), z_e_ref.numpy(), atol=2e-6, rtol=0)
+        zq_rows = z_q_ref.to(dev()).permute(0, 2, 3, 1).contiguous()
+        x_hat_c = torch.empty_like(xd)
+        _lib.check(L.vqvae_decoder_f32(cw, zq_rows.data_ptr(), B, H // 4, W // 4, x_hat_c.data_ptr(), ws.data_ptr(), nws, st))
+        np.testing.assert_allclose(x_hat_c.cpu().numpy(), x_hat_ref.numpy(), atol=1e-5, rtol=1e-4)
         # and the composed forward runs and agrees wherever no index flipped
         loss2, x_hat2, ppl2 = md(x.to(dev()))
         assert x_hat2.shape == x.shape and torch.isfinite(x_hat2).all() and torch.isfinite(loss2)
+
+
+def test_whole_path_per_image_scales_on_generic_maps():
+    """Images of very different magnitude in one batch through the whole-path encoder on maps that are NOT 8x8 (generic
+    kernels: a wave's pixel rows can belong to two images, every row carries its own image's scale; the maxima are
+    handed from layer to layer): every image against the oracle, tolerance relative to its own magnitude."""
+    from oracle import torch_port
+    from vqvae_amd import _lib, conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    h, rh, nl, K, D, B, H, W = 64, 16, 2, 100, 32, 7, 24, 40
+    torch.manual_seed(3)
+    m = VQVAE(h, rh, nl, K, D, 0.25).eval()
+    with torch.no_grad():
+        for p in m.encoder.parameters():
+            if p.dim() == 1:
+                p.zero_()                                   # no biases: the encoder is positively homogeneous in x
+        m.pre_quantization_conv.bias.zero_()
+    mags = torch.tensor([1.0, 1.0e-5, 3.0e3, 0.0, 2.0e-2, 4.0e4, 7.0]).view(-1, 1, 1, 1)
+    x = torch.randn(B, 3, H, W) * mags
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        z_e_ref = torch_port.encode(sd, x.clone(), nl)
+    md = m.to(dev())
+    L = _lib.load()
+    cw, _keep = md._c_weights()
+    nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+    xd = x.to(dev()).contiguous()
+    z_e = torch.empty(B, H // 4, W // 4, D, device=dev())
+    _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, H, W, z_e.data_ptr(), ws.data_ptr(), nws,
+                                   torch.cuda.current_stream().cuda_stream))
+    got = z_e.permute(0, 3, 1, 2).cpu().numpy()
+    for i in range(B):
+        r = z_e_ref[i].numpy()
+        np.testing.assert_allclose(got[i], r, atol=2e-5 * max(np.abs(r).max(), 1e-30), rtol=1e-4, err_msg=f"image {i}")
+    assert np.all(got[3] == 0.0)

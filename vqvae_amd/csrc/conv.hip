@@ -444,6 +444,27 @@ __global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restric
     }
 }
 
+// Per-image maximum of |x| for a tensor whose producer did not publish one (z_q in front of the decoder on large maps,
+// the generic first-layer kernel): grid (parts, B), one more read of the tensor.
+__global__ __launch_bounds__(256) void act_absmax_kernel(const float *__restrict__ x, long long elems_per_image,
+                                                         int *__restrict__ amax) {
+    __shared__ float red[4];
+    const float *p = x + (size_t)blockIdx.y * elems_per_image;
+    float m = 0.0f;
+    const long long n4 = elems_per_image >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = reinterpret_cast<const f32x4 *>(p)[i];
+        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+    }
+    if (blockIdx.x == 0)
+        for (long long i = (n4 << 2) + threadIdx.x; i < elems_per_image; i += 256) m = fmaxf(m, __builtin_fabsf(p[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(amax + blockIdx.y, __float_as_int(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
+}
+
 // H2 = false: three bf16 terms per element; H2 = true: two fp16 terms of w * 2^kw (kw from conv_wscale_kernel)
 template <bool H2>
 __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restrict__ w,
@@ -503,12 +524,17 @@ __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restr
 
 // The waves-per-SIMD hint of 2 keeps the accumulators in VGPRs: without it the compiler parks them in AGPRs
 // and copies all of them to VGPRs and back once per loop iteration (128 v_accvgpr moves per 96 MFMAs).
-template <int NT>
+// H2: two-term fp16 products (split8_h); every pixel row carries the power-of-two scale of ITS image (taps never cross
+// images, so the scale factors out of a row's accumulators); in_amax must then hold every image's maximum.
+template <int NT, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__restrict__ in,
                                                              const u32x4 *__restrict__ wimg,
                                                              const float *__restrict__ bias,
-                                                             float *__restrict__ out, ConvGeom g) {
-    constexpr int CH4 = NT * 384;                      // uint4 per chunk of this n-block (6 KiB per n-tile)
+                                                             float *__restrict__ out, ConvGeom g,
+                                                             const int *__restrict__ whdr, const int *__restrict__ in_amax,
+                                                             int *__restrict__ out_amax) {
+    constexpr int TERMS = H2 ? 2 : 3;
+    constexpr int CH4 = NT * 128 * TERMS;              // uint4 per chunk of this n-block (2 KiB per term and n-tile)
     __shared__ u32x4 Bs[2][CH4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -525,6 +551,8 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
                                 (unsigned long long)(g.B - b_first) * in_img_bytes);
     unsigned pbase, tapmask;
     long long myoff;
+    long long myimg = -1;                              // image of this lane's pixel row (-1: past the end)
+    float xsc = 1.0f, dsc = 1.0f;                      // H2: the image's scale 2^kx and the accumulator scale 2^-(kx + kw)
     {
         const long long p = (long long)blockIdx.x * 128 + wave * 32 + l31;
         const bool valid = p < M;
@@ -543,9 +571,19 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
         myoff = valid ? ((b * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride + g.opx[phase]) *
                             (long long)g.Cout
                       : -1;
+        if (valid) myimg = b;
+        if (H2 && valid) {
+            const float mx = __int_as_float(in_amax[b]);
+            int e = 15;
+            if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
+            int kx = 15 - e;
+            kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
+            xsc = __builtin_ldexpf(1.0f, kx);
+            dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+        }
     }
-    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 384;
-    const size_t wchunk = (size_t)g.ntile * 384;
+    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * (128 * TERMS);
+    const size_t wchunk = (size_t)g.ntile * (128 * TERMS);
 
     // Software pipeline over 32-channel chunks (static register names, loop unrolled by two):
     //   raw A ring of depth 2: the registers of chunk c+1 are split while chunk c's MFMAs run, then
@@ -569,7 +607,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
         for (int j = 0; j < 4; ++j)
             dst[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
     };
-    constexpr int NBQ = CH4 / 256, BREM = CH4 % 256;    // 384 uint4 per n-tile: NT = 1 leaves a 128-thread tail
+    constexpr int NBQ = CH4 / 256, BREM = CH4 % 256;    // 384 uint4 per n-tile (three terms): NT = 1 leaves a 128-thread tail
     u32x4 b_tail = {0, 0, 0, 0};
     auto load_b = [&](int c) {
         const u32x4 *src = wbase + (size_t)c * wchunk;
@@ -588,8 +626,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 #pragma unroll
             for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
         }
-        split8(raw[0], raw[1], S1[0], S2[0], S3[0]);
-        split8(raw[2], raw[3], S1[1], S2[1], S3[1]);
+        if constexpr (H2) {
+            split8_h(raw[0], raw[1], xsc, S1[0], S2[0]);
+            split8_h(raw[2], raw[3], xsc, S1[1], S2[1]);
+        } else {
+            split8(raw[0], raw[1], S1[0], S2[0], S3[0]);
+            split8(raw[2], raw[3], S1[1], S2[1], S3[1]);
+        }
     };
     // one chunk: MFMAs of chunk c from (S1,S2,S3); meanwhile split chunk c+1 (raw `rn`) into (T1,T2,T3)
     // and re-issue `rn`'s loads for chunk c+3
@@ -601,6 +644,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
         constexpr int NP = NT >= 2 ? 2 : 1;               // n-tiles interleaved per product chain
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
+            if constexpr (H2) {
+                const f16x8 h1 = __builtin_bit_cast(f16x8, S1[t]), h2 = __builtin_bit_cast(f16x8, S2[t]);
+#pragma unroll
+                for (int n0 = 0; n0 < NT; n0 += NP) {
+                    f16x8 G1[NP], G2[NP];
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) {
+                        const u32x4 *bp = bs + (n0 + u) * 256 + (t * 2 + h) * 32 + l31;
+                        G1[u] = __builtin_bit_cast(f16x8, bp[0]);
+                        G2[u] = __builtin_bit_cast(f16x8, bp[128]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h2, G1[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, G2[u], acc[n0 + u], 0, 0, 0);
+#pragma unroll
+                    for (int u = 0; u < NP; ++u) acc[n0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(h1, G1[u], acc[n0 + u], 0, 0, 0);
+                }
+                if (t == 0 && more) split_a(rn, T1, T2, T3);
+                continue;
+            }
             const bf16x8 a1 = __builtin_bit_cast(bf16x8, S1[t]), a2 = __builtin_bit_cast(bf16x8, S2[t]),
                          a3 = __builtin_bit_cast(bf16x8, S3[t]);
 #pragma unroll
@@ -657,22 +721,38 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
     }
+    // maxima for the next layer: one image per wave in the common case (one wave-wide reduction), per pixel row otherwise
+    const long long img0 = __shfl(myimg, 0);
+    const bool one_img = out_amax && __builtin_amdgcn_ballot_w64(myimg != img0) == 0 && img0 >= 0;
+    float omax = 0.0f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
         const long long off = __shfl(myoff, src);
+        const float drow = H2 ? __shfl(dsc, src) : 1.0f;
+        float rmax = 0.0f;
         if (off >= 0) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = (nb * NT + nt) * 32 + l31;
                 if (n < g.Cout) {
-                    float v = acc[nt][r] + bv[nt];
+                    float v = (H2 ? acc[nt][r] * drow : acc[nt][r]) + bv[nt];
                     if (relu_out) v = fmaxf(v, 0.0f);
+                    rmax = fmaxf(rmax, __builtin_fabsf(v));
                     out[off + n] = v;
                 }
             }
         }
+        if (out_amax && !one_img) {
+            const long long rimg = __shfl(myimg, src);
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+            if (l31 == 0 && rimg >= 0) atomicMax(out_amax + rimg, __float_as_int(rmax));
+        } else {
+            omax = fmaxf(omax, rmax);
+        }
     }
+    if (one_img) publish_amax(out_amax, img0, omax, lane);
 }
 
 
@@ -989,13 +1069,17 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 // see conv_igemm_bf3_kernel for the split).  GEMM1 (3x3, C -> 32 hidden) is barrier-free: each wave
 // reads its 6-KiB weight chunk (three bf16 terms) straight from L1/L2 next to its A operands.
 // GEMM2 (1x1, 32 -> C) takes the three-term W2 image from LDS.
-template <int NT2>
+// H2: two-term fp16 products; every pixel row carries its image's scale in the 3x3 GEMM (in_amax holds the maxima) and
+// its OWN scale (largest of its 32 hidden values) in the 1x1 GEMM, whose rows are independent.
+template <int NT2, bool H2 = false>
 __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__restrict__ in,
                                                             const u32x4 *__restrict__ w1img,
                                                             const u32x4 *__restrict__ w2img,
                                                             float *__restrict__ out, int B, int H, int W,
-                                                            int C, int flags) {
-    constexpr int MT = 2;
+                                                            int C, int flags, const int *__restrict__ hdr1,
+                                                            const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                            int *__restrict__ out_amax) {
+    constexpr int MT = 2, TERMS = H2 ? 2 : 3;
     __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1536 + 4 * MT * 32 * 33];
     u32x4 *W2s = reinterpret_cast<u32x4 *>(smem_res);                       // [NT2][384]
     float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1536);
@@ -1006,13 +1090,15 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
     const int nchunk = 9 * cpt;
     const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
 
-    for (int i = tid; i < NT2 * 384; i += 256) W2s[i] = w2img[i];
+    for (int i = tid; i < NT2 * 128 * TERMS; i += 256) W2s[i] = w2img[i];
 
     const long long wbase = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT);
     const long long img_px = (long long)H * W;
     const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
     const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
     unsigned pbase[MT], tapmask[MT];
+    long long myimg[MT];
+    float xsc[MT], d1[MT];                              // H2: image scale 2^kx and 3x3 accumulator scale 2^-(kx + kw1) of this lane's pixel rows
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const long long p = wbase + mt * 32 + l31;
@@ -1029,6 +1115,17 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
             if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) m |= 1u << t;
         }
         tapmask[mt] = m;
+        myimg[mt] = valid ? b : -1;
+        xsc[mt] = 1.0f; d1[mt] = 1.0f;
+        if (H2 && valid) {
+            const float mx = __int_as_float(in_amax[b]);
+            int e = 15;
+            if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
+            int kx = 15 - e;
+            kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
+            xsc[mt] = __builtin_ldexpf(1.0f, kx);
+            d1[mt] = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+        }
     }
 
     constexpr int KC = 2;
@@ -1047,7 +1144,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
         const int tapbytes = (dy * W + dx) * C * 4;
         const unsigned soff = (unsigned)cc * 128u;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) bd[q] = w1v[(size_t)c * 384 + q * 64];
+        for (int q = 0; q < 2 * TERMS; ++q) bd[q] = w1v[(size_t)c * (128 * TERMS) + q * 64];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
@@ -1071,16 +1168,25 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 #pragma unroll
                         for (int j = 0; j < 4; ++j) a[k][mt][j] = relu4(a[k][mt][j]);
                     }
-                    split8(a[k][mt][0], a[k][mt][1], S1[mt][0], S2[mt][0], S3[mt][0]);
-                    split8(a[k][mt][2], a[k][mt][3], S1[mt][1], S2[mt][1], S3[mt][1]);
+                    if constexpr (H2) {
+                        split8_h(a[k][mt][0], a[k][mt][1], xsc[mt], S1[mt][0], S2[mt][0]);
+                        split8_h(a[k][mt][2], a[k][mt][3], xsc[mt], S1[mt][1], S2[mt][1]);
+                    } else {
+                        split8(a[k][mt][0], a[k][mt][1], S1[mt][0], S2[mt][0], S3[mt][0]);
+                        split8(a[k][mt][2], a[k][mt][3], S1[mt][1], S2[mt][1], S3[mt][1]);
+                    }
                 }
 #pragma unroll
-                for (int q = 0; q < 6; ++q) bw[q] = bq[k][q];
+                for (int q = 0; q < 2 * TERMS; ++q) bw[q] = bq[k][q];
                 if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t)           // the two pixel tiles share the weights, separate accumulators
-                    prod6x2(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
-                            acc1[0], acc1[1]);
+                for (int t = 0; t < 2; ++t) {         // the two pixel tiles share the weights, separate accumulators
+                    if constexpr (H2)
+                        prod3x2(S1[0][t], S2[0][t], S1[1][t], S2[1][t], bw[t], bw[2 + t], acc1[0], acc1[1]);
+                    else
+                        prod6x2(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
+                                acc1[0], acc1[1]);
+                }
             }
         }
     }
@@ -1092,19 +1198,41 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-            Hs[wave][mt][prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+            const float dr = H2 ? __shfl(d1[mt], prow) : 1.0f;       // the row's 3x3 accumulator scale
+            Hs[wave][mt][prow * 33 + l31] = fmaxf(H2 ? acc1[mt][r] * dr : acc1[mt][r], 0.0f);
         }
     lds_order_wave();
-    u32x4 H1[MT][2], H2[MT][2], H3[MT][2];
+    u32x4 H1[MT][2], Hb[MT][2], H3[MT][2];
+    float d2[MT];                                       // H2: 1x1 accumulator scale of this lane's pixel rows
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         float a2[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a2[q] = Hs[wave][mt][l31 * 33 + 16 * h + q];
-        split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], H2[mt][0], H3[mt][0]);
-        split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], H2[mt][1],
-               H3[mt][1]);
+        d2[mt] = 1.0f;
+        if constexpr (H2) {
+            float m = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m = fmaxf(m, a2[q]);
+            m = fmaxf(m, __shfl_xor(m, 32));             // the pixel's other sixteen hidden values
+            int e = 15;
+            if (m > 0.0f && m < 3.0e38f) (void)__builtin_frexpf(m, &e);
+            int kh = 15 - e;
+            kh = kh > 100 ? 100 : (kh < -100 ? -100 : kh);
+            const float hsc = __builtin_ldexpf(1.0f, kh);
+            d2[mt] = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hsc, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hsc, H1[mt][1], Hb[mt][1]);
+        } else {
+            split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], Hb[mt][0], H3[mt][0]);
+            split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], Hb[mt][1],
+                   H3[mt][1]);
+        }
     }
+    // maxima for the next layer: one image per wave in the common case, per pixel row otherwise
+    const long long img0 = __shfl(myimg[0], 0);
+    const bool one_img = out_amax && img0 >= 0 && __builtin_amdgcn_ballot_w64(myimg[0] != img0 || myimg[1] != img0) == 0;
+    float omax = 0.0f;
 
     // second GEMM, one n-tile at a time (two pixel tiles = two interleaved accumulators)
 #pragma unroll
@@ -1116,25 +1244,42 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
             for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const u32x4 *bp = W2s + nt * 384 + (t * 2 + h) * 32 + l31;
-            const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
-            prod6x2(H1[0][t], H2[0][t], H3[0][t], H1[1][t], H2[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            const u32x4 *bp = W2s + nt * (128 * TERMS) + (t * 2 + h) * 32 + l31;
+            if constexpr (H2) {
+                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+            } else {
+                const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+                prod6x2(H1[0][t], Hb[0][t], H3[0][t], H1[1][t], Hb[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long long prow = wbase + mt * 32 + src;
                 const int n = nt * 32 + l31;
+                const float dr = H2 ? __shfl(d2[mt], src) : 1.0f;
+                float rmax = 0.0f;
                 if (prow < M && n < C) {
                     float u = in[prow * C + n];
                     if (relu_in) u = fmaxf(u, 0.0f);
-                    float v = u + acc2[mt][r];
+                    float v = u + (H2 ? acc2[mt][r] * dr : acc2[mt][r]);
                     if (relu_out) v = fmaxf(v, 0.0f);
+                    rmax = __builtin_fabsf(v);
                     out[prow * C + n] = v;
+                }
+                if (out_amax && !one_img) {
+                    const long long rimg = __shfl(myimg[mt], src);
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+                    if (l31 == 0 && rimg >= 0) atomicMax(out_amax + rimg, __float_as_int(rmax));
+                } else {
+                    omax = fmaxf(omax, rmax);
                 }
             }
     }
+    if (one_img) publish_amax(out_amax, img0, omax, lane);
 }
 
 // ---------------------------------------------------------------------------
@@ -2051,10 +2196,12 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                 if (n < Cout) {
                     float v = acc[mt][nt][r] + bv[nt];
                     if (relu_out) v = fmaxf(v, 0.0f);
+                    omax = fmaxf(omax, __builtin_fabsf(v));
                     out[prow * Cout + n] = v;
                 }
             }
         }
+    if (out_amax) publish_amax(out_amax, b, omax, lane);
 }
 
 template <int CIN>
@@ -2548,15 +2695,21 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             }
 #undef TILE8_LAUNCH
         }
-        else if (g.ntile % 4 == 0)
-            hipLaunchKernelGGL((conv_igemm_bf3_kernel<4>), dim3(gx, g.nphase * (g.ntile / 4)), dim3(256), 0, st, x,
-                               img3, bias, y, g);
-        else if (g.ntile % 2 == 0)
-            hipLaunchKernelGGL((conv_igemm_bf3_kernel<2>), dim3(gx, g.nphase * (g.ntile / 2)), dim3(256), 0, st, x,
-                               img3, bias, y, g);
-        else
-            hipLaunchKernelGGL((conv_igemm_bf3_kernel<1>), dim3(gx, g.nphase * g.ntile), dim3(256), 0, st, x, img3,
-                               bias, y, g);
+        else {
+            // generic maps: the two-term fp16 products need every image's maximum from the producing layer (in_amax); the
+            // per-layer C entry points have none and use the three-term bf16 products
+            const bool h2 = in_amax && !(flags & VQVAE_CONV_BF16_SPLIT);
+            const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
+            const int *whdr = reinterpret_cast<const int *>(h2base);
+            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + kH2Header) : img3;
+#define IGEMM_LAUNCH(NT_, H2_, GY_)                                                                                     \
+    hipLaunchKernelGGL((conv_igemm_bf3_kernel<NT_, H2_>), dim3(gx, GY_), dim3(256), 0, st, x, wsel, bias, y, g, whdr, in_amax, \
+                       out_amax)
+            if (g.ntile % 4 == 0) { if (h2) IGEMM_LAUNCH(4, true, g.nphase * (g.ntile / 4)); else IGEMM_LAUNCH(4, false, g.nphase * (g.ntile / 4)); }
+            else if (g.ntile % 2 == 0) { if (h2) IGEMM_LAUNCH(2, true, g.nphase * (g.ntile / 2)); else IGEMM_LAUNCH(2, false, g.nphase * (g.ntile / 2)); }
+            else { if (h2) IGEMM_LAUNCH(1, true, g.nphase * g.ntile); else IGEMM_LAUNCH(1, false, g.nphase * g.ntile); }
+#undef IGEMM_LAUNCH
+        }
     } else if (g.ntile % 4 == 0) {
         // exact-fp32 MFMA kernels: 32 pixels x 128 channels per wave when Cout fills it, else 64 x 64 / 32
         const unsigned gx = (unsigned)((M + 127) / 128);
@@ -2618,10 +2771,26 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
                 case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
                 case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
             }
-        } else switch (C / 32) {
-            case 1: hipLaunchKernelGGL((res_layer_bf3_kernel<1>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
-            case 2: hipLaunchKernelGGL((res_layer_bf3_kernel<2>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
-            case 4: hipLaunchKernelGGL((res_layer_bf3_kernel<4>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C, flags); break;
+        } else {
+            // generic maps: two-term fp16 products when the producing layer handed over the images' maxima
+            const bool h2 = in_amax && !(flags & VQVAE_CONV_BF16_SPLIT);
+            const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2p + kH2Header);
+            const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
+#define RES_GEN(NT_)                                                                                                             \
+    do {                                                                                                                         \
+        if (h2) hipLaunchKernelGGL((res_layer_bf3_kernel<NT_, true>), dim3(gx), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, \
+                                   flags, hd1, hd2, in_amax, out_amax);                                                          \
+        else hipLaunchKernelGGL((res_layer_bf3_kernel<NT_, false>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C,  \
+                                flags, nullptr, nullptr, nullptr, out_amax);                                                     \
+    } while (0)
+            switch (C / 32) {
+            case 1: RES_GEN(1); break;
+            case 2: RES_GEN(2); break;
+            case 4: RES_GEN(4); break;
+            }
+#undef RES_GEN
         }
     } else {
         switch (C / 32) {
@@ -2697,6 +2866,12 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
 }
 }  // extern "C"
 
+void vqvae::act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st) {
+    long long parts = (elems_per_image + 256 * 4 * 16 - 1) / (256 * 4 * 16);
+    parts = parts < 1 ? 1 : (parts > 64 ? 64 : parts);
+    hipLaunchKernelGGL(act_absmax_kernel, dim3((unsigned)parts, (unsigned)B), dim3(256), 0, st, x, elems_per_image, amax);
+}
+
 int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W,
                                 int Cin, int Cout, int flags, float *y, hipStream_t stream, int *out_amax) {
     if (!x_nchw || !packed || !y) return VQVAE_ERR_NULL;
@@ -2726,8 +2901,11 @@ int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const 
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, false>), dim3(gx), dim3(256), rows_lds, st, x_nchw, \
                                packed, bias, y, (int)B, H, W, Cout, flags, out_amax);                              \
         else                                                                                                       \
+        {                                                                                                          \
             hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
                                (int)B, H, W, Cout, flags);                                                         \
+            if (out_amax) act_absmax_impl(y, B, (long long)(H / 2) * (W / 2) * Cout, out_amax, st);               \
+        }                                                                                                          \
     } while (0)
 #define CI_NT(CIN_)                                                       \
     switch (ntile) {                                                      \

@@ -215,7 +215,14 @@ int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4
     const int h = d->h_dim;
     int rc;
     // decoder.py:28-29 (+ the stack's first in-place ReLU), :30, :31-33, :34-35
-    if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, nullptr, am)) != 0) return rc;
+    // z_q has no producer that publishes maxima: the 8x8-map kernel measures its image itself, the generic one gets them
+    // from one more pass over z_q (array [2 + n_res_layers] of the region)
+    int *amz = nullptr;
+    if (am && vqvae_conv_term_products(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, h, 0) != 3) {
+        amz = am + (size_t)(2 + d->n_res_layers) * B;
+        act_absmax_impl(z_q, B, (long long)h4 * w4 * d->embedding_dim, amz, st);
+    }
+    if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, amz, am)) != 0) return rc;
     const float *t = a;
     const int *amt = am;
     if (d->n_res_layers > 0) {
