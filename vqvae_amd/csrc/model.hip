@@ -152,7 +152,7 @@ size_t vqvae_workspace_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
     const size_t act = align_up(act_elems(d, B, H, W) * sizeof(float), 256);
     const size_t lat = align_up((size_t)B * (H / 4) * (W / 4) * d->embedding_dim * sizeof(float), 256);
     const size_t rows = (size_t)B * (H / 4) * (W / 4);
-    return 2 * act + amax_bytes(d, B) + 2 * lat + align_up(rows * sizeof(int64_t), 256) +
+    return 2 * act + 2 * amax_bytes(d, B) + 2 * lat + align_up(rows * sizeof(int64_t), 256) +
            align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) + align_up(vq, 256) + 256;
 }
 
@@ -166,8 +166,9 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
                      y, tmp, static_cast<hipStream_t>(stream), &res);
 }
 
-int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
-                      size_t workspace_bytes, vqvae_stream_t stream) {
+// am_given: a maxima region (amax_bytes) the caller has already set to -1, or NULL to carve and initialise one here
+static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
+                       size_t workspace_bytes, hipStream_t st, int *am_given) {
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return VQVAE_ERR_SHAPE;
@@ -175,11 +176,13 @@ int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     const size_t act = act_elems(d, B, H, W);
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     // optional: the per-image maxima (a workspace of the documented size has room; without them every consumer measures
     // its own image)
-    int *am = static_cast<int *>(c.raw(amax_bytes(d, B)));
-    if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    int *am = am_given;
+    if (!am) {
+        am = static_cast<int *>(c.raw(amax_bytes(d, B)));
+        if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    }
     int *am0 = am, *am1 = am ? am + B : nullptr, *am2 = am ? am + 2 * B : nullptr;     // conv_in, enc2, enc4 (+ residual layers)
     const int h = d->h_dim;
     int rc;
@@ -200,8 +203,13 @@ int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st, amt, nullptr);   // vqvae.py:33
 }
 
-int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
+int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                       size_t workspace_bytes, vqvae_stream_t stream) {
+    return encoder_run(w, x, B, H, W, z_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
+static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
+                       size_t workspace_bytes, hipStream_t st, int *am_given) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -209,9 +217,11 @@ int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4
     const size_t act = act_elems(d, B, 4 * h4, 4 * w4);
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    int *am = static_cast<int *>(c.raw(amax_bytes(d, B)));                    // optional, see vqvae_encoder_f32
-    if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    int *am = am_given;                                                       // optional, see encoder_run
+    if (!am) {
+        am = static_cast<int *>(c.raw(amax_bytes(d, B)));
+        if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    }
     const int h = d->h_dim;
     int rc;
     // decoder.py:28-29 (+ the stack's first in-place ReLU), :30, :31-33, :34-35
@@ -235,6 +245,11 @@ int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4
     return vqvae_convt_out_forward_f32(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st);
 }
 
+int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
+                      size_t workspace_bytes, vqvae_stream_t stream) {
+    return decoder_run(w, z_q, B, h4, w4, x_hat, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+}
+
 int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, float *x_hat,
                       float *loss, float *perplexity, int64_t *idx, void *workspace, size_t workspace_bytes,
                       void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream) {
@@ -246,7 +261,8 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     Carve c{static_cast<char *>(workspace), workspace_bytes};
     const size_t act = act_elems(d, B, H, W);
     const size_t rows = (size_t)B * (H / 4) * (W / 4);
-    void *acts = c.raw(2 * align_up(act * sizeof(float), 256) + amax_bytes(d, B));
+    void *acts = c.raw(2 * align_up(act * sizeof(float), 256));
+    int *am2 = static_cast<int *>(c.raw(2 * amax_bytes(d, B)));            // encoder's and decoder's maxima: one fill for both
     float *z_e = c.f32(rows * d->embedding_dim), *z_q = c.f32(rows * d->embedding_dim);
     int64_t *idx_ws = static_cast<int64_t *>(c.raw(rows * sizeof(int64_t)));
     int32_t *hist = static_cast<int32_t *>(c.raw((size_t)d->n_embeddings * sizeof(int32_t)));
@@ -259,14 +275,17 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
     }
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
-    const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256) + amax_bytes(d, B);
+    const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(am2) + amax_bytes(d, B));
     int rc;
-    if ((rc = vqvae_encoder_f32(w, x, B, H, W, z_e, acts, acts_bytes, stream)) != 0) return rc;                 // vqvae.py:31-33
+    if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2)) != 0) return rc;                     // vqvae.py:31-33
     if ((rc = vqvae_vq_forward_f32(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                                    (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
                                                 VQVAE_VQ_PRODUCER_CONSUMER)) | VQVAE_VQ_ROWMAJOR,
                                    z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream)) != 0) return rc;   // :34
-    return vqvae_decoder_f32(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, stream);                           // :36
+    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                             // :36
 }
 
 }  // extern "C"
