@@ -955,7 +955,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 }
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
+#if defined(TILE8_KNOB) && TILE8_KNOB == 3      // 3 = the weight operands of n-tile 0 for every n-tile (12 instead of 24 LDS reads per step pair)
+                    const u32x4 *bp = bs + (t * 2 + h) * 32 + l31;
+#else
                     const u32x4 *bp = bs + nt * 256 + (t * 2 + h) * 32 + l31;
+#endif
 #if defined(TILE8_KNOB) && TILE8_KNOB == 1      // timing-only knock-outs (wrong results): 1 = no MFMAs (operands still read)
                     asm volatile("" :: "v"(A1[0]), "v"(A2[0]), "v"(A1[1]), "v"(A2[1]), "v"(bp[0]), "v"(bp[128]));
                     continue;
