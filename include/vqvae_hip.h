@@ -141,9 +141,12 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
  * and, for callers that use sub-modules directly, through vqvae_transpose_f32.
  * Weights are passed PACKED: vqvae_*_pack_f32 rewrites a torch-layout weight into the
  * MFMA B-operand image once per weight version (bytes from vqvae_*_packed_bytes).
- * fp32 in, fp32 out, fp32 accumulation.  By default products are formed from exact three-term bf16 splits of
- * both fp32 operands on the bf16 matrix cores (per-product error <= 3*2^-24, fp32-grade);
- * VQVAE_CONV_EXACT_FP32 selects the exact-fp32 MFMA kernels.  Parity with the reference is
+ * fp32 in, fp32 out, fp32 accumulation.  Products are formed from exact 16-bit splits of both fp32 operands on the
+ * 16-bit matrix cores, per-product error <= 3*2^-24 (fp32-grade) either way: two fp16 terms per operand and three term
+ * products on 8x8 maps (operands carry exact power-of-two scales: per layer for the weights, per image for the
+ * activations, measured by the kernel itself), three bf16 terms and six term products on other map sizes (and everywhere
+ * with VQVAE_CONV_BF16_SPLIT).  The whole-path entry points (vqvae_forward_f32 ...) hand the per-image maxima from layer
+ * to layer and use the fp16 scheme on every map size.  VQVAE_CONV_EXACT_FP32 selects the exact-fp32 MFMA kernels.  Parity with the reference is
  * tolerance-level either way (oneDNN's summation order is opaque): |y - y_ref| <= 1e-5 + 1e-4|y_ref|.
  * All activation pointers must be 16-byte aligned (VQVAE_ERR_UNSUPPORTED otherwise).
  * Shapes the reference uses at 32x32 images (8x8 maps, and the 4x4 s2 conv on 16x16 maps) take
@@ -160,17 +163,16 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
 #define VQVAE_CONV_RELU_OUT 0x2 /* ReLU on the result (encoder.py:31,34, decoder.py:33)           */
 #define VQVAE_CONV_BF16_SPLIT 0x8 /* use round 1's three-term bf16 products (6 per fp32 product) where the default on 8x8
                                     maps is the two-term fp16 scheme (3 per product, same error bound; A/B and tests) */
-#define VQVAE_CONV_EXACT_FP32 0x4 /* use the exact-fp32 MFMA kernels (157 TF peak) instead of the default
-                                   split-bf16 ones: every fp32 operand is split exactly into three bf16 terms
-                                   and the six significant term products run on the bf16 matrix cores with
-                                   fp32 accumulation -- per-product error <= 3*2^-24, i.e. fp32-grade      */
+#define VQVAE_CONV_EXACT_FP32 0x4 /* use the exact-fp32 MFMA kernels (157 TF peak) instead of the default 16-bit
+                                   split products (see above)                                                  */
 
 VQVAE_API size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout);
 VQVAE_API int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed,
                                   vqvae_stream_t stream);
 /* y = conv(x) + bias [ReLU]; x (B,H,W,Cin) row-major, y (B,Hout,Wout,Cout) row-major; bias may be
  * NULL.  Cin must be a multiple of 4.  Replaces one nn.Conv2d / nn.ConvTranspose2d call.
- * packed: [fp32 image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]. */
+ * packed: [fp32 image][three-term bf16 image][4x4 s2 only: the same in space-to-depth chunk order]
+ *         [header {weight scale exponent}][two-term fp16 image][4x4 s2 only: the same in space-to-depth chunk order]. */
 /* How many 16-bit MFMA term products vqvae_conv_forward_f32 issues per fp32 multiply-add for this layer shape: 3 (two-term
  * fp16, 8x8 maps), 6 (three-term bf16), 1 (VQVAE_CONV_EXACT_FP32), 0 = unsupported shape.  For reporting (bench.py). */
 VQVAE_API int vqvae_conv_term_products(int kind, int H, int W, int Cin, int Cout, int flags);
