@@ -2356,10 +2356,18 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     __syncthreads();
     for (int c = 0; c < cpt; c += 2) {
         if (c + 1 < cpt) load_a(c + 1, a1);
+#if !defined(CTO_KNOB) || CTO_KNOB != 1          // timing-only knock-outs (wrong results): 1 = no MFMAs, 2 = no col2im
         mma(c, a0);
+#else
+        asm volatile("" :: "v"(a0[0][0]), "v"(a0[1][3]));
+#endif
         if (c + 1 < cpt) {
             if (c + 2 < cpt) load_a(c + 2, a0);
+#if !defined(CTO_KNOB) || CTO_KNOB != 1
             mma(c + 1, a1);
+#else
+            asm volatile("" :: "v"(a1[0][0]), "v"(a1[1][3]));
+#endif
         }
     }
 #pragma unroll
@@ -2401,6 +2409,14 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         const bool pow2 = ((qw & (qw - 1)) | (OH & (OH - 1))) == 0;
         const int lq = 31 - __builtin_clz(qw), lh = 31 - __builtin_clz(OH);
         for (int e = tid; e < nquad; e += 256) {
+#if defined(CTO_KNOB) && CTO_KNOB == 2
+            {
+                const int xq0 = e % qw, q0 = e / qw, oyl0 = q0 % OH, co0 = q0 / OH;
+                *reinterpret_cast<f32x4 *>(out + ((b * Cout + co0) * Ho + 2 * y0 + oyl0) * (long long)Wo + 2 * x0 + 4 * xq0) =
+                    f32x4{Ts[e], Ts[e + 1], 0.0f, 0.0f};
+                continue;
+            }
+#endif
             int xq, oyl, co;
             if (pow2) { xq = e & (qw - 1); oyl = (e >> lq) & (OH - 1); co = e >> (lq + lh); }
             else { xq = e % qw; const int q = e / qw; oyl = q % OH; co = q / OH; }
