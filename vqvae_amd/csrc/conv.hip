@@ -931,7 +931,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
             stage();
             if (cc + 1 < cpt) load_raw(cc + 1);
         }
+#if !defined(TILE8_KNOB) || TILE8_KNOB != 4      // 4 = no workgroup barrier in the main loop (races: timing only)
         __syncthreads();                                   // weights of this iteration + (tap 0) the fresh tile
+#else
+        lds_order_wave();
+#endif
         const u32x4 *bs = Bs[WB == 2 ? (it & 1) : 0];
         int shift, okbit;
         if (S2D) {
