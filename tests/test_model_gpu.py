@@ -179,8 +179,9 @@ def test_large_batch_config3_sampled_vs_reference_port():
 def test_whole_path_c_entry_points_match_layerwise(name):
     """vqvae_encoder_f32 / vqvae_decoder_f32 / vqvae_resstack_f32 / vqvae_forward_f32 (the whole-path C ABI of
     SURVEY.md 8b) against the layer-by-layer Python composition.  On 8x8 latent maps both run the same kernels on the
-    same per-image scales: outputs must be BITWISE equal (this also pins the fused residual pairs to the separate
-    layers).  On other map sizes the whole path hands the per-image maxima from layer to layer and uses the two-term
+    same per-image scales: the encoder output, the residual stack, the indices and the loss must be BITWISE equal (this
+    also pins the fused residual pairs to the separate layers); the decoder's last layer uses a different product scheme
+    in the whole path (tolerance).  On other map sizes the whole path hands the per-image maxima from layer to layer and uses the two-term
     fp16 products where the per-layer entry points use the three-term bf16 ones: equal to the fp32 tolerance tiers."""
     from vqvae_amd import _lib, conv, conv_hip, functional as F
     conv.set_conv_backend("hip")
@@ -211,7 +212,9 @@ def test_whole_path_c_entry_points_match_layerwise(name):
         same(z_e, z_e_ref, 2e-6, 0)
         x_hat = torch.empty_like(xd)
         _lib.check(L.vqvae_decoder_f32(cw, z_q_ref.data_ptr(), B, H // 4, W // 4, x_hat.data_ptr(), ws.data_ptr(), nws, st))
-        same(x_hat, x_hat_ref, 1e-5, 1e-4)
+        # (the last layer takes its input maxima from dec2 in the whole path and uses the two-term fp16 products there,
+        # the three-term bf16 ones from the per-layer entry point: tolerance, not bits)
+        np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.cpu().numpy(), atol=1e-5, rtol=1e-4)
         # residual stack on its own: relu-in + final relu (= ResidualStack.forward on a fresh tensor)
         stack = m.encoder.conv_stack[5]
         t = torch.randn(B, H // 4, W // 4, cw.dims.h_dim, device=dev())
@@ -223,7 +226,8 @@ def test_whole_path_c_entry_points_match_layerwise(name):
         # the whole forward, through the module (one ctypes call) and with indices
         loss, xh, ppl, idx = m._forward_c(xd, want_idx=True)
         if tile:
-            assert torch.equal(xh, x_hat_ref) and torch.equal(idx, idx_ref)
+            assert torch.equal(idx, idx_ref)
+            np.testing.assert_allclose(xh.cpu().numpy(), x_hat_ref.cpu().numpy(), atol=1e-5, rtol=1e-4)
             assert loss.item() == loss_ref.item() and ppl.item() == ppl_ref.item()
         else:
             # z_e differs in its last bits: an index may flip on a near-tie; images without a flip must agree

@@ -2264,18 +2264,21 @@ __global__ __launch_bounds__(256) void conv_in_pack_bf3_kernel(const float *__re
 // 2x upsampled outputs with coalesced NCHW stores.
 // BF3: products from exact three-term bf16 splits on the bf16 matrix cores (weights split at pack time, image
 // [chunk][n_tile][term][k-step][half][n] x 16 B; activations split in registers) instead of the fp32 MFMA.
-template <int NT, bool BF3>
+// MODE 0: exact fp32 MFMA, 1: three-term bf16 products, 2: two-term fp16 products (in_amax: the images' maxima, whdr: {kw})
+template <int NT, int MODE>
 __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ wimg,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ out, int B, int H, int W,
                                                         int Cin, int Cout, int TH, int TW, int halo_y,
-                                                        int halo_x, int tiles_y, int tiles_x) {
+                                                        int halo_x, int tiles_y, int tiles_x, const int *__restrict__ whdr,
+                                                        const int *__restrict__ in_amax) {
     constexpr int MT = 2;
+    constexpr bool BF3 = MODE == 1, H2 = MODE == 2;
     const int STRIDE = 16 * Cout + 1;              // T row: the 16*Cout used columns (odd stride: conflict-free)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cpt = (Cin + 31) / 32;
-    constexpr int WCH = BF3 ? 1536 : 1024;          // floats per (chunk, n-tile) of the weight image
+    constexpr int WCH = BF3 ? 1536 : 1024;          // floats per (chunk, n-tile) of the weight image (fp32: 1024 values, fp16: 2 x 1024 halves)
     float *Ws = smem;                               // [cpt][NT][WCH]
     float *Ts = smem + (size_t)cpt * NT * WCH;      // [256][STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2320,7 +2323,34 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                 a[mt][j] = v;
             }
     };
+    float xsc = 1.0f, dsc = 1.0f;                   // H2: the image's scale 2^kx and the accumulator scale 2^-(kx + kw)
+    if constexpr (H2) {
+        const float mx = __int_as_float(in_amax[b]);
+        int e = 15;
+        if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
+        int kx = 15 - e;
+        kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
+        xsc = __builtin_ldexpf(1.0f, kx);
+        dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+    }
     auto mma = [&](int c, const f32x4(&a)[MT][4]) {
+        if constexpr (H2) {
+            const u32x4 *wb = reinterpret_cast<const u32x4 *>(Ws + (size_t)c * NT * WCH);
+            u32x4 S1[MT][2], S2[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                split8_h(a[mt][0], a[mt][1], xsc, S1[mt][0], S2[mt][0]);
+                split8_h(a[mt][2], a[mt][3], xsc, S1[mt][1], S2[mt][1]);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const u32x4 *bp = wb + nt * 256 + (t * 2 + h) * 32 + l31;
+                    prod3x2(S1[0][t], S2[0][t], S1[1][t], S2[1][t], bp[0], bp[128], acc[0][nt], acc[1][nt]);
+                }
+            return;
+        }
         if (BF3) {
             const u32x4 *wb = reinterpret_cast<const u32x4 *>(Ws + (size_t)c * NT * WCH);
             u32x4 S1[MT][2], S2[MT][2], S3[MT][2];
@@ -2381,7 +2411,7 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
             const int p = wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                if (nt * 32 + l31 < STRIDE - 1) Ts[p * STRIDE + nt * 32 + l31] = acc[mt][nt][r];
+                if (nt * 32 + l31 < STRIDE - 1) Ts[p * STRIDE + nt * 32 + l31] = H2 ? acc[mt][nt][r] * dsc : acc[mt][nt][r];
         }
     __syncthreads();
 
@@ -2483,8 +2513,10 @@ __global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__rest
 }
 
 // split-bf16 image of the same weights: [chunk][n_tile][term 3][k-step 2][half 2][n 32] x 8 bf16 (cf. conv_pack_bf3)
+template <bool H2>
 __global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__restrict__ w, unsigned short *__restrict__ img,
-                                                                 int Cin, int Cout, int ntile) {
+                                                                 int Cin, int Cout, int ntile, const int *__restrict__ hdr) {
+    const float wsc = H2 ? __builtin_ldexpf(1.0f, hdr[0]) : 1.0f;
     const int cpt = (Cin + 31) / 32;
     const int total = cpt * ntile * 1024;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -2494,13 +2526,22 @@ __global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__
         const int ci = chunk * 32 + 16 * hh + 8 * t + i, col = nt * 32 + n;
         const int tap = col / Cout, co = col - tap * Cout;
         const float v = (ci < Cin && tap < 16) ? w[((size_t)ci * Cout + co) * 16 + tap] : 0.0f;
+        const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
+        if (H2) {
+            const float vs = v * wsc;
+            const _Float16 g1 = (_Float16)vs;
+            const _Float16 g2 = (_Float16)(vs - (float)g1);
+            const size_t base = (size_t)(chunk * ntile + nt) * 2048;
+            img[base + pos] = __builtin_bit_cast(unsigned short, g1);
+            img[base + 1024 + pos] = __builtin_bit_cast(unsigned short, g2);
+            continue;
+        }
         const unsigned short b1 = f32_to_bf16_rne(v);
         const float r1 = v - __uint_as_float((unsigned)b1 << 16);
         const unsigned short b2 = f32_to_bf16_rne(r1);
         const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
         const unsigned short b3 = f32_to_bf16_rne(r2);
         const size_t base = (size_t)(chunk * ntile + nt) * 3072;
-        const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
         img[base + pos] = b1;
         img[base + 1024 + pos] = b2;
         img[base + 2048 + pos] = b3;
@@ -2954,8 +2995,9 @@ extern "C" {
 size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
     if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;
     const int ntile = (16 * Cout + 31) / 32;
-    // [fp32 B-operand image][split-bf16 image]
-    return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    // [fp32 B-operand image][three-term bf16 image][header {kw}][two-term fp16 image]
+    return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short)) + kH2Header +
+           (size_t)((Cin + 31) / 32) * ntile * 2048 * sizeof(unsigned short);
 }
 
 int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -2964,14 +3006,27 @@ int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, v
     const int ntile_p = (16 * Cout + 31) / 32;
     hipLaunchKernelGGL(convt_out_pack_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w, packed,
                        Cin, Cout, ntile_p);
-    hipLaunchKernelGGL(convt_out_pack_bf3_kernel, dim3(32), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       reinterpret_cast<unsigned short *>(packed + (size_t)((Cin + 31) / 32) * ntile_p * 1024), Cin, Cout,
-                       ntile_p);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t cells = (size_t)((Cin + 31) / 32) * ntile_p;
+    hipLaunchKernelGGL(convt_out_pack_bf3_kernel<false>, dim3(32), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned short *>(packed + cells * 1024), Cin, Cout, ntile_p, (const int *)nullptr);
+    char *h2 = reinterpret_cast<char *>(packed) + cells * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    int *hdr = reinterpret_cast<int *>(h2);
+    hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * 16, hdr);
+    hipLaunchKernelGGL(convt_out_pack_bf3_kernel<true>, dim3(32), dim3(256), 0, st, w,
+                       reinterpret_cast<unsigned short *>(h2 + kH2Header), Cin, Cout, ntile_p, hdr);
     return (int)hipGetLastError();
 }
 
 int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
                                 int Cin, int Cout, int flags, float *y_nchw, vqvae_stream_t stream) {
+    return vqvae::convt_out_forward_impl(x, packed, bias, B, H, W, Cin, Cout, flags, y_nchw, static_cast<hipStream_t>(stream), nullptr);
+}
+}  // extern "C"
+
+// in_amax: the input images' maxima from the producing layer (whole-path entry points) -> two-term fp16 products
+int vqvae::convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
+                                  int Cout, int flags, float *y_nchw, hipStream_t stream, const int *in_amax) {
     if (!x || !packed || !y_nchw) return VQVAE_ERR_NULL;
     if (B < 1 || H < 1 || W < 1) return VQVAE_ERR_SHAPE;
     if (vqvae_convt_out_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
@@ -2982,9 +3037,12 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
     const long long ntiles = B * (long long)tiles_y * tiles_x;
     if (ntiles > INT32_MAX) return VQVAE_ERR_OVERFLOW;
     const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
-    const bool bf3 = !(flags & VQVAE_CONV_EXACT_FP32);     // default: split-bf16 products (image behind the fp32 one)
+    const bool h2 = in_amax && !(flags & (VQVAE_CONV_EXACT_FP32 | VQVAE_CONV_BF16_SPLIT));
+    const bool bf3 = !h2 && !(flags & VQVAE_CONV_EXACT_FP32);     // split products unless the fp32 MFMA is asked for
     const size_t lds = ((size_t)cpt * ntile * (bf3 ? 1536 : 1024) + 256 * (16 * Cout + 1)) * sizeof(float);
-    const float *wimg = bf3 ? packed + (size_t)cpt * ntile * 1024 : packed;
+    const char *h2base = reinterpret_cast<const char *>(packed) + (size_t)cpt * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const int *whdr = reinterpret_cast<const int *>(h2base);
+    const float *wimg = h2 ? reinterpret_cast<const float *>(h2base + kH2Header) : (bf3 ? packed + (size_t)cpt * ntile * 1024 : packed);
     prof_begin(VQVAE_PROF_CONV_OUT, st);
 #define CTO_LAUNCH(NT_, BF_)                                                                                          \
     do {                                                                                                              \
@@ -2992,14 +3050,16 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                   kLdsBytes);                                                                         \
         hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, wimg, bias, y_nchw, (int)B, H, W, Cin,   \
-                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x);                                           \
+                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x, whdr, in_amax);                            \
     } while (0)
-    if (ntile == 1) { if (bf3) CTO_LAUNCH(1, true); else CTO_LAUNCH(1, false); }
-    else { if (bf3) CTO_LAUNCH(2, true); else CTO_LAUNCH(2, false); }
+    if (ntile == 1) { if (h2) CTO_LAUNCH(1, 2); else if (bf3) CTO_LAUNCH(1, 1); else CTO_LAUNCH(1, 0); }
+    else { if (h2) CTO_LAUNCH(2, 2); else if (bf3) CTO_LAUNCH(2, 1); else CTO_LAUNCH(2, 0); }
 #undef CTO_LAUNCH
     prof_end(VQVAE_PROF_CONV_OUT, st);
     return (int)hipGetLastError();
 }
+
+extern "C" {
 
 int vqvae_transpose_f32(const float *x, int64_t batch, int R, int Cc, float *y, vqvae_stream_t stream) {
     if (!x || !y) return VQVAE_ERR_NULL;

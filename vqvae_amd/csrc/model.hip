@@ -67,8 +67,9 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
 }
 
 // per-image activation maxima handed from layer to layer (two-term fp16 product path): one array of B ints per
-// inter-layer activation of the encoder (conv_in, enc2, enc4, n residual layers) or the decoder (dec0, n residual layers)
-size_t amax_bytes(const VqvaeDims *d, int64_t B) { return align_up((size_t)(3 + d->n_res_layers) * B * sizeof(int), 256); }
+// inter-layer activation of the encoder (conv_in, enc2, enc4, n residual layers) or the decoder (dec0, n residual layers,
+// z_q where the decoder's first layer is a generic kernel, dec2)
+size_t amax_bytes(const VqvaeDims *d, int64_t B) { return align_up((size_t)(4 + d->n_res_layers) * B * sizeof(int), 256); }
 
 }  // namespace
 }  // namespace vqvae
@@ -241,8 +242,9 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
         if (am) amt = am + (size_t)d->n_res_layers * B;
     }
     float *u = (t == a) ? b : a;
-    if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st, amt, nullptr)) != 0) return rc;
-    return vqvae_convt_out_forward_f32(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st);
+    int *am_u = am ? am + (size_t)(3 + d->n_res_layers) * B : nullptr;       // dec2's output maxima for the last layer
+    if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st, amt, am_u)) != 0) return rc;
+    return convt_out_forward_impl(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st, am_u);
 }
 
 int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
