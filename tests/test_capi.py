@@ -109,3 +109,39 @@ def test_product_path_does_not_import_oracle():
             if fn.endswith((".py", ".hip", ".h", ".cpp")):
                 src = open(os.path.join(dirpath, fn)).read()
                 assert not pat.search(src), f"{fn} reaches into oracle/"
+
+
+def test_host_side_plans_without_gpu():
+    """Pure host logic of round 2: which quantizer kernel / conv product scheme a shape gets, and how the packed-weight and
+    workspace sizes are laid out (no HIP calls)."""
+    from vqvae_amd import _lib
+    L = _lib.load()
+    # quantizer dispatch (row-major flag 0x1): resident-image sweep for small codebooks, streamed image beyond, exact on request
+    assert _lib.vq_kernel_name(512, 64) == "vq_sweep_kernel_d64"
+    assert _lib.vq_kernel_name(1024, 64) == "vq_stream_sweep_kernel"
+    assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
+    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"
+    assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_filter_kernel_d64"          # NCHW rows
+    assert _lib.vq_kernel_name(512, 256) == "vq_exact_kernel"
+    assert _lib.vq_sweeps(512, 64) == 1 and _lib.vq_sweeps(512, 64, 0x1 | 0x8) == 2 and _lib.vq_sweeps(512, 256) == 0
+    # the streamed kernels' scratch does not grow with the row count (slabs of 2^18 rows)
+    a, b = L.vqvae_vq_workspace_bytes(1000, 8192, 128), L.vqvae_vq_workspace_bytes(10 ** 8, 8192, 128)
+    assert a == b and a > (1 << 18) * 128 * 2
+    assert L.vqvae_vq_workspace_bytes(1000, 512, 64) < 4 << 20                   # resident-image kernel: no row scratch
+    # conv product schemes
+    assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 0) == 3
+    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0) == 6
+    assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 8) == 6 and L.vqvae_conv_term_products(1, 8, 8, 128, 128, 4) == 1
+    assert L.vqvae_conv_term_products(7, 8, 8, 128, 128, 0) == 0                  # unknown kind
+    # packed weights: fp32 image + three-term bf16 image + header + two-term fp16 image (4x4 s2: both in two chunk orders)
+    cells = 9 * 4 * 4                                                            # taps x Cin chunks x Cout tiles
+    assert L.vqvae_conv_packed_bytes(1, 128, 128) == cells * (4096 + 6144) + 256 + cells * 4096
+    cells = 16 * 2 * 4
+    assert L.vqvae_conv_packed_bytes(0, 64, 128) == cells * (4096 + 2 * 6144) + 256 + 2 * cells * 4096
+    assert L.vqvae_convt_out_packed_bytes(64, 3) == 2 * 2 * (4096 + 6144) + 256 + 2 * 2 * 4096
+    # whole-path workspace covers two activation buffers, the latents and the two maxima regions
+    dims = _lib.VqvaeDims(128, 32, 2, 512, 64, 3, 0.25)
+    ws = L.vqvae_workspace_bytes(dims, 4096, 32, 32)
+    act = 4096 * 16 * 16 * 64 * 4
+    assert ws > 2 * act + 2 * 4096 * 64 * 64 * 4 + 2 * (4 + 2) * 4096 * 4
+    assert L.vqvae_workspace_bytes(dims, 4096, 30, 32) == 0
