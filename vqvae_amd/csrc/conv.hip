@@ -1541,12 +1541,16 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 //             tile's path), is split with the image's scale (maximum taken from the registers) and parked as the 3x3 GEMM's
 //             operands; the skip of the second 1x1 GEMM comes straight from Y.
 // HBM-side traffic per pair of layers: x read twice (reduction + skip), y2 written once -- 3 maps instead of 6.
-template <int NT2>
+// NT3 > 0: a 1x1 conv (C -> 32 NT3 channels, + bias; the encoder's pre-quantisation conv, models/vqvae.py:33) consumes the
+// pair's output straight from the registers: y2 is not stored at all, out3 receives the conv's result.
+template <int NT2, int NT3 = 0>
 __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w1img,
                                                               const u32x4 *__restrict__ w2img, float *__restrict__ out,
                                                               int B, int C, int flags, const int *__restrict__ hdr1,
                                                               const int *__restrict__ hdr2, const int *__restrict__ in_amax,
-                                                              int *__restrict__ out_amax) {
+                                                              int *__restrict__ out_amax, const u32x4 *__restrict__ w3img,
+                                                              const int *__restrict__ hdr3, const float *__restrict__ bias3,
+                                                              float *__restrict__ out3) {
     constexpr int MT = 2, PX = 64, TILE4 = 264, HP = PX + 1;
     __shared__ u32x4 W2s[NT2 * 256];
     __shared__ u32x4 As_all[4 * TILE4];
@@ -1793,13 +1797,71 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
                         if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                         omax = fmaxf(omax, __builtin_fabsf(v[r]));
                     }
-                    tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
-                        *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
-                    });
+                    if constexpr (NT3 > 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Y[mt][nt][r] = v[r];       // stays on chip for the 1x1 conv below
+                    } else {
+                        tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
+                            *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
+                        });
+                    }
                 }
             }
         }
         if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+
+        if constexpr (NT3 > 0) {
+            // ================================ 1x1 conv on y2 (same operand order as conv_tile8_bf3_kernel) ================
+            const int kx3 = wave_scale_exp(img_ok ? omax : 0.0f);
+            const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -(kx3 + hdr3[0]));
+            f32x16 acc3[MT][NT3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc3[mt][n3][r] = 0.0f;
+            const u32x4 *w3v = w3img + h * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < NT2; ++c) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 t1[MT], t2[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                        lds_order_wave();
+                        float a2[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                        split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xs3, t1[mt], t2[mt]);
+                    }
+                    // lane (pixel l31 of tile mt, half h) holds the A operands of ITS pixel row: exactly the MFMA A layout
+#pragma unroll
+                    for (int n3 = 0; n3 < NT3; ++n3) {
+                        const u32x4 *bp = w3v + (size_t)(c * NT3 + n3) * 256 + s2 * 64;
+                        prod3x2(t1[0], t2[0], t1[1], t2[1], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
+                    }
+                }
+            }
+            if (img_ok) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int n3 = 0; n3 < NT3; ++n3) {
+                        const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f;
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3 + bv;
+                        __builtin_amdgcn_wave_barrier();
+                        tile_epilogue(Hs, v, lane, n3 * 32, [&](int p, int n, f32x4 a4, int) {
+                            *reinterpret_cast<f32x4 *>(out3 + (wbase + mt * 32 + p) * (32 * NT3) + n) = a4;
+                        });
+                    }
+            }
+        }
     }
 }
 
@@ -2876,11 +2938,15 @@ bool vqvae::res_pair_supported(int H, int W, int C, int Rh, int flags) {
            !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32));
 }
 
+// post (optional): a 1x1 conv (+ bias) applied to the pair's output inside the same kernel; y is then not written.
+bool vqvae::res_pair_post_supported(int C, int Cout) { return C == 128 && (Cout == 32 || Cout == 64 || Cout == 128); }
+
 int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
-                                 int C, int Rh, int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax) {
-    if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
+                                 int C, int Rh, int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax,
+                                 const ResPairPost *post) {
+    if (!x || !packed_w1 || !packed_w2 || (!y && !post)) return VQVAE_ERR_NULL;
     if (B < 1 || !res_pair_supported(H, W, C, Rh, flags)) return VQVAE_ERR_UNSUPPORTED;
-    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(post ? post->out : nullptr)) & 15) return VQVAE_ERR_UNSUPPORTED;
     const int cpt = (C + 31) / 32;
     const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
@@ -2888,10 +2954,26 @@ int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const f
     const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
     const unsigned gt = (unsigned)((B + 3) / 4);
     prof_begin(VQVAE_PROF_RES_LAYER, st);
-    switch (C / 32) {
-        case 1: hipLaunchKernelGGL((res_pair8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
-        case 2: hipLaunchKernelGGL((res_pair8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
-        case 4: hipLaunchKernelGGL((res_pair8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+    if (post) {
+        if (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout)) return VQVAE_ERR_UNSUPPORTED;
+        ConvGeom g3;
+        if (make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK) return VQVAE_ERR_UNSUPPORTED;
+        const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
+        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + kH2Header);
+        const int *hd3 = reinterpret_cast<const int *>(h3);
+#define PAIR_POST(NT3_)                                                                                                         \
+    hipLaunchKernelGGL((res_pair8_h2_kernel<4, NT3_>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2,  \
+                       in_amax, out_amax, w3h, hd3, post->bias, post->out)
+        switch (post->Cout / 32) {
+            case 1: PAIR_POST(1); break;
+            case 2: PAIR_POST(2); break;
+            case 4: PAIR_POST(4); break;
+        }
+#undef PAIR_POST
+    } else switch (C / 32) {
+        case 1: hipLaunchKernelGGL((res_pair8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+        case 2: hipLaunchKernelGGL((res_pair8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+        case 4: hipLaunchKernelGGL((res_pair8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

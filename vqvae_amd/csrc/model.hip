@@ -37,7 +37,8 @@ size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
 
 // amax: NULL, or (n_layers + 1) arrays of B ints (-1 = not provided): [0] belongs to x, [i + 1] to layer i's output
 int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
-              bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr) {
+              bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr,
+              const ResPairPost *post = nullptr, bool *post_done = nullptr) {
     // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
     // the producer applies it.  Layers run in PAIRS where the fused two-layer kernel applies (8x8 maps, two-term fp16
     // products; the intermediate map stays on chip), a trailing odd layer alone; buffers alternate so that the result of
@@ -56,8 +57,15 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
         float *dst = ((nsteps - 1 - j) % 2 == 0) ? y : tmp;
         const int *ain = amax ? amax + (size_t)i * B : nullptr;
         int *aout = amax ? amax + (size_t)(last + 1) * B : nullptr;
-        const int rc = pair ? res_pair_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout)
+        // the 1x1 conv behind the stack rides in the last step when that step is a fused pair
+#ifdef VQVAE_NO_PAIR_POST        // A/B builds (tools/build_variant.py): keep the 1x1 conv as its own launch
+        const bool with_post = false;
+#else
+        const bool with_post = pair && post && j == nsteps - 1 && res_pair_post_supported(C, post->Cout);
+#endif
+        const int rc = pair ? res_pair_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout, with_post ? post : nullptr)
                             : res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout);
+        if (with_post && post_done) *post_done = true;
         if (rc != 0) return rc;
         cur = dst;
         i = last + 1;
@@ -196,8 +204,14 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     if (d->n_res_layers > 0) {                                                                  // encoder.py:37-38
         // the first layer must not write into its own input (a): with an even layer count the result comes back to a
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
-        if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am2)) != 0)
+        // vqvae.py:33: the pre-quantisation 1x1 conv consumes the stack's output inside its last kernel where that is a
+        // fused pair (8x8 maps, h_dim 128): the stack's output map is never written
+        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e};
+        bool post_done = false;
+        if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am2,
+                            &post, &post_done)) != 0)
             return rc;
+        if (post_done) return 0;
         if (am2) amt = am2 + (size_t)d->n_res_layers * B;
     }
     // n_res_layers == 0: F.relu of an already ReLU'd tensor is the identity
