@@ -118,6 +118,10 @@ bool res_pair_post_supported(int C, int Cout);
 int res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                           int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
                           const ResPairPost *post = nullptr);
+bool conv_res_pair_supported(int kind, int H, int W, int Cin, int C, int Rh);
+int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_front, const float *bias_front, int Cin,
+                               const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C, int Rh, int flags,
+                               float *y, hipStream_t stream, const int *in_amax, int *out_amax, const ResPairPost *post = nullptr);
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)

@@ -1866,6 +1866,335 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------------------
+// A 3x3 conv / 3x3 conv-transpose (stride 1) IN FRONT of a residual pair, all in one kernel (8x8 maps, two-term fp16
+// products): models/encoder.py:35-38 (conv 3x3 + ReLU -> ResidualStack) and models/decoder.py:28-30 (conv-transpose 3x3 ->
+// ResidualStack).  One wave owns one image.  The front conv accumulates straight into the registers that hold the
+// residual layers' map (Y[m-tile][n-tile], accumulator layout: 128 channels x 64 pixels = 128 registers per lane); BOTH
+// residual layers then take their 3x3 operands from Y through the in-LDS transposition of res_pair8_h2_kernel's second
+// layer and their skip from Y itself.  The conv's output map and the first layer's output map never exist in memory.
+// Operand order per accumulator = the separate kernels' (chunk, tap, k-step for the front conv as in
+// conv_tile8_bf3_kernel; slice, tap for the residual 3x3): results are bitwise those of the separate launches.
+// NT3 > 0: the 1x1 conv behind the pair as in res_pair8_h2_kernel.
+struct FrontConv {
+    const u32x4 *wimg;             // two-term fp16 image of the front conv (vqvae_conv_pack_f32), phase 0
+    const int *hdr;                // {kw}
+    const float *bias;
+    unsigned long long dym, dxm;   // 4 bits per tap: dy + 8, dx + 8 (ConvGeom)
+    int Cin;                       // multiple of 32
+};
+
+template <int NT3>
+__global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
+                                                                   const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
+                                                                   float *__restrict__ out, int B, int flags,
+                                                                   const int *__restrict__ hdr1, const int *__restrict__ hdr2,
+                                                                   const int *__restrict__ in_amax, int *__restrict__ out_amax,
+                                                                   const u32x4 *__restrict__ w3img, const int *__restrict__ hdr3,
+                                                                   const float *__restrict__ bias3, float *__restrict__ out3) {
+    constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
+    constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
+    __shared__ u32x4 W2s[NT2 * 256];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    float *Hs = reinterpret_cast<float *>(As);
+    const bool relu_out = flags & kFlagReluOut;            // of the SECOND residual layer (the stack's final ReLU)
+    constexpr int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+    const int kw1 = hdr1[0], kw2 = hdr2[0];
+
+    // pixel bookkeeping: the residual 3x3 (taps t/3-1, t%3-1) and the front conv (taps from the geometry masks)
+    int spx[MT];
+    unsigned tapok[MT], tapok0[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0, m0 = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+            const int y0 = y + (int)((fc.dym >> (4 * t)) & 15) - 8, x0 = x + (int)((fc.dxm >> (4 * t)) & 15) - 8;
+            if (y0 >= 0 && y0 < 8 && x0 >= 0 && x0 < 8) m0 |= 1u << t;
+        }
+        tapok[mt] = m;
+        tapok0[mt] = m0;
+    }
+
+    f32x16 Y[MT][NT2];
+    float ymax = 0.0f;                                     // largest |Y| (the next consumer's scale)
+    // =========================================== front conv ===========================================
+    {
+        const int cpt0 = fc.Cin >> 5;
+        const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * fc.Cin;     // this lane's pixel row
+        f32x4 raw[8];
+        auto load_raw0 = [&](int cc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(src + 32 * cc + 4 * j);
+        };
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+        if (given >= 0) m = __int_as_float(given);
+        else for (int cc = 0; cc < cpt0; ++cc) {
+            load_raw0(cc);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(raw[j].x), __builtin_fabsf(raw[j].y)), fmaxf(__builtin_fabsf(raw[j].z), __builtin_fabsf(raw[j].w))));
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        const float xs = __builtin_ldexpf(1.0f, kx), d0 = __builtin_ldexpf(1.0f, -(kx + fc.hdr[0]));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Y[mt][nt][r] = 0.0f;
+        if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
+        const u32x4 *wv = fc.wimg + h * 32 + l31;
+        load_raw0(0);
+        for (int cc = 0; cc < cpt0; ++cc) {
+            // park the chunk: k-step t, half hh hold channels 16 hh + 8 t + [0, 8) (conv_tile8_bf3_kernel's stage())
+            __builtin_amdgcn_wave_barrier();
+            u32x4 *dst = As + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    u32x4 t1, t2;
+                    split8_h(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], xs, t1, t2);
+                    dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
+                    dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
+                }
+            if (cc + 1 < cpt0) load_raw0(cc + 1);
+            lds_order_wave();
+#pragma unroll 1
+            for (int tap = 0; tap < 9; ++tap) {
+                const int shift = ((int)((fc.dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((fc.dxm >> (4 * tap)) & 15) - 8);
+                const u32x4 *wt = wv + (size_t)(tap * cpt0 + cc) * (NT2 * 256);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    u32x4 A1[MT], A2[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int p = ((tapok0[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                        const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
+                        A1[mt] = ap[0];
+                        A2[mt] = ap[PLANE];
+                    }
+#pragma unroll
+                    for (int nt = 0; nt < NT2; ++nt) {
+                        const u32x4 *bp = wt + nt * 256 + t * 64;
+                        prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], Y[0][nt], Y[1][nt]);
+                    }
+                }
+            }
+        }
+        // bias + ReLU (encoder.py:36 / the stack's first in-place ReLU applied by the producer, decoder.py:29-30)
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const float bv = fc.bias ? fc.bias[nt * 32 + l31] : 0.0f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float v = fmaxf(Y[mt][nt][r] * d0 + bv, 0.0f);
+                    Y[mt][nt][r] = v;
+                    ymax = fmaxf(ymax, v);
+                }
+        }
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+
+    // =========================================== residual layers from Y ===========================================
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    u32x4 bw[2][2];
+    auto load_w = [&](int tap, int sl, u32x4(&b)[2]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
+        b[0] = p[0]; b[1] = p[128];
+    };
+    f32x16 acc1[MT];
+    auto taps = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+            u32x4 S[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + h * HP + p;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+            }
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+        }
+    };
+    // Y <- [relu](Y + W2 relu(W1 (*) Y)); ymax in: largest Y, out: largest new Y.  always_inline: hipcc does not inline a
+    // lambda this size twice by itself, and Y (captured by reference) then lives in scratch memory -- 5 ms per launch,
+    // measured; a two-iteration loop around the body instead spills 275 registers
+    auto layer = [&](bool relu_after) __attribute__((always_inline)) {
+        const int kx = wave_scale_exp(img_ok ? ymax : 0.0f);
+        const float xscale = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+        load_w(0, 0, bw[0]);
+#pragma unroll
+        for (int c = 0; c < NT2; ++c) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 t1[MT], t2[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                    lds_order_wave();
+                    float a2[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                    split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xscale, t1[mt], t2[mt]);
+                }
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    As[(0 * 2 + h) * HP + 32 * mt + l31] = t1[mt];
+                    As[(1 * 2 + h) * HP + 32 * mt + l31] = t2[mt];
+                }
+                if (lane < 4) As[lane * HP + PX] = u32x4{0, 0, 0, 0};
+                lds_order_wave();
+                if (s2 == 0) taps(2 * c, std::integral_constant<int, 0>{});
+                else taps(2 * c + 1, std::integral_constant<int, 1>{});
+            }
+        }
+        // hidden tile -> A operands of the 1x1 GEMM
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
+                m = fmaxf(m, acc1[mt][r]);
+            }
+        const int kh = wave_scale_exp(m);
+        const float hscale = __builtin_ldexpf(1.0f, kh), d2 = __builtin_ldexpf(1.0f, -(kh + kw2));
+        u32x4 H1[MT][2], Hb[MT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc1[mt][r];
+            lds_order_wave();
+            float a2[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+        }
+        float nmax = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16 acc2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = Y[mt][nt][r] + acc2[mt][r] * d2;
+                    if (relu_after) v = fmaxf(v, 0.0f);
+                    Y[mt][nt][r] = v;
+                    nmax = fmaxf(nmax, __builtin_fabsf(v));
+                }
+        }
+        ymax = nmax;
+    };
+    layer(true);               // the second layer's in-place ReLU is applied by its producer
+    layer(relu_out);
+    if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
+
+    const long long wbase = img * PX;
+    if constexpr (NT3 > 0) {
+        const int kx3 = wave_scale_exp(img_ok ? ymax : 0.0f);
+        const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -(kx3 + hdr3[0]));
+        f32x16 acc3[MT][NT3];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc3[mt][n3][r] = 0.0f;
+        const u32x4 *w3v = w3img + h * 32 + l31;
+#pragma unroll
+        for (int c = 0; c < NT2; ++c) {
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                u32x4 t1[MT], t2[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                    lds_order_wave();
+                    float a2[8];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                    split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xs3, t1[mt], t2[mt]);
+                }
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3) {
+                    const u32x4 *bp = w3v + (size_t)(c * NT3 + n3) * 256 + s2 * 64;
+                    prod3x2(t1[0], t2[0], t1[1], t2[1], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
+                }
+            }
+        }
+        if (img_ok) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3) {
+                    const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3 + bv;
+                    __builtin_amdgcn_wave_barrier();
+                    tile_epilogue(Hs, v, lane, n3 * 32, [&](int p, int n, f32x4 a4, int) {
+                        *reinterpret_cast<f32x4 *>(out3 + (wbase + mt * 32 + p) * (32 * NT3) + n) = a4;
+                    });
+                }
+        }
+    } else if (img_ok) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = Y[mt][nt][r];
+                __builtin_amdgcn_wave_barrier();
+                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
+                    *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
+                });
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
@@ -2974,6 +3303,62 @@ int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const f
         case 1: hipLaunchKernelGGL((res_pair8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
         case 2: hipLaunchKernelGGL((res_pair8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
         case 4: hipLaunchKernelGGL((res_pair8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+    }
+    prof_end(VQVAE_PROF_RES_LAYER, st);
+    return (int)hipGetLastError();
+}
+
+// A 3x3 conv / conv-transpose (stride 1, Cin -> 128, + bias + ReLU) and the two residual layers behind it in one launch
+// (conv_res_pair8_h2_kernel); post as in res_pair_forward_impl.  x == y is not allowed (x has Cin channels).
+bool vqvae::conv_res_pair_supported(int kind, int H, int W, int Cin, int C, int Rh) {
+    return (kind == VQVAE_CONV_3x3_S1 || kind == VQVAE_CONVT_3x3_S1) && H == 8 && W == 8 && C == 128 && Cin >= 32 && Cin % 32 == 0 &&
+           Cin <= 256 && Rh >= 1 && Rh <= 32;
+}
+
+int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *packed_front, const float *bias_front, int Cin,
+                                      const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C, int Rh,
+                                      int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax,
+                                      const ResPairPost *post) {
+    if (!x || !packed_front || !packed_w1 || !packed_w2 || (!y && !post)) return VQVAE_ERR_NULL;
+    if (B < 1 || !conv_res_pair_supported(kind, H, W, Cin, C, Rh)) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(post ? post->out : nullptr)) & 15)
+        return VQVAE_ERR_UNSUPPORTED;
+    ConvGeom g;
+    if (make_geom(kind, B, H, W, Cin, C, 0, g) != VQVAE_OK || g.nphase != 1 || g.ntaps != 9) return VQVAE_ERR_UNSUPPORTED;
+    const char *hf = reinterpret_cast<const char *>(packed_front) + packed_h2_offset(g, kind);
+    FrontConv fc;
+    fc.wimg = reinterpret_cast<const u32x4 *>(hf + kH2Header);
+    fc.hdr = reinterpret_cast<const int *>(hf);
+    fc.bias = bias_front;
+    fc.dym = g.dymask[0];
+    fc.dxm = g.dxmask[0];
+    fc.Cin = Cin;
+    const int cpt = C / 32;
+    const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+    const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+    const unsigned gt = (unsigned)((B + 3) / 4);
+    prof_begin(VQVAE_PROF_RES_LAYER, st);
+    if (post) {
+        if (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout)) return VQVAE_ERR_UNSUPPORTED;
+        ConvGeom g3;
+        if (make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK) return VQVAE_ERR_UNSUPPORTED;
+        const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
+        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + kH2Header);
+        const int *hd3 = reinterpret_cast<const int *>(h3);
+#define CRP_POST(NT3_)                                                                                                          \
+    hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
+                       in_amax, out_amax, w3h, hd3, post->bias, post->out)
+        switch (post->Cout / 32) {
+            case 1: CRP_POST(1); break;
+            case 2: CRP_POST(2); break;
+            case 4: CRP_POST(4); break;
+        }
+#undef CRP_POST
+    } else {
+        hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
+                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr);
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

@@ -198,6 +198,16 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     // encoder.py:29-31, :32-34, :35-36 (+ the residual stack's first in-place ReLU, residual.py:19)
     if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st, am0)) != 0) return rc;
     if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st, am0, am1)) != 0) return rc;
+#ifndef VQVAE_NO_FRONT_FUSION    // A/B builds (tools/build_variant.py)
+    // encoder.py:35-38 + vqvae.py:33 in ONE launch where the shapes allow (8x8 latent maps, h_dim 128, two residual layers):
+    // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
+    if (d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
+        res_pair_post_supported(h, d->embedding_dim)) {
+        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e};
+        return conv_res_pair_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, h, w->enc_res_w1, w->enc_res_w2, B, H / 4, W / 4, h,
+                                          d->res_h_dim, VQVAE_CONV_RELU_OUT, nullptr, st, am1, nullptr, &post);
+    }
+#endif
     if ((rc = conv_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT, a, st, am1, am2)) != 0) return rc;
     const float *t = a;
     const int *amt = am2;
@@ -247,10 +257,21 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
         amz = am + (size_t)(2 + d->n_res_layers) * B;
         act_absmax_impl(z_q, B, (long long)h4 * w4 * d->embedding_dim, amz, st);
     }
-    if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, amz, am)) != 0) return rc;
     const float *t = a;
     const int *amt = am;
-    if (d->n_res_layers > 0) {
+#ifndef VQVAE_NO_FRONT_FUSION
+    // decoder.py:28-30 in one launch where the shapes allow: conv-transpose 3x3 (+ the stack's first ReLU) and both residual layers
+    const bool front = d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, h, d->res_h_dim);
+#else
+    const bool front = false;
+#endif
+    if (front) {
+        int *aout = am ? am + (size_t)2 * B : nullptr;
+        if ((rc = conv_res_pair_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, d->embedding_dim, w->dec_res_w1, w->dec_res_w2, B, h4,
+                                             w4, h, d->res_h_dim, VQVAE_CONV_RELU_OUT, a, st, amz, aout)) != 0) return rc;
+        amt = aout;
+    } else if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, amz, am)) != 0) return rc;
+    if (!front && d->n_res_layers > 0) {
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
         if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am)) != 0) return rc;
         if (am) amt = am + (size_t)d->n_res_layers * B;
