@@ -1893,8 +1893,10 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                                                                    const float *__restrict__ bias3, float *__restrict__ out3) {
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
-    __shared__ u32x4 W2s[NT2 * 256];
     __shared__ u32x4 As_all[4 * TILE4];
+    // 32 of the map's 128 registers per lane (n-tile 3 of both m-tiles) are parked here between their uses: with all 128 live
+    // next to a layer's own operands the compiler spills ~60 registers to scratch memory (60 MB of writes per launch, measured)
+    __shared__ float Ypark_all[4 * 32 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -1902,7 +1904,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     const bool relu_out = flags & kFlagReluOut;            // of the SECOND residual layer (the stack's final ReLU)
     constexpr int cpt = C >> 5, nslice = C >> 4;
 
-    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+    float *park = Ypark_all + wave * (32 * 64) + lane;
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
     const int kw1 = hdr1[0], kw2 = hdr2[0];
@@ -1926,7 +1928,13 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         tapok0[mt] = m0;
     }
 
-    f32x16 Y[MT][NT2];
+    f32x16 Y[MT][NT2];                                     // n-tile 3 lives in registers only while the front conv accumulates
+#define YGET(mt_, nt_, r_) ((nt_) == 3 ? park[((mt_) * 16 + (r_)) * 64] : Y[mt_][nt_][r_])
+#define YPUT(mt_, nt_, r_, v_)                                    \
+    do {                                                          \
+        if ((nt_) == 3) park[((mt_) * 16 + (r_)) * 64] = (v_);    \
+        else Y[mt_][nt_][r_] = (v_);                              \
+    } while (0)
     float ymax = 0.0f;                                     // largest |Y| (the next consumer's scale)
     // =========================================== front conv ===========================================
     {
@@ -2003,12 +2011,12 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = fmaxf(Y[mt][nt][r] * d0 + bv, 0.0f);
-                    Y[mt][nt][r] = v;
+                    YPUT(mt, nt, r, v);
                     ymax = fmaxf(ymax, v);
                 }
         }
     }
-    __syncthreads();          // W2 image (copied at kernel start) is complete
+    lds_order_wave();
 
     // =========================================== residual layers from Y ===========================================
     const u32x4 *w1v = w1img + h * 32 + l31;
@@ -2056,7 +2064,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                 for (int mt = 0; mt < MT; ++mt) {
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = YGET(mt, c, r);
                     lds_order_wave();
                     float a2[8];
 #pragma unroll
@@ -2109,16 +2117,16 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                 for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+                const u32x4 *bp = w2img + nt * 256 + (t * 2 + h) * 32 + l31;          // 1x1 weights straight from L1 / L2
                 prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = Y[mt][nt][r] + acc2[mt][r] * d2;
+                    float v = YGET(mt, nt, r) + acc2[mt][r] * d2;
                     if (relu_after) v = fmaxf(v, 0.0f);
-                    Y[mt][nt][r] = v;
+                    YPUT(mt, nt, r, v);
                     nmax = fmaxf(nmax, __builtin_fabsf(v));
                 }
         }
@@ -2149,7 +2157,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                 for (int mt = 0; mt < MT; ++mt) {
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = YGET(mt, c, r);
                     lds_order_wave();
                     float a2[8];
 #pragma unroll
@@ -2185,7 +2193,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             for (int nt = 0; nt < NT2; ++nt) {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = Y[mt][nt][r];
+                for (int r = 0; r < 16; ++r) v[r] = YGET(mt, nt, r);
                 __builtin_amdgcn_wave_barrier();
                 tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
                     *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
@@ -2193,6 +2201,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             }
     }
 }
+#undef YGET
+#undef YPUT
 
 // ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
