@@ -2680,8 +2680,10 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int cpt = (Cin + 31) / 32;
     constexpr int WCH = BF3 ? 1536 : 1024;          // floats per (chunk, n-tile) of the weight image (fp32: 1024 values, fp16: 2 x 1024 halves)
+    // H2: the 16 KiB weight image is read straight from L1 / L2 (every workgroup reads the same bytes), which leaves 50 KiB of
+    // LDS per workgroup -> three workgroups per CU instead of two
     float *Ws = smem;                               // [cpt][NT][WCH]
-    float *Ts = smem + (size_t)cpt * NT * WCH;      // [256][STRIDE]
+    float *Ts = H2 ? smem : smem + (size_t)cpt * NT * WCH;      // [256][STRIDE]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
 
@@ -2692,8 +2694,9 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     const int y0 = ty * TH, x0 = tx * TW;
     const int ry = y0 - halo_y, rx = x0 - halo_x;
 
-    for (int i = tid; i < cpt * NT * (WCH / 4); i += 256)
-        reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
+    if constexpr (!H2)
+        for (int i = tid; i < cpt * NT * (WCH / 4); i += 256)
+            reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -2736,7 +2739,7 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     }
     auto mma = [&](int c, const f32x4(&a)[MT][4]) {
         if constexpr (H2) {
-            const u32x4 *wb = reinterpret_cast<const u32x4 *>(Ws + (size_t)c * NT * WCH);
+            const u32x4 *wb = reinterpret_cast<const u32x4 *>(wimg + (size_t)c * NT * WCH);
             u32x4 S1[MT][2], S2[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
@@ -3516,7 +3519,7 @@ int vqvae::convt_out_forward_impl(const float *x, const float *packed, const flo
     const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
     const bool h2 = in_amax && !(flags & (VQVAE_CONV_EXACT_FP32 | VQVAE_CONV_BF16_SPLIT));
     const bool bf3 = !h2 && !(flags & VQVAE_CONV_EXACT_FP32);     // split products unless the fp32 MFMA is asked for
-    const size_t lds = ((size_t)cpt * ntile * (bf3 ? 1536 : 1024) + 256 * (16 * Cout + 1)) * sizeof(float);
+    const size_t lds = ((h2 ? 0 : (size_t)cpt * ntile * (bf3 ? 1536 : 1024)) + 256 * (16 * Cout + 1)) * sizeof(float);
     const char *h2base = reinterpret_cast<const char *>(packed) + (size_t)cpt * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const int *whdr = reinterpret_cast<const int *>(h2base);
     const float *wimg = h2 ? reinterpret_cast<const float *>(h2base + kH2Header) : (bf3 ? packed + (size_t)cpt * ntile * 1024 : packed);
