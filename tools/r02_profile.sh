@@ -3,7 +3,7 @@
 # same command, FETCH_SIZE / WRITE_SIZE (separate --pmc passes, kernel-trace only) for the bench step and for the VQ
 # kernel on a stream beyond the Infinity Cache, and the traffic JSON bench.py reads.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-O=$R/gpurun_out/r02; mkdir -p $O
+O=$R/gpurun_out/r02; rm -rf $O; mkdir -p $O          # gpurun MERGES into existing directories: stale counter files would be averaged in
 cd /tmp; export TMPDIR=/tmp
 (cd $R && timeout 300 python bench.py 2>/dev/null | tail -1) > $O/bench_c3.json
 (cd $R && timeout 240 rocprofv3 --kernel-trace --stats -d $O/prof -- python bench.py --no-cpu-baseline --steps 20 --min-seconds 0.2 > $O/prof.log 2>&1)
