@@ -1894,9 +1894,12 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
     __shared__ u32x4 As_all[4 * TILE4];
-    // 32 of the map's 128 registers per lane (n-tile 3 of both m-tiles) are parked here between their uses: with all 128 live
-    // next to a layer's own operands the compiler spills ~60 registers to scratch memory (60 MB of writes per launch, measured)
-    __shared__ float Ypark_all[4 * 32 * 64];
+    // Weights of the 3x3 GEMMs stream through two 18 KiB LDS buffers shared by the workgroup's four images, filled by LDS-DMA
+    // (no staging registers) one stage ahead: a stage = one (tap, chunk) of the front conv (16 pieces of 1 KiB) or the nine
+    // taps of one 16-channel slice of a residual 3x3 (18 pieces); one workgroup barrier per stage.  Per-wave loads straight
+    // from L2 cost 87 + 51 us per step in exposed latency (knock-outs, profiles/r02_vq_stream.txt).
+    constexpr int WBUF = 18 * 64;
+    __shared__ u32x4 Wb_all[2 * WBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -1904,7 +1907,6 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     const bool relu_out = flags & kFlagReluOut;            // of the SECOND residual layer (the stack's final ReLU)
     constexpr int cpt = C >> 5, nslice = C >> 4;
 
-    float *park = Ypark_all + wave * (32 * 64) + lane;
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
     const int kw1 = hdr1[0], kw2 = hdr2[0];
@@ -1929,13 +1931,26 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     }
 
     f32x16 Y[MT][NT2];                                     // n-tile 3 lives in registers only while the front conv accumulates
-#define YGET(mt_, nt_, r_) ((nt_) == 3 ? park[((mt_) * 16 + (r_)) * 64] : Y[mt_][nt_][r_])
-#define YPUT(mt_, nt_, r_, v_)                                    \
-    do {                                                          \
-        if ((nt_) == 3) park[((mt_) * 16 + (r_)) * 64] = (v_);    \
-        else Y[mt_][nt_][r_] = (v_);                              \
-    } while (0)
+#define YGET(mt_, nt_, r_) (Y[mt_][nt_][r_])
+#define YPUT(mt_, nt_, r_, v_) do { Y[mt_][nt_][r_] = (v_); } while (0)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // one 1 KiB piece global -> LDS: every lane's 16 bytes land at dst + 16 lane
+    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
+                                         (__attribute__((address_space(3))) void *)dst_piece, 16, 0, 0);
+    };
+    // the nine taps of slice sl of the residual 3x3 -> buffer `buf`: piece p = tap * 2 + term
+    auto dma_slice = [&](int sl, int buf) {
+        const u32x4 *base = w1img + (size_t)(sl >> 1) * 256 + (sl & 1) * 64 + lane;
+        for (int p = wave_u; p < 18; p += 4)
+            dma(base + (size_t)(p >> 1) * cpt * 256 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
+    };
+    auto dma_wait_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
     float ymax = 0.0f;                                     // largest |Y| (the next consumer's scale)
+    int wstage = 0;                                        // weight stages consumed so far (LDS buffer parity)
     // =========================================== front conv ===========================================
     {
         const int cpt0 = fc.Cin >> 5;
@@ -1963,8 +1978,17 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[mt][nt][r] = 0.0f;
         if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
-        const u32x4 *wv = fc.wimg + h * 32 + l31;
+        // stage (cc, tap) = 16 pieces: piece p = nt * 4 + t * 2 + term, four per wave
+        auto dma_front = [&](int cc, int tap, int buf) {
+            const u32x4 *base = fc.wimg + (size_t)(tap * cpt0 + cc) * (NT2 * 256) + lane;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int p = wave_u * 4 + j;
+                dma(base + (p >> 2) * 256 + ((p >> 1) & 1) * 64 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
+            }
+        };
         load_raw0(0);
+        dma_front(0, 0, 0);
         for (int cc = 0; cc < cpt0; ++cc) {
             // park the chunk: k-step t, half hh hold channels 16 hh + 8 t + [0, 8) (conv_tile8_bf3_kernel's stage())
             __builtin_amdgcn_wave_barrier();
@@ -1981,9 +2005,13 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             if (cc + 1 < cpt0) load_raw0(cc + 1);
             lds_order_wave();
 #pragma unroll 1
-            for (int tap = 0; tap < 9; ++tap) {
+            for (int tap = 0; tap < 9; ++tap, ++wstage) {
+                dma_wait_sync();                               // this stage's weights are in; everyone is done with the other buffer
+                if (tap + 1 < 9) dma_front(cc, tap + 1, (wstage + 1) & 1);
+                else if (cc + 1 < cpt0) dma_front(cc + 1, 0, (wstage + 1) & 1);
+                else dma_slice(0, (wstage + 1) & 1);           // the first slice of the first residual layer
                 const int shift = ((int)((fc.dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((fc.dxm >> (4 * tap)) & 15) - 8);
-                const u32x4 *wt = wv + (size_t)(tap * cpt0 + cc) * (NT2 * 256);
+                const u32x4 *wt = Wb_all + (wstage & 1) * WBUF + lane;
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     u32x4 A1[MT], A2[MT];
@@ -1996,8 +2024,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                     }
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) {
-                        const u32x4 *bp = wt + nt * 256 + t * 64;
-                        prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], Y[0][nt], Y[1][nt]);
+                        const u32x4 *bp = wt + (nt * 4 + t * 2) * 64;
+                        prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[64], Y[0][nt], Y[1][nt]);
                     }
                 }
             }
@@ -2019,20 +2047,14 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     lds_order_wave();
 
     // =========================================== residual layers from Y ===========================================
-    const u32x4 *w1v = w1img + h * 32 + l31;
-    u32x4 bw[2][2];
-    auto load_w = [&](int tap, int sl, u32x4(&b)[2]) {
-        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
-        b[0] = p[0]; b[1] = p[128];
-    };
     f32x16 acc1[MT];
-    auto taps = [&](int sl, auto PAR) {
-        constexpr int par = decltype(PAR)::value;
+    // nine taps of the parked slice; wb = this lane's column of the stage buffer: [tap * 2 + term] x 64 units
+    auto taps = [&](const u32x4 *wb) {
+        u32x4 bwc0 = wb[0], bwc1 = wb[64];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-            const int cur = (tap + par) & 1;
-            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
-            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            u32x4 bwn0 = bwc0, bwn1 = bwc1;
+            if (tap + 1 < 9) { bwn0 = wb[(tap + 1) * 128]; bwn1 = wb[(tap + 1) * 128 + 64]; }
             const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
             u32x4 S[MT][2];
 #pragma unroll
@@ -2041,20 +2063,21 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                 const u32x4 *ap = As + h * HP + p;
                 S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
             }
-            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bwc0, bwc1, acc1[0], acc1[1]);
+            bwc0 = bwn0; bwc1 = bwn1;
         }
     };
     // Y <- [relu](Y + W2 relu(W1 (*) Y)); ymax in: largest Y, out: largest new Y.  always_inline: hipcc does not inline a
     // lambda this size twice by itself, and Y (captured by reference) then lives in scratch memory -- 5 ms per launch,
     // measured; a two-iteration loop around the body instead spills 275 registers
-    auto layer = [&](bool relu_after) __attribute__((always_inline)) {
+    auto layer = [&](auto LT, bool relu_after) __attribute__((always_inline)) {
+        constexpr int LI = decltype(LT)::value;                // 0 or 1: global slice index gs = 8 LI + slice
         const int kx = wave_scale_exp(img_ok ? ymax : 0.0f);
         const float xscale = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
-        load_w(0, 0, bw[0]);
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
 #pragma unroll
@@ -2079,8 +2102,10 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                 }
                 if (lane < 4) As[lane * HP + PX] = u32x4{0, 0, 0, 0};
                 lds_order_wave();
-                if (s2 == 0) taps(2 * c, std::integral_constant<int, 0>{});
-                else taps(2 * c + 1, std::integral_constant<int, 1>{});
+                const int gs = 8 * LI + 2 * c + s2;              // compile-time after unrolling
+                dma_wait_sync();                               // this slice's weights are in; everyone is done with the other buffer
+                if (gs + 1 < 16) dma_slice((gs + 1) & 7, (wstage + gs + 1) & 1);
+                taps(Wb_all + ((wstage + gs) & 1) * WBUF + lane);
             }
         }
         // hidden tile -> A operands of the 1x1 GEMM
@@ -2132,8 +2157,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         }
         ymax = nmax;
     };
-    layer(true);               // the second layer's in-place ReLU is applied by its producer
-    layer(relu_out);
+    layer(std::integral_constant<int, 0>{}, true);         // the second layer's in-place ReLU is applied by its producer
+    layer(std::integral_constant<int, 1>{}, relu_out);
     if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
 
     const long long wbase = img * PX;
