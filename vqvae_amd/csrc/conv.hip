@@ -1883,6 +1883,46 @@ struct FrontConv {
     int Cin;                       // multiple of 32
 };
 
+// x[lanes 32..63] <-> z[lanes 0..31] (v_permlane32_swap_b32)
+__device__ __forceinline__ void swap_halves(float &x, float &z) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(z), false, false);
+    x = __uint_as_float(r[0]);
+    z = __uint_as_float(r[1]);
+}
+// A TRANSPOSED accumulator tile (weights as the A operand: lane = pixel l31, register r = channel (r & 3) + 8 (r >> 2) + 4 h
+// of the 32-channel tile) turned into the B operands of the next GEMM's two 16-deep k-steps, in the weight images' channel
+// order (k-step t, half h, element q = channel 16 h + 8 t + q): four half-wave register swaps per k-step bring channels
+// 16 h + 8 t + [0, 4) and + [4, 8) into one lane; no trip through LDS.
+__device__ __forceinline__ void acc_to_ksteps(const f32x16 &a, float sc, u32x4 (&t1)[2], u32x4 (&t2)[2]) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float P[4], Q[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            P[q] = a[4 * t + q];
+            Q[q] = a[8 + 4 * t + q];
+            swap_halves(P[q], Q[q]);
+        }
+        split8_h(f32x4{P[0], P[1], P[2], P[3]}, f32x4{Q[0], Q[1], Q[2], Q[3]}, sc, t1[t], t2[t]);
+    }
+}
+// prod3x2 with the operands exchanged: acc^T += W^T x^T (same products, same k order, transposed result)
+__device__ __forceinline__ void prod3x2t(const u32x4 &s1, const u32x4 &s2, const u32x4 &t1, const u32x4 &t2,
+                                         const u32x4 &w1, const u32x4 &w2, f32x16 &accA, f32x16 &accB) {
+#define HF(v) __builtin_bit_cast(f16x8, v)
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w1), HF(s2), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w1), HF(t2), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w2), HF(s1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w2), HF(t1), accB, 0, 0, 0);
+    accA = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w1), HF(s1), accA, 0, 0, 0);
+    accB = __builtin_amdgcn_mfma_f32_32x32x16_f16(HF(w1), HF(t1), accB, 0, 0, 0);
+#undef HF
+}
+
+// Everything is computed TRANSPOSED (weights = A operand, pixels = B operand): an accumulator lane then owns one pixel and
+// its registers run over channels, which is the B-operand layout of the next GEMM up to half-wave swaps (acc_to_ksteps) --
+// the 1x1 GEMMs take their inputs straight from registers and the 3x3 slices go registers -> fp16 planes in LDS without
+// the accumulator -> LDS -> transposed read round trip of res_pair8_h2_kernel.
 template <int NT3>
 __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
                                                                    const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
@@ -1891,21 +1931,25 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                                                                    const int *__restrict__ in_amax, int *__restrict__ out_amax,
                                                                    const u32x4 *__restrict__ w3img, const int *__restrict__ hdr3,
                                                                    const float *__restrict__ bias3, float *__restrict__ out3) {
+    static_assert(NT3 == 0 || NT3 == 1 || NT3 == 2 || NT3 == 4, "the 1x1 post conv streams through NT3 weight stages of 16 KiB");
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
+    constexpr int RBUF = 4 * HP;                           // residual slice: [term 2][half 2][pixel + zero]; two buffers = TILE4
     __shared__ u32x4 As_all[4 * TILE4];
-    // Weights of the 3x3 GEMMs stream through two 18 KiB LDS buffers shared by the workgroup's four images, filled by LDS-DMA
-    // (no staging registers) one stage ahead: a stage = one (tap, chunk) of the front conv (16 pieces of 1 KiB) or the nine
-    // taps of one 16-channel slice of a residual 3x3 (18 pieces); one workgroup barrier per stage.  Per-wave loads straight
-    // from L2 cost 87 + 51 us per step in exposed latency (knock-outs, profiles/r02_vq_stream.txt).
+    // Weights stream through two 18 KiB LDS buffers shared by the workgroup's four images, filled by LDS-DMA (no staging
+    // registers) one stage ahead; one workgroup barrier per stage.  Stages: one (tap, chunk) of the front conv (16 pieces
+    // of 1 KiB); then per residual layer the nine taps of each 16-channel slice of the 3x3 (18 pieces) x 8 and the 1x1
+    // (16 pieces); then the 1x1 post conv in NT3 parts of 4 / NT3 channel tiles (16 pieces each).  Per-wave loads straight from L2 cost 87 + 51 us
+    // per step in exposed latency (knock-outs, profiles/r02_vq_stream.txt).
     constexpr int WBUF = 18 * 64;
+    constexpr int NSTAGE = 18 + NT3;                       // stages after the front conv
     __shared__ u32x4 Wb_all[2 * WBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
     float *Hs = reinterpret_cast<float *>(As);
     const bool relu_out = flags & kFlagReluOut;            // of the SECOND residual layer (the stack's final ReLU)
-    constexpr int cpt = C >> 5, nslice = C >> 4;
+    constexpr int cpt = C >> 5;
 
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
@@ -1930,14 +1974,17 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         tapok0[mt] = m0;
     }
 
-    f32x16 Y[MT][NT2];                                     // n-tile 3 lives in registers only while the front conv accumulates
-#define YGET(mt_, nt_, r_) (Y[mt_][nt_][r_])
-#define YPUT(mt_, nt_, r_, v_) do { Y[mt_][nt_][r_] = (v_); } while (0)
+    // Y[mt][nt][r]: channel 32 nt + (r & 3) + 8 (r >> 2) + 4 h of pixel 32 mt + l31
+    f32x16 Y[MT][NT2];
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     // one 1 KiB piece global -> LDS: every lane's 16 bytes land at dst + 16 lane
+    // Issued as inline assembly: for the builtin hipcc puts s_waitcnt vmcnt(0) in front of every later LDS read that it
+    // cannot prove disjoint from the destination -- i.e. it waits for the NEXT stage's pieces before reading this stage's.
+    // The waits are explicit here (dma_wait_sync); the compiler's own vmcnt waits stay correct (loads return in order and an
+    // uncounted outstanding load only makes a counted wait longer).
     auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src_lane,
-                                         (__attribute__((address_space(3))) void *)dst_piece, 16, 0, 0);
+        const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
     };
     // the nine taps of slice sl of the residual 3x3 -> buffer `buf`: piece p = tap * 2 + term
     auto dma_slice = [&](int sl, int buf) {
@@ -1945,12 +1992,23 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         for (int p = wave_u; p < 18; p += 4)
             dma(base + (size_t)(p >> 1) * cpt * 256 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
     };
+    // 16 KiB of an image as it lies (the 1x1 GEMMs): four pieces per wave
+    auto dma_linear = [&](const u32x4 *src, int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma(src + (wave_u * 4 + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * 4 + j) * 64);
+    };
+    // stage k after the front conv: 9 LI + slice (3x3 of layer LI), 9 LI + 8 (its 1x1), 18 + j (part j of the post conv)
+    auto dma_stage = [&](int k, int buf) {
+        if (k >= 18) dma_linear(w3img + (size_t)(k - 18) * 1024, buf);
+        else if (k % 9 == 8) dma_linear(w2img, buf);
+        else dma_slice(k % 9, buf);
+    };
     auto dma_wait_sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     };
     float ymax = 0.0f;                                     // largest |Y| (the next consumer's scale)
-    int wstage = 0;                                        // weight stages consumed so far (LDS buffer parity)
+    int wstage = 0;                                        // weight stages of the front conv (LDS buffer parity)
     // =========================================== front conv ===========================================
     {
         const int cpt0 = fc.Cin >> 5;
@@ -1977,7 +2035,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Y[mt][nt][r] = 0.0f;
-        if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
+        // padding pixels of the eight planes (the residual slices' two plane buffers have theirs at the same units)
+        if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};
         // stage (cc, tap) = 16 pieces: piece p = nt * 4 + t * 2 + term, four per wave
         auto dma_front = [&](int cc, int tap, int buf) {
             const u32x4 *base = fc.wimg + (size_t)(tap * cpt0 + cc) * (NT2 * 256) + lane;
@@ -2006,109 +2065,142 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             lds_order_wave();
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap, ++wstage) {
-                dma_wait_sync();                               // this stage's weights are in; everyone is done with the other buffer
-                if (tap + 1 < 9) dma_front(cc, tap + 1, (wstage + 1) & 1);
-                else if (cc + 1 < cpt0) dma_front(cc + 1, 0, (wstage + 1) & 1);
-                else dma_slice(0, (wstage + 1) & 1);           // the first slice of the first residual layer
+                // the pixel operands do not depend on the stage buffer: read them before the barrier
                 const int shift = ((int)((fc.dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((fc.dxm >> (4 * tap)) & 15) - 8);
-                const u32x4 *wt = Wb_all + (wstage & 1) * WBUF + lane;
+                u32x4 X[2][MT][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    u32x4 A1[MT], A2[MT];
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int p = ((tapok0[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
                         const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
-                        A1[mt] = ap[0];
-                        A2[mt] = ap[PLANE];
+                        X[t][mt][0] = ap[0];
+                        X[t][mt][1] = ap[PLANE];
                     }
+                dma_wait_sync();                               // this stage's weights are in; everyone is done with the other buffer
+                if (tap + 1 < 9) dma_front(cc, tap + 1, (wstage + 1) & 1);
+                else if (cc + 1 < cpt0) dma_front(cc + 1, 0, (wstage + 1) & 1);
+                else dma_stage(0, (wstage + 1) & 1);           // the first slice of the first residual layer
+                const u32x4 *wt = Wb_all + (wstage & 1) * WBUF + lane;
+                // group g = (t, nt): weights one group ahead of the matrix instructions
+                u32x4 Wc0 = wt[0], Wc1 = wt[64];
 #pragma unroll
-                    for (int nt = 0; nt < NT2; ++nt) {
-                        const u32x4 *bp = wt + (nt * 4 + t * 2) * 64;
-                        prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[64], Y[0][nt], Y[1][nt]);
+                for (int g = 0; g < 8; ++g) {
+                    const int t = g >> 2, nt = g & 3;
+                    u32x4 Wn0 = Wc0, Wn1 = Wc1;
+                    if (g + 1 < 8) {
+                        const u32x4 *bp = wt + (((g + 1) & 3) * 4 + ((g + 1) >> 2) * 2) * 64;
+                        Wn0 = bp[0];
+                        Wn1 = bp[64];
                     }
+                    __builtin_amdgcn_sched_barrier(0);         // hipcc otherwise sinks the reads to just before their use
+                    prod3x2t(X[t][0][0], X[t][0][1], X[t][1][0], X[t][1][1], Wc0, Wc1, Y[0][nt], Y[1][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    Wc0 = Wn0;
+                    Wc1 = Wn1;
                 }
             }
         }
         // bias + ReLU (encoder.py:36 / the stack's first in-place ReLU applied by the producer, decoder.py:29-30)
 #pragma unroll
-        for (int nt = 0; nt < NT2; ++nt) {
-            const float bv = fc.bias ? fc.bias[nt * 32 + l31] : 0.0f;
+        for (int nt = 0; nt < NT2; ++nt)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (fc.bias) bv = *reinterpret_cast<const f32x4 *>(fc.bias + nt * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = fmaxf(Y[mt][nt][r] * d0 + bv, 0.0f);
-                    YPUT(mt, nt, r, v);
-                    ymax = fmaxf(ymax, v);
-                }
-        }
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaxf(Y[mt][nt][4 * g + q] * d0 + bv[q], 0.0f);
+                        Y[mt][nt][4 * g + q] = v;
+                        ymax = fmaxf(ymax, v);
+                    }
+            }
     }
     lds_order_wave();
 
     // =========================================== residual layers from Y ===========================================
+    // stage k: wait for its weights, start the next stage's, return this lane's column of its buffer
+    auto stage_sync = [&](int k) -> const u32x4 * {
+        dma_wait_sync();
+        if (k + 1 < NSTAGE) dma_stage(k + 1, (wstage + k + 1) & 1);
+        return Wb_all + ((wstage + k) & 1) * WBUF + lane;
+    };
     f32x16 acc1[MT];
-    // nine taps of the parked slice; wb = this lane's column of the stage buffer: [tap * 2 + term] x 64 units
-    auto taps = [&](const u32x4 *wb) {
-        u32x4 bwc0 = wb[0], bwc1 = wb[64];
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            u32x4 bwn0 = bwc0, bwn1 = bwc1;
-            if (tap + 1 < 9) { bwn0 = wb[(tap + 1) * 128]; bwn1 = wb[(tap + 1) * 128 + 64]; }
+    // nine taps of one slice: wb = this lane's column of the stage buffer ([tap * 2 + term] x 64 units), pl = this half-wave's
+    // planes of the slice; operands of tap + 1 are read while tap's products run
+    auto taps = [&](const u32x4 *wb, const u32x4 *pl) {
+        u32x4 Xc[MT][2], Wc[2];
+        auto ld = [&](int tap, u32x4(&X)[MT][2], u32x4(&W)[2]) {
             const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
-            u32x4 S[MT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
-                const u32x4 *ap = As + h * HP + p;
-                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+                X[mt][0] = pl[p];
+                X[mt][1] = pl[p + HP * 2];
             }
-            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bwc0, bwc1, acc1[0], acc1[1]);
-            bwc0 = bwn0; bwc1 = bwn1;
+            W[0] = wb[tap * 128];
+            W[1] = wb[tap * 128 + 64];
+        };
+        ld(0, Xc, Wc);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            u32x4 Xn[MT][2], Wn[2];
+            if (tap + 1 < 9) ld(tap + 1, Xn, Wn);
+            __builtin_amdgcn_sched_barrier(0);
+            prod3x2t(Xc[0][0], Xc[0][1], Xc[1][0], Xc[1][1], Wc[0], Wc[1], acc1[0], acc1[1]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < 9) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { Xc[mt][0] = Xn[mt][0]; Xc[mt][1] = Xn[mt][1]; }
+                Wc[0] = Wn[0]; Wc[1] = Wn[1];
+            }
+        }
+    };
+    // one k-step's operands of both pixel tiles -> plane buffer `buf`
+    auto put_planes = [&](int buf, const u32x4(&T1)[MT][2], const u32x4(&T2)[MT][2], int t) {
+        u32x4 *pb = As + buf * RBUF + h * HP + l31;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            pb[32 * mt] = T1[mt][t];
+            pb[32 * mt + 2 * HP] = T2[mt][t];
         }
     };
     // Y <- [relu](Y + W2 relu(W1 (*) Y)); ymax in: largest Y, out: largest new Y.  always_inline: hipcc does not inline a
     // lambda this size twice by itself, and Y (captured by reference) then lives in scratch memory -- 5 ms per launch,
     // measured; a two-iteration loop around the body instead spills 275 registers
     auto layer = [&](auto LT, bool relu_after) __attribute__((always_inline)) {
-        constexpr int LI = decltype(LT)::value;                // 0 or 1: global slice index gs = 8 LI + slice
+        constexpr int LI = decltype(LT)::value;                // 0 or 1: stages 9 LI ..
         const int kx = wave_scale_exp(img_ok ? ymax : 0.0f);
         const float xscale = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+        u32x4 T1[MT][2], T2[MT][2];                            // [pixel tile][k-step] of the current 32-channel tile
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(Y[mt][0], xscale, T1[mt], T2[mt]);
+        __builtin_amdgcn_wave_barrier();
+        put_planes(0, T1, T2, 0);
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
+            // slice (c, 0) from plane buffer 0; (c, 1)'s planes go to buffer 1 (last read by slice (c - 1, 1))
+            __builtin_amdgcn_wave_barrier();
+            put_planes(1, T1, T2, 1);
+            lds_order_wave();
+            taps(stage_sync(9 * LI + 2 * c), As + h * HP);
+            // slice (c, 1); the next tile's operands are made now and its first k-step goes to buffer 0
+            if (c + 1 < NT2) {
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 t1[MT], t2[MT];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = YGET(mt, c, r);
-                    lds_order_wave();
-                    float a2[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
-                    split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xscale, t1[mt], t2[mt]);
-                }
+                for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(Y[mt][c + 1], xscale, T1[mt], T2[mt]);
                 __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    As[(0 * 2 + h) * HP + 32 * mt + l31] = t1[mt];
-                    As[(1 * 2 + h) * HP + 32 * mt + l31] = t2[mt];
-                }
-                if (lane < 4) As[lane * HP + PX] = u32x4{0, 0, 0, 0};
-                lds_order_wave();
-                const int gs = 8 * LI + 2 * c + s2;              // compile-time after unrolling
-                dma_wait_sync();                               // this slice's weights are in; everyone is done with the other buffer
-                if (gs + 1 < 16) dma_slice((gs + 1) & 7, (wstage + gs + 1) & 1);
-                taps(Wb_all + ((wstage + gs) & 1) * WBUF + lane);
+                put_planes(0, T1, T2, 0);
             }
+            lds_order_wave();
+            taps(stage_sync(9 * LI + 2 * c + 1), As + RBUF + h * HP);
         }
-        // hidden tile -> A operands of the 1x1 GEMM
+        // hidden tile -> B operands of the 1x1 GEMM, in registers
         float m = 0.0f;
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -2121,39 +2213,40 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         const float hscale = __builtin_ldexpf(1.0f, kh), d2 = __builtin_ldexpf(1.0f, -(kh + kw2));
         u32x4 H1[MT][2], Hb[MT][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc1[mt][r];
-            lds_order_wave();
-            float a2[16];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
-            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
-            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
-        }
+        for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(acc1[mt], hscale, H1[mt], Hb[mt]);
+        const u32x4 *wb = stage_sync(9 * LI + 8);              // [nt][term][k-step] x 64 units
         float nmax = 0.0f;
+        u32x4 Wc[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { Wc[t][0] = wb[t * 64]; Wc[t][1] = wb[t * 64 + 128]; }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
+            u32x4 Wn[2][2];
+            if (nt + 1 < NT2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { Wn[t][0] = wb[(nt + 1) * 256 + t * 64]; Wn[t][1] = wb[(nt + 1) * 256 + t * 64 + 128]; }
+            }
             f32x16 acc2[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const u32x4 *bp = w2img + nt * 256 + (t * 2 + h) * 32 + l31;          // 1x1 weights straight from L1 / L2
-                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
-            }
+            for (int t = 0; t < 2; ++t)
+                prod3x2t(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], Wc[t][0], Wc[t][1], acc2[0], acc2[1]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    float v = YGET(mt, nt, r) + acc2[mt][r] * d2;
+                    float v = Y[mt][nt][r] + acc2[mt][r] * d2;
                     if (relu_after) v = fmaxf(v, 0.0f);
-                    YPUT(mt, nt, r, v);
+                    Y[mt][nt][r] = v;
                     nmax = fmaxf(nmax, __builtin_fabsf(v));
                 }
+            if (nt + 1 < NT2) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) { Wc[t][0] = Wn[t][0]; Wc[t][1] = Wn[t][1]; }
+            }
         }
         ymax = nmax;
     };
@@ -2161,6 +2254,20 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     layer(std::integral_constant<int, 1>{}, relu_out);
     if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
 
+    // one transposed 32-pixel x 32-channel tile -> rows of `ld` floats at dst (pixel-major), whole 128-byte lines per
+    // eight lanes: registers -> wave-private LDS tile [pixel][36] -> linear 16-byte reads
+    auto store_tile = [&](const float(&v)[16], float *dst, int ld) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4 *>(Hs + l31 * 36 + 8 * g + 4 * h) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        lds_order_wave();
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int p = (lane >> 3) + 8 * k;
+            *reinterpret_cast<f32x4 *>(dst + (size_t)p * ld + 4 * (lane & 7)) = *reinterpret_cast<const f32x4 *>(Hs + p * 36 + 4 * (lane & 7));
+        }
+    };
     const long long wbase = img * PX;
     if constexpr (NT3 > 0) {
         const int kx3 = wave_scale_exp(img_ok ? ymax : 0.0f);
@@ -2172,43 +2279,36 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             for (int n3 = 0; n3 < NT3; ++n3)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc3[mt][n3][r] = 0.0f;
-        const u32x4 *w3v = w3img + h * 32 + l31;
+        const u32x4 *wb = nullptr;
 #pragma unroll
         for (int c = 0; c < NT2; ++c) {
+            u32x4 T1[MT][2], T2[MT][2];
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                u32x4 t1[MT], t2[MT];
+            for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(Y[mt][c], xs3, T1[mt], T2[mt]);
+            constexpr int CPS = 4 / NT3;                       // channel tiles per stage: [c % CPS][n3][term][k-step] x 64 units
+            if (c % CPS == 0) wb = stage_sync(18 + c / CPS);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = YGET(mt, c, r);
-                    lds_order_wave();
-                    float a2[8];
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
-                    split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xs3, t1[mt], t2[mt]);
-                }
+            for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int n3 = 0; n3 < NT3; ++n3) {
-                    const u32x4 *bp = w3v + (size_t)(c * NT3 + n3) * 256 + s2 * 64;
-                    prod3x2(t1[0], t2[0], t1[1], t2[1], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
+                    const u32x4 *bp = wb + ((c % CPS) * NT3 + n3) * 256 + t * 64;
+                    prod3x2t(T1[0][t], T2[0][t], T1[1][t], T2[1][t], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
                 }
-            }
         }
         if (img_ok) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int n3 = 0; n3 < NT3; ++n3) {
-                    const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f;
                     float v[16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3 + bv;
-                    __builtin_amdgcn_wave_barrier();
-                    tile_epilogue(Hs, v, lane, n3 * 32, [&](int p, int n, f32x4 a4, int) {
-                        *reinterpret_cast<f32x4 *>(out3 + (wbase + mt * 32 + p) * (32 * NT3) + n) = a4;
-                    });
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (bias3) bv = *reinterpret_cast<const f32x4 *>(bias3 + n3 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[4 * g + q] = acc3[mt][n3][4 * g + q] * d3 + bv[q];
+                    }
+                    store_tile(v, out3 + (wbase + mt * 32) * (32 * NT3) + n3 * 32, 32 * NT3);
                 }
         }
     } else if (img_ok) {
@@ -2218,16 +2318,11 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
             for (int nt = 0; nt < NT2; ++nt) {
                 float v[16];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = YGET(mt, nt, r);
-                __builtin_amdgcn_wave_barrier();
-                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
-                    *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
-                });
+                for (int r = 0; r < 16; ++r) v[r] = Y[mt][nt][r];
+                store_tile(v, out + (wbase + mt * 32) * C + nt * 32, C);
             }
     }
 }
-#undef YGET
-#undef YPUT
 
 // ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
