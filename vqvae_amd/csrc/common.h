@@ -125,6 +125,10 @@ int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_fro
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)
+bool enc_front_supported(int H, int W, int Cin, int C1, int C2);
+int enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
+                           const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,
+                           int *out_amax);
 int conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
                          int Cout, int flags, float *y, hipStream_t stream, int *out_amax);
 

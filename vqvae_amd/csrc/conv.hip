@@ -2325,6 +2325,302 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
 }
 
 // ---------------------------------------------------------------------------
+// Encoder front in one launch (models/encoder.py:29-34): Conv2d(3 -> 64, 4x4 s2 p1) + ReLU + Conv2d(64 -> 128, 4x4 s2 p1)
+// + ReLU on 32x32 images; the 16x16x64 map between them (64 KiB per image, written and read back by the separate
+// kernels: 536 MB per 4096 images) never exists.  One wave owns one image; everything is computed transposed as in
+// conv_res_pair8_h2_kernel.  The second conv runs as in conv_tile8_bf3_kernel<.., S2D>: a conv over the 8x8 grid of 2x2
+// blocks of the 16x16 map, chunk = (block sub-position s, 32-channel slice), four block offsets (taps) per chunk.  Per
+// sub-position the wave builds ITS OWN operand slice: the 64 block pixels' 4x4x3 input patches are gathered from the NCHW
+// image (two 16-byte loads per channel and lane half: rows ky = 2h, 2h+1), split into fp16 terms and multiplied with the
+// first layer's weights on the matrix cores (3 k-steps of 16 = the 48 taps; +9 % matrix work), + bias, ReLU, and the
+// accumulator becomes the second conv's B operands by half-wave swaps (acc_to_ksteps).
+// Scales: the image's largest |x| is measured; the first layer's outputs are bounded by L1 * max|x| + max|b| (L1 = the
+// largest absolute row sum of its weights, in the header) -- a power of two up to ~8x above the true maximum, which costs
+// the second term's range three bits at the very bottom and nothing where it matters (see split8_h).
+template <int CIN>
+__global__ __launch_bounds__(256, 2) void enc_front8_h2_kernel(const float *__restrict__ x, const u32x4 *__restrict__ w0img,
+                                                               const int *__restrict__ hdr0, const float *__restrict__ bias0,
+                                                               const u32x4 *__restrict__ w2img, const int *__restrict__ hdr2,
+                                                               const float *__restrict__ bias2, float *__restrict__ out, int B,
+                                                               int *__restrict__ out_amax) {
+    constexpr int NT = 4, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2, C0 = 64, C = 128;
+    constexpr int TILE4 = 2 * 2 * PLANE;                   // [k-step 2][term 2][half 2][pixel + zero] = 520 units
+    constexpr int WBUF = 16 * 64, NSTAGE = 32;             // a stage = one (chunk, tap) of the second conv: 16 pieces of 1 KiB
+    __shared__ u32x4 As_all[4 * TILE4];
+    __shared__ u32x4 Wb_all[2 * WBUF];
+    __shared__ u32x4 W0s[2 * CIN * 2 * 64];                // first layer: [slice 2][ci][term 2] x 64 lanes
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    float *Hs = reinterpret_cast<float *>(As);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+
+    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+        const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+    };
+    // stage k = chunk * 4 + tap, chunk = 2 s + slice: 16 KiB as it lies in the space-to-depth image
+    auto dma_stage = [&](int k, int buf) {
+        const u32x4 *src = w2img + (size_t)k * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma(src + (wave_u * 4 + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * 4 + j) * 64);
+    };
+    auto dma_wait_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    dma_stage(0, 0);
+    for (int i = tid; i < 2 * CIN * 2 * 64; i += 256) W0s[i] = w0img[i];
+    if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
+
+    // block-pixel bookkeeping: bit sub * 4 + tap of tapok = block offset ((tap >> 1) - (sub >> 1), (tap & 1) - (sub & 1)) is inside
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, xx0 = spx[mt] & 7;
+        unsigned m = 0;
+        for (int q = 0; q < 16; ++q) {
+            const int yy = y + ((q >> 1) & 1) - (q >> 3), xx = xx0 + (q & 1) - ((q >> 2) & 1);
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << q;
+        }
+        tapok[mt] = m;
+    }
+
+    // scales: the image's largest |x| -> the first layer's operand scale; the bound on its outputs -> the second layer's
+    const float *ximg = x + (size_t)(img_ok ? img : 0) * (CIN * 1024);
+    float xm = 0.0f;
+#pragma unroll
+    for (int j = 0; j < CIN * 4; ++j) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(ximg + 4 * lane + 256 * j);
+        xm = fmaxf(xm, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o));
+    const int kx0 = wave_scale_exp(img_ok ? xm : 0.0f);
+    const float xs0 = __builtin_ldexpf(1.0f, kx0), d0 = __builtin_ldexpf(1.0f, -(kx0 + hdr0[0]));
+    float bm = bias0 ? __builtin_fabsf(bias0[lane]) : 0.0f;                                 // C0 = 64 channels
+    const float bound = (__int_as_float(hdr0[1]) * xm + bm) * 1.0001f;
+    const int k1 = wave_scale_exp(img_ok ? bound : 0.0f);                                     // (reduces bm over the wave)
+    const float xs1 = __builtin_ldexpf(1.0f, k1), d2 = __builtin_ldexpf(1.0f, -(k1 + hdr2[0]));
+
+    f32x16 Y[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Y[mt][nt][r] = 0.0f;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, (unsigned)(CIN * 4096), 0x00020000);
+    __syncthreads();                                       // W0s
+
+    // the four taps of chunk cc (its operand planes are in the wave's tile): stages 4 cc .. 4 cc + 3
+    auto taps = [&](int cc) {
+        const int sub = cc >> 1;
+#pragma unroll 1
+        for (int tap = 0; tap < 4; ++tap) {
+            const int k = cc * 4 + tap;
+            const int shift = ((tap >> 1) - (sub >> 1)) * 8 + ((tap & 1) - (sub & 1)), okbit = sub * 4 + tap;
+            u32x4 X[2][MT][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int p = ((tapok[mt] >> okbit) & 1u) ? spx[mt] + shift : PX;
+                    const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
+                    X[t][mt][0] = ap[0];
+                    X[t][mt][1] = ap[PLANE];
+                }
+            dma_wait_sync();                               // this stage's weights are in; everyone is done with the other buffer
+            if (k + 1 < NSTAGE) dma_stage(k + 1, (k + 1) & 1);
+            const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;      // [nt][term][k-step] x 64 units
+            u32x4 Wc0 = wt[0], Wc1 = wt[128];
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int t = g >> 2, nt = g & 3;
+                u32x4 Wn0 = Wc0, Wn1 = Wc1;
+                if (g + 1 < 8) {
+                    const u32x4 *bp = wt + ((g + 1) & 3) * 256 + ((g + 1) >> 2) * 64;
+                    Wn0 = bp[0];
+                    Wn1 = bp[128];
+                }
+                __builtin_amdgcn_sched_barrier(0);         // hipcc otherwise sinks the reads to just before their use
+                prod3x2t(X[t][0][0], X[t][0][1], X[t][1][0], X[t][1][1], Wc0, Wc1, Y[0][nt], Y[1][nt]);
+                __builtin_amdgcn_sched_barrier(0);
+                Wc0 = Wn0;
+                Wc1 = Wn1;
+            }
+        }
+    };
+    auto put_planes = [&](const u32x4(&T1)[MT][2], const u32x4(&T2)[MT][2]) {
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                As[(t * 2 + 0) * PLANE + h * HP + 32 * mt + l31] = T1[mt][t];
+                As[(t * 2 + 1) * PLANE + h * HP + 32 * mt + l31] = T2[mt][t];
+            }
+        lds_order_wave();
+    };
+    // first layer on the patches XB for output channels 32 sl .. +31: + bias, ReLU, -> the second layer's operands
+    auto first_layer = [&](int sl, const u32x4(&XB)[MT][CIN][2], u32x4(&T1)[MT][2], u32x4(&T2)[MT][2]) {
+        f32x16 acc0[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc0[mt][r] = 0.0f;
+        const u32x4 *wp = W0s + (sl * CIN) * 128 + lane;
+#pragma unroll
+        for (int ci = 0; ci < CIN; ++ci)
+            prod3x2t(XB[0][ci][0], XB[0][ci][1], XB[1][ci][0], XB[1][ci][1], wp[ci * 128], wp[ci * 128 + 64], acc0[0], acc0[1]);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+            if (bias0) bv = *reinterpret_cast<const f32x4 *>(bias0 + sl * 32 + 8 * g + 4 * h);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc0[mt][4 * g + q] = fmaxf(acc0[mt][4 * g + q] * d0 + bv[q], 0.0f);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(acc0[mt], xs1, T1[mt], T2[mt]);
+    };
+
+#pragma unroll 1
+    for (int s = 0; s < 4; ++s) {
+        const int sy = s >> 1, sx = s & 1;
+        // patches of the 64 block pixels at sub-position s: lane half h holds rows ky = 2h, 2h + 1 (4 columns each) per channel
+        u32x4 XB[MT][CIN][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int by = spx[mt] >> 3, bx = spx[mt] & 7;
+            const int col0 = 4 * bx + 2 * sx - 1;
+            const int adj = col0 < 0 ? 1 : (col0 + 3 > 31 ? -1 : 0);       // edge lanes load one column off and shift
+            f32x4 pv[CIN][2];
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const int row = 4 * by + 2 * sy - 1 + 2 * h + rr;
+                    const unsigned off = (row >= 0 && row < 32) ? (unsigned)(((ci * 32 + row) * 32 + col0 + adj) * 4) : kOobOffset;
+                    pv[ci][rr] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0));
+                }
+#pragma unroll
+            for (int ci = 0; ci < CIN; ++ci) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
+                    const f32x4 v = pv[ci][rr];
+                    f32x4 o;
+                    o.x = adj > 0 ? 0.0f : (adj < 0 ? v.y : v.x);
+                    o.y = adj > 0 ? v.x : (adj < 0 ? v.z : v.y);
+                    o.z = adj > 0 ? v.y : (adj < 0 ? v.w : v.z);
+                    o.w = adj > 0 ? v.z : (adj < 0 ? 0.0f : v.w);
+                    pv[ci][rr] = o;
+                }
+                split8_h(pv[ci][0], pv[ci][1], xs0, XB[mt][ci][0], XB[mt][ci][1]);
+            }
+        }
+        u32x4 T1[MT][2], T2[MT][2], U1[MT][2], U2[MT][2];
+        first_layer(0, XB, T1, T2);
+        put_planes(T1, T2);
+        first_layer(1, XB, U1, U2);
+        taps(2 * s);
+        put_planes(U1, U2);
+        taps(2 * s + 1);
+    }
+
+    // bias + ReLU (encoder.py:32-34), the image's maximum for the next layer, whole-line stores
+    float ymax = 0.0f;
+    const long long wbase = img * PX;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    v[4 * g + q] = fmaxf(Y[mt][nt][4 * g + q] * d2 + bv[q], 0.0f);
+                    ymax = fmaxf(ymax, v[4 * g + q]);
+                }
+            }
+            if (img_ok) {
+                float *dst = out + (wbase + mt * 32) * C + nt * 32;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *reinterpret_cast<f32x4 *>(Hs + l31 * 36 + 8 * g + 4 * h) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+                lds_order_wave();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = (lane >> 3) + 8 * k;
+                    *reinterpret_cast<f32x4 *>(dst + (size_t)p * C + 4 * (lane & 7)) = *reinterpret_cast<const f32x4 *>(Hs + p * 36 + 4 * (lane & 7));
+                }
+            }
+        }
+    if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
+    (void)C0;
+}
+
+// header of the first layer's two-term image: {kw, float bits of the largest absolute row sum of w} (one block)
+__global__ __launch_bounds__(256) void conv_in_hdr_kernel(const float *__restrict__ w, int per, int Cout, int *__restrict__ hdr) {
+    __shared__ float red[256], red1[256];
+    float m = 0.0f, l1 = 0.0f;
+    for (int co = threadIdx.x; co < Cout; co += 256) {
+        float s = 0.0f;
+        for (int i = 0; i < per; ++i) {
+            const float a = __builtin_fabsf(w[(size_t)co * per + i]);
+            m = fmaxf(m, a);
+            s += a;
+        }
+        l1 = fmaxf(l1, s);
+    }
+    red[threadIdx.x] = m;
+    red1[threadIdx.x] = l1;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+            red1[threadIdx.x] = fmaxf(red1[threadIdx.x], red1[threadIdx.x + o]);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        int e = 15;
+        const float mm = red[0];
+        if (mm > 0.0f && mm < 3.0e38f) (void)__builtin_frexpf(mm, &e);
+        e = 15 - e;
+        hdr[0] = e > 100 ? 100 : (e < -100 ? -100 : e);
+        hdr[1] = __float_as_int(red1[0] * 1.0001f);
+    }
+}
+// two-term fp16 A-operand image of the first layer's weights * 2^kw: [n_tile][ci][term] x 64 lanes x 16 B; lane (n, h),
+// element q = tap (ky = 2h + (q >> 2), kx = q & 3)
+template <int CIN>
+__global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int Cout,
+                                                              int ntile, const int *__restrict__ hdr) {
+    const float sc = __builtin_ldexpf(1.0f, hdr[0]);
+    const int total = ntile * CIN * 64;
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int lane = e & 63, t = e >> 6, ci = t % CIN, n = t / CIN;
+        const int co = n * 32 + (lane & 31), hh = lane >> 5;
+        float v[8];
+        for (int q = 0; q < 8; ++q) v[q] = co < Cout ? w[((co * CIN + ci) * 4 + 2 * hh + (q >> 2)) * 4 + (q & 3)] : 0.0f;
+        u32x4 t1, t2;
+        split8_h(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, sc, t1, t2);
+        img[(size_t)((n * CIN + ci) * 2) * 64 + lane] = t1;
+        img[(size_t)((n * CIN + ci) * 2 + 1) * 64 + lane] = t2;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
@@ -3502,8 +3798,9 @@ extern "C" {
 size_t vqvae_conv_in_packed_bytes(int Cin, int Cout) {
     if (!(Cin == 1 || Cin == 3 || Cin == 4) || Cout < 1 || Cout > 128) return 0;
     const int S = Cin * 8, JG = (S + 3) / 4;
-    // [fp32 B-operand image][split-bf16 image]
-    return (size_t)((Cout + 31) / 32) * ((size_t)JG * 256 + (size_t)Cin * 768) * sizeof(float);
+    // [fp32 B-operand image][split-bf16 image][header {kw, L1}][two-term fp16 A-operand image (enc_front8_h2_kernel)]
+    return (size_t)((Cout + 31) / 32) * ((size_t)JG * 256 + (size_t)Cin * 768) * sizeof(float) + kH2Header +
+           (size_t)((Cout + 31) / 32) * Cin * 2048;
 }
 
 int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -3522,6 +3819,15 @@ int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqv
         case 3: hipLaunchKernelGGL((conv_in_pack_bf3_kernel<3>), dim3(16), dim3(256), 0, st, w, img3, Cout, ntile); break;
         case 4: hipLaunchKernelGGL((conv_in_pack_bf3_kernel<4>), dim3(16), dim3(256), 0, st, w, img3, Cout, ntile); break;
     }
+    char *h2 = reinterpret_cast<char *>(packed) + (size_t)ntile * ((size_t)((Cin * 8 + 3) / 4) * 256 + (size_t)Cin * 768) * sizeof(float);
+    int *hdr = reinterpret_cast<int *>(h2);
+    u32x4 *img16 = reinterpret_cast<u32x4 *>(h2 + kH2Header);
+    hipLaunchKernelGGL(conv_in_hdr_kernel, dim3(1), dim3(256), 0, st, w, Cin * 16, Cout, hdr);
+    switch (Cin) {
+        case 1: hipLaunchKernelGGL((conv_in_pack_h2_kernel<1>), dim3(4), dim3(256), 0, st, w, img16, Cout, ntile, hdr); break;
+        case 3: hipLaunchKernelGGL((conv_in_pack_h2_kernel<3>), dim3(4), dim3(256), 0, st, w, img16, Cout, ntile, hdr); break;
+        case 4: hipLaunchKernelGGL((conv_in_pack_h2_kernel<4>), dim3(4), dim3(256), 0, st, w, img16, Cout, ntile, hdr); break;
+    }
     return (int)hipGetLastError();
 }
 
@@ -3530,6 +3836,30 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
     return vqvae::conv_in_forward_impl(x_nchw, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr);
 }
 }  // extern "C"
+
+// The encoder's first two layers in one launch (enc_front8_h2_kernel): 32x32 images, 3 input channels, 64 -> 128 channels.
+bool vqvae::enc_front_supported(int H, int W, int Cin, int C1, int C2) { return H == 32 && W == 32 && Cin == 3 && C1 == 64 && C2 == 128; }
+
+int vqvae::enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
+                                  const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,
+                                  int *out_amax) {
+    if (!x_nchw || !packed_in || !packed2 || !y) return VQVAE_ERR_NULL;
+    if (B < 1 || !enc_front_supported(H, W, Cin, C1, C2)) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    const int ntile0 = (C1 + 31) / 32;
+    const char *h0 = reinterpret_cast<const char *>(packed_in) +
+                     (size_t)ntile0 * ((size_t)((Cin * 8 + 3) / 4) * 256 + (size_t)Cin * 768) * sizeof(float);
+    ConvGeom g;
+    if (make_geom(VQVAE_CONV_4x4_S2, B, H / 2, W / 2, C1, C2, 0, g) != VQVAE_OK) return VQVAE_ERR_UNSUPPORTED;
+    const char *h2 = reinterpret_cast<const char *>(packed2) + packed_h2_offset(g, VQVAE_CONV_4x4_S2);
+    const u32x4 *w2s2d = reinterpret_cast<const u32x4 *>(h2 + kH2Header + packed_h2_bytes(g));     // space-to-depth chunk order
+    prof_begin(VQVAE_PROF_CONV_IGEMM, st);
+    hipLaunchKernelGGL((enc_front8_h2_kernel<3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x_nchw,
+                       reinterpret_cast<const u32x4 *>(h0 + kH2Header), reinterpret_cast<const int *>(h0), bias_in, w2s2d,
+                       reinterpret_cast<const int *>(h2), bias2, y, (int)B, out_amax);
+    prof_end(VQVAE_PROF_CONV_IGEMM, st);
+    return (int)hipGetLastError();
+}
 
 void vqvae::act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st) {
     long long parts = (elems_per_image + 256 * 4 * 16 - 1) / (256 * 4 * 16);

@@ -196,8 +196,16 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     const int h = d->h_dim;
     int rc;
     // encoder.py:29-31, :32-34, :35-36 (+ the residual stack's first in-place ReLU, residual.py:19)
-    if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st, am0)) != 0) return rc;
-    if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st, am0, am1)) != 0) return rc;
+#ifndef VQVAE_NO_ENC_FRONT_FUSION    // A/B builds (tools/build_variant.py)
+    // encoder.py:29-34 in ONE launch on 32x32 RGB images: the 16x16 x h/2 map between the two stride-2 convs is never written
+    if (enc_front_supported(H, W, d->in_ch, h / 2, h)) {
+        if ((rc = enc_front_forward_impl(x, w->enc0, w->enc0_b, w->enc2, w->enc2_b, B, H, W, d->in_ch, h / 2, h, b, st, am1)) != 0) return rc;
+    } else
+#endif
+    {
+        if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st, am0)) != 0) return rc;
+        if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st, am0, am1)) != 0) return rc;
+    }
 #ifndef VQVAE_NO_FRONT_FUSION    // A/B builds (tools/build_variant.py)
     // encoder.py:35-38 + vqvae.py:33 in ONE launch where the shapes allow (8x8 latent maps, h_dim 128, two residual layers):
     // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
