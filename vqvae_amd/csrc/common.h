@@ -129,6 +129,9 @@ bool enc_front_supported(int H, int W, int Cin, int C1, int C2);
 int enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
                            const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,
                            int *out_amax);
+bool dec_tail_supported(int h4, int w4, int C, int C1, int Cout);
+int dec_tail_forward_impl(const float *x, const float *packed2, const float *bias2, const float *packed4, const float *bias4,
+                          int64_t B, int h4, int w4, int C, int C1, int Cout, float *y_nchw, hipStream_t st, const int *in_amax);
 int conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
                          int Cout, int flags, float *y, hipStream_t stream, int *out_amax);
 

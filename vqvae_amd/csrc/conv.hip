@@ -2621,6 +2621,280 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 }
 
 // ---------------------------------------------------------------------------
+// Decoder tail in one launch (models/decoder.py:31-35): ConvTranspose2d(128 -> 64, 4x4 s2 p1) + ReLU +
+// ConvTranspose2d(64 -> 3, 4x4 s2 p1) on 8x8 maps -> 32x32 NCHW images; the 16x16x64 map between them (64 KiB per image)
+// never exists.  One wave owns one image and walks the four output phases (py, px) of the first layer; everything is
+// computed transposed as in conv_res_pair8_h2_kernel.
+//   layer 1, phase (py, px): u[2y + py][2x + px][c] = relu(b + sum over 2x2 taps and 128 channels), as in
+//       conv_tile8_bf3_kernel (4 chunks of 32 channels parked as fp16 planes, tap = shifted plane read), weights streamed
+//       by LDS-DMA two taps per stage; the accumulator (lane = block pixel, registers = channels) becomes the second
+//       layer's B operands by half-wave swaps (acc_to_ksteps), scaled by the phase tile's own maximum;
+//   layer 2 in its GEMM + col2im form: T[co * 16 + tap][pixel] = sum_c w4[c][co][tap] u[pixel][c] (48 rows = two A tiles),
+//       and out[co][4y + 2py - 1 + ky][4x + 2px - 1 + kx] += T: every output element receives exactly ONE term per phase.
+//       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 40 LDS tile (the operand planes
+//       are free then) and leave as whole 128-byte rows: out = bias + tile in phase 0, out += tile in phases 1..3 with
+//       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident, agent-scope accesses; a phase's stores are
+//       complete -- eight s_waitcnt vmcnt(0) later -- before the next phase's loads are issued): a fixed summation order,
+//       no atomics, no 12 KiB accumulation tile per wave.  (Scattered 4-byte read-modify-writes straight from the
+//       accumulator layout were measured first: 570 us instead of 330 for the two separate kernels -- L2 request bound.)
+struct TailGeom {
+    unsigned long long dym[4], dxm[4];             // 4 bits per tap: dy + 8, dx + 8 (ConvGeom) of each phase
+};
+
+__global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w2img,
+                                                              const int *__restrict__ hdr2, const float *__restrict__ bias2,
+                                                              TailGeom tg, const u32x4 *__restrict__ w4img,
+                                                              const int *__restrict__ hdr4, const float *__restrict__ bias4,
+                                                              float *__restrict__ out, int B, const int *__restrict__ in_amax) {
+    constexpr int NT = 2, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2, CIN = 128, CPT = CIN / 32, CO = 3;
+    constexpr int TILE4 = 2 * 2 * PLANE;                   // [k-step 2][term 2][half 2][pixel + zero] = 520 units
+    constexpr int WBUF = 16 * 64, NSTAGE = 36;             // per phase: 4 chunks x 2 tap pairs (16 pieces each) + the second layer's image
+    __shared__ u32x4 As_all[4 * TILE4];
+    __shared__ u32x4 Wb_all[2 * WBUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+
+    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+        const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+    };
+    // stage k = 9 phase + i: i < 8: chunk i >> 1, taps 2 (i & 1) and 2 (i & 1) + 1 of the first layer (8 pieces each: [nt][term][k-step]);
+    // i = 8: the second layer's A image (16 pieces)
+    auto dma_stage = [&](int k, int buf) {
+        const int ph = k / 9, i = k - 9 * ph;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int p = wave_u * 4 + j;
+            const u32x4 *src = i == 8 ? w4img + p * 64
+                                      : w2img + (size_t)(ph * 16 + (2 * (i & 1) + (p >> 3)) * CPT + (i >> 1)) * 512 + (p & 7) * 64;
+            dma(src + lane, Wb_all + buf * WBUF + p * 64);
+        }
+    };
+    auto dma_wait_sync = [&]() {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    dma_stage(0, 0);
+    if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
+
+    const auto ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(img_ok ? img : 0) * (CO * 1024), 0, img_ok ? (unsigned)(CO * 4096) : 0u, 0x00020000);
+    int spx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) spx[mt] = 32 * mt + l31;
+    const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * CIN;                 // this lane's pixel row
+    f32x4 raw[8];
+    auto load_raw = [&](int cc) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(src + 32 * cc + 4 * j);
+    };
+    float m = 0.0f;
+    const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+    if (given >= 0) m = __int_as_float(given);
+    else for (int cc = 0; cc < CPT; ++cc) {
+        load_raw(cc);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(raw[j].x), __builtin_fabsf(raw[j].y)), fmaxf(__builtin_fabsf(raw[j].z), __builtin_fabsf(raw[j].w))));
+    }
+    const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+    const float xs = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + hdr2[0]));
+    const int kw4 = hdr4[0];
+    load_raw(0);
+
+#pragma unroll 1
+    for (int ph = 0; ph < 4; ++ph) {
+        const int py = ph >> 1, px = ph & 1;
+        const unsigned long long dym = tg.dym[ph], dxm = tg.dxm[ph];
+        unsigned tapok[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int y = spx[mt] >> 3, x = spx[mt] & 7;
+            unsigned mk = 0;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int yy = y + (int)((dym >> (4 * t)) & 15) - 8, xx = x + (int)((dxm >> (4 * t)) & 15) - 8;
+                if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) mk |= 1u << t;
+            }
+            tapok[mt] = mk;
+        }
+        f32x16 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+        // ----------------------------- layer 1, this phase -----------------------------
+#pragma unroll 1
+        for (int cc = 0; cc < CPT; ++cc) {
+            __builtin_amdgcn_wave_barrier();
+            u32x4 *dst = As + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    u32x4 t1, t2;
+                    split8_h(raw[4 * hh + 2 * t], raw[4 * hh + 2 * t + 1], xs, t1, t2);
+                    dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
+                    dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
+                }
+            load_raw(cc + 1 < CPT ? cc + 1 : 0);           // (the next phase starts over at chunk 0)
+            lds_order_wave();
+#pragma unroll 1
+            for (int j = 0; j < 2; ++j) {
+                const int k = ph * 9 + cc * 2 + j;
+                u32x4 X[2][2][MT][2];                      // [tap of the pair][k-step][pixel tile][term]
+#pragma unroll
+                for (int ts = 0; ts < 2; ++ts) {
+                    const int tap = 2 * j + ts;
+                    const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm >> (4 * tap)) & 15) - 8);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                            const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
+                            X[ts][t][mt][0] = ap[0];
+                            X[ts][t][mt][1] = ap[PLANE];
+                        }
+                }
+                dma_wait_sync();                           // this stage's weights are in; everyone is done with the other buffer
+                dma_stage(k + 1, (k + 1) & 1);
+                const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;      // [tap of the pair][nt][term][k-step] x 64 units
+                u32x4 Wc0 = wt[0], Wc1 = wt[128];
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {              // group g = (tap of the pair, k-step, nt)
+                    const int ts = g >> 2, t = (g >> 1) & 1, nt = g & 1;
+                    u32x4 Wn0 = Wc0, Wn1 = Wc1;
+                    if (g + 1 < 8) {
+                        const int g1 = g + 1;
+                        const u32x4 *bp = wt + (g1 >> 2) * 512 + (g1 & 1) * 256 + ((g1 >> 1) & 1) * 64;
+                        Wn0 = bp[0];
+                        Wn1 = bp[128];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks the reads to just before their use
+                    prod3x2t(X[ts][t][0][0], X[ts][t][0][1], X[ts][t][1][0], X[ts][t][1][1], Wc0, Wc1, acc[0][nt], acc[1][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    Wc0 = Wn0;
+                    Wc1 = Wn1;
+                }
+            }
+        }
+        // ----------------------------- bias + ReLU, the phase tile's scale, operands of layer 2 -----------------------------
+        float um = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float v = fmaxf(acc[mt][nt][4 * g + q] * d1 + bv[q], 0.0f);
+                        acc[mt][nt][4 * g + q] = v;
+                        um = fmaxf(um, v);
+                    }
+            }
+        const int ku = wave_scale_exp(img_ok ? um : 0.0f);
+        const float us = __builtin_ldexpf(1.0f, ku), d4 = __builtin_ldexpf(1.0f, -(ku + kw4));
+        u32x4 U1[MT][NT][2], U2[MT][NT][2];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc_to_ksteps(acc[mt][nt], us, U1[mt][nt], U2[mt][nt]);
+        // ----------------------------- layer 2: T = W4 u, then out += T at the col2im positions -----------------------------
+        // row rho = 32 m + (r & 3) + 8 (r >> 2) + 4 h of T is (co = rho >> 4, tap = rho & 15 = ky * 4 + kx): register r of A tile m
+        // holds co = 2 m + (r >> 3), ky = h + 2 ((r >> 2) & 1), kx = r & 3; rows >= 48 (m = 1, r >= 8) are padding
+        f32x4 ov[CO][4];                                   // this lane's 16-byte pieces of the image so far (phases 1..3)
+        if (ph > 0) {
+#pragma unroll
+            for (int co = 0; co < CO; ++co)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    ov[co][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 16));
+        }
+        f32x16 T[2][MT];
+#pragma unroll
+        for (int m2 = 0; m2 < 2; ++m2)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) T[m2][mt][r] = 0.0f;
+        {
+            const int k = ph * 9 + 8;
+            dma_wait_sync();
+            if (k + 1 < NSTAGE) dma_stage(k + 1, (k + 1) & 1);
+            const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;          // [m][k-step 4][term] x 64 units
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const u32x4 *bp = wt + (m2 * 4 + kk) * 128;
+                    prod3x2t(U1[0][kk >> 1][kk & 1], U2[0][kk >> 1][kk & 1], U1[1][kk >> 1][kk & 1], U2[1][kk >> 1][kk & 1], bp[0], bp[64],
+                             T[m2][0], T[m2][1]);
+                }
+        }
+        // col2im through a wave-private LDS tile (the operand planes are free until the next phase): per output channel the
+        // phase's 32 x 32 terms land at [Y + 1][X + 4] of a zeroed 34 x 40 tile (every element at most once) and leave as whole
+        // 128-byte rows: out = bias + tile in phase 0, out += tile afterwards
+        float *tile = reinterpret_cast<float *>(As);
+#pragma unroll
+        for (int co = 0; co < CO; ++co) {
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                if (lane + 64 * i < 340) reinterpret_cast<f32x4 *>(tile)[lane + 64 * i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            lds_order_wave();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int y = spx[mt] >> 3, x = spx[mt] & 7;
+                float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) tp[((rr >> 2) & 1) * 80 + (rr & 3)] = T[co >> 1][mt][8 * (co & 1) + rr] * d4;
+            }
+            lds_order_wave();
+            const float bv = bias4 ? bias4[co] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = (lane >> 3) + 8 * i;
+                f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (row + 1) * 40 + 4 + 4 * (lane & 7));
+                if (ph > 0) v = ov[co][i] + v;
+                else v = f32x4{bv, bv, bv, bv} + v;
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 16);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};   // the planes' padding pixels again
+    }
+}
+
+// A-operand image of the last layer's weights * 2^kw for dec_tail8_h2_kernel: [m 2][k-step 4][term 2] x 64 lanes x 16 B;
+// lane (row rho - 32 m with rho = co * 16 + tap, h), element q = input channel 32 (k >> 1) + 16 h + 8 (k & 1) + q (acc_to_ksteps' order)
+__global__ __launch_bounds__(256) void convt_out_pack_a_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int Cin, int Cout,
+                                                               const int *__restrict__ hdr) {
+    const float sc = __builtin_ldexpf(1.0f, hdr[0]);
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < 8 * 64; e += gridDim.x * 256) {
+        const int lane = e & 63, kk = (e >> 6) & 3, m2 = e >> 8;
+        const int rho = 32 * m2 + (lane & 31), hh = lane >> 5;
+        float v[8];
+        for (int q = 0; q < 8; ++q) {
+            const int c = 32 * (kk >> 1) + 16 * hh + 8 * (kk & 1) + q;
+            v[q] = (rho < 16 * Cout && c < Cin) ? w[((size_t)c * Cout + (rho >> 4)) * 16 + (rho & 15)] : 0.0f;
+        }
+        u32x4 t1, t2;
+        split8_h(f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]}, sc, t1, t2);
+        img[(size_t)((m2 * 4 + kk) * 2) * 64 + lane] = t1;
+        img[(size_t)((m2 * 4 + kk) * 2 + 1) * 64 + lane] = t2;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer (models/residual.py:18-29):
 //     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
 // W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
@@ -3926,8 +4200,9 @@ size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
     if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;
     const int ntile = (16 * Cout + 31) / 32;
     // [fp32 B-operand image][three-term bf16 image][header {kw}][two-term fp16 image]
+    // ... [A-operand image of dec_tail8_h2_kernel: 16 KiB]
     return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short)) + kH2Header +
-           (size_t)((Cin + 31) / 32) * ntile * 2048 * sizeof(unsigned short);
+           (size_t)((Cin + 31) / 32) * ntile * 2048 * sizeof(unsigned short) + 16384;
 }
 
 int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -3945,6 +4220,8 @@ int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, v
     hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * 16, hdr);
     hipLaunchKernelGGL(convt_out_pack_bf3_kernel<true>, dim3(32), dim3(256), 0, st, w,
                        reinterpret_cast<unsigned short *>(h2 + kH2Header), Cin, Cout, ntile_p, hdr);
+    hipLaunchKernelGGL(convt_out_pack_a_kernel, dim3(2), dim3(256), 0, st, w,
+                       reinterpret_cast<u32x4 *>(h2 + kH2Header + cells * 2048 * sizeof(unsigned short)), Cin, Cout, hdr);
     return (int)hipGetLastError();
 }
 
@@ -3953,6 +4230,31 @@ int vqvae_convt_out_forward_f32(const float *x, const float *packed, const float
     return vqvae::convt_out_forward_impl(x, packed, bias, B, H, W, Cin, Cout, flags, y_nchw, static_cast<hipStream_t>(stream), nullptr);
 }
 }  // extern "C"
+
+// The decoder's last two layers in one launch (dec_tail8_h2_kernel): 8x8 maps, 128 -> 64 -> 3 channels.
+bool vqvae::dec_tail_supported(int h4, int w4, int C, int C1, int Cout) { return h4 == 8 && w4 == 8 && C == 128 && C1 == 64 && Cout == 3; }
+
+int vqvae::dec_tail_forward_impl(const float *x, const float *packed2, const float *bias2, const float *packed4, const float *bias4,
+                                 int64_t B, int h4, int w4, int C, int C1, int Cout, float *y_nchw, hipStream_t st, const int *in_amax) {
+    if (!x || !packed2 || !packed4 || !y_nchw) return VQVAE_ERR_NULL;
+    if (B < 1 || !dec_tail_supported(h4, w4, C, C1, Cout)) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y_nchw)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    ConvGeom g;
+    if (make_geom(VQVAE_CONVT_4x4_S2, B, h4, w4, C, C1, 0, g) != VQVAE_OK) return VQVAE_ERR_UNSUPPORTED;
+    const char *h2 = reinterpret_cast<const char *>(packed2) + packed_h2_offset(g, VQVAE_CONVT_4x4_S2);
+    TailGeom tg;
+    for (int ph = 0; ph < 4; ++ph) { tg.dym[ph] = g.dymask[ph]; tg.dxm[ph] = g.dxmask[ph]; }
+    const int ntile4 = (16 * Cout + 31) / 32, cpt4 = (C1 + 31) / 32;
+    const size_t cells = (size_t)cpt4 * ntile4;
+    const char *h4p = reinterpret_cast<const char *>(packed4) + cells * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    prof_begin(VQVAE_PROF_CONV_OUT, st);
+    hipLaunchKernelGGL(dec_tail8_h2_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x,
+                       reinterpret_cast<const u32x4 *>(h2 + kH2Header), reinterpret_cast<const int *>(h2), bias2, tg,
+                       reinterpret_cast<const u32x4 *>(h4p + kH2Header + cells * 2048 * sizeof(unsigned short)),
+                       reinterpret_cast<const int *>(h4p), bias4, y_nchw, (int)B, in_amax);
+    prof_end(VQVAE_PROF_CONV_OUT, st);
+    return (int)hipGetLastError();
+}
 
 // in_amax: the input images' maxima from the producing layer (whole-path entry points) -> two-term fp16 products
 int vqvae::convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,

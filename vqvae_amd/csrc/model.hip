@@ -284,6 +284,11 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
         if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am)) != 0) return rc;
         if (am) amt = am + (size_t)d->n_res_layers * B;
     }
+#ifndef VQVAE_NO_DEC_TAIL_FUSION    // A/B builds (tools/build_variant.py)
+    // decoder.py:31-35 in ONE launch on 8x8 latent maps: the 16x16 x h/2 map between the two stride-2 transposed convs is never written
+    if (dec_tail_supported(h4, w4, h, h / 2, d->in_ch))
+        return dec_tail_forward_impl(t, w->dec2, w->dec2_b, w->dec4, w->dec4_b, B, h4, w4, h, h / 2, d->in_ch, x_hat, st, amt);
+#endif
     float *u = (t == a) ? b : a;
     int *am_u = am ? am + (size_t)(3 + d->n_res_layers) * B : nullptr;       // dec2's output maxima for the last layer
     if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st, amt, am_u)) != 0) return rc;
