@@ -57,9 +57,14 @@ WORKLOADS = {
 }
 
 
-def conv_flops_per_image(H, W, D, h_dim=128, res_h=32, n_res=2):
-    """2*MAC of every conv / conv-transpose / residual layer between the first and the last."""
+def conv_flops_per_image(H, W, D, h_dim=128, res_h=32, n_res=2, ends=False):
+    """2*MAC of every conv / conv-transpose / residual layer between the first and the last; ends=True:
+    plus the first (4x4 s2, 3 -> h/2) and the last (conv-transpose 4x4 s2, h/2 -> 3) layer."""
     h2, h4 = (H // 2) * (W // 2), (H // 4) * (W // 4)
+    if ends:
+        first = 2 * h2 * 3 * 16 * (h_dim // 2)
+        last = 2 * (H * W) * (h_dim // 2) * 4 * 3              # 4 phases x 2x2 taps per output pixel
+        return conv_flops_per_image(H, W, D, h_dim, res_h, n_res) + first + last
     enc2 = 2 * h4 * (h_dim // 2) * 16 * h_dim                  # 4x4 s2, 64 -> 128
     enc4 = 2 * h4 * h_dim * 9 * h_dim                          # 3x3, 128 -> 128
     res = n_res * 2 * h4 * (h_dim * 9 * res_h + res_h * h_dim)  # per stack
@@ -316,15 +321,23 @@ def main():
                             "(VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic at K=512, D=64",
                 }
             if conv_backend == "hip" and "conv_igemm" in extra and "res_layer" in extra:
-                t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"]) * 1e-3
-                alg_tf = B * conv_flops_per_image(H, W, D) / t_conv / 1e12
+                # 32x32 images: the first layer runs inside the encoder's second conv (enc_front8_h2_kernel, "conv_igemm") and
+                # the last inside the decoder's tail kernel (dec_tail8_h2_kernel, "conv_out"): every conv kernel counts then
+                ends = "conv_in" not in extra and "conv_out" in extra
+                t_conv = (extra["conv_igemm"]["ms_per_step"] + extra["res_layer"]["ms_per_step"] +
+                          (extra["conv_out"]["ms_per_step"] if ends else 0.0)) * 1e-3
+                flops_img = conv_flops_per_image(H, W, D, ends=ends)
+                alg_tf = B * flops_img / t_conv / 1e12
                 # 16-bit MFMA term products per fp32 multiply-add on this workload's maps (3 = two-term fp16 on 8x8 maps,
                 # 6 = three-term bf16 on larger ones), asked of the library for the 3x3 layer at the latent resolution
                 terms = _lib.load().vqvae_conv_term_products(1, H // 4, W // 4, 128, 128, 0) or 6
                 scheme = ("two-term fp16 products: 3 fp16 MFMA term products per fp32 product" if terms == 3 else
                           "three-term bf16 products: 6 bf16 MFMA term products per fp32 product")
                 line["roofline_conv"] = {
-                    "kernel": "conv / conv-transpose / fused residual-layer kernels between the first and the last layer "
+                    "kernel": ("all four conv kernels of the step: encoder front (first two layers), encoder 3x3 + residual stack + "
+                               "pre-quantisation 1x1, decoder conv-transpose 3x3 + residual stack, decoder tail (last two layers) "
+                               if ends else
+                               "conv / conv-transpose / fused residual-layer kernels between the first and the last layer ") +
                               f"({scheme})",
                     "bound": "mfma", "achieved": round(terms * alg_tf, 1), "peak": MFMA_16BIT_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(terms * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4),
@@ -334,7 +347,7 @@ def main():
                     "frac_of_fp32_mfma_peak": round(alg_tf / MFMA_F32_PEAK_TFLOPS, 4),
                     "traffic": int(pmc["conv_bytes_per_image"] * B) if pmc and "conv_bytes_per_image" in pmc else None,
                     "traffic_source": pmc["_path"] if pmc and "conv_bytes_per_image" in pmc else None,
-                    "flops_per_image": conv_flops_per_image(H, W, D), "ms_per_step": round(t_conv * 1e3, 4),
+                    "flops_per_image": flops_img, "ms_per_step": round(t_conv * 1e3, 4),
                     "note": f"achieved = 16-bit MFMA flop ISSUED ({terms} term products per fp32 product) / live HIP-event "
                             "time; achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
                             f"would be credited with): its ceiling on this path is 2500/{terms} = {2500 // terms} TF",

@@ -44,7 +44,8 @@ def main():
         per_step = cnt / steps
         byts = (2 * rd + wr) * 1024 * per_step
         table[n[:70]] = {"launches_per_step": round(per_step, 2), "read_KiB_x2": round(2 * rd), "write_KiB": round(wr)}
-        if any(t in n for t in ("conv_tile8", "res_tile8", "res_pair8", "conv_res_pair8", "res_layer", "conv_igemm")):
+        if any(t in n for t in ("conv_tile8", "res_tile8", "res_pair8", "conv_res_pair8", "res_layer", "conv_igemm", "enc_front8",
+                                "dec_tail8")):
             conv += byts
     res["conv_bytes_per_image"] = round(conv / B, 1)
     res["per_kernel_KiB_per_dispatch"] = table

@@ -2633,7 +2633,8 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 //       and out[co][4y + 2py - 1 + ky][4x + 2px - 1 + kx] += T: every output element receives exactly ONE term per phase.
 //       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 40 LDS tile (the operand planes
 //       are free then) and leave as whole 128-byte rows: out = bias + tile in phase 0, out += tile in phases 1..3 with
-//       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident, agent-scope accesses; a phase's stores are
+//       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident; plain accesses: the same lanes of the same wave
+//       on the same CU re-read what they wrote, its write-through L1 does not keep a stale copy, and a phase's stores are
 //       complete -- eight s_waitcnt vmcnt(0) later -- before the next phase's loads are issued): a fixed summation order,
 //       no atomics, no 12 KiB accumulation tile per wave.  (Scattered 4-byte read-modify-writes straight from the
 //       accumulator layout were measured first: 570 us instead of 330 for the two separate kernels -- L2 request bound.)
@@ -2817,7 +2818,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
             for (int co = 0; co < CO; ++co)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    ov[co][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 16));
+                    ov[co][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0));
         }
         f32x16 T[2][MT];
 #pragma unroll
@@ -2866,7 +2867,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
                 f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (row + 1) * 40 + 4 + 4 * (lane & 7));
                 if (ph > 0) v = ov[co][i] + v;
                 else v = f32x4{bv, bv, bv, bv} + v;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 16);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0);
             }
         }
         __builtin_amdgcn_wave_barrier();
