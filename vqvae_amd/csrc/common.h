@@ -113,7 +113,8 @@ int res_layer_forward_impl(const float *x, const float *packed_w1, const float *
                            int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
 bool res_pair_supported(int H, int W, int C, int Rh, int flags);
 // a 1x1 conv (+ bias) fused behind a residual pair: packed = vqvae_conv_pack_f32(VQVAE_CONV_1x1, ...), out (B,8,8,Cout) row-major
-struct ResPairPost { const float *packed; const float *bias; int Cout; float *out; };
+// zero / zero_n (conv_res_pair_forward_impl only): ints the kernel clears for the next kernel of the stream
+struct ResPairPost { const float *packed; const float *bias; int Cout; float *out; int *zero = nullptr; int zero_n = 0; };
 bool res_pair_post_supported(int C, int Cout);
 int res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                           int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
@@ -125,6 +126,9 @@ int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_fro
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)
+int vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W, int K, float beta, int flags,
+                    float *z_q, int64_t *idx, int32_t *hist, float *loss, float *perplexity, void *workspace,
+                    size_t workspace_bytes, vqvae_stream_t stream, bool hist_zeroed);
 bool enc_front_supported(int H, int W, int Cin, int C1, int C2);
 int enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
                            const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,

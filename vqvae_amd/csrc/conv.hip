@@ -424,6 +424,14 @@ __device__ __forceinline__ void publish_amax(int *out_amax, long long img, float
     if (lane == 0) atomicMax(out_amax + img, __float_as_int(om));
 }
 
+// The same where exactly ONE wave ever produces image `img` (the one-wave-per-image kernels): a plain store, and the array
+// needs no -1 fill in front of the launch.
+__device__ __forceinline__ void publish_amax_exclusive(int *out_amax, long long img, float om, int lane) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) om = fmaxf(om, __shfl_xor(om, o));
+    if (lane == 0) out_amax[img] = __float_as_int(om);
+}
+
 // Weight scale of a layer: header {int kw} in front of its two-term fp16 image (one block).
 __global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, long long n, int *__restrict__ hdr) {
     __shared__ float red[256];
@@ -1930,7 +1938,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                                                                    const int *__restrict__ hdr1, const int *__restrict__ hdr2,
                                                                    const int *__restrict__ in_amax, int *__restrict__ out_amax,
                                                                    const u32x4 *__restrict__ w3img, const int *__restrict__ hdr3,
-                                                                   const float *__restrict__ bias3, float *__restrict__ out3) {
+                                                                   const float *__restrict__ bias3, float *__restrict__ out3,
+                                                                   int *__restrict__ zero_buf, int zero_n) {
     static_assert(NT3 == 0 || NT3 == 1 || NT3 == 2 || NT3 == 4, "the 1x1 post conv streams through NT3 weight stages of 16 KiB");
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
@@ -1954,6 +1963,9 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
     const int kw1 = hdr1[0], kw2 = hdr2[0];
+    // a buffer the NEXT kernel of the stream wants zeroed (the quantizer's histogram: saves a fill launch per step)
+    if (zero_buf && blockIdx.x == 0)
+        for (int i = tid; i < zero_n; i += 256) zero_buf[i] = 0;
 
     // pixel bookkeeping: the residual 3x3 (taps t/3-1, t%3-1) and the front conv (taps from the geometry masks)
     int spx[MT];
@@ -2252,7 +2264,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     };
     layer(std::integral_constant<int, 0>{}, true);         // the second layer's in-place ReLU is applied by its producer
     layer(std::integral_constant<int, 1>{}, relu_out);
-    if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
+    if (out_amax && img_ok) publish_amax_exclusive(out_amax, img, ymax, lane);
 
     // one transposed 32-pixel x 32-channel tile -> rows of `ld` floats at dst (pixel-major), whole 128-byte lines per
     // eight lanes: registers -> wave-private LDS tile [pixel][36] -> linear 16-byte reads
@@ -2565,7 +2577,7 @@ __global__ __launch_bounds__(256, 2) void enc_front8_h2_kernel(const float *__re
                 }
             }
         }
-    if (out_amax && img_ok) publish_amax(out_amax, img, ymax, lane);
+    if (out_amax && img_ok) publish_amax_exclusive(out_amax, img, ymax, lane);
     (void)C0;
 }
 
@@ -4053,7 +4065,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         const int *hd3 = reinterpret_cast<const int *>(h3);
 #define CRP_POST(NT3_)                                                                                                          \
     hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
-                       in_amax, out_amax, w3h, hd3, post->bias, post->out)
+                       in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n)
         switch (post->Cout / 32) {
             case 1: CRP_POST(1); break;
             case 2: CRP_POST(2); break;
@@ -4062,7 +4074,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
 #undef CRP_POST
     } else {
         hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
-                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr);
+                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

@@ -176,8 +176,11 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
 }
 
 // am_given: a maxima region (amax_bytes) the caller has already set to -1, or NULL to carve and initialise one here
+// zero_buf / zero_n / zeroed: ints the last encoder kernel should clear for the quantizer behind it (its histogram);
+// *zeroed tells the caller whether a kernel that can do so ran
 static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *am_given) {
+                       size_t workspace_bytes, hipStream_t st, int *am_given, int *zero_buf = nullptr, int zero_n = 0,
+                       bool *zeroed = nullptr, bool am_exclusive = false) {
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return VQVAE_ERR_SHAPE;
@@ -190,7 +193,8 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     int *am = am_given;
     if (!am) {
         am = static_cast<int *>(c.raw(amax_bytes(d, B)));
-        if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+        // (no fill where every array that is read has a one-wave-per-image producer with plain stores: fused_c3_path)
+        if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
     }
     int *am0 = am, *am1 = am ? am + B : nullptr, *am2 = am ? am + 2 * B : nullptr;     // conv_in, enc2, enc4 (+ residual layers)
     const int h = d->h_dim;
@@ -211,7 +215,8 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
     if (d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
         res_pair_post_supported(h, d->embedding_dim)) {
-        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e};
+        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, zero_buf, zero_n};
+        if (zeroed) *zeroed = zero_buf != nullptr;
         return conv_res_pair_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, h, w->enc_res_w1, w->enc_res_w2, B, H / 4, W / 4, h,
                                           d->res_h_dim, VQVAE_CONV_RELU_OUT, nullptr, st, am1, nullptr, &post);
     }
@@ -236,13 +241,29 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st, amt, nullptr);   // vqvae.py:33
 }
 
+// 32x32 RGB images, h_dim 128, two residual layers: the step is four fused conv kernels (+ the quantizer), every per-image
+// maximum that is read has ONE producing wave that stores it plainly -- the maxima arrays need no fill
+static bool fused_c3_path(const VqvaeDims *d, int H, int W) {
+#if defined(VQVAE_NO_FRONT_FUSION) || defined(VQVAE_NO_ENC_FRONT_FUSION) || defined(VQVAE_NO_DEC_TAIL_FUSION)
+    (void)d; (void)H; (void)W;
+    return false;
+#else
+    const int h = d->h_dim;
+    return d->n_res_layers == 2 && enc_front_supported(H, W, d->in_ch, h / 2, h) &&
+           conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) && res_pair_post_supported(h, d->embedding_dim) &&
+           conv_res_pair_supported(VQVAE_CONVT_3x3_S1, H / 4, W / 4, d->embedding_dim, h, d->res_h_dim) &&
+           dec_tail_supported(H / 4, W / 4, h, h / 2, d->in_ch);
+#endif
+}
+
 int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                       size_t workspace_bytes, vqvae_stream_t stream) {
-    return encoder_run(w, x, B, H, W, z_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+    return encoder_run(w, x, B, H, W, z_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, 0, nullptr,
+                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, H, W));
 }
 
 static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *am_given) {
+                       size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -253,7 +274,7 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     int *am = am_given;                                                       // optional, see encoder_run
     if (!am) {
         am = static_cast<int *>(c.raw(amax_bytes(d, B)));
-        if (am && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+        if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
     }
     const int h = d->h_dim;
     int rc;
@@ -297,7 +318,8 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
 
 int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
                       size_t workspace_bytes, vqvae_stream_t stream) {
-    return decoder_run(w, z_q, B, h4, w4, x_hat, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr);
+    return decoder_run(w, z_q, B, h4, w4, x_hat, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr,
+                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, 4 * h4, 4 * w4));
 }
 
 int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, float *x_hat,
@@ -327,14 +349,19 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
     const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    // two fill launches per step saved on the fused 32x32 path: the maxima need none there, and the quantizer's histogram
+    // is cleared by the encoder's last kernel
+    const bool fused = fused_c3_path(d, H, W);
+    if (!fused && hipMemsetAsync(am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
     int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(am2) + amax_bytes(d, B));
     int rc;
-    if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2)) != 0) return rc;                     // vqvae.py:31-33
-    if ((rc = vqvae_vq_forward_f32(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
-                                   (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
-                                                VQVAE_VQ_PRODUCER_CONSUMER)) | VQVAE_VQ_ROWMAJOR,
-                                   z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream)) != 0) return rc;   // :34
+    bool hist_zeroed = false;
+    if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed)) != 0)
+        return rc;                                                                                              // vqvae.py:31-33
+    if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
+                              (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
+                                           VQVAE_VQ_PRODUCER_CONSUMER)) | VQVAE_VQ_ROWMAJOR,
+                              z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed)) != 0) return rc;   // :34
     return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                             // :36
 }
 

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void vq_decode_indices_kernel(const long long 
 template <int D>
 static int launch_vq(const float *z, const float *cb, long long N, int HW, int K, float beta,
                      int flags, float *zq, long long *idx, int *hist, float *loss, float *ppl,
-                     char *ws, hipStream_t st) {
+                     char *ws, hipStream_t st, bool hist_zeroed) {
     const VqPlan p = vq_plan(K, D);
     int *wflags = reinterpret_cast<int *>(ws + p.off_flags);
     float *ee = reinterpret_cast<float *>(ws + p.off_ee);
@@ -444,7 +444,8 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     double *partials = reinterpret_cast<double *>(ws + p.off_partials);
 
     hipError_t e;
-    if ((e = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)K, st)) != hipSuccess) return (int)e;
+    // (hist_zeroed: the kernel in front of this one in the stream has cleared it -- vqvae_forward_f32's fused path)
+    if (!hist_zeroed && (e = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)K, st)) != hipSuccess) return (int)e;
     if (!(flags & VQVAE_VQ_CODEBOOK_PREPARED)) {
         if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
         const int kmax = p.K_pad > p.K32 ? p.K_pad : p.K32;
@@ -561,6 +562,15 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
                          int K, float beta, int flags, float *z_q, int64_t *idx, int32_t *hist,
                          float *loss, float *perplexity, void *workspace, size_t workspace_bytes,
                          vqvae_stream_t stream) {
+    return vqvae::vq_forward_impl(z_e, codebook, B, D, H, W, K, beta, flags, z_q, idx, hist, loss, perplexity, workspace,
+                                  workspace_bytes, stream, false);
+}
+}  // extern "C"
+
+int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W,
+                           int K, float beta, int flags, float *z_q, int64_t *idx, int32_t *hist,
+                           float *loss, float *perplexity, void *workspace, size_t workspace_bytes,
+                           vqvae_stream_t stream, bool hist_zeroed) {
     if (!z_e || !codebook || !idx || !hist || !loss || !perplexity) return VQVAE_ERR_NULL;
     if (B < 1 || D < 1 || H < 1 || W < 1 || K < 1) return VQVAE_ERR_SHAPE;
     if (K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return VQVAE_ERR_UNSUPPORTED;
@@ -574,13 +584,15 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
     const int HW = H * W;
     long long *idx_ll = reinterpret_cast<long long *>(idx);
     switch (D) {
-        case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
-        case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
-        case 128: return launch_vq<128>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
-        case 256: return launch_vq<256>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st);
+        case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
+        case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
+        case 128: return launch_vq<128>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
+        case 256: return launch_vq<256>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
     }
     return VQVAE_ERR_UNSUPPORTED;
 }
+
+extern "C" {
 
 int vqvae_vq_onehot_f32(const int64_t *idx, int64_t N, int K, float *onehot, vqvae_stream_t stream) {
     if (!idx || !onehot) return VQVAE_ERR_NULL;
