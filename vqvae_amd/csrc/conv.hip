@@ -2228,16 +2228,12 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(acc1[mt], hscale, H1[mt], Hb[mt]);
         const u32x4 *wb = stage_sync(9 * LI + 8);              // [nt][term][k-step] x 64 units
         float nmax = 0.0f;
-        u32x4 Wc[2][2];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) { Wc[t][0] = wb[t * 64]; Wc[t][1] = wb[t * 64 + 128]; }
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
-            u32x4 Wn[2][2];
-            if (nt + 1 < NT2) {
+            // (no read-ahead here: four short GEMMs per layer, and 32 more live registers spill next to Y, H and acc2)
+            u32x4 Wc[2][2];
 #pragma unroll
-                for (int t = 0; t < 2; ++t) { Wn[t][0] = wb[(nt + 1) * 256 + t * 64]; Wn[t][1] = wb[(nt + 1) * 256 + t * 64 + 128]; }
-            }
+            for (int t = 0; t < 2; ++t) { Wc[t][0] = wb[nt * 256 + t * 64]; Wc[t][1] = wb[nt * 256 + t * 64 + 128]; }
             f32x16 acc2[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -2255,10 +2251,6 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
                     Y[mt][nt][r] = v;
                     nmax = fmaxf(nmax, __builtin_fabsf(v));
                 }
-            if (nt + 1 < NT2) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) { Wc[t][0] = Wn[t][0]; Wc[t][1] = Wn[t][1]; }
-            }
         }
         ymax = nmax;
     };
