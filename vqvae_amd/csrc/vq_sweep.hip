@@ -103,8 +103,12 @@ __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restric
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// NW waves per workgroup (one workgroup per CU).  A wave owns PAIRS of 32-row tiles (64 consecutive rows).
-template <int NW, bool PREFETCH>
+// NW waves per workgroup (one workgroup per CU).  A wave owns UNITS of T 32-row tiles (T = 2: pairs, 64 consecutive rows,
+// eight waves per CU; T = 1: single tiles, SIXTEEN waves per CU where the codebook image leaves room for them (K <= 512):
+// a unit is a latency chain -- rows landing, LDS round trips, codebook gathers -- around a VALU-bound sweep, and two waves
+// per SIMD keep a SIMD busy 40 % of the time; four need <= 128 registers per lane, which a single tile's rows, operands and
+// accumulators fit with one operand set instead of two).
+template <int NW, bool PREFETCH, int T = 2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
@@ -119,12 +123,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     float *ee_s = reinterpret_cast<float *>(hist_s + K + (K & 1));                      // [K] ||e_k||^2 (ATen order), for the refines
     double *red = reinterpret_cast<double *>(ee_s + K + (K & 1));                       // [NW]
     int *ticket_s = reinterpret_cast<int *>(red + NW);                                  // next pair of this workgroup (+ pad)
-    unsigned char *wave_base = reinterpret_cast<unsigned char *>(red + NW + 2);             // per wave: 8 KiB (the pair's fp16 rows, later fp32 row slots) + 1.25 KiB task tables
+    unsigned char *wave_base = reinterpret_cast<unsigned char *>(red + NW + 2);             // per wave: 4 KiB per tile (the unit's fp16 rows, later 16 fp32 row slots) + 1.5 KiB task tables
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
     const int j16 = lane & 15, g4 = lane >> 4;                 // coalesced layout: 16 lanes per row, 4 rows per instruction
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    unsigned char *tile_s = wave_base + (size_t)wave_u * (8192 + 1664);
+    constexpr int RU = 32 * T;                                  // rows per unit
+    constexpr int TILEB = 4096 * T, TABB = 1552;
+    unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);
+    unsigned char *tab_s = tile_s + TILEB;
 
 #ifdef VQ_SWEEP_TIMING
     // debug build (tools/build_variant.py NAME -DVQ_SWEEP_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
@@ -154,12 +161,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     // ---- row I/O: F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the pair (1 KiB contiguous per instruction) ----
     // a buffer descriptor over the pair's 16 KiB clipped at the end of z: rows past the end read zeros (their results are
     // never stored), one 32-bit lane offset serves all 16 loads -- no per-load 64-bit index math or clamps
-    auto load_pair = [&](long long p, f32x4(&F)[2][8], int lane) {
-        const long long left = (N - p * 64) * (D * 4);
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z + (size_t)p * 64 * D), 0,
-                                                          (unsigned)(left < 16384 ? left : 16384), 0x00020000);
+    auto load_pair = [&](long long p, f32x4(&F)[T][8], int lane) {
+        const long long left = (N - p * RU) * (D * 4);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z + (size_t)p * RU * D), 0,
+                                                          (unsigned)(left < RU * 256 ? left : RU * 256), 0x00020000);
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int i = 0; i < 8; ++i)
                 F[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, (unsigned)lane * 16u, (unsigned)(t * 8 + i) * 1024u, 0));
@@ -167,7 +174,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 
     const long long pstride = (long long)gridDim.x * NW;
     long long p = (long long)blockIdx.x * NW + wave_u;
-    f32x4 F[2][8];
+    f32x4 F[T][8];
     if (p < npairs) load_pair(p, F, lane);
 
     // codebook image and seeds -> LDS (eight 16-byte requests in flight per thread)
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     // A workgroup owns the pairs {(q / NW) * gridDim * NW + blockIdx * NW + q % NW}; after its first pair a wave draws
     // q from an LDS ticket, so a wave slowed down by a rare path (rescan, scalar rows) simply takes fewer pairs.
     while (p < npairs) {
-        const long long r0 = p * 64;
+        const long long r0 = p * RU;
         // lane-derived indices are made opaque once per iteration: hipcc otherwise hoists ~40 per-lane address values out
         // of this loop, spills them and reloads them from scratch inside it (cdna_hip_programming.md, "lane-constant
         // address hoisted to kernel entry")
@@ -225,11 +232,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
         const float *sp0 = seeds + h * 16;
 
         // ================= fp32 rows -> fp16 B operands (through the wave's LDS tile), |z^|^2 ==========================
-        f16x8 zb[2][4];
-        float zn2[2], dz2[2];
-        float *dz_s = reinterpret_cast<float *>(tile_s + 8192 + 1408);     // [64] |z - z^|^2 per row of the pair
+        f16x8 zb[T][4];
+        float zn2[T], dz2[T];
+        float *dz_s = reinterpret_cast<float *>(tab_s + 1296);     // [64] |z - z^|^2 per row of the unit
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < T; ++t) {
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
@@ -269,9 +276,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 
         VQ_STAMP(1);                                           // rows landed, fp16 conversion
         // ================= the sweep: 4 MFMAs per (code tile, row tile), top-3 keys per lane ==========================
-        float m1[2], m2[2], m3[2];
+        float m1[T], m2[T], m3[T];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { m1[t] = -inf; m2[t] = -inf; m3[t] = -inf; }
+        for (int t = 0; t < T; ++t) { m1[t] = -inf; m2[t] = -inf; m3[t] = -inf; }
         // max(m1, key) is written med3(m1, key, +inf) with an OPAQUE +inf: given the literal, hipcc turns it into v_max
         // plus a canonicalising v_max of the integer-built key -- a fifth VALU op per element in a VALU-bound loop
         float pinf = inf;
@@ -294,9 +301,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
         // triple.  (Adding the tile number itself reorders near-tied NEGATIVE scores of one lane, after which med3
         // duplicates one key and drops the other.)
         auto cell = [&](int ct, const u32x4(&a)[4], const f32x16 &seed, u32x4(&an)[4], f32x16 &seedn) {
-            f32x16 acc[2];
+            f32x16 acc[T];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[t][0], seed, 0, 0, 0);
 #pragma unroll
                 for (int q = 1; q < 4; ++q)
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             fetch(ct + 1 < ntile ? ct + 1 : ct, an, seedn);
             const unsigned fix = (unsigned)(2 * (ntile - ct) - 1);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float key = __uint_as_float((__float_as_uint(acc[t][r]) & keymask) | (unsigned)(r | 16));
@@ -330,7 +337,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             // the prefetched operands are first "used" here: their loads cannot sink below, their wait cannot rise above
             asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]));
         };
-        {
+        if constexpr (T == 2) {
             u32x4 aA[4], aB[4];
             f32x16 sA, sB;
             fetch(0, aA, sA);
@@ -340,16 +347,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                 cell(ct + 1, aB, sB, aA, sA);
             }
             if (ct < ntile) cell(ct, aA, sA, aB, sB);
+        } else {
+            // one operand set (the register budget of four waves per SIMD): the next tile's operands are requested into
+            // the registers the MFMAs have just read
+            u32x4 aA[4];
+            f32x16 sA;
+            fetch(0, aA, sA);
+            for (int ct = 0; ct < ntile; ++ct) cell(ct, aA, sA, aA, sA);
         }
 
         VQ_STAMP(2);                                           // sweep
         // ================= merge the two lane halves of every row, classify ===========================================
-        int kbest[2];
-        bool valid[2], bad[2], pairf[2], hardf[2];
-        int c2[2];
-        float thr[2];
+        int kbest[T];
+        bool valid[T], bad[T], pairf[T], hardf[T];
+        int c2[T];
+        float thr[T];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
+        for (int t = 0; t < T; ++t) {
             const long long row = r0 + 32 * t + l31;
             valid[t] = row < N;
             const float a1 = __uint_as_float(__float_as_uint(m1[t]) | ((unsigned)h << 4));
@@ -404,9 +418,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
         {
             // lane L of the wave speaks for row L of the pair (tile L >> 5, row L & 31)
             const bool o_pair = false;                        // two-candidate rows are refined in place by the epilogue
-            const bool o_hard = h ? hardf[1] : hardf[0];
-            bool o_bad = h ? bad[1] : bad[0];
-            const int o_k1 = h ? kbest[1] : kbest[0], o_k2 = h ? c2[1] : c2[0];
+            // (T = 1: the unit has 32 rows, lanes 32..63 speak for none)
+            const bool o_hard = h ? (T == 2 && hardf[T - 1]) : hardf[0];
+            bool o_bad = h ? (T == 2 && bad[T - 1]) : bad[0];
+            const int o_k1 = h ? kbest[T - 1] : kbest[0], o_k2 = h ? c2[T - 1] : c2[0];
 #if defined(VQ_KNOB) && (VQ_KNOB == 3 || VQ_KNOB >= 5)          // knock-out: no exact part
             const unsigned long long fm = 0ull;
 #else
@@ -414,10 +429,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #endif
             if (fm) {
                 unsigned char *zrow_s = tile_s;                                          // [16 row slots][64] fp32 (over the fp16 rows, after the rescan)
-                unsigned *task_s = reinterpret_cast<unsigned *>(tile_s + 8192);          // [64] row | a << 6 | b << 19
-                float *res_s = reinterpret_cast<float *>(tile_s + 8192 + 256);           // [64][2] distances
-                float *zz_s = reinterpret_cast<float *>(tile_s + 8192 + 768);            // [64] ||z||^2 per row of the pair
-                int *cnt_s = reinterpret_cast<int *>(tile_s + 8192 + 1024);              // counter of the rescan's tasks
+                unsigned *task_s = reinterpret_cast<unsigned *>(tab_s);                  // [64] row | a << 6 | b << 19
+                float *res_s = reinterpret_cast<float *>(tab_s + 256);                   // [64][2] distances
+                float *zz_s = reinterpret_cast<float *>(tab_s + 768);                    // [64] ||z||^2 per row of the unit
+                int *cnt_s = reinterpret_cast<int *>(tab_s + 1024);                      // counter of the rescan's tasks
                 const unsigned long long lowmask = (1ull << lane) - 1ull;
                 const unsigned long long tm = __builtin_amdgcn_ballot_w64(o_pair || o_bad);
                 const int ndirect = __builtin_popcountll(tm);
@@ -431,7 +446,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                     if (lane == 0) cnt_s[0] = 0;
                     lds_order_wave();
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < T; ++t) {
                         if ((unsigned)(hmask >> (32 * t))) {
                             // B operands once per tile; the next code tile's A / seed operands are requested behind this tile's MFMAs
                             f16x8 zbr[4];
@@ -490,7 +505,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                     // copy this round's rows (ranks 16 rd .. 16 rd + 15 among the flagged rows) into the row slots
                     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                    for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < T; ++t)
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {
                             if ((fm >> (32 * t + 4 * i)) & 0xfull) {
@@ -597,7 +612,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                 }
                 const int k0n = __shfl(o_best, l31), k1n = __shfl(o_best, 32 + l31);
                 if (hardf[0] || bad[0]) kbest[0] = k0n;
-                if (hardf[1] || bad[1]) kbest[1] = k1n;
+                if (T == 2 && (hardf[T - 1] || bad[T - 1])) kbest[T - 1] = k1n;
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -609,14 +624,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #if defined(VQ_KNOB) && (VQ_KNOB == 4 || VQ_KNOB >= 6)
         const unsigned pm[2] = {0u, 0u};
 #else
-        const unsigned pm[2] = {(unsigned)__builtin_amdgcn_ballot_w64(pairf[0]), (unsigned)__builtin_amdgcn_ballot_w64(pairf[1])};
+        const unsigned pm[2] = {(unsigned)__builtin_amdgcn_ballot_w64(pairf[0]), T == 2 ? (unsigned)__builtin_amdgcn_ballot_w64(pairf[T - 1]) : 0u};
 #endif
         const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
-        f32x4 ev[2][8];
+        f32x4 ev[T][8];
         f32x4 pool[4];
         int npool = 0;
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < T; ++t)
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int kr = __shfl(kbest[t], 4 * i + g4);
@@ -636,7 +651,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             }
         VQ_STAMP(4);                                           // exact part
         // ================= epilogue: refine of two-candidate rows in place, z + (e_k - z), squared error, index, histogram ===
-        int *kb_s = reinterpret_cast<int *>(tile_s + 8192 + 1152);     // [64] refined indices of two-candidate rows
+        int *kb_s = reinterpret_cast<int *>(tab_s + 1040);     // [64] refined indices of two-candidate rows
         {
             int slot = 0;
 #ifdef VQ_SWEEP_DEBUG
@@ -644,13 +659,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 #else
             const bool store_zq = zq != nullptr;
 #endif
-            const int nleft = (int)(N - r0 < 64 ? N - r0 : 64);         // rows of this pair that exist
+            const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
             // the descriptor covers exactly the pair's existing rows: stores of rows past the end are dropped by the hardware
-            const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq ? zq + (size_t)p * 64 * D : const_cast<float *>(z), 0,
+            const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq ? zq + (size_t)p * RU * D : const_cast<float *>(z), 0,
                                                                  store_zq ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
             float sacc = 0.0f;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
 #pragma unroll
                 for (int i = 0; i < 8; ++i) {
                     const int rr = 32 * t + 4 * i + g4;
@@ -705,7 +720,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             dacc += (double)sacc;
             lds_order_wave();
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < T; ++t) {
                 if (pairf[t]) kbest[t] = kb_s[32 * t + l31];
                 if (valid[t] && h == 0) {
                     idx[r0 + 32 * t + l31] = kbest[t];
@@ -1421,9 +1436,9 @@ __global__ __launch_bounds__(512, 2) void vq_pc_kernel_d64(
     }
 }
 
-size_t vq_sweep_lds_bytes(int K, int nw) {
+size_t vq_sweep_lds_bytes(int K, int nw) {          // nw = 16: one 32-row tile per unit and wave, nw = 8: two
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + 2 * (size_t)(K + (K & 1)) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * (8192 + 1664);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + 2 * (size_t)(K + (K & 1)) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nw > 8 ? 4096 : 8192) + 1552);
 }
 
 size_t vq_pc_lds_bytes(int K) {
@@ -1450,19 +1465,30 @@ void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out) {
     const VqPlan p = vq_plan(K, 64);
-    const long long npairs = (N + 63) / 64;
-    constexpr int NW = 8;
     const int cus = num_cus();
-    long long grid = (npairs + NW - 1) / NW;
+#ifdef VQVAE_VQ_NW8                          // A/B builds (tools/build_variant.py nw8 -DVQVAE_VQ_NW8)
+    const bool wide = false;
+#else
+    // Sixteen waves per CU with 32-row units where the codebook image leaves room (K <= 512) AND a wave gets at most two
+    // units: the kernel's fixed phases and memory round trips then overlap four-fold (67 vs 71 us at 262 144 rows); with more
+    // rows per wave the sweep's vector work dominates and the 128-register version (63 spills) loses (133 vs 115 us at 524 288)
+    const bool wide = vq_sweep_lds_bytes(K, 16) <= (size_t)kLdsBytes && (N + 31) / 32 <= 2LL * 16 * cus;
+#endif
+    const int NW = wide ? 16 : 8, RU = wide ? 32 : 64;
+    const long long nunits = (N + RU - 1) / RU;
+    long long grid = (nunits + NW - 1) / NW;
     if (grid > cus) grid = cus;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
     *grid_out = (int)grid;
-    auto kfn = vq_sweep_kernel_d64<NW, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_sweep_lds_bytes(K, NW), st, z, cb,
-                       reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
-                       reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K,
-                       p.K32, npairs, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials));
+    auto launch = [&](auto kfn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_sweep_lds_bytes(K, NW), st, z, cb,
+                           reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
+                           reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K,
+                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials));
+    };
+    if (wide) launch(vq_sweep_kernel_d64<16, false, 1>);
+    else launch(vq_sweep_kernel_d64<8, false, 2>);
     return (int)hipGetLastError();
 }
 
