@@ -348,12 +348,50 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             }
             if (ct < ntile) cell(ct, aA, sA, aB, sB);
         } else {
-            // one operand set (the register budget of four waves per SIMD): the next tile's operands are requested into
-            // the registers the MFMAs have just read
+            // one A-operand set (the register budget of four waves per SIMD: the next tile's operands are requested into
+            // the registers the MFMAs have just read) and two accumulators that take turns: a tile's seeds are loaded
+            // straight into the accumulator its MFMAs will run in, while the other one's keys are being extracted
+            // (with one accumulator and a seed set hipcc copies 16 registers per tile)
             u32x4 aA[4];
-            f32x16 sA;
-            fetch(0, aA, sA);
-            for (int ct = 0; ct < ntile; ++ct) cell(ct, aA, sA, aA, sA);
+            f32x16 accA, accB;
+            auto fetch1 = [&](int ct, f32x16 &seed) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) aA[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
+                    seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
+                }
+            };
+            auto cell1 = [&](int ct, f32x16 &acc, f32x16 &nxt) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, aA[q]), zb[0][q], acc, 0, 0, 0);
+                fetch1(ct + 1 < ntile ? ct + 1 : ct, nxt);
+                const unsigned fix = (unsigned)(2 * (ntile - ct) - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float key = __uint_as_float((__float_as_uint(acc[r]) & keymask) | (unsigned)(r | 16));
+                    m3[0] = __builtin_amdgcn_fmed3f(m2[0], m3[0], key);
+                    m2[0] = __builtin_amdgcn_fmed3f(m1[0], m2[0], key);
+                    m1[0] = __builtin_amdgcn_fmed3f(m1[0], key, pinf);
+                }
+                unsigned b1 = __float_as_uint(m1[0]), b2 = __float_as_uint(m2[0]), b3 = __float_as_uint(m3[0]);
+                b1 += __umul24(b1 & 16u, fix);
+                b2 += __umul24(b2 & 16u, fix);
+                b3 += __umul24(b3 & 16u, fix);
+                m1[0] = __uint_as_float(b1);
+                m2[0] = __uint_as_float(b2);
+                m3[0] = __uint_as_float(b3);
+                asm volatile("" : "+v"(aA[0]), "+v"(aA[1]), "+v"(aA[2]), "+v"(aA[3]));
+            };
+            fetch1(0, accA);
+            int ct = 0;
+            for (; ct + 1 < ntile; ct += 2) {
+                cell1(ct, accA, accB);
+                cell1(ct + 1, accB, accA);
+            }
+            if (ct < ntile) cell1(ct, accA, accB);
         }
 
         VQ_STAMP(2);                                           // sweep
