@@ -2627,8 +2627,8 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 // ---------------------------------------------------------------------------
 // Decoder tail in one launch (models/decoder.py:31-35): ConvTranspose2d(128 -> 64, 4x4 s2 p1) + ReLU +
 // ConvTranspose2d(64 -> 3, 4x4 s2 p1) on 8x8 maps -> 32x32 NCHW images; the 16x16x64 map between them (64 KiB per image)
-// never exists.  One wave owns one image and walks the four output phases (py, px) of the first layer; everything is
-// computed transposed as in conv_res_pair8_h2_kernel.
+// never exists.  One wave owns one image and walks the four output phases (py, px) of the first layer, two per pass (the
+// phases (py, 0) and (py, 1) share the parked input planes); everything is computed transposed as in conv_res_pair8_h2_kernel.
 //   layer 1, phase (py, px): u[2y + py][2x + px][c] = relu(b + sum over 2x2 taps and 128 channels), as in
 //       conv_tile8_bf3_kernel (4 chunks of 32 channels parked as fp16 planes, tap = shifted plane read), weights streamed
 //       by LDS-DMA two taps per stage; the accumulator (lane = block pixel, registers = channels) becomes the second
@@ -2636,7 +2636,8 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 //   layer 2 in its GEMM + col2im form: T[co * 16 + tap][pixel] = sum_c w4[c][co][tap] u[pixel][c] (48 rows = two A tiles),
 //       and out[co][4y + 2py - 1 + ky][4x + 2px - 1 + kx] += T: every output element receives exactly ONE term per phase.
 //       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 40 LDS tile (the operand planes
-//       are free then) and leave as whole 128-byte rows: out = bias + tile in phase 0, out += tile in phases 1..3 with
+//       are free then; the second phase of a pass reads, adds and stores) and leave as whole 128-byte rows: out = bias + tile
+//       in pass 0, out += tile in pass 1 with
 //       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident; plain accesses: the same lanes of the same wave
 //       on the same CU re-read what they wrote, its write-through L1 does not keep a stale copy, and a phase's stores are
 //       complete -- eight s_waitcnt vmcnt(0) later -- before the next phase's loads are issued): a fixed summation order,
@@ -2653,7 +2654,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
                                                               float *__restrict__ out, int B, const int *__restrict__ in_amax) {
     constexpr int NT = 2, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2, CIN = 128, CPT = CIN / 32, CO = 3;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // [k-step 2][term 2][half 2][pixel + zero] = 520 units
-    constexpr int WBUF = 16 * 64, NSTAGE = 36;             // per phase: 4 chunks x 2 tap pairs (16 pieces each) + the second layer's image
+    constexpr int WBUF = 16 * 64, NSTAGE = 34;             // per pass: 4 chunks x 4 tap pairs (16 pieces each) + the second layer's image
     __shared__ u32x4 As_all[4 * TILE4];
     __shared__ u32x4 Wb_all[2 * WBUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -2667,15 +2668,18 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
         asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
     };
-    // stage k = 9 phase + i: i < 8: chunk i >> 1, taps 2 (i & 1) and 2 (i & 1) + 1 of the first layer (8 pieces each: [nt][term][k-step]);
-    // i = 8: the second layer's A image (16 pieces)
+    // A PASS covers the two phases (py, 0) and (py, 1): they share the parked planes, and where their taps read the same
+    // input offset (dx = 0) also the operand reads.  stage k = 17 py + i: i < 16: chunk i >> 2, tap pair i & 3 = (ty, kind) of
+    // the first layer -- kind 0: the two phases' dx = 0 taps (tx = 0 of px = 0, tx = 1 of px = 1), kind 1: the other two;
+    // pieces 0..7 = phase (py, 0)'s tap, 8..15 = phase (py, 1)'s ([nt][term][k-step] each); i = 16: the second layer's A image
     auto dma_stage = [&](int k, int buf) {
-        const int ph = k / 9, i = k - 9 * ph;
+        const int py = k / 17, i = k - 17 * py;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int p = wave_u * 4 + j;
-            const u32x4 *src = i == 8 ? w4img + p * 64
-                                      : w2img + (size_t)(ph * 16 + (2 * (i & 1) + (p >> 3)) * CPT + (i >> 1)) * 512 + (p & 7) * 64;
+            const int p = wave_u * 4 + j, half = p >> 3;
+            const int ty = (i >> 1) & 1, kind = i & 1, tap = ty * 2 + (half ? 1 - kind : kind);
+            const u32x4 *src = i == 16 ? w4img + p * 64
+                                       : w2img + (size_t)((2 * py + half) * 16 + tap * CPT + (i >> 2)) * 512 + (p & 7) * 64;
             dma(src + lane, Wb_all + buf * WBUF + p * 64);
         }
     };
@@ -2686,7 +2690,9 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
     dma_stage(0, 0);
     if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
 
-    const auto ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(img_ok ? img : 0) * (CO * 1024), 0, img_ok ? (unsigned)(CO * 4096) : 0u, 0x00020000);
+    // (built from the wave-uniform image index: with a lane-derived one hipcc wraps every access in a waterfall loop)
+    const long long img_u = (long long)blockIdx.x * 4 + wave_u;
+    const auto ors = __builtin_amdgcn_make_buffer_rsrc(out + (size_t)(img_u < B ? img_u : 0) * (CO * 1024), 0, img_u < B ? (unsigned)(CO * 4096) : 0u, 0x00020000);
     int spx[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) spx[mt] = 32 * mt + l31;
@@ -2711,29 +2717,35 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
     load_raw(0);
 
 #pragma unroll 1
-    for (int ph = 0; ph < 4; ++ph) {
-        const int py = ph >> 1, px = ph & 1;
-        const unsigned long long dym = tg.dym[ph], dxm = tg.dxm[ph];
-        unsigned tapok[MT];
+    for (int py = 0; py < 2; ++py) {
+        unsigned long long dym[2], dxm[2];
+        unsigned tapok[2][MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int y = spx[mt] >> 3, x = spx[mt] & 7;
-            unsigned mk = 0;
+        for (int px = 0; px < 2; ++px) {
+            dym[px] = tg.dym[2 * py + px];
+            dxm[px] = tg.dxm[2 * py + px];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int yy = y + (int)((dym >> (4 * t)) & 15) - 8, xx = x + (int)((dxm >> (4 * t)) & 15) - 8;
-                if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) mk |= 1u << t;
+            for (int mt = 0; mt < MT; ++mt) {
+                const int y = spx[mt] >> 3, x = spx[mt] & 7;
+                unsigned mk = 0;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int yy = y + (int)((dym[px] >> (4 * t)) & 15) - 8, xx = x + (int)((dxm[px] >> (4 * t)) & 15) - 8;
+                    if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) mk |= 1u << t;
+                }
+                tapok[px][mt] = mk;
             }
-            tapok[mt] = mk;
         }
-        f32x16 acc[MT][NT];
+        f32x16 acc[2][MT][NT];                              // [px][pixel tile][channel tile]
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int px = 0; px < 2; ++px)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-        // ----------------------------- layer 1, this phase -----------------------------
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[px][mt][nt][r] = 0.0f;
+        // ----------------------------- layer 1, both phases of the pass -----------------------------
 #pragma unroll 1
         for (int cc = 0; cc < CPT; ++cc) {
             __builtin_amdgcn_wave_barrier();
@@ -2747,33 +2759,35 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
                     dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
                     dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
                 }
-            load_raw(cc + 1 < CPT ? cc + 1 : 0);           // (the next phase starts over at chunk 0)
+            load_raw(cc + 1 < CPT ? cc + 1 : 0);           // (the next pass starts over at chunk 0)
             lds_order_wave();
 #pragma unroll 1
-            for (int j = 0; j < 2; ++j) {
-                const int k = ph * 9 + cc * 2 + j;
-                u32x4 X[2][2][MT][2];                      // [tap of the pair][k-step][pixel tile][term]
+            for (int i = 0; i < 4; ++i) {
+                const int k = py * 17 + cc * 4 + i;
+                const int ty = i >> 1, kind = i & 1;
+                const int tapA = ty * 2 + kind, tapB = ty * 2 + 1 - kind;     // of phase px = 0 / px = 1
+                u32x4 X[2][MT][2];                          // [k-step][pixel tile][term] of the half-stage in flight
+                // k-step t of tap `tap` of phase px (a k-step's registers are reloaded for the second half as soon as the first
+                // half's groups that read them have been issued)
+                auto ldX = [&](int t, int px, int tap) {
+                    const int shift = ((int)((dym[px] >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm[px] >> (4 * tap)) & 15) - 8);
 #pragma unroll
-                for (int ts = 0; ts < 2; ++ts) {
-                    const int tap = 2 * j + ts;
-                    const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * 8 + ((int)((dxm >> (4 * tap)) & 15) - 8);
-#pragma unroll
-                    for (int t = 0; t < 2; ++t)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt) {
-                            const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
-                            const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
-                            X[ts][t][mt][0] = ap[0];
-                            X[ts][t][mt][1] = ap[PLANE];
-                        }
-                }
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int p = ((tapok[px][mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                        const u32x4 *ap = As + (t * 2) * PLANE + h * HP + p;
+                        X[t][mt][0] = ap[0];
+                        X[t][mt][1] = ap[PLANE];
+                    }
+                };
+                ldX(0, 0, tapA);
+                ldX(1, 0, tapA);
                 dma_wait_sync();                           // this stage's weights are in; everyone is done with the other buffer
                 dma_stage(k + 1, (k + 1) & 1);
-                const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;      // [tap of the pair][nt][term][k-step] x 64 units
+                const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;      // [phase of the pair][nt][term][k-step] x 64 units
                 u32x4 Wc0 = wt[0], Wc1 = wt[128];
 #pragma unroll
-                for (int g = 0; g < 8; ++g) {              // group g = (tap of the pair, k-step, nt)
-                    const int ts = g >> 2, t = (g >> 1) & 1, nt = g & 1;
+                for (int g = 0; g < 8; ++g) {              // group g = (phase of the pair, k-step, nt)
+                    const int px = g >> 2, t = (g >> 1) & 1, nt = g & 1;
                     u32x4 Wn0 = Wc0, Wn1 = Wc1;
                     if (g + 1 < 8) {
                         const int g1 = g + 1;
@@ -2781,73 +2795,81 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
                         Wn0 = bp[0];
                         Wn1 = bp[128];
                     }
+                    if (g == 2) ldX(0, 1, tapB);           // groups 0, 1 (the readers of k-step 0) are behind us
+                    if (g == 4) ldX(1, 1, tapB);           // groups 2, 3 likewise
                     __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise sinks the reads to just before their use
-                    prod3x2t(X[ts][t][0][0], X[ts][t][0][1], X[ts][t][1][0], X[ts][t][1][1], Wc0, Wc1, acc[0][nt], acc[1][nt]);
+                    prod3x2t(X[t][0][0], X[t][0][1], X[t][1][0], X[t][1][1], Wc0, Wc1, acc[px][0][nt], acc[px][1][nt]);
                     __builtin_amdgcn_sched_barrier(0);
                     Wc0 = Wn0;
                     Wc1 = Wn1;
                 }
             }
         }
-        // ----------------------------- bias + ReLU, the phase tile's scale, operands of layer 2 -----------------------------
-        float um = 0.0f;
+        // ----------------------------- per phase: bias + ReLU, its scale, T = W4 u -----------------------------
+        // row rho = 32 m + (r & 3) + 8 (r >> 2) + 4 h of T is (co = rho >> 4, tap = rho & 15 = ky * 4 + kx): register r of A tile m
+        // holds co = 2 m + (r >> 3), ky = h + 2 ((r >> 2) & 1), kx = r & 3; rows >= 48 (m = 1, r >= 8) are padding
+        f32x16 T[2][2][MT];                                 // [px][A tile][pixel tile]
+        float d4[2];
+        const u32x4 *wt4 = nullptr;
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int px = 0; px < 2; ++px) {
+            float um = 0.0f;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                    if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float v = fmaxf(acc[px][mt][nt][4 * g + q] * d1 + bv[q], 0.0f);
+                            acc[px][mt][nt][4 * g + q] = v;
+                            um = fmaxf(um, v);
+                        }
+                }
+            const int ku = wave_scale_exp(img_ok ? um : 0.0f);
+            const float us = __builtin_ldexpf(1.0f, ku);
+            d4[px] = __builtin_ldexpf(1.0f, -(ku + kw4));
+            u32x4 U1[MT][NT][2], U2[MT][NT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc_to_ksteps(acc[px][mt][nt], us, U1[mt][nt], U2[mt][nt]);
+#pragma unroll
+            for (int m2 = 0; m2 < 2; ++m2)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = fmaxf(acc[mt][nt][4 * g + q] * d1 + bv[q], 0.0f);
-                        acc[mt][nt][4 * g + q] = v;
-                        um = fmaxf(um, v);
-                    }
+                    for (int r = 0; r < 16; ++r) T[px][m2][mt][r] = 0.0f;
+            if (px == 0) {
+                const int k = py * 17 + 16;
+                dma_wait_sync();
+                if (k + 1 < NSTAGE) dma_stage(k + 1, (k + 1) & 1);
+                wt4 = Wb_all + (k & 1) * WBUF + lane;       // [m][k-step 4][term] x 64 units
             }
-        const int ku = wave_scale_exp(img_ok ? um : 0.0f);
-        const float us = __builtin_ldexpf(1.0f, ku), d4 = __builtin_ldexpf(1.0f, -(ku + kw4));
-        u32x4 U1[MT][NT][2], U2[MT][NT][2];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc_to_ksteps(acc[mt][nt], us, U1[mt][nt], U2[mt][nt]);
-        // ----------------------------- layer 2: T = W4 u, then out += T at the col2im positions -----------------------------
-        // row rho = 32 m + (r & 3) + 8 (r >> 2) + 4 h of T is (co = rho >> 4, tap = rho & 15 = ky * 4 + kx): register r of A tile m
-        // holds co = 2 m + (r >> 3), ky = h + 2 ((r >> 2) & 1), kx = r & 3; rows >= 48 (m = 1, r >= 8) are padding
-        f32x4 ov[CO][4];                                   // this lane's 16-byte pieces of the image so far (phases 1..3)
-        if (ph > 0) {
+                for (int m2 = 0; m2 < 2; ++m2) {
+                    const u32x4 *bp = wt4 + (m2 * 4 + kk) * 128;
+                    prod3x2t(U1[0][kk >> 1][kk & 1], U2[0][kk >> 1][kk & 1], U1[1][kk >> 1][kk & 1], U2[1][kk >> 1][kk & 1], bp[0], bp[64],
+                             T[px][m2][0], T[px][m2][1]);
+                }
+        }
+        // ----------------------------- col2im of the pass -----------------------------
+        // through a wave-private LDS tile (the operand planes are free until the next pass): per output channel the two phases'
+        // terms land at [Y + 1][X + 4] of a zeroed 34 x 40 tile -- phase (py, 0) stores (every element at most once), phase (py, 1)
+        // adds -- and leave as whole 128-byte rows: out = bias + tile in pass 0, out += tile in pass 1
+        f32x4 ov[CO][4];                                   // this lane's 16-byte pieces of the image after pass 0
+        if (py > 0) {
 #pragma unroll
             for (int co = 0; co < CO; ++co)
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     ov[co][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0));
         }
-        f32x16 T[2][MT];
-#pragma unroll
-        for (int m2 = 0; m2 < 2; ++m2)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) T[m2][mt][r] = 0.0f;
-        {
-            const int k = ph * 9 + 8;
-            dma_wait_sync();
-            if (k + 1 < NSTAGE) dma_stage(k + 1, (k + 1) & 1);
-            const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;          // [m][k-step 4][term] x 64 units
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int m2 = 0; m2 < 2; ++m2) {
-                    const u32x4 *bp = wt + (m2 * 4 + kk) * 128;
-                    prod3x2t(U1[0][kk >> 1][kk & 1], U2[0][kk >> 1][kk & 1], U1[1][kk >> 1][kk & 1], U2[1][kk >> 1][kk & 1], bp[0], bp[64],
-                             T[m2][0], T[m2][1]);
-                }
-        }
-        // col2im through a wave-private LDS tile (the operand planes are free until the next phase): per output channel the
-        // phase's 32 x 32 terms land at [Y + 1][X + 4] of a zeroed 34 x 40 tile (every element at most once) and leave as whole
-        // 128-byte rows: out = bias + tile in phase 0, out += tile afterwards
         float *tile = reinterpret_cast<float *>(As);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
@@ -2857,19 +2879,37 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
                 if (lane + 64 * i < 340) reinterpret_cast<f32x4 *>(tile)[lane + 64 * i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             lds_order_wave();
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int y = spx[mt] >> 3, x = spx[mt] & 7;
-                float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+            for (int px = 0; px < 2; ++px) {
+                // phase (py, 0) stores; phase (py, 1) reads, adds and stores (no two lanes of one instruction meet, the wave's
+                // LDS operations execute in order; ds_add_f32 does the same 110 us per step slower, measured)
+                float old[MT][8];
+                if (px == 1) {
 #pragma unroll
-                for (int rr = 0; rr < 8; ++rr) tp[((rr >> 2) & 1) * 80 + (rr & 3)] = T[co >> 1][mt][8 * (co & 1) + rr] * d4;
+                    for (int mt = 0; mt < MT; ++mt) {
+                        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+                        const float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) old[mt][rr] = tp[((rr >> 2) & 1) * 80 + (rr & 3)];
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int y = spx[mt] >> 3, x = spx[mt] & 7;
+                    float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const float v = T[px][co >> 1][mt][8 * (co & 1) + rr] * d4[px];
+                        tp[((rr >> 2) & 1) * 80 + (rr & 3)] = px == 0 ? v : old[mt][rr] + v;
+                    }
+                }
+                lds_order_wave();
             }
-            lds_order_wave();
             const float bv = bias4 ? bias4[co] : 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (lane >> 3) + 8 * i;
                 f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (row + 1) * 40 + 4 + 4 * (lane & 7));
-                if (ph > 0) v = ov[co][i] + v;
+                if (py > 0) v = ov[co][i] + v;
                 else v = f32x4{bv, bv, bv, bv} + v;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0);
             }
