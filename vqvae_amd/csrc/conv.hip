@@ -2418,7 +2418,10 @@ __global__ __launch_bounds__(256, 2) void enc_front8_h2_kernel(const float *__re
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Y[mt][nt][r] = 0.0f;
-    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(ximg), 0, (unsigned)(CIN * 4096), 0x00020000);
+    // (built from the wave-uniform image index: with a lane-derived one hipcc wraps every gather in a waterfall loop)
+    const long long img_u = (long long)blockIdx.x * 4 + wave_u;
+    const auto xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x + (size_t)(img_u < B ? img_u : 0) * (CIN * 1024)), 0,
+                                                       (unsigned)(CIN * 4096), 0x00020000);
     __syncthreads();                                       // W0s
 
     // the four taps of chunk cc (its operand planes are in the wave's tile): stages 4 cc .. 4 cc + 3
