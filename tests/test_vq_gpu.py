@@ -18,13 +18,15 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, producer_consumer=False):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, producer_consumer=False,
+         sixteen_waves=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact, bf16_filter=bf16_filter, producer_consumer=producer_consumer)
+                                            exact_sweep=exact, bf16_filter=bf16_filter, producer_consumer=producer_consumer,
+                                            sixteen_waves=sixteen_waves)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -32,7 +34,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "producer_consumer", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "producer_consumer", "sixteen_waves", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -41,7 +43,7 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
     loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter",
-                                    producer_consumer=kernel == "producer_consumer")
+                                    producer_consumer=kernel == "producer_consumer", sixteen_waves=kernel == "sixteen_waves")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -111,6 +113,9 @@ def test_vq_filter_adversarial_near_ties():
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, sixteen_waves=True)       # 32-row units: rescan / hard-row paths of that form
+    np.testing.assert_array_equal(idx, ref["idx"])
+    assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
 @pytest.mark.parametrize("p", [8, 11], ids=["bf16mid", "fp16mid"])
@@ -128,6 +133,8 @@ def test_vq_aligned_rounding_adversarial(p, seed):
     z = torch.from_numpy(np.ascontiguousarray(zr.reshape(n // 64, 8, 8, d).transpose(0, 3, 1, 2)))
     cbt = torch.from_numpy(cb)
     ref = c_oracle.vq_forward(z.numpy(), cb, 0.25)
+    loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, True, sixteen_waves=True)
+    np.testing.assert_array_equal(idx, ref["idx"])
     for rowmajor, exact, bf in ((True, False, False), (True, False, True), (False, False, False), (True, True, False)):
         loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, rowmajor, exact=exact, bf16_filter=bf)
         np.testing.assert_array_equal(idx, ref["idx"])
@@ -184,7 +191,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
     z = torch.randn(B, D, H, W, generator=g) * 0.066
     ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
-    for kw in ({}, {"producer_consumer": True}, {"bf16_filter": True}):
+    for kw in ({}, {"producer_consumer": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
         loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
         np.testing.assert_array_equal(idx, ref_idx)
         assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))

@@ -103,7 +103,7 @@ void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st
 int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,
                       char *ws, hipStream_t st, int *grid_out);
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out);
+                        char *ws, hipStream_t st, int *grid_out, bool sixteen);
 
 // conv.hip: the per-layer entry points with the per-image activation maxima of the two-term fp16 product path
 // (arrays of B ints, -1 = not provided; NULL = none): written by a producing layer, read by the consuming one.

@@ -462,7 +462,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
             const int rc = (vq_pc_ok(K, D) && (flags & VQVAE_VQ_PRODUCER_CONSUMER))
                                ? launch_vq_pc_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid)
-                               : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid);
+                               : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, (flags & VQVAE_VQ_SIXTEEN_WAVES) != 0);
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
             hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,

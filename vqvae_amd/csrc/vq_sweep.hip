@@ -1501,17 +1501,15 @@ void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st
 }
 
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out) {
+                        char *ws, hipStream_t st, int *grid_out, bool sixteen) {
     const VqPlan p = vq_plan(K, 64);
     const int cus = num_cus();
-#ifdef VQVAE_VQ_NW8                          // A/B builds (tools/build_variant.py nw8 -DVQVAE_VQ_NW8)
-    const bool wide = false;
-#else
-    // Sixteen waves per CU with 32-row units where the codebook image leaves room (K <= 512) AND a wave gets at most two
-    // units: the kernel's fixed phases and memory round trips then overlap four-fold (67 vs 71 us at 262 144 rows); with more
-    // rows per wave the sweep's vector work dominates and the 128-register version (63 spills) loses (133 vs 115 us at 524 288)
-    const bool wide = vq_sweep_lds_bytes(K, 16) <= (size_t)kLdsBytes && (N + 31) / 32 <= 2LL * 16 * cus;
-#endif
+    // VQVAE_VQ_SIXTEEN_WAVES: sixteen waves per CU with 32-row units where the codebook image leaves room (K <= 512) and a
+    // wave gets at most two units: the kernel's fixed phases and memory round trips then overlap four-fold (62 vs 70 us at
+    // 262 144 rows on an otherwise idle chip; with more rows per wave the sweep's vector work dominates and the 128-register
+    // version loses: 133 vs 115 us at 524 288).  Not the default: inside the forward (behind the encoder's last kernel) the
+    // two forms take the same 71 us, and the 92 registers this one spills turn into 1.6x the algorithmic traffic.
+    const bool wide = sixteen && vq_sweep_lds_bytes(K, 16) <= (size_t)kLdsBytes && (N + 31) / 32 <= 2LL * 16 * cus;
     const int NW = wide ? 16 : 8, RU = wide ? 32 : 64;
     const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
