@@ -382,3 +382,68 @@ def test_encoder_front_fusion_scales_and_borders():
     for i in range(B):
         r = z_e_ref[i].numpy()
         np.testing.assert_allclose(got[i], r, atol=4e-6 * max(np.abs(r).max(), 1e-30), rtol=1e-4, err_msg=f"image {i}")
+
+
+def test_decoder_tail_fusion_scales_and_borders():
+    """dec_tail8_h2_kernel (the decoder's last two layers in one launch: 8x8 latent maps, h_dim 128, 3 output channels)
+    against the oracle's decoder on latents chosen for its risks: single bright latent pixels in every corner and on the
+    edges (the col2im borders of BOTH transposed convs), magnitudes from 1e-6 to 1e4 in one batch (the per-image and
+    per-phase power-of-two scales), an all-zero latent (only the biases remain).  Tolerance relative to every image's own
+    magnitude."""
+    from oracle import torch_port
+    from vqvae_amd import _lib, conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    h, rh, nl, K, D = 128, 32, 2, 512, 64
+    torch.manual_seed(12)
+    m = VQVAE(h, rh, nl, K, D, 0.25).eval()
+    g = torch.Generator().manual_seed(6)
+    lat = []
+    for (yy, xx) in [(0, 0), (0, 7), (7, 0), (7, 7), (0, 3), (7, 4), (3, 0), (4, 7)]:
+        t = torch.zeros(D, 8, 8)
+        t[:, yy, xx] = torch.randn(D, generator=g)
+        lat.append(t)
+    for mag in [1.0, 1.0e-6, 3.0e2, 0.0, 1.0e4, 2.0e-3]:
+        lat.append(torch.randn(D, 8, 8, generator=g) * mag)
+    z_q = torch.stack(lat)                                   # (B, D, 8, 8)
+    B = z_q.shape[0]
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = torch_port.decode(sd, z_q.clone(), nl).numpy()
+    md = m.to(dev())
+    L = _lib.load()
+    cw, _keep = md._c_weights()
+    nws = L.vqvae_workspace_bytes(cw.dims, B, 32, 32)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+    zr = z_q.permute(0, 2, 3, 1).contiguous().to(dev())      # row-major latents, the whole-path layout
+    x_hat = torch.empty(B, 3, 32, 32, device=dev())
+    _lib.check(L.vqvae_decoder_f32(cw, zr.data_ptr(), B, 8, 8, x_hat.data_ptr(), ws.data_ptr(), nws,
+                                   torch.cuda.current_stream().cuda_stream))
+    got = x_hat.cpu().numpy()
+    for i in range(B):
+        np.testing.assert_allclose(got[i], want[i], atol=4e-6 * max(np.abs(want[i]).max(), 1e-30), rtol=1e-4, err_msg=f"image {i}")
+
+
+@pytest.mark.parametrize("B", [1, 3, 5, 6, 9])
+def test_whole_path_ragged_batches_vs_oracle(B):
+    """Batches that do not fill the fused kernels' four-image workgroups (idle waves must neither read nor write) through
+    vqvae_forward_f32, against the oracle: z_e tolerance, indices exact except provable near-ties, x_hat where no index
+    flipped."""
+    from oracle import torch_port
+    from vqvae_amd import conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    torch.manual_seed(20 + B)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval()
+    x = torch.randn(B, 3, 32, 32)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        r_loss, r_xhat, r_ppl, r_ze, r_zq, r_idx = torch_port.forward(sd, x.clone(), 0.25, 2, full=True)
+    md = m.to(dev())
+    with torch.no_grad():
+        loss, xh, ppl, idx = md._forward_c(x.to(dev()), want_idx=True)
+    flips = (idx.view(B, -1).cpu().numpy() != r_idx.reshape(B, -1).numpy()).any(1)
+    assert flips.mean() <= 0.34
+    np.testing.assert_allclose(xh.cpu().numpy()[~flips], r_xhat.numpy()[~flips], atol=1e-5, rtol=1e-4)
+    if not flips.any():
+        np.testing.assert_allclose(loss.item(), float(r_loss), rtol=1e-4)
