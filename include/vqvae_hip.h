@@ -198,7 +198,8 @@ VQVAE_API int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1
 
 /* First encoder conv, nn.Conv2d(Cin,Cout,k=4,s=2,p=1) (models/encoder.py:29-31), reading the NCHW
  * image x (B,Cin,H,W) and writing row-major (B,H/2,W/2,Cout).  Cin in {1,3,4}, Cout <= 128.
- * flags: VQVAE_CONV_RELU_OUT, VQVAE_CONV_EXACT_FP32 (fp32 MFMA instead of the split-bf16 products). */
+ * flags: VQVAE_CONV_RELU_OUT, VQVAE_CONV_EXACT_FP32 (fp32 MFMA instead of the split-bf16 products).
+ * (The packed image also carries the two-term fp16 operand image of the fused encoder front, see vqvae_encoder_f32.)  */
 VQVAE_API size_t vqvae_conv_in_packed_bytes(int Cin, int Cout);
 VQVAE_API int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed,
                                      vqvae_stream_t stream);
@@ -340,7 +341,11 @@ VQVAE_API int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2,
                                  int C, int Rh, int n_layers, int flags, float *y, float *tmp, vqvae_stream_t stream);
 
 /* Encoder + pre_quantization_conv: x (B,in_ch,H,W) NCHW -> z_e (B,H/4,W/4,D) ROW-MAJOR (the layout vqvae_vq_forward_f32
- * takes with VQVAE_VQ_ROWMAJOR).  workspace: at least the two activation buffers of vqvae_workspace_bytes.          */
+ * takes with VQVAE_VQ_ROWMAJOR).  workspace: at least the two activation buffers of vqvae_workspace_bytes.
+ * On 32x32 RGB images with h_dim 128 and two residual layers (the reference's defaults) the encoder is two launches
+ * (models/encoder.py:29-34, then :35-38 + models/vqvae.py:33) and the decoder two (models/decoder.py:28-30, :31-35): no
+ * intermediate map is written inside a launch; other shapes run layer by layer through the kernels of the per-layer
+ * entry points above.                                                                                                  */
 VQVAE_API int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e,
                                 void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
 /* Decoder: z_q (B,h,w,D) row-major -> x_hat (B,in_ch,4h,4w) NCHW. */
