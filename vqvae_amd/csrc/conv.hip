@@ -2638,7 +2638,7 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 //       layer's B operands by half-wave swaps (acc_to_ksteps), scaled by the phase tile's own maximum;
 //   layer 2 in its GEMM + col2im form: T[co * 16 + tap][pixel] = sum_c w4[c][co][tap] u[pixel][c] (48 rows = two A tiles),
 //       and out[co][4y + 2py - 1 + ky][4x + 2px - 1 + kx] += T: every output element receives exactly ONE term per phase.
-//       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 40 LDS tile (the operand planes
+//       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 42 LDS tile (the operand planes
 //       are free then; the second phase of a pass reads, adds and stores) and leave as whole 128-byte rows: out = bias + tile
 //       in pass 0, out += tile in pass 1 with
 //       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident; plain accesses: the same lanes of the same wave
@@ -2863,7 +2863,9 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
         }
         // ----------------------------- col2im of the pass -----------------------------
         // through a wave-private LDS tile (the operand planes are free until the next pass): per output channel the two phases'
-        // terms land at [Y + 1][X + 4] of a zeroed 34 x 40 tile -- phase (py, 0) stores (every element at most once), phase (py, 1)
+        // terms land at row Y + 1, column slot ((X + 4) & 3) * 10 + ((X + 4) >> 2) of a zeroed 34 x 42 tile (the four
+        // column residues side by side and a row stride of 42: the scatter's lanes, 4 floats apart in x and 4 rows apart
+        // in y, then hit 32 different banks; in plain [Y][X] order they share 8) -- phase (py, 0) stores (every element at most once), phase (py, 1)
         // adds -- and leave as whole 128-byte rows: out = bias + tile in pass 0, out += tile in pass 1
         f32x4 ov[CO][4];                                   // this lane's 16-byte pieces of the image after pass 0
         if (py > 0) {
@@ -2879,7 +2881,7 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
             for (int i = 0; i < 6; ++i)
-                if (lane + 64 * i < 340) reinterpret_cast<f32x4 *>(tile)[lane + 64 * i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                if (lane + 64 * i < 357) reinterpret_cast<f32x4 *>(tile)[lane + 64 * i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
             lds_order_wave();
 #pragma unroll
             for (int px = 0; px < 2; ++px) {
@@ -2890,19 +2892,19 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
                         const int y = spx[mt] >> 3, x = spx[mt] & 7;
-                        const float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+                        const float *tp = tile + (4 * y + 2 * py + h) * 42 + x;
 #pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) old[mt][rr] = tp[((rr >> 2) & 1) * 80 + (rr & 3)];
+                        for (int rr = 0; rr < 8; ++rr) old[mt][rr] = tp[((rr >> 2) & 1) * 84 + ((2 * px + 3 + (rr & 3)) & 3) * 10 + ((2 * px + 3 + (rr & 3)) >> 2)];
                     }
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     const int y = spx[mt] >> 3, x = spx[mt] & 7;
-                    float *tp = tile + (4 * y + 2 * py + h) * 40 + 4 * x + 2 * px + 3;
+                    float *tp = tile + (4 * y + 2 * py + h) * 42 + x;
 #pragma unroll
                     for (int rr = 0; rr < 8; ++rr) {
                         const float v = T[px][co >> 1][mt][8 * (co & 1) + rr] * d4[px];
-                        tp[((rr >> 2) & 1) * 80 + (rr & 3)] = px == 0 ? v : old[mt][rr] + v;
+                        tp[((rr >> 2) & 1) * 84 + ((2 * px + 3 + (rr & 3)) & 3) * 10 + ((2 * px + 3 + (rr & 3)) >> 2)] = px == 0 ? v : old[mt][rr] + v;
                     }
                 }
                 lds_order_wave();
@@ -2911,7 +2913,8 @@ __global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__res
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = (lane >> 3) + 8 * i;
-                f32x4 v = *reinterpret_cast<const f32x4 *>(tile + (row + 1) * 40 + 4 + 4 * (lane & 7));
+                const float *rp = tile + (row + 1) * 42 + (lane & 7) + 1;
+                f32x4 v = {rp[0], rp[10], rp[20], rp[30]};
                 if (py > 0) v = ov[co][i] + v;
                 else v = f32x4{bv, bv, bv, bv} + v;
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0);
