@@ -1931,8 +1931,13 @@ __device__ __forceinline__ void prod3x2t(const u32x4 &s1, const u32x4 &s2, const
 // its registers run over channels, which is the B-operand layout of the next GEMM up to half-wave swaps (acc_to_ksteps) --
 // the 1x1 GEMMs take their inputs straight from registers and the 3x3 slices go registers -> fp16 planes in LDS without
 // the accumulator -> LDS -> transposed read round trip of res_pair8_h2_kernel.
+#ifndef CRP_NW
+#define CRP_NW 4        // waves (= images) per workgroup of conv_res_pair8_h2_kernel.  8 (one workgroup per CU, weights shared by eight
+                        // images, every stage barrier spanning all waves of the CU; tools/build_variant.py nw8 -DCRP_NW=8) is 17 us per
+                        // step SLOWER: 0.589 vs 0.572 ms for the two launches
+#endif
 template <int NT3>
-__global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
+__global__ __launch_bounds__(CRP_NW * 64, 2) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
                                                                    const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
                                                                    float *__restrict__ out, int B, int flags,
                                                                    const int *__restrict__ hdr1, const int *__restrict__ hdr2,
@@ -1944,7 +1949,7 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
     constexpr int RBUF = 4 * HP;                           // residual slice: [term 2][half 2][pixel + zero]; two buffers = TILE4
-    __shared__ u32x4 As_all[4 * TILE4];
+    __shared__ u32x4 As_all[CRP_NW * TILE4];
     // Weights stream through two 18 KiB LDS buffers shared by the workgroup's four images, filled by LDS-DMA (no staging
     // registers) one stage ahead; one workgroup barrier per stage.  Stages: one (tap, chunk) of the front conv (16 pieces
     // of 1 KiB); then per residual layer the nine taps of each 16-channel slice of the 3x3 (18 pieces) x 8 and the 1x1
@@ -1960,12 +1965,12 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     const bool relu_out = flags & kFlagReluOut;            // of the SECOND residual layer (the stack's final ReLU)
     constexpr int cpt = C >> 5;
 
-    const long long img = (long long)blockIdx.x * 4 + wave;
+    const long long img = (long long)blockIdx.x * CRP_NW + wave;
     const bool img_ok = img < B;
     const int kw1 = hdr1[0], kw2 = hdr2[0];
     // a buffer the NEXT kernel of the stream wants zeroed (the quantizer's histogram: saves a fill launch per step)
     if (zero_buf && blockIdx.x == 0)
-        for (int i = tid; i < zero_n; i += 256) zero_buf[i] = 0;
+        for (int i = tid; i < zero_n; i += CRP_NW * 64) zero_buf[i] = 0;
 
     // pixel bookkeeping: the residual 3x3 (taps t/3-1, t%3-1) and the front conv (taps from the geometry masks)
     int spx[MT];
@@ -2001,13 +2006,13 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
     // the nine taps of slice sl of the residual 3x3 -> buffer `buf`: piece p = tap * 2 + term
     auto dma_slice = [&](int sl, int buf) {
         const u32x4 *base = w1img + (size_t)(sl >> 1) * 256 + (sl & 1) * 64 + lane;
-        for (int p = wave_u; p < 18; p += 4)
+        for (int p = wave_u; p < 18; p += CRP_NW)
             dma(base + (size_t)(p >> 1) * cpt * 256 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
     };
     // 16 KiB of an image as it lies (the 1x1 GEMMs): four pieces per wave
     auto dma_linear = [&](const u32x4 *src, int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma(src + (wave_u * 4 + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * 4 + j) * 64);
+        for (int j = 0; j < 16 / CRP_NW; ++j) dma(src + (wave_u * (16 / CRP_NW) + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * (16 / CRP_NW) + j) * 64);
     };
     // stage k after the front conv: 9 LI + slice (3x3 of layer LI), 9 LI + 8 (its 1x1), 18 + j (part j of the post conv)
     auto dma_stage = [&](int k, int buf) {
@@ -2053,8 +2058,8 @@ __global__ __launch_bounds__(256, 2) void conv_res_pair8_h2_kernel(const float *
         auto dma_front = [&](int cc, int tap, int buf) {
             const u32x4 *base = fc.wimg + (size_t)(tap * cpt0 + cc) * (NT2 * 256) + lane;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int p = wave_u * 4 + j;
+            for (int j = 0; j < 16 / CRP_NW; ++j) {
+                const int p = wave_u * (16 / CRP_NW) + j;
                 dma(base + (p >> 2) * 256 + ((p >> 1) & 1) * 64 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
             }
         };
@@ -4092,6 +4097,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
     const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+    const unsigned gtc = (unsigned)((B + CRP_NW - 1) / CRP_NW);
     const unsigned gt = (unsigned)((B + 3) / 4);
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {
@@ -4102,7 +4108,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + kH2Header);
         const int *hd3 = reinterpret_cast<const int *>(h3);
 #define CRP_POST(NT3_)                                                                                                          \
-    hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
+    hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
                        in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n)
         switch (post->Cout / 32) {
             case 1: CRP_POST(1); break;
@@ -4111,7 +4117,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         }
 #undef CRP_POST
     } else {
-        hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gt), dim3(256), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
+        hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
                            in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
