@@ -80,15 +80,16 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
 #define VQVAE_VQ_BF16_FILTER    0x8  /* use round 1's two-sweep bf16 filter kernel where the default would be the
                                         single-sweep fp16 kernel (identical outputs; A/B timing and tests) */
 
-#define VQVAE_VQ_PRODUCER_CONSUMER 0x10 /* use the producer / consumer form of the fp16 kernel (sweeper + I/O wave per SIMD) where the
-                                        default is its single-role form (identical outputs; A/B timing and tests) */
+#define VQVAE_VQ_TOP3_KEYS      0x10 /* use round 2's tracker (the three largest screen values of a lane as index-carrying keys,
+                                        vq_sweep_kernel_d64) where the default is round 3's stream tracker (vq_track_kernel_d64;
+                                        identical outputs; A/B timing and tests) */
 
-#define VQVAE_VQ_SIXTEEN_WAVES 0x20 /* run the resident-image fp16 kernel with 32-row units on sixteen waves per CU (K <= 512, at most two
+#define VQVAE_VQ_SIXTEEN_WAVES 0x20 /* run round 2's kernel (implies VQVAE_VQ_TOP3_KEYS) with 32-row units on sixteen waves per CU (K <= 512, at most two
                                         units per wave) instead of 64-row pairs on eight (identical outputs).  8 us faster on an idle
                                         chip at 262 144 rows, no faster inside the forward, and its 92 spilled registers cost 1.6x the
                                         algorithmic traffic: not the default */
 
-/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_pc_kernel_d64", "vq_sweep_kernel_d64" (codebook image
+/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" / "vq_sweep_kernel_d64" (codebook image
  * resident in LDS: D = 64, K <= ~600), "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
  * "vq_filter_kernel_d64", "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix
  * cores per row (0 for the exact-fp32 kernel).  For reporting (bench.py). */
@@ -353,7 +354,7 @@ VQVAE_API int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t
                                 void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
 /* VQVAE.forward: x -> (embedding_loss, x_hat, perplexity) (models/vqvae.py:44); idx (B*H/4*W/4 int64) is optional.
  * vq_flags: VQVAE_VQ_CODEBOOK_PREPARED (only meaningful with a persistent vq_workspace of vqvae_vq_workspace_bytes),
- * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _PRODUCER_CONSUMER / _SIXTEEN_WAVES.  vq_workspace may be NULL (then the codebook images are
+ * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _TOP3_KEYS / _SIXTEEN_WAVES.  vq_workspace may be NULL (then the codebook images are
  * rebuilt inside `workspace` on every call).                                                                         */
 VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags,
                                 float *x_hat, float *loss, float *perplexity, int64_t *idx, void *workspace,

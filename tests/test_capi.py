@@ -117,7 +117,8 @@ def test_host_side_plans_without_gpu():
     from vqvae_amd import _lib
     L = _lib.load()
     # quantizer dispatch (row-major flag 0x1): resident-image sweep for small codebooks, streamed image beyond, exact on request
-    assert _lib.vq_kernel_name(512, 64) == "vq_sweep_kernel_d64"
+    assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
+    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "vq_sweep_kernel_d64"      # VQVAE_VQ_TOP3_KEYS: round 2's tracker
     assert _lib.vq_kernel_name(1024, 64) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"

@@ -18,14 +18,14 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, producer_consumer=False,
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, top3_keys=False,
          sixteen_waves=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact, bf16_filter=bf16_filter, producer_consumer=producer_consumer,
+                                            exact_sweep=exact, bf16_filter=bf16_filter, top3_keys=top3_keys,
                                             sixteen_waves=sixteen_waves)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
@@ -34,7 +34,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "producer_consumer", "sixteen_waves", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "top3_keys", "sixteen_waves", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -43,7 +43,7 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
     loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter",
-                                    producer_consumer=kernel == "producer_consumer", sixteen_waves=kernel == "sixteen_waves")
+                                    top3_keys=kernel == "top3_keys", sixteen_waves=kernel == "sixteen_waves")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -191,7 +191,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
     z = torch.randn(B, D, H, W, generator=g) * 0.066
     ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
-    for kw in ({}, {"producer_consumer": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
+    for kw in ({}, {"top3_keys": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
         loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
         np.testing.assert_array_equal(idx, ref_idx)
         assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
@@ -203,7 +203,8 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
 
 def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
-    assert _lib.vq_kernel_name(512, 64) == "vq_sweep_kernel_d64"
+    assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
+    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "vq_sweep_kernel_d64"      # VQVAE_VQ_TOP3_KEYS: round 2's tracker
     for K, D in ((640, 64), (1024, 64), (16384, 64), (64, 128), (8192, 128)):
         assert _lib.vq_kernel_name(K, D) == "vq_stream_sweep_kernel", (K, D)
         assert _lib.vq_sweeps(K, D) == 1

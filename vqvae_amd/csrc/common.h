@@ -95,9 +95,10 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
                          float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out);
 
 // vq_sweep.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel (D = 64, row-major rows)
-bool vq_pc_ok(int K, int D);
-int launch_vq_pc_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                     char *ws, hipStream_t st, int *grid_out);
+// vq_track.hip: the same screen with round 3's stream tracker (the default where it fits)
+bool vq_track_ok(int K, int D);
+int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
+                        char *ws, hipStream_t st, int *grid_out);
 void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);
 // vq_chunk.hip: the same screen with the codebook image streamed through LDS (D = 64 / 128, any K <= 16384)
 int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,

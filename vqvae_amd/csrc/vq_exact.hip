@@ -460,8 +460,8 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
         if (rowmajor && vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
-            const int rc = (vq_pc_ok(K, D) && (flags & VQVAE_VQ_PRODUCER_CONSUMER))
-                               ? launch_vq_pc_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid)
+            const int rc = (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)))
+                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid)
                                : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, (flags & VQVAE_VQ_SIXTEEN_WAVES) != 0);
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
@@ -538,7 +538,7 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
     if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return "unsupported";
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_sweep_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER))
-            return (vq_pc_ok(K, D) && (flags & VQVAE_VQ_PRODUCER_CONSUMER)) ? "vq_pc_kernel_d64" : "vq_sweep_kernel_d64";
+            return (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))) ? "vq_track_kernel_d64" : "vq_sweep_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
         if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
     }
@@ -549,7 +549,7 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
 
 int vqvae_vq_screen_sweeps(int K, int D, int flags) {
     const char *n = vqvae_vq_kernel_name(K, D, flags);
-    return (n[3] == 's' || n[3] == 'p') ? 1 : (n[3] == 'f' ? 2 : 0);
+    return (n[3] == 's' || n[3] == 't') ? 1 : (n[3] == 'f' ? 2 : 0);
 }
 
 size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D) {

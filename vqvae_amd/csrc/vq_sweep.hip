@@ -811,680 +811,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Producer / consumer form of the same kernel: one 512-thread workgroup per CU = four DUOS, each a SWEEPER wave and an
-// I/O wave (waves j and j + 4 of the workgroup; the hardware deals a workgroup's waves round-robin over the four SIMDs,
-// so every SIMD hosts one wave of each role).
-//   I/O wave      loads a pair's rows (registers, load layout), writes them as fp16 B-operand tiles into one of the duo's
-//                 two LDS buffers and flags it; later reads the sweeper's verdict for that pair and does everything that
-//                 touches memory: codebook gathers, the exact part, z + (e_k - z), stores, index, histogram, loss.
-//   sweeper wave  waits for a tile pair, sweeps the codebook (MFMA + top-3 keys), merges / classifies and publishes per
-//                 row {index, second candidate, threshold, flags}.
-// The sweep is bound by VALU issue and the I/O by ~2 us memory round trips; in the single-role kernel the two waves of a
-// SIMD do both in turn and mostly in phase (and the exact part's VALU work lands on the partner's sweep: knock-out runs,
-// profiles/r02_vq_knockout.txt).  Here the round trips of pair k+1 / k-1 run under the sweep of pair k.
-// Hand-off: LDS only, release/acquire at workgroup scope, one flag word per buffer and direction carrying the pair's
-// sequence number (never reused); every spin is bounded and raises flags[8] instead of hanging the GPU.
-__device__ __forceinline__ bool vq_spin_until(volatile int *flag, int expect) {
-    for (int i = 0; i < (1 << 20); ++i) {
-        if (__builtin_amdgcn_readfirstlane(*flag) == expect) return true;
-        __builtin_amdgcn_s_sleep(4);
-    }
-    return false;
-}
-
-__global__ __launch_bounds__(512, 2) void vq_pc_kernel_d64(
-    const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
-    const float *__restrict__ seeds_g, const float *__restrict__ ee_g, int *__restrict__ flags,
-    long long N, int K, int K32, long long npairs, float *__restrict__ zq, long long *__restrict__ idx,
-    int *__restrict__ hist, double *__restrict__ partials) {
-    constexpr int D = 64, NW = 8;
-    constexpr int kDuoBytes = 2 * 8192 + 2 * 1024 + 1280 + 64;   // two tile buffers, two verdict tables, task tables, flags
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int ntile = K32 >> 5;
-    uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                                  // [ntile][4][2][32] x 16 B
-    float *seeds = reinterpret_cast<float *>(Eimg + (size_t)ntile * 256);               // [ntile][2][16]
-    int *hist_s = reinterpret_cast<int *>(seeds + (size_t)ntile * 32);                  // [K]
-    double *red = reinterpret_cast<double *>(hist_s + K + (K & 1));                     // [NW]
-    unsigned char *duo_base = reinterpret_cast<unsigned char *>(red + NW);
-
-    const int tid = threadIdx.x;
-    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int duo = wave_u & 3;
-    const bool is_io = wave_u >= 4;
-    unsigned char *duo_s = duo_base + (size_t)duo * kDuoBytes;
-    u32x4 *verdict_s = reinterpret_cast<u32x4 *>(duo_s + 2 * 8192);                     // [2][64] {k1, k2, thr, flags}
-    volatile int *ready_s = reinterpret_cast<volatile int *>(duo_s + 2 * 8192 + 2 * 1024 + 1280);       // [2] tiles of pair seq are in LDS
-    volatile int *done_s = ready_s + 2;                                                  // [2] verdict of pair seq is in LDS
-
-#ifdef VQ_SWEEP_TIMING
-    unsigned *tsum = reinterpret_cast<unsigned *>(red);       // the loss scratch is not used before the loop ends
-    if (tid < 16) tsum[tid] = 0;
-    unsigned long long tprev = wall_clock64();
-#define PC_STAMP(slot)                                                       \
-    do {                                                                     \
-        const unsigned long long tnow = wall_clock64();                      \
-        if ((tid & 63) == 0) atomicAdd(&tsum[slot], (unsigned)(tnow - tprev)); \
-        tprev = tnow;                                                        \
-    } while (0)
-#else
-#define PC_STAMP(slot) do {} while (0)
-#endif
-    const int cb_bad = flags[0];
-    const int a_e = flags[5];
-    const float A = __builtin_ldexpf(1.0f, a_e);
-    const float EEmax = __int_as_float(flags[1]) * 1.0001f;               // max ee_k (unscaled)
-    const float Ehat = __builtin_sqrtf(__int_as_float(flags[3])) * 1.0001f;
-    const float dE = __builtin_sqrtf(__int_as_float(flags[4])) * 1.0001f;
-    const float EmaxS = __builtin_sqrtf(EEmax) * A * 1.0001f;
-    const float EEh = 0.5f * EEmax * A, EEa = EEmax * A;
-
-    // rows past the end read row N-1 again (their results are never stored), so the loads need no branches
-    auto load_pair = [&](long long p, f32x4(&F)[2][8], int g4, int j16) {
-        const long long r0 = p * 64 + g4;
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                long long row = r0 + 32 * t + 4 * i;
-                row = row < N ? row : N - 1;
-                F[t][i] = *reinterpret_cast<const f32x4 *>(z + (size_t)row * D + 4 * j16);
-            }
-    };
-    // the duo's k-th pair: workgroups take quads of pairs round-robin
-    auto pair_of = [&](int k) -> long long { return ((long long)k * gridDim.x + blockIdx.x) * 4 + duo; };
-    int np = 0;
-    while (pair_of(np) < npairs) ++np;
-
-    f32x4 Fcur[2][8], Fprev[2][8];
-    if (is_io && np > 0) load_pair(pair_of(0), Fcur, (tid & 63) >> 4, tid & 15);
-
-    // codebook image and seeds -> LDS (eight 16-byte requests in flight per thread)
-    {
-        const u32x4 *src16 = reinterpret_cast<const u32x4 *>(img_g);
-        u32x4 *dst16 = reinterpret_cast<u32x4 *>(Eimg);
-        const int n16 = ntile * 256;
-        for (int i0 = 0; i0 < n16; i0 += 8 * NW * 64) {
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * NW * 64 + tid;
-                v[j] = src16[i < n16 ? i : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * NW * 64 + tid;
-                if (i < n16) dst16[i] = v[j];
-            }
-        }
-    }
-    for (int i = tid; i < ntile * 32; i += NW * 64) seeds[i] = seeds_g[i];
-    for (int k = tid; k < K; k += NW * 64) hist_s[k] = 0;
-    if (tid < 4) {                                         // flags of every duo start at 0 (sequence numbers start at 1)
-        volatile int *f = reinterpret_cast<volatile int *>(duo_base + (size_t)tid * kDuoBytes + 2 * 8192 + 2 * 1024 + 1280);
-        f[0] = 0; f[1] = 0; f[2] = 0; f[3] = 0;
-    }
-    __syncthreads();
-
-    PC_STAMP(0);                                                // prologue
-    const float inf = __builtin_inff();
-    // low key bits: [ntile - tile : 5 or 6][half (fresh flag during the sweep) : 1][r : 4]
-    const unsigned keymask = ntile <= 31 ? 0xfffffc00u : 0xfffff800u;
-    const unsigned fieldmask = ntile <= 31 ? 31u : 63u;
-    const float trunc_c = ntile <= 31 ? 2.45e-4f : 4.9e-4f;
-    double dacc = 0.0;
-    bool stuck = false;
-
-    if (!is_io) {
-        // =============================================== sweeper ====================================================
-        for (int k = 0; k < np; ++k) {
-            const int bsel = k & 1;
-            const long long r0 = pair_of(k) * 64;
-            int lane_v = tid & 63;
-            asm volatile("" : "+v"(lane_v));
-            const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5;
-            const uint4 *ap0 = Eimg + h * 32 + l31;
-            const float *sp0 = seeds + h * 16;
-            const unsigned char *tile_s = duo_s + bsel * 8192;
-            if (!vq_spin_until(ready_s + bsel, k + 1)) { stuck = true; break; }
-            lds_acquire_workgroup();
-            PC_STAMP(1);                                        // sweeper: waiting for tiles
-            f16x8 zb[2][4];
-            float zn2[2], dz2[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float s = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4));
-                    zb[t][q] = __builtin_bit_cast(f16x8, v);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), s, false);
-                }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-                zn2[t] = s + __uint_as_float(h ? sw[0] : sw[1]);
-                dz2[t] = reinterpret_cast<const float *>(verdict_s + bsel * 64)[32 * t + l31];
-            }
-            float m1[2], m2[2], m3[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) { m1[t] = -inf; m2[t] = -inf; m3[t] = -inf; }
-            // max(m1, key) is written med3(m1, key, +inf) with an OPAQUE +inf: given the literal, hipcc turns it into v_max
-            // plus a canonicalising v_max of the integer-built key -- a fifth VALU op per element in a VALU-bound loop
-            float pinf = inf;
-            asm volatile("" : "+v"(pinf));
-            // Operands of tile ct+1 are requested right behind the MFMAs of tile ct and land under its ~130 VALU ops; two
-            // operand sets ping-pong through a loop unrolled by two, so nothing is copied.
-            auto fetch = [&](int ct, u32x4(&a)[4], f32x16 &seed) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
-                    seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
-                }
-            };
-            // Fresh keys (low field 16 | r) get their tile at the end of the tile: m += (m & 16) (2 f - 1) turns the field into
-            // (f << 5) | r with f = ntile - tile.  Storing ntile - tile (not tile) keeps the order of two keys with EQUAL upper
-            // bits the same before and after the fix-up -- a fresh key's field (16..31) is below every older key's (>= 32),
-            // and so is (ntile - tile) << 5 against any earlier tile's -- so med3 / max always see a consistently ordered
-            // triple.  (Adding the tile number itself reorders near-tied NEGATIVE scores of one lane, after which med3
-            // duplicates one key and drops the other.)
-            auto cell = [&](int ct, const u32x4(&a)[4], const f32x16 &seed, u32x4(&an)[4], f32x16 &seedn) {
-                f32x16 acc[2];
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[t][0], seed, 0, 0, 0);
-#pragma unroll
-                    for (int q = 1; q < 4; ++q)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[t][q], acc[t], 0, 0, 0);
-                }
-                fetch(ct + 1 < ntile ? ct + 1 : ct, an, seedn);
-                const unsigned fix = (unsigned)(2 * (ntile - ct) - 1);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float key = __uint_as_float((__float_as_uint(acc[t][r]) & keymask) | (unsigned)(r | 16));
-#if defined(VQ_KNOB) && VQ_KNOB == 2          // knock-out builds (timing only, wrong results): 1 = no m3, 2 = one op per element
-                        m1[t] = __builtin_amdgcn_fmed3f(m1[t], acc[t][r], pinf);
-                        continue;
-#endif
-#if !defined(VQ_KNOB) || VQ_KNOB != 1
-                        m3[t] = __builtin_amdgcn_fmed3f(m2[t], m3[t], key);
-#endif
-                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], key);
-                        m1[t] = __builtin_amdgcn_fmed3f(m1[t], key, pinf);
-                    }
-                    unsigned b1 = __float_as_uint(m1[t]), b2 = __float_as_uint(m2[t]), b3 = __float_as_uint(m3[t]);
-                    b1 += __umul24(b1 & 16u, fix);
-                    b2 += __umul24(b2 & 16u, fix);
-                    b3 += __umul24(b3 & 16u, fix);
-                    m1[t] = __uint_as_float(b1);
-                    m2[t] = __uint_as_float(b2);
-                    m3[t] = __uint_as_float(b3);
-                }
-                // the prefetched operands are first "used" here: their loads cannot sink below, their wait cannot rise above
-                asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]));
-            };
-            {
-                u32x4 aA[4], aB[4];
-                f32x16 sA, sB;
-                fetch(0, aA, sA);
-                int ct = 0;
-                for (; ct + 1 < ntile; ct += 2) {
-                    cell(ct, aA, sA, aB, sB);
-                    cell(ct + 1, aB, sB, aA, sA);
-                }
-                if (ct < ntile) cell(ct, aA, sA, aB, sB);
-            }
-
-
-            int kbest[2];
-            bool valid[2], bad[2], pairf[2], hardf[2];
-            int c2[2];
-            float thr[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const long long row = r0 + 32 * t + l31;
-                valid[t] = row < N;
-                const float a1 = __uint_as_float(__float_as_uint(m1[t]) | ((unsigned)h << 4));
-                const float a2 = __uint_as_float(__float_as_uint(m2[t]) | ((unsigned)h << 4));
-                const float a3 = __uint_as_float(__float_as_uint(m3[t]) | ((unsigned)h << 4));
-                const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a1), __float_as_uint(a1), false, false);
-                const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a2), __float_as_uint(a2), false, false);
-                const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(a3), __float_as_uint(a3), false, false);
-                const float b1 = __uint_as_float(h ? s1[0] : s1[1]), b2 = __uint_as_float(h ? s2[0] : s2[1]);
-                const float b3 = __uint_as_float(h ? s3[0] : s3[1]);
-                // top three of two sorted triples
-                const float v1 = fmaxf(a1, b1);
-                const float v2 = fmaxf(fminf(a1, b1), fmaxf(a2, b2));
-                const float v3 = fmaxf(fmaxf(a3, b3), fmaxf(fminf(a2, b1), fminf(a1, b2)));
-                const unsigned k1 = __float_as_uint(v1), k2 = __float_as_uint(v2);
-                kbest[t] = (ntile - (int)((k1 >> 5) & fieldmask)) * 32 + (int)((k1 & 3u) + 8u * ((k1 >> 2) & 3u) + 4u * ((k1 >> 4) & 1u));
-                c2[t] = (ntile - (int)((k2 >> 5) & fieldmask)) * 32 + (int)((k2 & 3u) + 8u * ((k2 >> 2) & 3u) + 4u * ((k2 >> 4) & 1u));
-                // DELTA in accumulator units, every factor rounded up
-                const float zs = zn2[t] * 1.0001f;                                         // |z^|^2
-                const float errz = __builtin_sqrtf(dz2[t] * 1.0001f) * 1.0001f;            // |z - z^|, measured at conversion
-                const float zn = __builtin_sqrtf(zs) * 1.0001f + errz;                     // |z| <= |z^| + |z - z^|
-                const float eps = errz * Ehat + (zn + errz) * dE + 7.76e-6f * (zn * Ehat + EEh);
-                const float xi = 3.86e-6f * zn * EmaxS + 1.2e-7f * (A * zn * zn + EEa);         // g = 64 * 2^-24 * 1.01; 2^-23
-                const float trunc = trunc_c * (zn * Ehat + EEh);                           // 2 * 2^-13 (2^-12 with the 11-bit field)
-                const float delta = (2.0f * eps + 2.0f * xi + trunc) * 1.001f;
-                bad[t] = valid[t] && (cb_bad || !(zs < 1.0e30f) || !(dz2[t] < 1.0e30f) || !(v1 > -1.0e37f) || !(delta < 1.0e37f));
-                const bool amb2 = !(v1 - v2 >= delta), amb3 = !(v1 - v3 >= delta);
-                thr[t] = v1 - delta;
-                pairf[t] = valid[t] && !bad[t] && amb2 && !amb3 && kbest[t] >= 0 && kbest[t] < K && c2[t] >= 0 && c2[t] < K;
-                hardf[t] = valid[t] && !bad[t] && amb2 && !pairf[t];
-#ifdef VQ_SWEEP_DEBUG   // debug build (tools/build_variant.py dbg -DVQ_SWEEP_DEBUG): the screen's view of every row INSTEAD of z_q
-                if (valid[t] && h == 0 && zq) {
-                    float *dbg = zq + (size_t)(r0 + 32 * t + l31) * D;
-                    dbg[0] = v1; dbg[1] = v2; dbg[2] = v3; dbg[3] = (float)kbest[t]; dbg[4] = (float)c2[t]; dbg[5] = delta;
-                    dbg[6] = (float)((int)pairf[t] | ((int)hardf[t] << 1) | ((int)bad[t] << 2)); dbg[7] = zn;
-                }
-#endif
-                if (kbest[t] < 0 || kbest[t] >= K) kbest[t] = 0;                              // only reachable on bad / hard rows
-                if (c2[t] < 0 || c2[t] >= K) c2[t] = 0;
-            }
-
-
-            // publish: lane L speaks for row L of the pair
-            {
-                u32x4 v;
-                v.x = (unsigned)(h ? kbest[1] : kbest[0]);
-                v.y = (unsigned)(h ? c2[1] : c2[0]);
-                v.z = __float_as_uint(h ? thr[1] : thr[0]);
-                v.w = (unsigned)((h ? pairf[1] : pairf[0]) ? 1 : 0) | ((unsigned)((h ? hardf[1] : hardf[0]) ? 1 : 0) << 1) |
-                      ((unsigned)((h ? bad[1] : bad[0]) ? 1 : 0) << 2);
-                verdict_s[bsel * 64 + lane] = v;
-            }
-            lds_release_workgroup();
-            if (lane == 0) done_s[bsel] = k + 1;
-            PC_STAMP(2);                                        // sweeper: sweep + merge + publish
-        }
-    } else {
-        // ================================================ I/O wave ==================================================
-        // finish(k): everything after the sweep for the duo's k-th pair, on the rows still held in F
-        auto finish = [&](int k, f32x4(&F)[2][8]) {
-            const int bsel = k & 1;
-            const long long p = pair_of(k);
-            const long long r0 = p * 64;
-            int lane_v = tid & 63;
-            asm volatile("" : "+v"(lane_v));
-            const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5, j16 = lane_v & 15, g4 = lane_v >> 4;
-            const uint4 *ap0 = Eimg + h * 32 + l31;
-            const float *sp0 = seeds + h * 16;
-            unsigned char *tile_s = duo_s + bsel * 8192;
-            unsigned char *task_base = duo_s + 2 * 8192 + 2 * 1024;
-            PC_STAMP(3);                                        // I/O: convert + publish (and whatever preceded finish)
-            if (!vq_spin_until(done_s + bsel, k + 1)) { stuck = true; return; }
-            lds_acquire_workgroup();
-            PC_STAMP(4);                                        // I/O: waiting for the verdict
-            int kbest[2], c2[2];
-            bool valid[2], bad[2], pairf[2], hardf[2];
-            float thr[2];
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const u32x4 v = verdict_s[bsel * 64 + 32 * t + l31];
-                kbest[t] = (int)v.x; c2[t] = (int)v.y; thr[t] = __uint_as_float(v.z);
-                pairf[t] = v.w & 1u; hardf[t] = v.w & 2u; bad[t] = v.w & 4u;
-                valid[t] = r0 + 32 * t + l31 < N;
-            }
-            // Codebook rows for the epilogue are requested NOW with the screen's index (final for every row the screen
-            // decided, ~95 %), together with the exact part's own gathers: one memory round trip per iteration instead of
-            // three in series (each costs ~2 us under load).  Two-candidate rows are finished by their task group below.
-            f32x4 ev[2][8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {                    // tile 0 now, tile 1 behind the exact part (register budget)
-                const int kr = __shfl(kbest[0], 4 * i + g4);
-                ev[0][i] = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
-            }
-            unsigned long long done_mask = 0ull, late_mask = 0ull;   // rows finished by a task group / rows that need a late gather
-            PC_STAMP(9);                                        //   verdict read + tile-0 gathers issued
-
-            // ================= exact part (rows the screen left open) =========================================================
-            // An open row becomes a TASK (row, code a, code b); four tasks run per pass, one per 16-lane group, on the row's
-            // fp32 data (copied from its owner lanes into the wave's LDS tile): ||z||^2 in ATen's summation order and the two
-            // c-ordered fmaf chains, all with DPP row operations, then d = fl(fl(zz + ee_k) - 2 m).  Each row finally takes
-            // the lexicographic (d, k) minimum over its tasks = torch.argmin's first-index rule.
-            //   two-candidate rows: one task (row, c1, c2)
-            //   rows with three or more candidates: the tile's screen is run again with the row's now-known threshold
-            //       v1 - DELTA and every code at or above it becomes a task (same accumulators as in the sweep)
-            //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
-            {
-                // lane L of the wave speaks for row L of the pair (tile L >> 5, row L & 31)
-                const bool o_pair = h ? pairf[1] : pairf[0], o_hard = h ? hardf[1] : hardf[0];
-                bool o_bad = h ? bad[1] : bad[0];
-                const int o_k1 = h ? kbest[1] : kbest[0], o_k2 = h ? c2[1] : c2[0];
-#if defined(VQ_KNOB) && VQ_KNOB == 3          // knock-out: no exact part
-                const unsigned long long fm = 0ull;
-#else
-                const unsigned long long fm = __builtin_amdgcn_ballot_w64(o_pair || o_hard || o_bad);
-#endif
-                if (fm) {
-                    unsigned char *zrow_s = tile_s;                                          // [16 row slots][64] fp32 (over the fp16 rows, after the rescan)
-                    unsigned *task_s = reinterpret_cast<unsigned *>(task_base);          // [64] row | a << 6 | b << 19
-                    float *res_s = reinterpret_cast<float *>(task_base + 256);           // [64][2] distances
-                    float *zz_s = reinterpret_cast<float *>(task_base + 768);            // [64] ||z||^2 per row of the pair
-                    int *cnt_s = reinterpret_cast<int *>(task_base + 1024);              // counter of the rescan's tasks
-                    const unsigned long long lowmask = (1ull << lane) - 1ull;
-                    const unsigned long long tm = __builtin_amdgcn_ballot_w64(o_pair || o_bad);
-                    const int ndirect = __builtin_popcountll(tm);
-                    __builtin_amdgcn_wave_barrier();
-                    if (o_pair || o_bad)
-                        task_s[__builtin_popcountll(tm & lowmask)] = (unsigned)lane | ((unsigned)(o_bad ? 0 : o_k1) << 6) | ((unsigned)(o_bad ? 0 : o_k2) << 19);
-                    int ntasks = ndirect;
-                    PC_STAMP(10);                                   //   task list of the direct rows
-                    const unsigned long long hmask = __builtin_amdgcn_ballot_w64(o_hard);
-                    if (hmask) {
-                        // rows with >= 3 candidates: the tile's screen again, hits (acc >= v1 - DELTA) become tasks
-                        if (lane == 0) cnt_s[0] = 0;
-                        lds_order_wave();
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            if ((unsigned)(hmask >> (32 * t))) {
-                                // B operands once per tile; the next code tile's A / seed operands are requested behind this tile's MFMAs
-                                f16x8 zbr[4];
-#pragma unroll
-                                for (int q = 0; q < 4; ++q)
-                                    zbr[q] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4)));
-                                u32x4 ra[4];
-                                f32x16 rs;
-                                auto rfetch = [&](int ct) {
-#pragma unroll
-                                    for (int q = 0; q < 4; ++q) ra[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
-#pragma unroll
-                                    for (int g = 0; g < 4; ++g) {
-                                        const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
-                                        rs[4 * g] = e4.x; rs[4 * g + 1] = e4.y; rs[4 * g + 2] = e4.z; rs[4 * g + 3] = e4.w;
-                                    }
-                                };
-                                rfetch(0);
-                                const float thr_t = hardf[t] ? thr[t] : inf;             // only the open rows can hit
-                                for (int ct = 0; ct < ntile; ++ct) {
-                                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[0]), zbr[0], rs, 0, 0, 0);
-#pragma unroll
-                                    for (int q = 1; q < 4; ++q)
-                                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[q]), zbr[q], acc, 0, 0, 0);
-                                    rfetch(ct + 1 < ntile ? ct + 1 : ct);
-                                    const float x0 = fmaxf(fmaxf(acc[0], acc[1]), acc[2]), x1 = fmaxf(fmaxf(acc[3], acc[4]), acc[5]);
-                                    const float x2 = fmaxf(fmaxf(acc[6], acc[7]), acc[8]), x3 = fmaxf(fmaxf(acc[9], acc[10]), acc[11]);
-                                    const float x4 = fmaxf(fmaxf(acc[12], acc[13]), acc[14]);
-                                    const float mx = fmaxf(fmaxf(fmaxf(x0, x1), x2), fmaxf(fmaxf(x3, x4), acc[15]));
-                                    if (__builtin_amdgcn_ballot_w64(mx >= thr_t)) {
-#pragma unroll
-                                        for (int r = 0; r < 16; ++r) {
-                                            const int code = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                                            if (acc[r] >= thr_t && code < K) {
-                                                const int sl = ndirect + atomicAdd(&cnt_s[0], 1);
-                                                if (sl < 64) task_s[sl] = (unsigned)(32 * t + l31) | ((unsigned)code << 6) | ((unsigned)code << 19);
-                                            }
-                                        }
-                                    }
-                                    asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]));
-                                }
-                            }
-                        }
-                        lds_order_wave();
-                        ntasks = ndirect + cnt_s[0];
-                    }
-                    if (ntasks > 64) {                      // pathological tie counts: every open row takes the scalar path;
-                        o_bad = o_bad || o_pair || o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
-                        __builtin_amdgcn_wave_barrier();
-                        if (o_bad) task_s[__builtin_popcountll(fm & lowmask)] = (unsigned)lane;
-                        ntasks = __builtin_popcountll(fm);
-                    }
-                    const unsigned long long pm = __builtin_amdgcn_ballot_w64(o_pair && !o_bad);   // rows their task group finishes
-                    done_mask = pm;
-                    late_mask = fm & ~pm;
-                    const int nrows = __builtin_popcountll(fm);
-                    PC_STAMP(11);                                   //   rescan of tiles with >= 3-candidate rows
-                    for (int rd = 0; rd * 16 < nrows; ++rd) {
-                        // copy this round's rows (ranks 16 rd .. 16 rd + 15 among the flagged rows) into the row slots
-                        __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-#pragma unroll
-                            for (int i = 0; i < 8; ++i) {
-                                if ((fm >> (32 * t + 4 * i)) & 0xfull) {
-                                    const int rr = 32 * t + 4 * i + g4;
-                                    const int rank = __builtin_popcountll(fm & ((1ull << rr) - 1ull));
-                                    if (((fm >> rr) & 1ull) && (rank >> 4) == rd)
-                                        *reinterpret_cast<f32x4 *>(zrow_s + (rank & 15) * 256 + 16 * j16) = F[t][i];
-                                }
-                            }
-                        lds_order_wave();
-                        PC_STAMP(12);                               //   row copy
-                        for (int base = 0; base < ntasks; base += 4) {
-                            const int jj = base + g4;
-                            const unsigned task = task_s[jj < ntasks ? jj : 0];
-                            const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
-                            const f32x4 ea = *reinterpret_cast<const f32x4 *>(cb + (size_t)ka * D + 4 * j16);
-                            const f32x4 eb = *reinterpret_cast<const f32x4 *>(cb + (size_t)kb2 * D + 4 * j16);
-                            const float eea = ee_g[ka], eeb = ee_g[kb2];
-                            const int rank = __builtin_popcountll(fm & ((1ull << rr) - 1ull));
-                            const bool mine = jj < ntasks && (rank >> 4) == rd;
-                            const f32x4 zv = *reinterpret_cast<const f32x4 *>(zrow_s + (rank & 15) * 256 + 16 * j16);
-                            // ||z||^2 in ATen's order (lane j16 holds elements 4 j16 .. +3): P = v_q + v_{q+4} (lane j + lane j+8),
-                            // A = ((P0 + P1) + P2) + P3 (lanes b, b+2, b+4, b+6), then A0..A7 in order (lane 0, then lane 1)
-                            float Aq[4];
-                            const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
-                                const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
-                                const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
-                                const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
-                                Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
-                            }
-                            const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
-                            const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
-                            const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
-                            // c-ordered fmaf chains: lane j continues lane j-1's partial sum (row_shr:1, 0 enters lane 0)
-                            float ma = 0.0f, mb = 0.0f;
-#pragma unroll
-                            for (int sidx = 0; sidx < 16; ++sidx) {
-                                const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
-                                const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
-                                ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
-                                mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
-                            }
-                            const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
-                            const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
-                            const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
-                            if (j16 == 1 && mine) {
-                                res_s[2 * jj] = da;
-                                res_s[2 * jj + 1] = db;
-                                zz_s[rr] = zz;
-                            }
-                            // a two-candidate row has this one task: its group holds the row and both code rows, so it
-                            // writes the row's z_q and squared error right here (the epilogue skips the row)
-                            const bool finish = mine && jj < ndirect && ((pm >> rr) & 1ull);
-                            if (__builtin_amdgcn_ballot_w64(finish)) {
-                                const bool take_b = __shfl((int)(db < da || (db == da && kb2 < ka)), 1, 16) != 0;
-                                const f32x4 ew = take_b ? eb : ea;
-                                const float d0 = ew.x - zv.x, d1 = ew.y - zv.y, d2 = ew.z - zv.z, d3 = ew.w - zv.w;
-                                f32x4 o;
-                                o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
-                                if (finish) {
-                                    dacc += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
-#ifndef VQ_SWEEP_DEBUG
-                                    if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)(r0 + rr) * D + 4 * j16) = o;
-#endif
-                                }
-                            }
-                        }
-                    }
-                    lds_order_wave();
-                    PC_STAMP(13);                                   //   task passes
-                    int o_best = o_k1;
-                    if ((o_pair || o_hard) && !o_bad) {
-                        float bd = inf;
-                        int bk = 0x7fffffff;
-                        for (int jj = 0; jj < ntasks; ++jj) {
-                            const unsigned task = task_s[jj];
-                            if ((int)(task & 63u) == lane) {
-                                const float da = res_s[2 * jj], db = res_s[2 * jj + 1];
-                                const int ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
-                                if (da < bd || (da == bd && ka < bk)) { bd = da; bk = ka; }
-                                if (db < bd || (db == bd && kb2 < bk)) { bd = db; bk = kb2; }
-                            }
-                        }
-                        if (bk != 0x7fffffff) o_best = bk; else o_bad = true;            // no task came back (cannot happen): scalar path
-                    }
-                    if (o_bad) {
-                        // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
-                        const long long grow = r0 + lane;
-                        const float *zr = z + (size_t)(grow < N ? grow : N - 1) * D;
-                        const float zz = zz_s[lane];                                      // every open row had a task
-                        int best = 0;
-                        if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
-                            float bd = 0.0f;
-                            for (int k = 0; k < K; ++k) {
-                                float m = 0.0f;
-                                for (int c = 0; c < D; ++c) m = __builtin_fmaf(zr[c], cb[(size_t)k * D + c], m);
-                                const float d = (zz + ee_g[k]) - 2.0f * m;
-                                const bool dn = d != d, bn = bd != bd;
-                                if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
-                            }
-                        }
-                        o_best = best;
-                    }
-                    const int k0n = __shfl(o_best, l31), k1n = __shfl(o_best, 32 + l31);
-                    if (pairf[0] || hardf[0] || bad[0]) kbest[0] = k0n;
-                    if (pairf[1] || hardf[1] || bad[1]) kbest[1] = k1n;
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-
-
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kr = __shfl(kbest[1], 4 * i + g4);
-                ev[1][i] = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
-            }
-            PC_STAMP(5);                                        // I/O: gathers + exact part
-            // ================= epilogue: z + (e_k - z), squared error, index, histogram ======================================
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-#ifdef VQ_SWEEP_DEBUG
-                float *obase = nullptr;
-#else
-                float *obase = zq ? zq + (size_t)p * 64 * D : nullptr;
-#endif
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int rr = 32 * t + 4 * i + g4;
-                    f32x4 e = ev[t][i];
-                    if ((late_mask >> (32 * t + 4 * i)) & 0xfull) {      // rows decided by several tasks / the scalar path (rare)
-                        const int kr = __shfl(kbest[t], 4 * i + g4);
-                        if ((late_mask >> rr) & 1ull) e = *reinterpret_cast<const f32x4 *>(cb + (size_t)kr * D + 4 * j16);
-                    }
-                    const f32x4 zv = F[t][i];
-                    f32x4 o;
-                    const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
-                    o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
-                    const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-                    if (r0 + rr < N && !((done_mask >> rr) & 1ull)) {
-                        dacc += (double)sq;
-                        if (obase) *reinterpret_cast<f32x4 *>(obase + (size_t)((t * 8 + i) * 64 + lane) * 4) = o;
-                    }
-                }
-                if (valid[t] && h == 0) {
-                    idx[r0 + 32 * t + l31] = kbest[t];
-                    atomicAdd(&hist_s[kbest[t]], 1);
-                }
-            }
-
-            PC_STAMP(6);                                        // I/O: epilogue
-        };
-        for (int k = 0; k <= np && !stuck; ++k) {
-            PC_STAMP(7);                                        // I/O: rows landing (load wait) + loop overhead
-            const int bsel = k & 1;
-            // ---- rows of pair k -> fp16 B-operand tiles of buffer k & 1 (free: pair k-2 was finished last iteration) ----
-            if (k < np) {
-                int lane_v = tid & 63;
-                asm volatile("" : "+v"(lane_v));
-                const int j16 = lane_v & 15, g4 = lane_v >> 4;
-                unsigned char *tile_s = duo_s + bsel * 8192;
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int row = 4 * i + g4;
-                        const f16x2 lo = {(_Float16)Fcur[t][i].x, (_Float16)Fcur[t][i].y};
-                        const f16x2 hi = {(_Float16)Fcur[t][i].z, (_Float16)Fcur[t][i].w};
-                        u32x2 w;
-                        w.x = __builtin_bit_cast(unsigned, lo);
-                        w.y = __builtin_bit_cast(unsigned, hi);
-                        *reinterpret_cast<u32x2 *>(tile_s + t * 4096 + row * 128 + ((((j16 >> 1) ^ (row >> 1)) & 7) << 4) + ((j16 & 1) << 3)) = w;
-                        // |z - z^|^2 of the row: exact differences, summed over the row's 16 lanes with row rotations
-                        const float e0 = Fcur[t][i].x - (float)lo[0], e1 = Fcur[t][i].y - (float)lo[1];
-                        const float e2 = Fcur[t][i].z - (float)hi[0], e3 = Fcur[t][i].w - (float)hi[1];
-                        float dd = __builtin_fmaf(e3, e3, __builtin_fmaf(e2, e2, __builtin_fmaf(e1, e1, e0 * e0)));
-                        dd += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dd), 0x128, 0xf, 0xf, true));
-                        dd += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dd), 0x124, 0xf, 0xf, true));
-                        dd += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dd), 0x122, 0xf, 0xf, true));
-                        dd += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(dd), 0x121, 0xf, 0xf, true));
-                        // parked in the (not yet written) verdict table of this buffer
-                        if (j16 == 0) reinterpret_cast<float *>(verdict_s + bsel * 64)[32 * t + row] = dd;
-                    }
-                lds_release_workgroup();
-                if (lane_v == 0) ready_s[bsel] = k + 1;
-            }
-            if (k > 0) finish(k - 1, Fprev);
-            if (k < np) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) Fprev[t][i] = Fcur[t][i];
-                if (k + 1 < np) {
-                    int lane_v = tid & 63;
-                    asm volatile("" : "+v"(lane_v));
-                    load_pair(pair_of(k + 1), Fcur, lane_v >> 4, lane_v & 15);
-                }
-            }
-        }
-    }
-    if (stuck && (tid & 63) == 0) atomicOr(flags + 8, 1);
-#ifdef VQ_SWEEP_TIMING
-    PC_STAMP(8);
-    __syncthreads();
-    if (tid < 16 && blockIdx.x < 32) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 16 + tid] = tsum[tid];
-    __syncthreads();
-#endif
-
-    const int lane = tid & 63;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
-    __syncthreads();
-    if (lane == 0) red[wave_u] = dacc;
-    __syncthreads();
-    if (tid == 0) {
-        double s = 0.0;
-        for (int w = 0; w < NW; ++w) s += red[w];
-        partials[blockIdx.x] = s;
-    }
-    for (int k = tid; k < K; k += NW * 64) {
-        const int c = hist_s[k];
-        if (c) atomicAdd(&hist[k], c);
-    }
-}
-
 size_t vq_sweep_lds_bytes(int K, int nw) {          // nw = 16: one 32-row tile per unit and wave, nw = 8: two
     const int K32 = (K + 31) / 32 * 32;
     return (size_t)K32 * 128 + (size_t)K32 * 4 + 2 * (size_t)(K + (K & 1)) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nw > 8 ? 4096 : 8192) + 1552);
 }
 
-size_t vq_pc_lds_bytes(int K) {
-    const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)(K + (K & 1)) * 4 + 8 * 8 + 4 * (size_t)(2 * 8192 + 2 * 1024 + 1280 + 64);
-}
-
-bool vq_pc_ok(int K, int D) { return D == 64 && K <= 1024 && vq_pc_lds_bytes(K) <= (size_t)kLdsBytes; }
 
 bool vq_sweep_ok(int K, int D) {
     return D == 64 && K <= 1024 && vq_sweep_lds_bytes(K, 8) <= (size_t)kLdsBytes;
@@ -1528,22 +859,5 @@ int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, flo
     return (int)hipGetLastError();
 }
 
-int launch_vq_pc_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                     char *ws, hipStream_t st, int *grid_out) {
-    const VqPlan p = vq_plan(K, 64);
-    const long long npairs = (N + 63) / 64;
-    const int cus = num_cus();
-    long long grid = (npairs + 3) / 4;
-    if (grid > cus) grid = cus;
-    if (grid > kVqMaxGrid) grid = kVqMaxGrid;
-    *grid_out = (int)grid;
-    auto kfn = vq_pc_kernel_d64;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), vq_pc_lds_bytes(K), st, z, cb,
-                       reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
-                       reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<int *>(ws + p.off_flags), N, K,
-                       p.K32, npairs, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials));
-    return (int)hipGetLastError();
-}
 
 }  // namespace vqvae

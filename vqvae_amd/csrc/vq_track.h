@@ -1,0 +1,175 @@
+// Per-lane logic of the stream tracker of vq_track.hip (round 3), written so that the SAME source compiles for gfx950
+// (hipcc, device) and for the host (g++: tests/test_vq_track_host.py builds a harness that emulates a wave lane by lane
+// and checks the tracker's verdicts against a brute-force scan of the same accumulator matrix).
+//
+// What is tracked.  The screen of models/quantizer.py:49-54 is acc[k] = z^ . e^_k - A ||e_k||^2 / 2 for the K codes of a
+// row; an accumulator lane (row n, half h) sees 16 of every 32-code tile's values, acc[r] <-> code 32 T + (r & 3) +
+// 8 (r >> 2) + 4 h.  Round 2 kept the three largest values of a lane as index-carrying keys (5 vector instructions per
+// value).  Here a lane keeps maxima over TWO partitions of its values instead:
+//     streams   S[a]      = max over all tiles of max(acc[a], acc[a + 8]),  a = 0..7          (position in the tile)
+//     cells     (T, s)    = max of acc[8 s .. 8 s + 7] of tile T,  as the top three KEYS       (which tile, which half-tile)
+// Every value of the lane lies in exactly one stream and one cell, and a (stream, cell) pair holds exactly ONE value.
+// Hence, for a threshold thr = v1 - DELTA below the row's largest value v1:
+//   * every code with acc >= thr lies in a stream whose maximum is >= thr AND in a cell whose maximum is >= thr;
+//   * if exactly one stream and exactly one cell of the row (both halves together) reach thr, exactly one code does, and
+//     its index is (stream, cell) -- no index bits were carried through the sweep;
+//   * otherwise the candidates are the (stream, cell) products of each half: a superset of the codes at or above thr,
+//     each evaluated EXACTLY afterwards (phantom products merely lose).
+// Cost in the sweep: 8 v_max3 for the streams + 8 v_max3 for the two cell maxima + 2 x (and_or, med3, med3, med3) for the
+// keys = 24 vector instructions per 16 values (1.5 per value instead of 5), and DELTA loses the 10-bit truncation term
+// (only the cell keys are truncated, by 6 bits, and only the test of a key against the threshold pays for it).
+#pragma once
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define VQT_FN __device__ __forceinline__
+#else
+#include <cmath>
+#include <cstring>
+#define VQT_FN inline
+#endif
+
+namespace vqvae {
+namespace trk {
+
+VQT_FN unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
+VQT_FN float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// three-operand forms only: hipcc lowers a two-operand fmaxf to v_max_f32 plus a canonicalising v_max_f32 x, x per input
+VQT_FN float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+VQT_FN float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
+VQT_FN unsigned shl1_in(unsigned bits, float d) { return __builtin_amdgcn_alignbit(bits, f2u(d), 31); }
+VQT_FN int popc(unsigned x) { return __builtin_popcount(x); }
+VQT_FN int clz(unsigned x) { return __builtin_clz(x); }
+#else
+VQT_FN float max3(float a, float b, float c) { return std::fmax(std::fmax(a, b), c); }
+VQT_FN float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
+VQT_FN unsigned shl1_in(unsigned bits, float d) { return (bits << 1) | (f2u(d) >> 31); }
+VQT_FN int popc(unsigned x) { return __builtin_popcount(x); }
+VQT_FN int clz(unsigned x) { return __builtin_clz(x); }
+#endif
+
+constexpr unsigned kCellBits = 6;                 // cell id = 2 * tile + s < 64  (K <= 1024)
+constexpr unsigned kCellMask = (1u << kCellBits) - 1u;
+constexpr unsigned kKeyMask = ~kCellMask;
+
+struct Lane {                                     // tracker state of one accumulator lane and one 32-row tile
+    float S[8];
+    float m1, m2, m3;
+};
+
+VQT_FN void init(Lane &L, float ninf) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) L.S[a] = ninf;
+    L.m1 = ninf; L.m2 = ninf; L.m3 = ninf;
+}
+
+// One 32-code tile.  acc: the lane's 16 accumulator values (anything indexable); cell0 = 2 * tile, cell1 = cell0 + 1 (wave-uniform);
+// ninf / pinf: -inf / +inf in registers the compiler cannot see through (so max(x, y) stays ONE v_max3 / v_med3);
+// keymask: kKeyMask, likewise in a register (gfx950's v_and_or_b32 takes no literal: given the constant, hipcc emits v_and + v_or).
+template <class ACC>
+VQT_FN void tile(Lane &L, const ACC &acc, unsigned cell0, unsigned cell1, unsigned keymask, float ninf, float pinf) {
+#pragma unroll
+    for (int a = 0; a < 8; ++a) L.S[a] = max3(L.S[a], acc[a], acc[a + 8]);
+    const float x0 = max3(max3(max3(acc[0], acc[1], acc[2]), max3(acc[3], acc[4], acc[5]), acc[6]), acc[7], ninf);
+    const float x1 = max3(max3(max3(acc[8], acc[9], acc[10]), max3(acc[11], acc[12], acc[13]), acc[14]), acc[15], ninf);
+    const float k0 = u2f((f2u(x0) & keymask) | cell0);
+    const float k1 = u2f((f2u(x1) & keymask) | cell1);
+    L.m3 = med3(L.m2, L.m3, k0);
+    L.m2 = med3(L.m1, L.m2, k0);
+    L.m1 = med3(L.m1, k0, pinf);
+    L.m3 = med3(L.m2, L.m3, k1);
+    L.m2 = med3(L.m1, L.m2, k1);
+    L.m1 = med3(L.m1, k1, pinf);
+}
+
+// largest value the lane has seen (exact accumulator bits)
+VQT_FN float lane_max(const Lane &L, float ninf) {
+    return max3(max3(max3(L.S[0], L.S[1], L.S[2]), max3(L.S[3], L.S[4], L.S[5]), L.S[6]), L.S[7], ninf);
+}
+
+VQT_FN int code_of(int a, int cell, int h) { return 32 * (cell >> 1) + (a & 3) + 8 * (a >> 2) + 16 * (cell & 1) + 4 * h; }
+
+// Stage 1 (every row): what one half of a row knows once the row's threshold is known.
+struct Half {
+    unsigned ge;           // bit 7 - a: stream a of this half is at or above thr
+    int popA;              // streams of this half at or above thr
+    int nB;                // cell keys of this half at or above thrB = thr - (key truncation), 0..3 (3 = "three or more")
+    int k11;               // code of (largest stream at or above thr, largest cell key)
+};
+
+VQT_FN Half half_of(const Lane &L, float thr, float thrB, int h) {
+    unsigned lt = 0u;                                     // bit 7 - a = (S[a] < thr)
+#pragma unroll
+    for (int a = 0; a < 8; ++a) lt = shl1_in(lt, L.S[a] - thr);
+    Half H;
+    H.ge = ~lt & 0xffu;
+    H.popA = popc(H.ge);
+    H.nB = (L.m1 >= thrB ? 1 : 0) + (L.m2 >= thrB ? 1 : 0) + (L.m3 >= thrB ? 1 : 0);
+    const int p1 = 31 - clz(H.ge | 1u);                   // highest set bit (ge == 0: p1 = 0, and popA = 0 says it is unused)
+    H.k11 = code_of((7 - p1) & 7, (int)(f2u(L.m1) & kCellMask), h);
+    return H;
+}
+
+// the word the two halves of a row swap: [popA : 4][nB : 2][k11 : 14]
+VQT_FN unsigned pack(const Half &H) { return (unsigned)H.popA | ((unsigned)H.nB << 4) | ((unsigned)H.k11 << 6); }
+
+struct Verdict {           // the same on both halves of a row
+    bool closed;           // exactly one code reaches the threshold: kbest is the reference's argmin
+    bool hard;             // more candidates than two streams x two cells per half cover: the row tile is screened again
+    int kbest;             // closed rows
+};
+
+VQT_FN Verdict verdict_of(const Half &H, unsigned other, int K) {
+    const int popO = (int)(other & 15u), nBO = (int)((other >> 4) & 3u), k11O = (int)(other >> 6);
+    Verdict V;
+    V.kbest = H.popA == 1 ? H.k11 : k11O;
+    V.closed = (H.popA + popO == 1) && (H.nB + nBO == 1);
+    V.hard = H.popA > 2 || H.nB > 2 || popO > 2 || nBO > 2;
+    // a padding code (k >= K) at or above the threshold can only come from a broken screen: scan the row again
+    if (V.closed && V.kbest >= K) { V.closed = false; V.hard = true; }
+    if (V.hard) V.closed = false;
+    return V;
+}
+
+// Stage 2 (rows that are neither closed nor hard): the exact tasks THIS half contributes -- the products of its (at most
+// two) streams and (at most two) cells at or above the threshold, as pairs of codes.
+struct Cands {
+    int ntask;             // 0..2
+    int ta[2], tb[2];
+};
+
+VQT_FN Cands cands_of(const Lane &L, const Half &H, int h, int K) {
+    const int p1 = 31 - clz(H.ge | 1u);
+    const unsigned ge2 = H.ge & ~(1u << p1);
+    const int p2 = ge2 ? 31 - clz(ge2) : p1;
+    const int a1 = (7 - p1) & 7, a2 = (7 - p2) & 7;
+    const int c1 = (int)(f2u(L.m1) & kCellMask);
+    const int c2 = H.nB >= 2 ? (int)(f2u(L.m2) & kCellMask) : c1;
+    int k11 = code_of(a1, c1, h), k12 = code_of(a1, c2, h), k21 = code_of(a2, c1, h), k22 = code_of(a2, c2, h);
+    // a product that is a padding code (k >= K; the last tile of a codebook with K % 32 != 0) is a phantom -- padding
+    // scores sit at -3e38 -- and is replaced by a product that is a real code (one exists: the half's value at or above thr)
+    const int kv = k11 < K ? k11 : (k12 < K ? k12 : (k21 < K ? k21 : k22));
+    if (k11 >= K) k11 = kv;
+    if (k12 >= K) k12 = kv;
+    if (k21 >= K) k21 = kv;
+    if (k22 >= K) k22 = kv;
+    const bool two = H.popA == 2 && H.nB == 2;
+    const bool any = H.popA >= 1 && H.nB >= 1 && kv < K;
+    Cands C;
+    C.ntask = any ? (two ? 2 : 1) : 0;
+    C.ta[0] = k11; C.tb[0] = k22;
+    C.ta[1] = k12; C.tb[1] = k21;
+    return C;
+}
+
+// torch.argmin's order on (distance, index) as one unsigned 64-bit key (finite distances; -0 cannot occur: x - y of
+// x >= +0 is never -0): smaller distance first, then smaller index
+VQT_FN unsigned long long dist_key(float d, int k) {
+    const unsigned u = f2u(d);
+    const unsigned s = (u >> 31) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)s << 32) | (unsigned)k;
+}
+
+}  // namespace trk
+}  // namespace vqvae

@@ -13,7 +13,7 @@ VQ_ROWMAJOR = 0x1
 VQ_CODEBOOK_PREPARED = 0x2
 VQ_EXACT_SWEEP = 0x4
 VQ_BF16_FILTER = 0x8
-VQ_PRODUCER_CONSUMER = 0x10
+VQ_TOP3_KEYS = 0x10
 VQ_SIXTEEN_WAVES = 0x20
 
 
@@ -38,7 +38,7 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
-               exact_sweep: bool = False, bf16_filter: bool = False, producer_consumer: bool = False,
+               exact_sweep: bool = False, bf16_filter: bool = False, top3_keys: bool = False,
                sixteen_waves: bool = False):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
@@ -46,8 +46,8 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
     Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
     exact_sweep=True forces the exhaustive fp32-MFMA kernel, bf16_filter=True round 1's two-sweep bf16 filter
     kernel, instead of the default (single-sweep fp16 screen for row-major D=64 rows); all three produce
-    identical bits, the flags exist for testing and A/B timing (so do producer_consumer and sixteen_waves, two other
-    forms of the default kernel).
+    identical bits, the flags exist for testing and A/B timing (so do top3_keys and sixteen_waves: round 2's tracker
+    in its two forms, where the default is round 3's stream tracker).
     """
     _check_dev("z_e", z_e)
     _check_dev("codebook", codebook)
@@ -75,7 +75,7 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
             (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0) | \
-            (VQ_PRODUCER_CONSUMER if producer_consumer else 0) | (VQ_SIXTEEN_WAVES if sixteen_waves else 0)
+            (VQ_TOP3_KEYS if top3_keys else 0) | (VQ_SIXTEEN_WAVES if sixteen_waves else 0)
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
