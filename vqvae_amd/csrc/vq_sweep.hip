@@ -701,6 +701,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             // the descriptor covers exactly the pair's existing rows: stores of rows past the end are dropped by the hardware
             const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq ? zq + (size_t)p * RU * D : const_cast<float *>(z), 0,
                                                                  store_zq ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
+            // store offsets without a scalar offset register: see vq_track.hip (hipcc does not guard the SGPR-soffset form
+            // of a 16-byte store against an overwrite of its data registers by the next vector instruction)
+            unsigned vo[T * 2];
+#pragma unroll
+            for (int k = 0; k < T * 2; ++k) {
+                vo[k] = (unsigned)lane * 16u + 4096u * k;
+                asm volatile("" : "+v"(vo[k]));
+            }
             float sacc = 0.0f;
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -752,7 +760,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
                     o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
                     const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
                     sacc += rr < nleft ? sq : 0.0f;              // fp32 over the pair's 16 groups, one fp64 add per pair
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zq_rs, (unsigned)lane * 16u, (unsigned)(t * 8 + i) * 1024u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
                 }
             }
             dacc += (double)sacc;

@@ -442,6 +442,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             // the descriptor covers exactly the unit's existing rows: stores of rows past the end are dropped by the hardware
             const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq ? zq + (size_t)p * RU * D : const_cast<float *>(z), 0,
                                                                  zq ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
+            // Store offsets: four lane bases 4 KiB apart + an immediate, NO scalar offset register.  hipcc (ROCm 7.2) does not
+            // guard a 16-byte buffer store whose soffset is an SGPR against the next vector instruction overwriting its data
+            // registers (LLVM exempts that form from the store-data hazard); on gfx950 the overwrite corrupted the last dword
+            // of lanes 12..15 of each row here.  Without an soffset register the compiler inserts the wait states itself
+            // (tools/hazard_scan.py checks the assembly of every source for this pattern; tests/test_build_hazards.py runs it).
+            unsigned vo[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                vo[k] = (unsigned)lane * 16u + 4096u * k;
+                asm volatile("" : "+v"(vo[k]));
+            }
             float sacc = 0.0f;
 #pragma unroll
             for (int t = 0; t < T; ++t)
@@ -454,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                     const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
                     if (nleft == RU) sacc += sq;                   // fp32 over the unit's 16 groups, one fp64 add per unit
                     else sacc += 32 * t + 4 * i + g4 < nleft ? sq : 0.0f;
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zq_rs, (unsigned)lane * 16u, (unsigned)(t * 8 + i) * 1024u, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
                 }
             dacc += (double)sacc;
 #pragma unroll
