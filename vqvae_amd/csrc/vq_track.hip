@@ -63,6 +63,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);                // the unit's fp16 rows; later 16 fp32 row slots
     unsigned char *tab_s = tile_s + TILEB;
 
+#ifdef VQ_SWEEP_TIMING
+    // debug build (tools/build_variant.py NAME -DVQ_SWEEP_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
+    // ticks) over the waves of the first 64 workgroups, collected in LDS and written to the spare tail of `partials`
+    unsigned *tsum = reinterpret_cast<unsigned *>(red);       // the loss scratch is not used before the loop ends
+    if (tid < 8) tsum[tid] = 0;
+    unsigned long long tprev = wall_clock64();
+    const unsigned long long tstart = tprev;
+#define VQ_STAMP(slot)                                                          \
+    do {                                                                        \
+        const unsigned long long tnow = wall_clock64();                         \
+        if ((tid & 63) == 0) atomicAdd(&tsum[slot], (unsigned)(tnow - tprev));  \
+        tprev = tnow;                                                           \
+    } while (0)
+#else
+#define VQ_STAMP(slot) do {} while (0)
+#endif
+
     const int cb_bad = flags[0];
     const int a_e = flags[5];
     const float A = __builtin_ldexpf(1.0f, a_e);
@@ -120,6 +137,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     __syncthreads();
 
     const float inf = __builtin_inff();
+    VQ_STAMP(0);                                               // codebook image copy + first row requests
     float pinf = inf, ninf = -inf;                           // opaque: see vq_track.h
     unsigned keymask = trk::kKeyMask;
     asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
@@ -172,6 +190,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             }
         }
 
+        VQ_STAMP(1);                                           // rows landed, fp16 conversion
         // ================= the sweep: 4 MFMAs per (code tile, row tile), stream / cell maxima per lane ====================
         trk::Lane L[T];
 #pragma unroll
@@ -216,6 +235,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             if (ct < ntile) cell(ct, aA, sA, aB, sB);
         }
 
+        VQ_STAMP(2);                                           // sweep
         // ================= threshold, merge of the two lane halves of every row, verdict ===================================
         int kbest[T];
         bool valid[T], bad[T], openf[T], hardf[T];
@@ -266,6 +286,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             }
         }
 
+        VQ_STAMP(3);                                           // threshold + verdict
         // ================= exact part (rows the screen left open) =========================================================
         // A TASK is (row, code a, code b); four tasks run per pass, one per 16-lane group, on the row's fp32 data (read again
         // from L2: it was loaded a few microseconds ago): ||z||^2 in ATen's summation order and the two c-ordered fmaf
@@ -427,6 +448,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             }
         }
 
+        VQ_STAMP(4);                                           // exact part
         // ================= epilogue: gather, z + (e_k - z), squared error, index, histogram ==================================
         {
             const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
@@ -475,6 +497,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                     atomicAdd(&hist_s[kbest[t]], 1);
                 }
         }
+        VQ_STAMP(5);                                           // epilogue
         {
             int q = 0;
             if (lane == 0) q = atomicAdd(ticket_s, 1);
@@ -484,6 +507,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         }
     }
 
+#ifdef VQ_SWEEP_TIMING
+    VQ_STAMP(6);
+    if ((tid & 63) == 0) atomicMax(&tsum[7], (unsigned)(wall_clock64() - tstart));     // slowest wave of the workgroup
+    __syncthreads();
+    if (tid < 8 && blockIdx.x < 64) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + tid] = tsum[tid];
+    __syncthreads();
+#endif
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
     __syncthreads();
