@@ -84,6 +84,8 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on the timed work (sets the repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-other-workloads", action="store_true",
+                    help="skip the appended measurements of BASELINE configs 2 / 4 / 5 (default line, 1 GPU, c3 only)")
     ap.add_argument("--dry-run", action="store_true",
                     help="control-flow check without a GPU (gloo, a stub CPU step): exercises the rank spawn, the "
                          "barriers, the max-reduce and the JSON line; its numbers are NOT measurements")
@@ -145,18 +147,117 @@ def cpu_baseline(seconds: float, torch):
                       f", {ncpu} logical cpus); ~{per:.1f}s per (threads,batch) point, img/s: " + " ".join(detail)}
 
 
-def pmc_traffic(workload: str):
+def source_sha():
+    """Fingerprint of the kernel sources the running library was built from (vqvae_amd/csrc/*): ties a committed
+    profile to the build it was taken on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "vqvae_amd", "csrc", "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(workload: str, vq_kernel: str):
     """HBM bytes per row / per image from the committed rocprofv3 PMC summary for this workload, or None.
     The file is written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled on
-    gfx950, as MI355X_MICROARCH.md prescribes)."""
+    gfx950, as MI355X_MICROARCH.md prescribes) and stamped with the fingerprint of the kernel sources it was measured on
+    and the quantizer kernel's name: a file taken on other sources, or for another kernel, is NOT used (`traffic` null and
+    `traffic_stale` says why) -- a traffic regression cannot hide behind an old file."""
     path = os.path.join(ROOT, "profiles", f"hbm_traffic_{workload}.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        d["_path"] = os.path.relpath(path, ROOT)
-        return d
     except (OSError, ValueError):
-        return None
+        return None, None
+    rel = os.path.relpath(path, ROOT)
+    if d.get("source_sha") != source_sha():
+        return None, f"{rel}: measured on kernel sources {d.get('source_sha')}, running {source_sha()}"
+    if vq_kernel and vq_kernel not in d.get("vq_kernel", ""):
+        return None, f"{rel}: measured on {d.get('vq_kernel')!r}, running {vq_kernel}"
+    d["_path"] = rel
+    return d, None
+
+
+def index_flips(model, x, torch):
+    """min_encoding_indices of the HIP path against the reference's algorithm (oracle/torch_port.py) on THIS batch: every
+    row compared, the flips counted (z_e differs by conv rounding noise, so rows whose two best codes are closer than that
+    may flip: SURVEY.md 8c expects <= 1e-4).  Checker only; runs after the timed region."""
+    from oracle import torch_port
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        out = model._forward_c(x, want_idx=True)
+        got = out[3].view(-1).cpu()
+        xc = x.cpu()
+        want = []
+        for i in range(0, xc.shape[0], 512):
+            z_e = torch_port.encode(sd, xc[i:i + 512].clone(), 2)
+            want.append(torch_port.quantize(z_e, sd["vector_quantization.embedding.weight"], 0.25)[4].view(-1))
+        want = torch.cat(want)
+    n = int((got != want).sum())
+    return {"flips": n, "rows": int(got.numel()), "rate": n / got.numel(), "expected_at_most": 1e-4,
+            "reference": "oracle/torch_port.py (bitwise the imported reference) on the same batch, host CPU"}
+
+
+def other_workload(name, torch, dev, seconds=1.0):
+    """One of BASELINE's other single-GPU configurations, timed like the main line (>= `seconds` of timed steps, median
+    of 5 repeats), with the live per-kernel figures of its quantizer and conv kernels."""
+    import statistics
+    from vqvae_amd import _lib, conv as conv_mod
+    from vqvae_amd.modules import VQVAE
+    desc, B, HW, K, D, conv_backend = WORKLOADS[name]
+    conv_mod.set_conv_backend(conv_backend)
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+    x = torch.randn(B, 3, HW, HW, generator=torch.Generator().manual_seed(1000)).to(dev)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                out = model(x)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    run(2)
+    t1, _ = run(2)
+    steps = max(2, int(seconds / 5 / max(t1 / 2, 1e-6)) + 1)
+    times = [run(steps)[0] for _ in range(5)]
+    el = statistics.median(times)
+    _lib.profile_enable(True)
+    nprof = min(steps, 10)
+    run(nprof)
+    vq_ms, vq_n = _lib.profile_collect("vq_main")
+    conv_ms = 0.0
+    for k in ("conv_igemm", "res_layer", "conv_in", "conv_out"):
+        ms, n = _lib.profile_collect(k)
+        conv_ms += ms
+    _lib.profile_enable(False)
+    rows = B * (HW // 4) * (HW // 4)
+    res = {"workload": desc, "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1),
+           "ms_per_step": round(el / steps * 1e3, 4), "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps}
+    if vq_n:
+        t_vq = vq_ms / vq_n * 1e-3
+        res["vq"] = {"kernel": _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0), "avg_kernel_us": round(t_vq * 1e6, 2),
+                     "hbm_GBps": round(rows * (8 * D + 8) / t_vq / 1e9, 1),
+                     "hbm_frac": round(rows * (8 * D + 8) / t_vq / 1e9 / HBM_PEAK_GBPS, 4),
+                     # SURVEY.md 7.2-H1: at K >= 1024 the screen is matrix-bound, not HBM-bound
+                     "screen_tflops_16bit": round(2.0 * rows * K * D / t_vq / 1e12, 1),
+                     "mfma_frac": round(2.0 * rows * K * D / t_vq / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4)}
+    if conv_backend == "hip" and conv_ms > 0:
+        t_conv = conv_ms / nprof * 1e-3
+        flops_img = conv_flops_per_image(HW, HW, D, ends=True)
+        terms = _lib.load().vqvae_conv_term_products(1, HW // 4, HW // 4, 128, 128, 0x100) or 6
+        alg_tf = B * flops_img / t_conv / 1e12
+        res["conv"] = {"ms_per_step": round(t_conv * 1e3, 4), "term_products_per_mac": terms,
+                       "achieved_algorithmic_tflops": round(alg_tf, 1), "issued_tflops_16bit": round(terms * alg_tf, 1),
+                       "mfma_frac": round(terms * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4), "timing": "hip-event brackets (event_inflated)"}
+    del model, x
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -284,10 +385,14 @@ def main():
             "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            # fp32 in/out and fp32 accumulation everywhere; conv products are formed from exact three-term bf16
-            # splits of the fp32 operands (error <= 3*2^-24 per product, fp32-grade; VQVAE_CONV_EXACT_FP32 selects the
-            # plain fp32-MFMA kernels); quantizer indices bit-exact
-            "dtype": "f32", "data": "synthetic",
+            # fp32 in/out and fp32 accumulation everywhere; the conv products of the whole-path kernels are formed from two
+            # fp16 terms per operand (three term products, relative error <= 2^-21 per product: representation 2^-23 per
+            # operand + the dropped pair 2^-22 -- fp32's own is 2^-24; VQVAE_CONV_BF16_SPLIT selects the exact three-term
+            # bf16 splits, 3*2^-24, VQVAE_CONV_EXACT_FP32 the plain fp32-MFMA kernels); quantizer indices bit-exact for
+            # identical z_e
+            "dtype": "f32 (fp32 in/out/accumulate; conv products from two fp16 terms per operand, <= 2^-21 rel per product)"
+                     if conv_backend == "hip" else "f32",
+            "data": "synthetic",
             "config": {"workload": desc, "per_gpu_batch": B, "global_batch": B * n_gpus, "image": [3, H, W],
                        "K": K, "D": D, "parallelism": f"batch-sharded replicas x{n_gpus}, no collective"},
             "timing": {"repeats": len(times), "steps_per_repeat": args.steps, "statistic": "median repeat",
@@ -300,18 +405,19 @@ def main():
             line["data"] = "dry-run stub (no kernels ran; not a measurement)"
         else:
             rows = B * (H // 4) * (W // 4)
-            pmc = pmc_traffic(args.workload)
+            pmc, pmc_stale = pmc_traffic(args.workload, _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0))
             if vq_n:
                 t_vq = vq_ms / vq_n * 1e-3                     # seconds per launch
                 alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
                 achieved = alg_bytes / t_vq / 1e9
                 line["roofline"] = {
-                    "kernel": _lib.vq_kernel_name(K, D) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
+                    "kernel": _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
                               "fp32 refine of the surviving codes; bit-exact indices)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": int(pmc["vq_bytes_per_row"] * rows) if pmc and "vq_bytes_per_row" in pmc else None,
                     "traffic_source": pmc["_path"] if pmc and "vq_bytes_per_row" in pmc else None,
+                    "traffic_stale": pmc_stale,
                     "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
                     "alg_bytes_per_row": 8 * D + 8,
                     "screen_tflops_16bit": round(2.0 * rows * K * D * _lib.vq_sweeps(K, D) / t_vq / 1e12, 1),
@@ -330,7 +436,7 @@ def main():
                 alg_tf = B * flops_img / t_conv / 1e12
                 # 16-bit MFMA term products per fp32 multiply-add on this workload's maps (3 = two-term fp16 on 8x8 maps,
                 # 6 = three-term bf16 on larger ones), asked of the library for the 3x3 layer at the latent resolution
-                terms = _lib.load().vqvae_conv_term_products(1, H // 4, W // 4, 128, 128, 0) or 6
+                terms = _lib.load().vqvae_conv_term_products(1, H // 4, W // 4, 128, 128, 0x100) or 6   # 0x100: as the whole path launches it
                 scheme = ("two-term fp16 products: 3 fp16 MFMA term products per fp32 product" if terms == 3 else
                           "three-term bf16 products: 6 bf16 MFMA term products per fp32 product")
                 line["roofline_conv"] = {
@@ -352,9 +458,24 @@ def main():
                             "time; achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
                             f"would be credited with): its ceiling on this path is 2500/{terms} = {2500 // terms} TF",
                 }
-            line["kernels"] = extra
+            # the library's four timing slots, named by what runs in them on this workload
+            fusedp = conv_backend == "hip" and "conv_in" not in extra and "conv_out" in extra
+            slot_names = ({"conv_igemm": "enc_front8_h2_kernel", "res_layer": "conv_res_pair8_h2_kernel<2> + <0>",
+                           "conv_out": "dec_tail8_h2_kernel"} if fusedp else
+                          {"conv_igemm": "conv_igemm_bf3 / conv_tile8_bf3 kernels", "res_layer": "res_layer / res_pair kernels",
+                           "conv_in": "conv_in kernels", "conv_out": "convt_out_kernel"})
+            line["kernels"] = {slot_names.get(k, k): dict(v, timing="hip-event brackets (event_inflated: the brackets add "
+                                                                   "~10 % to a step; profiles/ holds the rocprofv3 figures)")
+                               for k, v in extra.items()}
+            line["source_sha"] = source_sha()
             if n_gpus == 1 and not args.no_cpu_baseline:
+                if args.workload == "c3" and conv_backend == "hip":
+                    line["index_flips_vs_reference"] = index_flips(model, x, torch)
                 line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, torch)
+            if n_gpus == 1 and args.workload == "c3" and not args.no_other_workloads and not args.batch:
+                del out
+                line["other_workloads"] = {w: other_workload(w, torch, dev) for w in ("c2", "c4", "c5")}
+                conv_mod.set_conv_backend(conv_backend)
         print(json.dumps(line), flush=True)
     if dist:
         dist.barrier()

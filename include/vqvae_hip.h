@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 1
+#define VQVAE_HIP_ABI_VERSION 3   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS */
 
 #define VQVAE_OK               0
 #define VQVAE_ERR_NULL        -1   /* a required pointer is NULL                       */
@@ -147,11 +147,12 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
  * and, for callers that use sub-modules directly, through vqvae_transpose_f32.
  * Weights are passed PACKED: vqvae_*_pack_f32 rewrites a torch-layout weight into the
  * MFMA B-operand image once per weight version (bytes from vqvae_*_packed_bytes).
- * fp32 in, fp32 out, fp32 accumulation.  Products are formed from exact 16-bit splits of both fp32 operands on the
- * 16-bit matrix cores, per-product error <= 3*2^-24 (fp32-grade) either way: two fp16 terms per operand and three term
- * products on 8x8 maps (operands carry exact power-of-two scales: per layer for the weights, per image for the
- * activations, measured by the kernel itself), three bf16 terms and six term products on other map sizes (and everywhere
- * with VQVAE_CONV_BF16_SPLIT).  The whole-path entry points (vqvae_forward_f32 ...) hand the per-image maxima from layer
+ * fp32 in, fp32 out, fp32 accumulation.  Products are formed from 16-bit splits of both fp32 operands on the
+ * 16-bit matrix cores: two fp16 terms per operand and three term products on 8x8 maps (operands carry exact
+ * power-of-two scales: per layer for the weights, per image for the activations, measured by the kernel itself) --
+ * relative error per product <= 2^-21 (representation 2^-23 per operand, dropped term pair 2^-22; fp32's own is 2^-24);
+ * three bf16 terms (an exact split) and six term products on other map sizes and everywhere with VQVAE_CONV_BF16_SPLIT --
+ * per product <= 3*2^-24.  The whole-path entry points (vqvae_forward_f32 ...) hand the per-image maxima from layer
  * to layer and use the fp16 scheme on every map size.  VQVAE_CONV_EXACT_FP32 selects the exact-fp32 MFMA kernels.  Parity with the reference is
  * tolerance-level either way (oneDNN's summation order is opaque): |y - y_ref| <= 1e-5 + 1e-4|y_ref|.
  * All activation pointers must be 16-byte aligned (VQVAE_ERR_UNSUPPORTED otherwise).
@@ -180,7 +181,10 @@ VQVAE_API int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, f
  * packed: [fp32 image][three-term bf16 image][4x4 s2 only: the same in space-to-depth chunk order]
  *         [header {weight scale exponent}][two-term fp16 image][4x4 s2 only: the same in space-to-depth chunk order]. */
 /* How many 16-bit MFMA term products vqvae_conv_forward_f32 issues per fp32 multiply-add for this layer shape: 3 (two-term
- * fp16, 8x8 maps), 6 (three-term bf16), 1 (VQVAE_CONV_EXACT_FP32), 0 = unsupported shape.  For reporting (bench.py). */
+ * fp16, 8x8 maps), 6 (three-term bf16), 1 (VQVAE_CONV_EXACT_FP32), 0 = unsupported shape.  With
+ * VQVAE_CONV_QUERY_WHOLE_PATH in flags: what the whole-path entry points (vqvae_forward_f32 ...) launch for the layer --
+ * they hand the per-image maxima over, so every map size runs the two-term fp16 products (3).  For reporting (bench.py). */
+#define VQVAE_CONV_QUERY_WHOLE_PATH 0x100
 VQVAE_API int vqvae_conv_term_products(int kind, int H, int W, int Cin, int Cout, int flags);
 
 VQVAE_API int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const float *bias,

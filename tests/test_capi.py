@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(lib):
     lib.vqvae_strerror.restype = ctypes.c_char_p
     lib.vqvae_vq_workspace_bytes.restype = ctypes.c_size_t
     lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
-    assert lib.vqvae_abi_version() == 1
+    assert lib.vqvae_abi_version() == 3
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
     assert b"NULL" in lib.vqvae_strerror(-1)
@@ -147,3 +147,26 @@ def test_host_side_plans_without_gpu():
     act = 4096 * 16 * 16 * 64 * 4
     assert ws > 2 * act + 2 * 4096 * 64 * 64 * 4 + 2 * (4 + 2) * 4096 * 4
     assert L.vqvae_workspace_bytes(dims, 4096, 30, 32) == 0
+
+
+def test_modules_pickle_and_deepcopy_like_the_reference(tmp_path):
+    """The reference's VQVAE is a plain nn.Module: torch.save(model) and copy.deepcopy(model) (EMA copies,
+    checkpoint-by-module) work.  Runtime caches live in a weak side table (vqvae_amd/_cache.py), never in __dict__."""
+    import copy
+    import io
+    import torch
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25)
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m2 = torch.load(buf, weights_only=False)
+    m3 = copy.deepcopy(m)
+    for a in (m2, m3):
+        for (k1, v1), (k2, v2) in zip(m.state_dict().items(), a.state_dict().items()):
+            assert k1 == k2 and torch.equal(v1, v2)
+        # the aliased residual weights stay aliased in the copy (models/residual.py:44-45)
+        st = a.encoder.conv_stack[5].stack
+        assert st[0].res_block[1].weight is st[1].res_block[1].weight
+    assert not any(k.startswith("_c_") or "vqvae_amd" in k for k in m.__dict__)

@@ -132,7 +132,9 @@ def test_conv_term_products_query():
     L = _lib.load()
     assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 0) == 3         # 8x8 map: two-term fp16
     assert L.vqvae_conv_term_products(0, 16, 16, 64, 128, 0) == 3        # 4x4 s2 on a 16x16 map (tile kernel)
-    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0) == 6       # larger maps: three-term bf16
+    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0) == 6       # larger maps, per-layer entry: three-term bf16
+    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0x100) == 3   # the same layer inside vqvae_forward_f32 (maxima handed over)
+    assert L.vqvae_conv_term_products(1, 56, 56, 128, 128, 0x100 | 0x8) == 6
     assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 8) == 6         # VQVAE_CONV_BF16_SPLIT
     assert L.vqvae_conv_term_products(1, 8, 8, 128, 128, 4) == 1         # VQVAE_CONV_EXACT_FP32
 
@@ -258,3 +260,44 @@ def test_transpose_roundtrip():
     r = conv_hip.nchw_to_rows(x)
     assert torch.equal(r, x.permute(0, 2, 3, 1).contiguous())
     assert torch.equal(conv_hip.rows_to_nchw(r), x)
+
+
+ALIGNED = float(np.float32(1.0) + np.float32(4093.0) * np.float32(2.0 ** -23))      # 1 + 4093 * 2^-23
+
+
+@pytest.mark.parametrize("kind,ctor,Cin,Cout,H,W", [
+    ("conv3x3", lambda ci, co: nn.Conv2d(ci, co, 3, 1, 1, bias=False), 128, 128, 8, 8),       # Kred 1152
+    ("conv4x4s2", lambda ci, co: nn.Conv2d(ci, co, 4, 2, 1, bias=False), 64, 128, 16, 16),    # Kred 1024
+    ("conv1x1", lambda ci, co: nn.Conv2d(ci, co, 1, 1, bias=False), 128, 64, 8, 8),           # Kred 128
+    ("convT3x3", lambda ci, co: nn.ConvTranspose2d(ci, co, 3, 1, 1, bias=False), 64, 128, 8, 8),
+    ("convT4x4s2", lambda ci, co: nn.ConvTranspose2d(ci, co, 4, 2, 1, bias=False), 128, 64, 8, 8),
+])
+def test_fp16_two_term_product_bound_on_aligned_operands(kind, ctor, Cin, Cout, H, W, capsys):
+    """The documented error of the two-term fp16 products (include/vqvae_hip.h): x = h1 + h2 + r with
+    h1 = fp16(x), h2 = fp16(x - h1), |r| <= 2^-23 |x|; the product keeps h1 g1 + h1 g2 + h2 g1 and drops
+    h2 g2 (<= 2^-22 |x w|) + r w + x s (<= 2^-23 |x w| each): at most 2^-21 |x w| per product -- NOT fp32's 2^-24.
+    Operands built so that every one of the 64..1152 products of an output errs by that maximum in the SAME direction
+    (x = w = 1 + 4093 * 2^-23 up to sign-free powers of two: h2 = 4092 * 2^-23, r = +2^-23), against an fp64 conv:
+    the relative error of every output must stay below 2^-21 plus the fp32 accumulation's share, and on these operands it
+    must also come out ABOVE 2^-22 (the test would otherwise not be exercising the worst case)."""
+    from vqvae_amd import conv_hip
+    m = ctor(Cin, Cout)
+    B = 3
+    with torch.no_grad():
+        m.weight.fill_(ALIGNED)
+        m.weight.mul_(2.0 ** -7)                                   # exact
+    x = torch.full((B, Cin, H, W), ALIGNED) * torch.tensor([1.0, 2.0 ** 9, 2.0 ** -20]).view(-1, 1, 1, 1)
+    with torch.no_grad():
+        ref = m.double()(x.double())                               # every term positive: ref = sum |x_i w_i|
+    md = ctor(Cin, Cout).to(dev())
+    md.load_state_dict(m.float().state_dict())
+    worst = {}
+    for name, flags in (("two-term fp16 (default)", 0), ("three-term bf16", 8), ("fp32 MFMA", 4)):
+        y = nchw(conv_hip.conv(KIND[kind], rows(x.to(dev())), md, md.weight, md.bias, Cin, Cout, flags)).cpu().double()
+        worst[name] = float(((y - ref).abs() / ref).max())
+    with capsys.disabled():
+        print(f"\n   {kind}: worst relative output error on aligned operands, in units of 2^-24: " +
+              ", ".join(f"{k} {v * 2 ** 24:.2f}" for k, v in worst.items()))
+    assert worst["two-term fp16 (default)"] <= 2.0 ** -21 + 2.0 ** -22        # 8 units of 2^-24 + the fp32 accumulation's share
+    assert worst["two-term fp16 (default)"] >= 2.0 ** -22
+    assert worst["three-term bf16"] <= 2.0 ** -22 and worst["fp32 MFMA"] <= 2.0 ** -22    # these two stay at fp32's own level

@@ -69,9 +69,9 @@ def test_forward_matches_reference_golden(name, golden_models):
     for r in bad:
         d = ((zr[r][None, :] - cb) ** 2).sum(1)
         gap = abs(d[got[r]] - d[g_idx[r]])
-        bound = 8 * 2.0 ** -24 * ((zr[r] ** 2).sum() + (cb[g_idx[r]] ** 2).sum()) + 4e-6 * np.sqrt((zr[r] ** 2).sum()) * 0.2
+        bound = 8 * 2.0 ** -24 * ((zr[r] ** 2).sum() + (cb[g_idx[r]] ** 2).sum())       # SURVEY.md 8c, un-widened
         assert gap <= bound, f"row {r}: index {got[r]} vs reference {g_idx[r]} is not a near-tie (gap {gap:.3g})"
-    assert len(bad) <= max(1, int(1e-3 * got.size)), f"{len(bad)} index flips"
+    assert len(bad) <= max(1, int(1e-4 * got.size)), f"{len(bad)} index flips"
 
     g_xhat = golden_models[f"{name}/x_hat"]
     xh = x_hat.cpu().numpy()
@@ -133,11 +133,14 @@ def test_forward_only_and_no_cpu_fallback():
     assert out[1].shape == x.shape
 
 
-def test_large_batch_config3_sampled_vs_reference_port():
-    """BASELINE config-3 size (B=4096) against the reference's algorithm: every 64th image (64 images) is run through
-    oracle/torch_port.py (bitwise the imported reference, tests/test_oracle.py) and compared stage by stage --
-    z_e atol 2e-6, indices exact except provable near-ties (counted), x_hat atol 1e-5 + rtol 1e-4 on images without a
-    flip.  Also shard-additivity of x_hat (independent images)."""
+def test_large_batch_config3_every_row_vs_reference_port(capsys):
+    """BASELINE config-3 size (B=4096) against the reference's algorithm, EVERY image: all 4096 images run through
+    oracle/torch_port.py (bitwise the imported reference, tests/test_oracle.py) and are compared stage by stage --
+    z_e atol 2e-6; indices exact except provable near-ties: the flips over all 262 144 rows are COUNTED, printed and must
+    stay at or below SURVEY.md 8c's 1e-4 of the rows, each one an fp64 near-tie under the un-widened bound
+    8 eps32 (|z|^2 + |e|^2); x_hat atol 1e-5 + rtol 1e-4 on every image without a flip.  Also shard-additivity of x_hat
+    (independent images).  (The conv products are two-term fp16, <= 2^-21 per product: this is the test that says what
+    that does to the indices.)"""
     from oracle import torch_port
     from vqvae_amd import conv, conv_hip
     conv.set_conv_backend("hip")
@@ -148,31 +151,40 @@ def test_large_batch_config3_sampled_vs_reference_port():
     x = torch.randn(4096, 3, 32, 32, generator=g)
     xd = x.to(dev())
     with torch.no_grad():
-        loss, x_hat, ppl = m(xd)
+        loss, x_hat, ppl, idx = m._forward_c(xd, want_idx=True)                         # ONE vqvae_forward_f32 call
         z_e = conv_hip.encoder_forward(m.encoder, xd, m.pre_quantization_conv)          # (B, 8, 8, D)
-        idx = m.encode(xd).view(4096, 64)
         l0, xh0, p0 = m(xd[:2048])
         l1, xh1, p1 = m(xd[2048:])
     assert torch.equal(x_hat[:2048], xh0) and torch.equal(x_hat[2048:], xh1)
     np.testing.assert_allclose(loss.item(), 0.5 * (l0.item() + l1.item()), rtol=1e-5)
-    sel = torch.arange(0, 4096, 64)
     with torch.no_grad():
-        z_e_ref = torch_port.encode(sd, x[sel].clone(), 2)                                  # (64, D, 8, 8)
+        z_e_ref = torch.cat([torch_port.encode(sd, x[i:i + 512].clone(), 2) for i in range(0, 4096, 512)])   # (B, D, 8, 8)
         cbk = sd["vector_quantization.embedding.weight"]
-        _, z_q_ref, _, _, idx_ref = torch_port.quantize(z_e_ref, cbk, 0.25)
-        x_hat_ref = torch_port.decode(sd, z_q_ref.clone(), 2)
-    np.testing.assert_allclose(z_e[sel].permute(0, 3, 1, 2).cpu().numpy(), z_e_ref.numpy(), atol=2e-6, rtol=0)
-    got = idx[sel].cpu().numpy().reshape(-1)
+        outs = [torch_port.quantize(z_e_ref[i:i + 512], cbk, 0.25) for i in range(0, 4096, 512)]
+        z_q_ref = torch.cat([o[1] for o in outs])
+        idx_ref = torch.cat([o[4] for o in outs])
+        x_hat_ref = torch.cat([torch_port.decode(sd, z_q_ref[i:i + 512].clone(), 2) for i in range(0, 4096, 512)])
+    ze = z_e.permute(0, 3, 1, 2).cpu().numpy()
+    dev_ze = float(np.abs(ze - z_e_ref.numpy()).max())
+    assert dev_ze <= 2e-6, f"max |z_e - reference| = {dev_ze:.3g}"
+    got = idx.cpu().numpy().reshape(-1)
     want = idx_ref.numpy().reshape(-1)
     flips = np.nonzero(got != want)[0]
-    assert len(flips) <= 4, f"{len(flips)} index flips in 4096 sampled rows"
     zf = z_e_ref.permute(0, 2, 3, 1).reshape(-1, 64).double().numpy()
     e = cbk.double().numpy()
+    worst = 0.0
     for r in flips:                                                    # every flip must be a near-tie in fp64
         d = (zf[r] ** 2).sum() + (e ** 2).sum(1) - 2 * e @ zf[r]
-        assert abs(d[got[r]] - d[want[r]]) <= 8 * 2.0 ** -24 * ((zf[r] ** 2).sum() + (e[want[r]] ** 2).sum()) * 4
-    clean = np.setdiff1d(np.arange(64), np.unique(flips // 64))
-    np.testing.assert_allclose(x_hat[sel][clean].cpu().numpy(), x_hat_ref[clean].numpy(), atol=1e-5, rtol=1e-4)
+        bound = 8 * 2.0 ** -24 * ((zf[r] ** 2).sum() + (e[want[r]] ** 2).sum())
+        worst = max(worst, abs(d[got[r]] - d[want[r]]) / bound)
+    with capsys.disabled():
+        print(f"\n   B=4096 forward vs the reference's algorithm: {len(flips)} index flips in {got.size} rows "
+              f"({len(flips) / got.size:.2e}); largest fp64 gap of a flip = {worst:.3f} x the near-tie bound; "
+              f"max |z_e - reference| = {dev_ze:.3g}")
+    assert len(flips) <= 1e-4 * got.size, f"{len(flips)} index flips in {got.size} rows"
+    assert worst <= 1.0, f"a flipped row is not a near-tie: gap = {worst:.3f} x 8 eps32 (|z|^2 + |e|^2)"
+    clean = np.setdiff1d(np.arange(4096), np.unique(flips // 64))
+    np.testing.assert_allclose(x_hat.cpu().numpy()[clean], x_hat_ref.numpy()[clean], atol=1e-5, rtol=1e-4)
 
 
 @pytest.mark.parametrize("name", ["kat1", "small"])
@@ -447,3 +459,32 @@ def test_whole_path_ragged_batches_vs_oracle(B):
     np.testing.assert_allclose(xh.cpu().numpy()[~flips], r_xhat.numpy()[~flips], atol=1e-5, rtol=1e-4)
     if not flips.any():
         np.testing.assert_allclose(loss.item(), float(r_loss), rtol=1e-4)
+
+
+def test_model_pickles_and_deepcopies_after_a_forward():
+    """after an inference forward the module held a ctypes struct and cached workspaces in its __dict__, and
+    its load_state_dict hook was a local lambda -- torch.save(model) / copy.deepcopy(model) failed.  Both must work, and
+    the copies must run and agree bit for bit."""
+    import copy
+    import io
+    from vqvae_amd.modules import VQVAE
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev)
+    x = torch.randn(8, 3, 32, 32, device=dev)
+    with torch.no_grad():
+        ref = m(x)
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        buf.seek(0)
+        m2 = torch.load(buf, weights_only=False)
+        m3 = copy.deepcopy(m)
+        for other in (m2, m3):
+            out = other(x)
+            assert torch.equal(out[1], ref[1]) and torch.equal(out[0], ref[0]) and torch.equal(out[2], ref[2])
+        # two streams: separate workspaces, same bits
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            out_s = m(x)
+        s.synchronize()
+        assert torch.equal(out_s[1], ref[1])

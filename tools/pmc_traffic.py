@@ -8,7 +8,9 @@ KiB per dispatch; FETCH_SIZE is doubled (gfx950 tallies the 128-B requests of 16
 calibrated on a 1 GiB copy in round 1, profiles/r01_vq_hbm_traffic.txt); WRITE_SIZE is taken as is.  Infinity-Cache hits
 are counted, so these are fabric-side bytes (an upper bound on HBM bytes).  The VQ figure comes from a stream far beyond
 the 256 MiB Infinity Cache (tools/vq_traffic.py), the conv figure from the bench workload itself."""
-import collections, csv, glob, json, sys
+import collections, csv, glob, json, os, subprocess, sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def per_kernel(d):
@@ -17,6 +19,17 @@ def per_kernel(d):
         for r in csv.DictReader(open(f)):
             agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in agg.items()}
+
+
+def resources(d):
+    """VGPRs / accumulation VGPRs / scratch bytes per lane / LDS bytes of every kernel, from the kernel-trace CSV of a pass."""
+    out = {}
+    for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            out[r["Kernel_Name"][:70]] = {"vgpr": int(r.get("VGPR_Count") or 0), "accum_vgpr": int(r.get("Accum_VGPR_Count") or 0),
+                                          "scratch_bytes_per_lane": int(r.get("Scratch_Size") or r.get("Private_Segment_Size") or 0),
+                                          "lds_bytes": int(r.get("LDS_Block_Size") or r.get("Group_Segment_Size") or 0)}
+    return out
 
 
 def main():
@@ -48,6 +61,15 @@ def main():
                                 "dec_tail8")):
             conv += byts
     res["conv_bytes_per_image"] = round(conv / B, 1)
+    # stamp: bench.py uses this file only while the kernel sources are the ones it was measured on
+    import bench
+    res["source_sha"] = bench.source_sha()
+    try:
+        res["git_head"] = subprocess.check_output(["git", "-C", bench.ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+    except Exception:
+        res["git_head"] = None
+    rsrc = resources(sys.argv[3])
+    res["kernel_resources"] = {k: v for k, v in rsrc.items() if "vqvae::" in k and "pack" not in k and "prepare" not in k}
     res["per_kernel_KiB_per_dispatch"] = table
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps({k: v for k, v in res.items() if k != "per_kernel_KiB_per_dispatch"}))

@@ -13,7 +13,7 @@ from __future__ import annotations
 
 import torch
 
-from . import _lib, conv_hip
+from . import _cache, _lib, conv_hip
 from .conv_hip import (CONV_1x1, CONV_3x3_S1, CONV_4x4_S2, CONVT_3x3_S1, CONVT_4x4_S2, RELU_IN, RELU_OUT, _sp)
 
 CONVT_1x1 = 5
@@ -32,7 +32,7 @@ class _Holder:
 
 
 def _holder(mod, tag):
-    h = mod.__dict__.setdefault("_vqvae_amd_bwd", {})
+    h = _cache.side(mod).setdefault("bwd", {})
     if tag not in h:
         h[tag] = _Holder()
     return h[tag]

@@ -1,13 +1,14 @@
 """HIP backend of vqvae_amd.conv: drives the conv / residual kernels of libvqvae_hip.so.
 
 Activations stay row-major (B,H,W,C) between layers; packed weight images are cached on
-the parameter-holding nn.Module and rebuilt when the parameter changes (data_ptr/_version).
+the parameter-holding nn.Module (in a weak side table, vqvae_amd/_cache.py: never in the module's __dict__, so the
+modules pickle and deep-copy like the reference's) and rebuilt when the parameter changes (data_ptr/_version).
 """
 from __future__ import annotations
 
 import torch
 
-from . import _lib
+from . import _cache, _lib
 
 CONV_4x4_S2, CONV_3x3_S1, CONV_1x1, CONVT_3x3_S1, CONVT_4x4_S2 = range(5)
 RELU_IN, RELU_OUT = 1, 2
@@ -28,7 +29,7 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
     """Packed-weight cache on the owning module, keyed by the parameter's identity/version."""
     w = weight.detach()
     key = (kind, w.data_ptr(), w._version, str(w.device), tuple(w.shape))
-    cache = mod.__dict__.setdefault("_vqvae_amd_packed", {})
+    cache = _cache.side(mod).setdefault("packed", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == key:
         return hit[1]
@@ -43,7 +44,7 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
 
 def invalidate(mod):
     """Forget the packed-weight images cached on `mod` (see modules.VQVAE.invalidate_caches)."""
-    mod.__dict__.pop("_vqvae_amd_packed", None)
+    _cache.drop(mod, "packed")
 
 
 def _pack_conv(mod, kind, weight, Cin, Cout):

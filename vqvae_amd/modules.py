@@ -26,6 +26,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import _cache
 from . import functional as F_hip
 from ._lib import VqvaeHipError
 
@@ -53,38 +54,42 @@ class VectorQuantizer(nn.Module):
         self.beta = beta
         self.embedding = nn.Embedding(self.n_e, self.e_dim)
         self.embedding.weight.data.uniform_(-1.0 / self.n_e, 1.0 / self.n_e)   # quantizer.py:27
-        self._ws = None
-        self._ws_key = None
 
     def invalidate(self):
         """Forget the prepared codebook image.  The cache is keyed on (data_ptr, _version, device), which in-place ops
         and optimizers bump; writes through `.data` (`weight.data.copy_()`, EMA updates) do NOT -- call this after
         such a write.  `load_state_dict` and `.to()/.cuda()` call it for you."""
-        self._ws_key = None
+        for slot in _cache.side(self).get("ws", {}).values():
+            slot[1] = None
 
     def _workspace(self):
-        """-> (workspace, prepared, key): per-module workspace holding the codebook's LDS images; re-prepared only when
-        the embedding tensor changes.  The caller stores `key` once the launch has succeeded."""
+        """-> (workspace, prepared, key, slot): workspace holding the codebook's LDS images and the per-call scratch,
+        ONE PER (device, stream) -- two forwards of one model on different streams must not share scratch -- re-prepared
+        only when the embedding tensor changes.  The caller stores `key` in slot[1] once the launch has succeeded."""
         w = self.embedding.weight
         key = (w.data_ptr(), w._version, w.device)
-        if self._ws is None or self._ws.device != w.device:
-            self._ws = F_hip.vq_workspace(self.n_e, self.e_dim, w.device)
-            self._ws_key = None
-        return self._ws, self._ws_key == key, key
+        table = _cache.side(self).setdefault("ws", {})
+        skey = (str(w.device), torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
+        slot = table.get(skey)
+        if slot is None:
+            if len(table) >= 8:                                  # streams come and go: keep the table small
+                table.clear()
+            slot = table[skey] = [F_hip.vq_workspace(self.n_e, self.e_dim, w.device), None]
+        return slot[0], slot[1] == key, key, slot
 
     def quantize(self, z, *, rowmajor=False, want_zq=True):
         """-> (loss, z_q, perplexity, min_encoding_indices, hist); no one-hot."""
         w = self.embedding.weight
-        ws, prepared, key = self._workspace()
+        ws, prepared, key, slot = self._workspace()
         if not prepared:
-            self._ws_key = None                                  # a failed launch must not leave a stale "prepared" image
+            slot[1] = None                                       # a failed launch must not leave a stale "prepared" image
         if torch.is_grad_enabled() and (z.requires_grad or w.requires_grad):
             from .training import VQStraightThrough          # HIP forward + HIP backward
             out = VQStraightThrough.apply(z, w, self.beta, rowmajor, ws, prepared)
         else:
             out = F_hip.vq_forward(z, w.detach(), self.beta, rowmajor=rowmajor, workspace=ws,
                                    prepared=prepared, want_zq=want_zq)
-        self._ws_key = key
+        slot[1] = key
         return out
 
     def _apply(self, fn, *args, **kwargs):
@@ -177,6 +182,11 @@ class Decoder(nn.Module):
         return C_hip.decoder_forward(self, x, rowmajor_in=False)
 
 
+def _invalidate_after_load(module, incompatible):
+    """load_state_dict post-hook (a module-level function: a local lambda here made the model unpicklable)."""
+    module.invalidate_caches()
+
+
 class VQVAE(nn.Module):
     """Mirrors models/vqvae.py:10-44."""
 
@@ -191,13 +201,13 @@ class VQVAE(nn.Module):
             self.img_to_embedding_map = {i: [] for i in range(n_embeddings)}
         else:
             self.img_to_embedding_map = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: module.invalidate_caches())
+        self.register_load_state_dict_post_hook(_invalidate_after_load)
 
     def invalidate_caches(self):
         """Drop the prepared codebook image and every packed-weight image (they are keyed on the parameters'
         data_ptr / _version, which writes through `.data` do not change; `load_state_dict` calls this)."""
         from . import conv_hip
-        self.__dict__.pop("_c_weights_cache", None)
+        _cache.drop(self, "c_weights")
         for mod in self.modules():
             conv_hip.invalidate(mod)
             if isinstance(mod, VectorQuantizer):
@@ -230,7 +240,7 @@ class VQVAE(nn.Module):
             else:
                 tensors[f] = params[k]
         key = tuple((t.data_ptr(), t._version) for t in tensors.values()) + (str(tensors["enc0_w"].device),)
-        hit = self.__dict__.get("_c_weights_cache")
+        hit = _cache.side(self).get("c_weights")
         if hit is not None and hit[0] == key:
             return hit[1], hit[2]
         L = _lib.load()
@@ -248,7 +258,7 @@ class VQVAE(nn.Module):
         with torch.cuda.device(w0.device):
             _lib.check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, cw,
                                                 torch.cuda.current_stream(w0.device).cuda_stream))
-        self.__dict__["_c_weights_cache"] = (key, cw, (keep, packed))
+        _cache.side(self)["c_weights"] = (key, cw, (keep, packed))
         return cw, (keep, packed)
 
     def _forward_c(self, x, want_idx=False):
@@ -265,24 +275,27 @@ class VQVAE(nn.Module):
             nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
             if nws == 0:
                 raise VqvaeHipError(f"shape {tuple(x.shape)} not supported by the gfx950 whole-path entry points")
-            wkey = (nws, str(dev))
-            hit = self.__dict__.get("_c_ws_cache")
-            if hit is None or hit[0] != wkey:                 # one activation workspace per (shape, device), reused
-                hit = (wkey, torch.empty(nws, dtype=torch.uint8, device=dev))
-                self.__dict__["_c_ws_cache"] = hit
-            ws = hit[1]
+            # one activation workspace per (shape, device, stream), reused: forwards on different streams never share one
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            wkey = (nws, str(dev), stream)
+            table = _cache.side(self).setdefault("c_ws", {})
+            ws = table.get(wkey)
+            if ws is None:
+                if len(table) >= 4:
+                    table.clear()
+                ws = table[wkey] = torch.empty(nws, dtype=torch.uint8, device=dev)
             vq = self.vector_quantization
-            vws, prepared, key = vq._workspace()
+            vws, prepared, key, slot = vq._workspace()
             if not prepared:
-                vq._ws_key = None
+                slot[1] = None
             x_hat = torch.empty_like(x)
             scal = torch.empty(2, dtype=torch.float32, device=dev)
             idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev) if want_idx else None
             _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, F_hip.VQ_CODEBOOK_PREPARED if prepared else 0,
                                            x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
                                            idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
-                                           torch.cuda.current_stream(dev).cuda_stream))
-            vq._ws_key = key
+                                           stream))
+            slot[1] = key
         return (scal[0], x_hat, scal[1]) + ((idx,) if want_idx else ())
 
     def forward(self, x, verbose=False):

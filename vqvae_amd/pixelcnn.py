@@ -20,7 +20,7 @@ import ctypes as C
 import torch
 import torch.nn as nn
 
-from . import _lib, conv_hip
+from . import _cache, _lib, conv_hip
 from ._lib import VqvaeHipError
 from .conv_hip import CONV_1x1, RELU_OUT, _sp
 
@@ -109,7 +109,7 @@ class GatedMaskedConv2d(nn.Module):
         """(Cout, Cin, kh, kw) -> (Cout, kh*kw*Cin, 1, 1) in im2col order, cached per parameter version."""
         w = conv.weight
         key = (w.data_ptr(), w._version, str(w.device))
-        cache = self.__dict__.setdefault("_vqvae_amd_gemm", {})
+        cache = _cache.side(self).setdefault("gemm", {})
         hit = cache.get(tag)
         if hit is not None and hit[0] == key and self.mask_type != 'A':
             return hit[1], hit[2]
