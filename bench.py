@@ -289,9 +289,13 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    # VQVAE_BENCH_FORCE_DIST=1: initialise the process group even for ONE rank -- RCCL refuses two ranks on one device
+    # ("Duplicate GPU detected", profiles/r03_rccl_2rank_shared_gpu.log), so on a 1-GPU box this is how the NCCL branch
+    # (init with device_id, barrier, device-side MAX all-reduce) gets executed at all
+    if world > 1 or os.environ.get("VQVAE_BENCH_FORCE_DIST") == "1":
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
