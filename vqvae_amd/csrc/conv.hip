@@ -1942,8 +1942,12 @@ __device__ __forceinline__ void prod3x2t(const u32x4 &s1, const u32x4 &s2, const
                         // images, every stage barrier spanning all waves of the CU; tools/build_variant.py nw8 -DCRP_NW=8) is 17 us per
                         // step SLOWER: 0.589 vs 0.572 ms for the two launches
 #endif
+#ifndef CRP_MINW
+#define CRP_MINW 2      // waves per SIMD the register allocation must allow (tools/build_variant.py crp1 -DCRP_MINW=1: 388 registers, no
+                        // scratch, one workgroup per CU)
+#endif
 template <int NT3>
-__global__ __launch_bounds__(CRP_NW * 64, 2) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
+__global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
                                                                    const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
                                                                    float *__restrict__ out, int B, int flags,
                                                                    const int *__restrict__ hdr1, const int *__restrict__ hdr2,
@@ -2352,8 +2356,11 @@ __global__ __launch_bounds__(CRP_NW * 64, 2) void conv_res_pair8_h2_kernel(const
 // Scales: the image's largest |x| is measured; the first layer's outputs are bounded by L1 * max|x| + max|b| (L1 = the
 // largest absolute row sum of its weights, in the header) -- a power of two up to ~8x above the true maximum, which costs
 // the second term's range three bits at the very bottom and nothing where it matters (see split8_h).
+#ifndef EF_MINW
+#define EF_MINW 2
+#endif
 template <int CIN>
-__global__ __launch_bounds__(256, 2) void enc_front8_h2_kernel(const float *__restrict__ x, const u32x4 *__restrict__ w0img,
+__global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float *__restrict__ x, const u32x4 *__restrict__ w0img,
                                                                const int *__restrict__ hdr0, const float *__restrict__ bias0,
                                                                const u32x4 *__restrict__ w2img, const int *__restrict__ hdr2,
                                                                const float *__restrict__ bias2, float *__restrict__ out, int B,
@@ -2661,7 +2668,10 @@ struct TailGeom {
     unsigned long long dym[4], dxm[4];             // 4 bits per tap: dy + 8, dx + 8 (ConvGeom) of each phase
 };
 
-__global__ __launch_bounds__(256, 2) void dec_tail8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w2img,
+#ifndef DT_MINW
+#define DT_MINW 2
+#endif
+__global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w2img,
                                                               const int *__restrict__ hdr2, const float *__restrict__ bias2,
                                                               TailGeom tg, const u32x4 *__restrict__ w4img,
                                                               const int *__restrict__ hdr4, const float *__restrict__ bias4,

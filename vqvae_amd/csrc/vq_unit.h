@@ -1,0 +1,307 @@
+// What a wave does with ONE unit of the stream-tracker quantizer (64 rows = two 32-row tiles) once the sweep has filled its
+// trackers -- shared by the standalone kernel (vq_track.hip: codebook image resident in LDS, rows in registers in the load
+// layout) and by the encoder's last kernel (conv.hip, conv_res_pair8_h2_kernel<2, true>: z_e straight from the 1x1 conv's
+// accumulators, codebook image streamed through the weight stages, rows parked in LDS).  The pieces:
+//     classify     threshold per row, merge of the two lane halves, verdict; open rows' exact tasks into the task table
+//     exact_begin  flagged rows (open / hard / non-finite), their table entries; hard rows are then screened again by the
+//                  CALLER (it owns the codebook image) and appended as tasks
+//     exact_end    the exact chains (four tasks per pass, one per 16-lane group), decision by 64-bit LDS minimum, the scalar
+//                  torch.argmin path for non-finite rows / overflow
+//     epilogue     codebook gather, z + (e_k - z), squared error, z_q stores, index, histogram
+// Row data come through functors, so the two callers keep their own layouts.  models/quantizer.py:45-74; the bound is
+// derived in vq_track.hip's header.
+#pragma once
+#include "common.h"
+#include "vq_track.h"
+
+namespace vqvae {
+namespace vqu {
+
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void lds_order_wave() { asm volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+
+struct Bound {                       // what DELTA needs of the codebook (vq_prepare_kernel / vq_prepare16_kernel -> flags[])
+    int cb_bad;
+    float A, Ehat, dE, EmaxS, EEh, EEa;
+};
+
+__device__ __forceinline__ Bound load_bound(const int *__restrict__ flags) {
+    Bound b;
+    b.cb_bad = flags[0];
+    b.A = __builtin_ldexpf(1.0f, flags[5]);
+    const float EEmax = __int_as_float(flags[1]) * 1.0001f;               // max ee_k (unscaled)
+    b.Ehat = __builtin_sqrtf(__int_as_float(flags[3])) * 1.0001f;
+    b.dE = __builtin_sqrtf(__int_as_float(flags[4])) * 1.0001f;
+    b.EmaxS = __builtin_sqrtf(EEmax) * b.A * 1.0001f;
+    b.EEh = 0.5f * EEmax * b.A;
+    b.EEa = EEmax * b.A;
+    return b;
+}
+
+// per-wave tables (1552 bytes): [64] tasks  row | a << 6 | b << 19;  [64] (distance, index) minima;  [64] ||z||^2;  counter
+constexpr int kTabBytes = 1552;
+struct Tables {
+    unsigned *task_s;
+    unsigned long long *best_s;
+    float *zz_s;
+    int *cnt_s;
+};
+__device__ __forceinline__ Tables tables(unsigned char *tab_s) {
+    return Tables{reinterpret_cast<unsigned *>(tab_s), reinterpret_cast<unsigned long long *>(tab_s + 256),
+                  reinterpret_cast<float *>(tab_s + 768), reinterpret_cast<int *>(tab_s + 1024)};
+}
+
+struct Rows {                        // per lane, per row tile t: row 32 t + (lane & 31) of the unit
+    int kbest[2];
+    bool valid[2], bad[2], openf[2], hardf[2];
+    float thr[2];
+    int ncls;                        // tasks the classification wrote (wave-uniform)
+};
+
+// ---- threshold, merge of the two lane halves of every row, verdict --------------------------------------------------
+// zn2[t]: |z^|^2 of the lane's row (both halves hold the full sum); R.valid[] set by the caller
+__device__ __forceinline__ void classify(const trk::Lane (&L)[2], const float (&zn2)[2], const Bound &B, int K, int lane,
+                                         float ninf, unsigned *task_s, Rows &R) {
+    const int l31 = lane & 31, h = lane >> 5;
+    R.ncls = 0;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const float vA = trk::lane_max(L[t], ninf);
+        const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(vA), __float_as_uint(vA), false, false);
+        const float v1 = trk::max3(vA, __uint_as_float(h ? sv[0] : sv[1]), ninf);
+        // DELTA in accumulator units, every factor rounded up
+        const float zs = zn2[t] * 1.0001f;                                         // |z^|^2
+        const float zh = __builtin_sqrtf(zs) * 1.0001f;                            // |z^|
+        const float errz = zh * 4.89e-4f + 2.5e-7f;                                // |z - z^| <= u |z| + 2^-22, |z| <= |z^| / (1 - u)
+        const float zn = zh + errz;                                                // |z| <= |z^| + |z - z^|
+        const float mag = zn * B.Ehat + B.EEh;                                     // bounds every |acc|
+        const float eps = errz * B.Ehat + (zn + errz) * B.dE + 7.76e-6f * mag;
+        const float xi = 3.86e-6f * zn * B.EmaxS + 1.2e-7f * (B.A * zn * zn + B.EEa);   // g = 64 * 2^-24 * 1.01; 2^-23
+        const float delta = (2.0f * eps + 2.0f * xi) * 1.001f;
+        const float th = v1 - delta;
+        R.thr[t] = th;
+        // |v1| below 1e-30: a key could be a denormal whose cell field a flush would lose -- never on real data
+        R.bad[t] = R.valid[t] && (B.cb_bad || !(zs < 1.0e30f) || !(v1 > -1.0e37f) || !(v1 < 1.0e37f) || !(delta < 1.0e37f) ||
+                                  (v1 > -1.0e-30f && v1 < 1.0e-30f));
+        const trk::Half H = trk::half_of(L[t], th, th - 8.0e-6f * mag, h);
+        const unsigned mine = trk::pack(H);
+        const auto so = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+        const trk::Verdict V = trk::verdict_of(H, h ? so[0] : so[1], K);
+        const bool live = R.valid[t] && !R.bad[t];
+        R.openf[t] = live && !V.closed && !V.hard;
+        R.hardf[t] = live && V.hard;
+        R.kbest[t] = V.closed ? V.kbest : 0;
+        if (__builtin_amdgcn_ballot_w64(R.openf[t])) {
+            // open rows: this half's exact tasks
+            const trk::Cands C = trk::cands_of(L[t], H, h, K);
+            const int nt = R.openf[t] ? C.ntask : 0;
+            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(nt >= 1), b2 = __builtin_amdgcn_ballot_w64(nt >= 2);
+            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
+                              __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+            const int slot = R.ncls + below;
+            const unsigned rowu = (unsigned)(32 * t + l31);
+            if (nt >= 1 && slot < 64) task_s[slot] = rowu | ((unsigned)C.ta[0] << 6) | ((unsigned)C.tb[0] << 19);
+            if (nt >= 2 && slot + 1 < 64) task_s[slot + 1] = rowu | ((unsigned)C.ta[1] << 6) | ((unsigned)C.tb[1] << 19);
+            R.ncls += __builtin_popcountll(b1) + __builtin_popcountll(b2);
+        }
+    }
+}
+
+// ---- exact part, first half: who is flagged; table entries of the non-finite rows -------------------------------------
+// lane L of the wave speaks for row L of the unit (tile L >> 5, row L & 31)
+struct Flagged {
+    bool o_open, o_hard, o_bad;
+    unsigned long long fm, hmask;    // flagged rows / rows to be screened again (wave-uniform)
+    int ndirect;                     // tasks so far: classification + one per non-finite row
+};
+
+__device__ __forceinline__ Flagged exact_begin(const Rows &R, int lane, const Tables &tb) {
+    const int h = lane >> 5;
+    Flagged F;
+    F.o_open = h ? R.openf[1] : R.openf[0];
+    F.o_hard = h ? R.hardf[1] : R.hardf[0];
+    F.o_bad = h ? R.bad[1] : R.bad[0];
+    F.fm = __builtin_amdgcn_ballot_w64(F.o_open || F.o_hard || F.o_bad);
+    F.hmask = 0ull;
+    F.ndirect = R.ncls;
+    if (F.fm) {
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        tb.best_s[lane] = ~0ull;
+        // non-finite rows: one task each, for the row's ||z||^2
+        const unsigned long long tmb = __builtin_amdgcn_ballot_w64(F.o_bad);
+        if (F.o_bad && R.ncls + __builtin_popcountll(tmb & lowmask) < 64) tb.task_s[R.ncls + __builtin_popcountll(tmb & lowmask)] = (unsigned)lane;
+        F.ndirect = R.ncls + __builtin_popcountll(tmb);
+        F.hmask = __builtin_amdgcn_ballot_w64(F.o_hard);
+        if (F.hmask && lane == 0) tb.cnt_s[0] = 0;
+        lds_order_wave();
+    }
+    return F;
+}
+
+// one 32-code tile of a row tile screened again: every code at or above the row's threshold becomes a task
+__device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int ct, int t, int lane, int K, int ndirect, float ninf,
+                                            const Tables &tb) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const float x0 = trk::max3(trk::max3(acc[0], acc[1], acc[2]), trk::max3(acc[3], acc[4], acc[5]), trk::max3(acc[6], acc[7], acc[8]));
+    const float x1 = trk::max3(trk::max3(acc[9], acc[10], acc[11]), trk::max3(acc[12], acc[13], acc[14]), acc[15]);
+    const float mx = trk::max3(x0, x1, ninf);
+    if (__builtin_amdgcn_ballot_w64(mx >= thr_t)) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int code = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (acc[r] >= thr_t && code < K) {
+                const int sl = ndirect + atomicAdd(&tb.cnt_s[0], 1);
+                if (sl < 64) tb.task_s[sl] = (unsigned)(32 * t + l31) | ((unsigned)code << 6) | ((unsigned)code << 19);
+            }
+        }
+    }
+}
+
+// ---- exact part, second half: chains, decision, scalar path; R.kbest[] final afterwards ------------------------------------
+// ntasks: ndirect + what the caller's rescan appended.  zrow(rr, j16) -> floats 4 j16 .. +3 of row rr of the unit;
+// zscalar(rr, c) -> one float of it (non-finite rows only)
+template <class ZRow, class ZScalar>
+__device__ __forceinline__ void exact_end(Rows &R, Flagged &F, int ntasks, int lane, const Tables &tb, const float *__restrict__ cb,
+                                          const float *__restrict__ ee_g, int K, ZRow &&zrow, ZScalar &&zscalar) {
+    constexpr int D = 64;
+    if (!F.fm) return;
+    const int l31 = lane & 31, j16 = lane & 15, g4 = lane >> 4;
+    const float inf = __builtin_inff();
+    if (ntasks > 64) {                      // pathological tie counts: every open row takes the scalar path;
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        F.o_bad = F.o_bad || F.o_open || F.o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
+        __builtin_amdgcn_wave_barrier();
+        if (F.o_bad) tb.task_s[__builtin_popcountll(F.fm & lowmask)] = (unsigned)lane;
+        ntasks = __builtin_popcountll(F.fm);
+    }
+    lds_order_wave();
+    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
+    for (int base = 0; base < ntasks; base += 4) {
+        const int jj = base + g4;
+        const unsigned task = tb.task_s[jj < ntasks ? jj : 0];
+        const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
+        const f32x4 zv = zrow(rr, j16);
+        const f32x4 ea = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)ka * 256u + (unsigned)j16 * 16u, 0, 0));
+        const f32x4 eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kb2 * 256u + (unsigned)j16 * 16u, 0, 0));
+        const float eea = ee_g[ka], eeb = ee_g[kb2];
+        // ||z||^2 in ATen's order (lane j16 holds elements 4 j16 .. +3): P = v_q + v_{q+4} (lane j + lane j+8),
+        // A = ((P0 + P1) + P2) + P3 (lanes b, b+2, b+4, b+6), then A0..A7 in order (lane 0, then lane 1)
+        float Aq[4];
+        const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
+            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
+            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
+            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
+            Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
+        }
+        const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
+        const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
+        const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
+        // c-ordered fmaf chains: lane j continues lane j-1's partial sum (row_shr:1, 0 enters lane 0)
+        float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
+            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
+            ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
+            mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
+        }
+        const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
+        const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
+        const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
+        if (j16 == 1 && jj < ntasks) {
+            atomicMin(&tb.best_s[rr], trk::dist_key(da, ka));
+            atomicMin(&tb.best_s[rr], trk::dist_key(db, kb2));
+            tb.zz_s[rr] = zz;
+        }
+    }
+    lds_order_wave();
+    int o_best = 0;
+    if ((F.o_open || F.o_hard) && !F.o_bad) {
+        const unsigned long long bk = tb.best_s[lane];
+        if (bk != ~0ull) o_best = (int)(unsigned)bk; else F.o_bad = true;   // no task came back (cannot happen): scalar path
+    }
+    if (F.o_bad) {
+        // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
+        const float zz = tb.zz_s[lane];                                   // every flagged row had a task
+        int best = 0;
+        if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
+            float bd = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                float m = 0.0f;
+                for (int c = 0; c < D; ++c) m = __builtin_fmaf(zscalar(lane, c), cb[(size_t)k * D + c], m);
+                const float d = (zz + ee_g[k]) - 2.0f * m;
+                const bool dn = d != d, bn = bd != bd;
+                if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
+            }
+        }
+        o_best = best;
+    }
+    const int k0n = __shfl(o_best, l31), k1n = __shfl(o_best, 32 + l31);
+    if (R.openf[0] || R.hardf[0] || R.bad[0]) R.kbest[0] = k0n;
+    if (R.openf[1] || R.hardf[1] || R.bad[1]) R.kbest[1] = k1n;
+    (void)inf;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- epilogue: gather, z + (e_k - z), squared error, z_q stores, index, histogram -> the unit's squared error (this lane) ---
+// frow(t, i) -> floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the unit (the coalesced load layout); zq_unit: z_q of the
+// unit's first row (or NULL); nleft: rows of the unit that exist; idx_unit: index of its first row
+template <class FRow>
+__device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
+                                          float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
+                                          int *__restrict__ hist_s) {
+    constexpr int D = 64, T = 2, RU = 64;
+    const int l31 = lane & 31, h = lane >> 5, j16 = lane & 15, g4 = lane >> 4;
+    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
+    f32x4 ev[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kr = __builtin_amdgcn_ds_bpermute((4 * i + g4) << 2, R.kbest[t]);
+            ev[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr * (D * 4) + (unsigned)j16 * 16u, 0, 0));
+        }
+    // the descriptor covers exactly the unit's existing rows: stores of rows past the end are dropped by the hardware
+    const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq_unit ? zq_unit : const_cast<float *>(cb), 0,
+                                                         zq_unit ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
+    // Store offsets: four lane bases 4 KiB apart + an immediate, NO scalar offset register.  hipcc (ROCm 7.2) does not
+    // guard a 16-byte buffer store whose soffset is an SGPR against the next vector instruction overwriting its data
+    // registers (LLVM exempts that form from the store-data hazard); on gfx950 the overwrite corrupted the last dword
+    // of lanes 12..15 of each row here.  Without an soffset register the compiler inserts the wait states itself
+    // (tools/hazard_scan.py checks the assembly of every source for this pattern; tests/test_build_hazards.py runs it).
+    unsigned vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vo[k] = (unsigned)lane * 16u + 4096u * k;
+        asm volatile("" : "+v"(vo[k]));
+    }
+    float sacc = 0.0f;
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 zv = frow(t, i), e = ev[t][i];
+            const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
+            f32x4 o;
+            o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
+            const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+            if (nleft == RU) sacc += sq;                   // fp32 over the unit's 16 groups, one fp64 add per unit
+            else sacc += 32 * t + 4 * i + g4 < nleft ? sq : 0.0f;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
+        }
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+        if (R.valid[t] && h == 0) {
+            idx_unit[32 * t + l31] = R.kbest[t];
+            atomicAdd(&hist_s[R.kbest[t]], 1);
+        }
+    return sacc;
+}
+
+}  // namespace vqu
+}  // namespace vqvae
