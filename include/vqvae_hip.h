@@ -89,6 +89,10 @@ VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launch
                                         chip at 262 144 rows, no faster inside the forward, and its 92 spilled registers cost 1.6x the
                                         algorithmic traffic: not the default */
 
+#define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
+                                        kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 512, D = 64: z_e is
+                                        then never written); identical outputs, A/B timing and tests */
+
 /* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" / "vq_sweep_kernel_d64" (codebook image
  * resident in LDS: D = 64, K <= ~600), "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
  * "vq_filter_kernel_d64", "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix

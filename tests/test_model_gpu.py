@@ -488,3 +488,50 @@ def test_model_pickles_and_deepcopies_after_a_forward():
             out_s = m(x)
         s.synchronize()
         assert torch.equal(out_s[1], ref[1])
+
+
+@pytest.mark.parametrize("B", [4096, 37, 1])
+def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B):
+    """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the
+    encoder's last kernel (conv_res_pair8_h2_kernel<2, true>: z_e never leaves the chip).  Same z_e bits, same tracker,
+    same exact part as the separate launch (VQVAE_VQ_UNFUSED): indices and x_hat must be BITWISE equal, loss / perplexity
+    equal to summation order (rtol 1e-6); ragged batches leave waves of the four-image workgroups idle."""
+    from vqvae_amd import functional as F
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev())
+    with torch.no_grad():
+        a = m._forward_c(x, want_idx=True)
+        b = m._forward_c(x, want_idx=True, vq_flags=F.VQ_UNFUSED)
+    torch.cuda.synchronize()
+    assert torch.equal(a[3], b[3]), f"{int((a[3] != b[3]).sum())} indices differ"
+    assert torch.equal(a[1], b[1])
+    np.testing.assert_allclose(a[0].item(), b[0].item(), rtol=1e-6)
+    np.testing.assert_allclose(a[2].item(), b[2].item(), rtol=1e-6)
+
+
+def test_quantizer_inside_the_encoder_kernel_hard_and_nonfinite_rows():
+    """The fused quantizer's rare paths: a codebook with duplicated / near-tied codes (rows that are open, and rows whose
+    candidates the stream x cell products do not cover -> the workgroup streams the codebook stages again) and images that
+    drive z_e to Inf / NaN (scalar torch.argmin path); against the separate launch, bit for bit."""
+    from vqvae_amd import functional as F
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(1)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    with torch.no_grad():
+        cb = m.vector_quantization.embedding.weight
+        cb[8:16] = cb[0:8]                                   # exact duplicates: ties, first index wins
+        cb[16:48] = cb[0:1] + 1e-9 * torch.randn(32, 64, device=dev())    # a cluster of 32 near-ties around code 0
+        cb[100:164] = cb[300:301] * (1 + 1e-7 * torch.arange(64, device=dev()).view(-1, 1))
+    m.invalidate_caches()
+    x = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(4)).to(dev())
+    x[5] *= 1e20                                             # z_e overflows: Inf / NaN rows
+    x[9, 0, 0, 0] = float("nan")
+    with torch.no_grad():
+        a = m._forward_c(x, want_idx=True)
+        b = m._forward_c(x, want_idx=True, vq_flags=F.VQ_UNFUSED)
+    torch.cuda.synchronize()
+    assert torch.equal(a[3], b[3]), f"{int((a[3] != b[3]).sum())} indices differ"
+    fin = torch.isfinite(b[1])
+    assert torch.equal(torch.isfinite(a[1]), fin) and torch.equal(a[1][fin], b[1][fin])

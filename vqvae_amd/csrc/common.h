@@ -41,7 +41,7 @@ struct VqPlan {
     int KC;           // codes per LDS chunk (multiple of 32)
     int nchunks;      // ceil(K / KC)
     int K_pad;        // nchunks * KC
-    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, off_imgh, off_seeds, off_chunk, total;
+    size_t off_flags, off_ee, off_img, off_partials, off_img16, off_neh, off_imgh, off_seeds, off_imgf, off_chunk, total;
     size_t lds_bytes;
     // filter-and-refine kernel (bf16 screening): usable when the whole bf16 image fits LDS
     bool filter_ok;
@@ -80,7 +80,9 @@ inline VqPlan vq_plan(int K, int D) {
     p.off_imgh = align_up(p.off_neh + (size_t)p.K32 * 4, 256);        // fp16 image + seeds of the single-sweep kernel
     // (+ 512 codes / 4 KiB of padding: the streamed-codebook kernel copies whole chunks)
     p.off_seeds = align_up(p.off_imgh + (size_t)(p.K32 + 512) * D * 2, 256);
-    p.off_chunk = align_up(p.off_seeds + (size_t)p.K32 * 4 + 4096, 256);
+    // the same fp16 image in the fused conv kernels' channel order (the quantizer inside the encoder's last kernel, D = 64)
+    p.off_imgf = align_up(p.off_seeds + (size_t)p.K32 * 4 + 4096, 256);
+    p.off_chunk = align_up(p.off_imgf + (size_t)(p.K32 + 512) * D * 2, 256);
     // row scratch of the streamed-codebook kernels: only where they are the default path
     p.total = p.off_chunk + ((vq_chunk_ok(K, D) && !vq_sweep_ok(K, D)) ? vq_chunk_scratch_bytes(D) : 0);
     // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
@@ -115,7 +117,16 @@ int res_layer_forward_impl(const float *x, const float *packed_w1, const float *
 bool res_pair_supported(int H, int W, int C, int Rh, int flags);
 // a 1x1 conv (+ bias) fused behind a residual pair: packed = vqvae_conv_pack_f32(VQVAE_CONV_1x1, ...), out (B,8,8,Cout) row-major
 // zero / zero_n (conv_res_pair_forward_impl only): ints the kernel clears for the next kernel of the stream
-struct ResPairPost { const float *packed; const float *bias; int Cout; float *out; int *zero = nullptr; int zero_n = 0; };
+// The quantizer inside the encoder's last kernel (conv_res_pair8_h2_kernel<2, true>, models/vqvae.py:33-34 in one launch):
+// the codebook's prepared images (vq_prepare_impl: fp16 image in that kernel's channel order, seeds, ||e||^2, bound
+// statistics), the codebook itself and where the quantizer's outputs go.  K32 must be a multiple of 128, K <= 512, D = 64.
+struct VqFuse {
+    const uint4 *imgf; const float *seeds; const float *ee; const int *flags; const float *cb;
+    int K, K32;
+    float *zq; long long *idx; int *hist; double *partials;
+};
+struct ResPairPost { const float *packed; const float *bias; int Cout; float *out; int *zero = nullptr; int zero_n = 0;
+                     const VqFuse *vq = nullptr; };
 bool res_pair_post_supported(int C, int Cout);
 int res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                           int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
@@ -127,13 +138,19 @@ int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_fro
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)
+// the pieces of vq_forward_impl around its main kernel, for the whole-path entry that quantizes inside the encoder's last kernel
+bool vq_fuse_ok(int K, int D, int64_t B, int flags);
+int vq_prepare_impl(const float *codebook, int K, int D, int flags, void *workspace, size_t workspace_bytes, hipStream_t st);
+VqFuse vq_fuse_args(const float *codebook, int K, void *workspace, float *z_q, int64_t *idx, int32_t *hist);
+int vq_finalize_impl(void *workspace, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss, float *perplexity,
+                     hipStream_t st);
 int vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W, int K, float beta, int flags,
                     float *z_q, int64_t *idx, int32_t *hist, float *loss, float *perplexity, void *workspace,
                     size_t workspace_bytes, vqvae_stream_t stream, bool hist_zeroed);
 bool enc_front_supported(int H, int W, int Cin, int C1, int C2);
 int enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
                            const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,
-                           int *out_amax);
+                           int *out_amax, int *zero_buf = nullptr, int zero_n = 0);
 bool dec_tail_supported(int h4, int w4, int C, int C1, int Cout);
 int dec_tail_forward_impl(const float *x, const float *packed2, const float *bias2, const float *packed4, const float *bias4,
                           int64_t B, int h4, int w4, int C, int C1, int Cout, float *y_nchw, hipStream_t st, const int *in_amax);

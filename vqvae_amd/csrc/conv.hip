@@ -27,6 +27,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "vq_unit.h"
 
 namespace vqvae {
 
@@ -381,6 +382,7 @@ __device__ __forceinline__ void prod6x2(const u32x4 &s1, const u32x4 &s2, const 
 // error 2^-25 in scaled units = 2^-40 of the maximum), which is invisible next to the fp32 accumulation itself.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2_h(float a, float b, unsigned &p1, unsigned &p2) {
     const f16x2 h = {(_Float16)a, (_Float16)b};                      // v_cvt_pk_f16_f32, round to nearest even
@@ -1946,7 +1948,7 @@ __device__ __forceinline__ void prod3x2t(const u32x4 &s1, const u32x4 &s2, const
 #define CRP_MINW 2      // waves per SIMD the register allocation must allow (tools/build_variant.py crp1 -DCRP_MINW=1: 388 registers, no
                         // scratch, one workgroup per CU)
 #endif
-template <int NT3>
+template <int NT3, bool VQ = false>
 __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
                                                                    const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
                                                                    float *__restrict__ out, int B, int flags,
@@ -1954,8 +1956,9 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                                                                    const int *__restrict__ in_amax, int *__restrict__ out_amax,
                                                                    const u32x4 *__restrict__ w3img, const int *__restrict__ hdr3,
                                                                    const float *__restrict__ bias3, float *__restrict__ out3,
-                                                                   int *__restrict__ zero_buf, int zero_n) {
+                                                                   int *__restrict__ zero_buf, int zero_n, VqFuse vq) {
     static_assert(NT3 == 0 || NT3 == 1 || NT3 == 2 || NT3 == 4, "the 1x1 post conv streams through NT3 weight stages of 16 KiB");
+    static_assert(!VQ || (NT3 == 2 && CRP_NW == 4), "the fused quantizer takes the 64-channel z_e of four images per workgroup");
     constexpr int NT2 = 4, C = 128, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // front conv: [k-step 2][term 2][half 2][pixel + zero] = 520 units
     constexpr int RBUF = 4 * HP;                           // residual slice: [term 2][half 2][pixel + zero]; two buffers = TILE4
@@ -1966,8 +1969,17 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     // (16 pieces); then the 1x1 post conv in NT3 parts of 4 / NT3 channel tiles (16 pieces each).  Per-wave loads straight from L2 cost 87 + 51 us
     // per step in exposed latency (knock-outs, profiles/r02_vq_stream.txt).
     constexpr int WBUF = 18 * 64;
-    constexpr int NSTAGE = 18 + NT3;                       // stages after the front conv
+    // stages after the front conv: 18 (two residual layers) + NT3 (post conv) + (VQ) one per four 32-code tiles of the codebook
+    const int nvq = VQ ? (vq.K32 >> 7) : 0;
+    const int NSTAGE = 18 + NT3 + nvq;
     __shared__ u32x4 Wb_all[2 * WBUF];
+    // fused quantizer: per-wave tables (vq_unit.h), the workgroup's histogram and loss partials
+    __shared__ __attribute__((aligned(16))) unsigned char vq_tab_all[VQ ? CRP_NW * 1040 : 16];
+    __shared__ int vq_hist_s[VQ ? 512 : 1];
+    __shared__ double vq_red_s[VQ ? CRP_NW : 1];
+    if constexpr (VQ) {
+        for (int i = threadIdx.x; i < vq.K; i += CRP_NW * 64) vq_hist_s[i] = 0;        // (a stage barrier precedes every use)
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -2026,7 +2038,13 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     };
     // stage k after the front conv: 9 LI + slice (3x3 of layer LI), 9 LI + 8 (its 1x1), 18 + j (part j of the post conv)
     auto dma_stage = [&](int k, int buf) {
-        if (k >= 18) dma_linear(w3img + (size_t)(k - 18) * 1024, buf);
+        if (VQ && k >= 18 + NT3) {
+            // four 32-code tiles of the codebook's fp16 image (16 pieces) + their seeds -A ee / 2 (512 bytes of piece 16)
+            const int j = k - (18 + NT3);
+            dma_linear(reinterpret_cast<const u32x4 *>(vq.imgf) + (size_t)j * 1024, buf);
+            if (wave_u == 0) dma(reinterpret_cast<const u32x4 *>(vq.seeds) + (size_t)j * 32 + lane, Wb_all + buf * WBUF + 16 * 64);
+        }
+        else if (k >= 18) dma_linear(w3img + (size_t)(k - 18) * 1024, buf);
         else if (k % 9 == 8) dma_linear(w2img, buf);
         else dma_slice(k % 9, buf);
     };
@@ -2314,6 +2332,175 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     prod3x2t(T1[0][t], T2[0][t], T1[1][t], T2[1][t], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
                 }
         }
+        if constexpr (VQ) {
+            // ================= the quantizer on z_e = this image's 64 rows, straight from the accumulators =================
+            // (models/vqvae.py:33-34: z_e is never written.)  acc3 <- z_e: lane = row 32 mt + l31, register = channel
+            // 32 n3 + (r & 3) + 8 (r >> 2) + 4 h.  The codebook's fp16 image streams through the weight stages (four 32-code
+            // tiles + their seeds per stage, the image in THIS kernel's channel order: vq_prepare16_kernel's `imgf`); the sweep,
+            // the trackers and everything behind them are vq_track.hip's (vq_track.h / vq_unit.h).
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
+                        if (bias3) bv = *reinterpret_cast<const f32x4 *>(bias3 + n3 * 32 + 8 * g + 4 * h);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) acc3[mt][n3][4 * g + q] = acc3[mt][n3][4 * g + q] * d3 + bv[q];
+                    }
+            // fp16 B operands of the screen: k-step ks = 2 n3 + t, this half's channels 32 n3 + 16 h + 8 t + [0, 8)
+            u32x4 zb[MT][4];
+            float zn2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float sq = 0.0f;
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float P[4], Q[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            P[q] = acc3[mt][n3][4 * t + q];
+                            Q[q] = acc3[mt][n3][8 + 4 * t + q];
+                            swap_halves(P[q], Q[q]);
+                        }
+                        u32x4 v;
+                        v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{P[0], P[1]}), f16x2));
+                        v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{P[2], P[3]}), f16x2));
+                        v.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{Q[0], Q[1]}), f16x2));
+                        v.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{Q[2], Q[3]}), f16x2));
+                        zb[mt][2 * n3 + t] = v;
+                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), sq, false);
+                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), sq, false);
+                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), sq, false);
+                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), sq, false);
+                    }
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+                zn2[mt] = sq + __uint_as_float(h ? sw[0] : sw[1]);
+            }
+            const float inf = __builtin_inff();
+            float pinf = inf, ninf = -inf;
+            unsigned keymask = trk::kKeyMask;
+            asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
+            trk::Lane L[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) trk::init(L[mt], ninf);
+            // one stage = four code tiles: [tile][k-step 4][half 2][code 32] x 16 bytes, seeds [tile][half][16] floats in piece 16
+            auto sweep_stage = [&](const u32x4 *wb, const float *sd, int j, auto &&use) {
+#pragma unroll
+                for (int ctl = 0; ctl < 4; ++ctl) {
+                    f32x16 seed;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sd + ctl * 32 + h * 16 + 4 * g);
+                        seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
+                    }
+                    u32x4 a[4];
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) a[ks] = wb[ctl * 256 + ks * 64];
+                    use(4 * j + ctl, a, seed);
+                }
+            };
+            for (int j = 0; j < nvq; ++j) {
+                const u32x4 *wb = stage_sync(18 + NT3 + j);
+                const float *sd = reinterpret_cast<const float *>(wb - lane + 16 * 64);
+                sweep_stage(wb, sd, j, [&](int ct, const u32x4(&a)[4], const f32x16 &seed) {
+                    f32x16 acc[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, zb[mt][0]), seed, 0, 0, 0);
+#pragma unroll
+                        for (int ks = 1; ks < 4; ++ks)
+                            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks]), __builtin_bit_cast(f16x8, zb[mt][ks]), acc[mt], 0, 0, 0);
+                    }
+                    unsigned cell0 = (unsigned)(2 * ct), cell1 = cell0 + 1u;
+                    asm volatile("" : "+s"(cell0), "+s"(cell1));
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) trk::tile(L[mt], acc[mt], cell0, cell1, keymask, ninf, pinf);
+                });
+            }
+            // ---- verdicts; exact tasks
+            vqu::Tables tb = vqu::tables(vq_tab_all + wave_u * 1040);
+            const vqu::Bound bound = vqu::load_bound(vq.flags);
+            vqu::Rows R;
+            R.valid[0] = img_ok;
+            R.valid[1] = img_ok;
+            vqu::classify(L, zn2, bound, vq.K, lane, ninf, tb.task_s, R);
+            vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
+            int ntasks = FL.ndirect;
+            // rows whose candidates the stream x cell products do not cover (~0.01 %) need the codebook image once more: the
+            // workgroup votes, and if any of its waves has one, all four stream the stages again (the others only keep the barriers)
+            const bool rescan_me = FL.hmask && FL.ndirect <= 64;
+            if (__syncthreads_or(rescan_me ? 1 : 0)) {
+                dma_stage(18 + NT3, 0);
+                for (int j = 0; j < nvq; ++j) {
+                    dma_wait_sync();
+                    if (j + 1 < nvq) dma_stage(18 + NT3 + j + 1, (j + 1) & 1);
+                    if (rescan_me) {
+                        const u32x4 *wb = Wb_all + (j & 1) * WBUF + lane;
+                        const float *sd = reinterpret_cast<const float *>(Wb_all + (j & 1) * WBUF + 16 * 64);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            if ((unsigned)(FL.hmask >> (32 * mt))) {
+                                const float thr_t = R.hardf[mt] ? R.thr[mt] : inf;
+                                sweep_stage(wb, sd, j, [&](int ct, const u32x4(&a)[4], const f32x16 &seed) {
+                                    f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, zb[mt][0]), seed, 0, 0, 0);
+#pragma unroll
+                                    for (int ks = 1; ks < 4; ++ks)
+                                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks]), __builtin_bit_cast(f16x8, zb[mt][ks]), acc, 0, 0, 0);
+                                    vqu::rescan_tile(acc, thr_t, ct, mt, lane, vq.K, FL.ndirect, ninf, tb);
+                                });
+                            }
+                    }
+                }
+                if (rescan_me) {
+                    lds_order_wave();
+                    ntasks = FL.ndirect + tb.cnt_s[0];
+                }
+            }
+            __syncthreads();                        // every wave is done with the weight buffers: they hold half of the rows now
+            // ---- z_e rows (fp32) -> LDS: rows 0..31 in this wave's plane region, 32..63 in its quarter of the weight buffers;
+            // 256 bytes per row, the 16-byte chunk c of row r at slot c ^ (r & 15)
+            unsigned char *zlo = reinterpret_cast<unsigned char *>(As);
+            unsigned char *zhi = reinterpret_cast<unsigned char *>(Wb_all) + (size_t)wave_u * 9216;
+            auto zchunk = [&](int row, int c16) -> f32x4 * {
+                unsigned char *b = row < 32 ? zlo + row * 256 : zhi + (row - 32) * 256;
+                return reinterpret_cast<f32x4 *>(b + (((unsigned)c16 ^ ((unsigned)row & 15u)) << 4));
+            };
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *zchunk(32 * mt + l31, 8 * n3 + 2 * g + h) = f32x4{acc3[mt][n3][4 * g], acc3[mt][n3][4 * g + 1], acc3[mt][n3][4 * g + 2], acc3[mt][n3][4 * g + 3]};
+            lds_order_wave();
+            vqu::exact_end(R, FL, ntasks, lane, tb, vq.cb, vq.ee, vq.K,
+                           [&](int rr, int jc) { return *zchunk(rr, jc); },
+                           [&](int rr, int c) { return reinterpret_cast<const float *>(zchunk(rr, c >> 2))[c & 3]; });
+            const int j16 = lane & 15, g4 = lane >> 4;
+            const float sacc = vqu::epilogue(R, lane, vq.cb, vq.K, [&](int t, int i) { return *zchunk(32 * t + 4 * i + g4, j16); },
+                                             (img_ok && vq.zq) ? vq.zq + (size_t)img * PX * 64 : nullptr, img_ok ? PX : 0,
+                                             vq.idx + (size_t)(img_ok ? img : 0) * PX, vq_hist_s);
+            // loss partial and histogram of the workgroup (fixed order: run-to-run bitwise loss / perplexity)
+            double dacc = img_ok ? (double)sacc : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+            if (lane == 0) vq_red_s[wave_u] = dacc;
+            __syncthreads();
+            if (tid == 0) {
+                double sum = 0.0;
+                for (int w = 0; w < CRP_NW; ++w) sum += vq_red_s[w];
+                vq.partials[blockIdx.x] = sum;
+            }
+            for (int k = tid; k < vq.K; k += CRP_NW * 64) {
+                const int c = vq_hist_s[k];
+                if (c) atomicAdd(&vq.hist[k], c);
+            }
+        } else
         if (img_ok) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -2364,8 +2551,11 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
                                                                const int *__restrict__ hdr0, const float *__restrict__ bias0,
                                                                const u32x4 *__restrict__ w2img, const int *__restrict__ hdr2,
                                                                const float *__restrict__ bias2, float *__restrict__ out, int B,
-                                                               int *__restrict__ out_amax) {
+                                                               int *__restrict__ out_amax, int *__restrict__ zero_buf, int zero_n) {
     constexpr int NT = 4, MT = 2, PX = 64, HP = PX + 1, PLANE = HP * 2, C0 = 64, C = 128;
+    // ints a LATER kernel of the stream wants zeroed (the quantizer's histogram when the encoder's last kernel quantizes)
+    if (zero_buf && blockIdx.x == 0)
+        for (int i = threadIdx.x; i < zero_n; i += 256) zero_buf[i] = 0;
     constexpr int TILE4 = 2 * 2 * PLANE;                   // [k-step 2][term 2][half 2][pixel + zero] = 520 units
     constexpr int WBUF = 16 * 64, NSTAGE = 32;             // a stage = one (chunk, tap) of the second conv: 16 pieces of 1 KiB
     __shared__ u32x4 As_all[4 * TILE4];
@@ -4123,6 +4313,8 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     ConvGeom g3;
     if (post && (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout) ||
                  make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK)) return VQVAE_ERR_UNSUPPORTED;
+    if (post && post->vq && (post->Cout != 64 || CRP_NW != 4 || post->vq->K32 % 128 || post->vq->K32 > 512 || gtc > (unsigned)kVqMaxGrid))
+        return VQVAE_ERR_UNSUPPORTED;
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {
         const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
@@ -4130,7 +4322,12 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         const int *hd3 = reinterpret_cast<const int *>(h3);
 #define CRP_POST(NT3_)                                                                                                          \
     hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
-                       in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n)
+                       in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n, VqFuse{})
+        if (post->vq) {
+            // the quantizer rides behind the 1x1 conv: z_e is never written (post->out unused)
+            hipLaunchKernelGGL((conv_res_pair8_h2_kernel<2, true>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags,
+                               hd1, hd2, in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n, *post->vq);
+        } else
         switch (post->Cout / 32) {
             case 1: CRP_POST(1); break;
             case 2: CRP_POST(2); break;
@@ -4139,7 +4336,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
 #undef CRP_POST
     } else {
         hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
-                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0);
+                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, VqFuse{});
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();
@@ -4194,7 +4391,7 @@ bool vqvae::enc_front_supported(int H, int W, int Cin, int C1, int C2) { return 
 
 int vqvae::enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
                                   const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,
-                                  int *out_amax) {
+                                  int *out_amax, int *zero_buf, int zero_n) {
     if (!x_nchw || !packed_in || !packed2 || !y) return VQVAE_ERR_NULL;
     if (B < 1 || !enc_front_supported(H, W, Cin, C1, C2)) return VQVAE_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;
@@ -4208,7 +4405,7 @@ int vqvae::enc_front_forward_impl(const float *x_nchw, const float *packed_in, c
     prof_begin(VQVAE_PROF_CONV_IGEMM, st);
     hipLaunchKernelGGL((enc_front8_h2_kernel<3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x_nchw,
                        reinterpret_cast<const u32x4 *>(h0 + kH2Header), reinterpret_cast<const int *>(h0), bias_in, w2s2d,
-                       reinterpret_cast<const int *>(h2), bias2, y, (int)B, out_amax);
+                       reinterpret_cast<const int *>(h2), bias2, y, (int)B, out_amax, zero_buf, zero_n);
     prof_end(VQVAE_PROF_CONV_IGEMM, st);
     return (int)hipGetLastError();
 }

@@ -178,9 +178,10 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
 // am_given: a maxima region (amax_bytes) the caller has already set to -1, or NULL to carve and initialise one here
 // zero_buf / zero_n / zeroed: ints the last encoder kernel should clear for the quantizer behind it (its histogram);
 // *zeroed tells the caller whether a kernel that can do so ran
+// vq: quantize inside the last kernel (fused 32x32 path only; z_e is then NOT written and zero_buf is cleared by the FIRST kernel)
 static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, int *zero_buf = nullptr, int zero_n = 0,
-                       bool *zeroed = nullptr, bool am_exclusive = false) {
+                       bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr) {
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return VQVAE_ERR_SHAPE;
@@ -203,7 +204,8 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
 #ifndef VQVAE_NO_ENC_FRONT_FUSION    // A/B builds (tools/build_variant.py)
     // encoder.py:29-34 in ONE launch on 32x32 RGB images: the 16x16 x h/2 map between the two stride-2 convs is never written
     if (enc_front_supported(H, W, d->in_ch, h / 2, h)) {
-        if ((rc = enc_front_forward_impl(x, w->enc0, w->enc0_b, w->enc2, w->enc2_b, B, H, W, d->in_ch, h / 2, h, b, st, am1)) != 0) return rc;
+        if ((rc = enc_front_forward_impl(x, w->enc0, w->enc0_b, w->enc2, w->enc2_b, B, H, W, d->in_ch, h / 2, h, b, st, am1,
+                                         vq ? zero_buf : nullptr, vq ? zero_n : 0)) != 0) return rc;
     } else
 #endif
     {
@@ -215,7 +217,7 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
     if (d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
         res_pair_post_supported(h, d->embedding_dim)) {
-        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, zero_buf, zero_n};
+        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, vq ? nullptr : zero_buf, vq ? 0 : zero_n, vq};
         if (zeroed) *zeroed = zero_buf != nullptr;
         return conv_res_pair_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, h, w->enc_res_w1, w->enc_res_w2, B, H / 4, W / 4, h,
                                           d->res_h_dim, VQVAE_CONV_RELU_OUT, nullptr, st, am1, nullptr, &post);
@@ -356,6 +358,16 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(am2) + amax_bytes(d, B));
     int rc;
     bool hist_zeroed = false;
+    if (fused && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
+        // vqvae.py:31-34 in TWO launches: the encoder's last kernel quantizes its own z_e (never written); the codebook's
+        // images are prepared first, the histogram is cleared by the encoder's first kernel, loss / perplexity by the finalize
+        if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, vqws, vqws_bytes, st)) != 0) return rc;
+        const VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, vqws, z_q, idx ? idx : idx_ws, hist);
+        if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, hist, d->n_embeddings, &hist_zeroed, false, &vf)) != 0) return rc;
+        if ((rc = vq_finalize_impl(vqws, (int)((B + 3) / 4), hist, d->n_embeddings, (int64_t)rows, d->embedding_dim, d->beta, loss,
+                                   perplexity, st)) != 0) return rc;
+        return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                         // :36
+    }
     if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed)) != 0)
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,

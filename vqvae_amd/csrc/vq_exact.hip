@@ -433,6 +433,21 @@ __global__ __launch_bounds__(256) void vq_decode_indices_kernel(const long long 
 }
 
 // ---------------------------------------------------------------------------
+// codebook images and bound statistics into the workspace (every kernel family's)
+template <int D>
+static int launch_vq_prepare(const float *cb, int K, char *ws, hipStream_t st) {
+    const VqPlan p = vq_plan(K, D);
+    int *wflags = reinterpret_cast<int *>(ws + p.off_flags);
+    hipError_t e;
+    if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
+    const int kmax = p.K_pad > p.K32 ? p.K_pad : p.K32;
+    hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((kmax + 63) / 64), dim3(64), 0, st, cb, K, p.KC, p.K_pad,
+                       reinterpret_cast<float *>(ws + p.off_ee), reinterpret_cast<float *>(ws + p.off_img), wflags, p.K32,
+                       reinterpret_cast<unsigned short *>(ws + p.off_img16), reinterpret_cast<float *>(ws + p.off_neh));
+    if (vq_sweep_ok(K, D) || vq_chunk_ok(K, D)) launch_vq_prepare16(cb, K, D, ws, st);
+    return (int)hipGetLastError();
+}
+
 template <int D>
 static int launch_vq(const float *z, const float *cb, long long N, int HW, int K, float beta,
                      int flags, float *zq, long long *idx, int *hist, float *loss, float *ppl,
@@ -447,13 +462,8 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     // (hist_zeroed: the kernel in front of this one in the stream has cleared it -- vqvae_forward_f32's fused path)
     if (!hist_zeroed && (e = hipMemsetAsync(hist, 0, sizeof(int) * (size_t)K, st)) != hipSuccess) return (int)e;
     if (!(flags & VQVAE_VQ_CODEBOOK_PREPARED)) {
-        if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
-        const int kmax = p.K_pad > p.K32 ? p.K_pad : p.K32;
-        hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((kmax + 63) / 64), dim3(64), 0, st, cb, K, p.KC,
-                           p.K_pad, ee, img, wflags, p.K32,
-                           reinterpret_cast<unsigned short *>(ws + p.off_img16),
-                           reinterpret_cast<float *>(ws + p.off_neh));
-        if (vq_sweep_ok(K, D) || vq_chunk_ok(K, D)) launch_vq_prepare16(cb, K, D, ws, st);
+        const int rc = launch_vq_prepare<D>(cb, K, ws, st);
+        if (rc != 0) return rc;
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
     if constexpr (D == 64) {
@@ -566,6 +576,47 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
                                   workspace_bytes, stream, false);
 }
 }  // extern "C"
+
+// ---- the quantizer inside the encoder's last kernel (conv.hip): what vqvae_forward_f32 does around that launch ---------
+bool vqvae::vq_fuse_ok(int K, int D, int64_t B, int flags) {
+    const VqPlan p = vq_plan(K > 0 ? K : 1, 64);
+    return D == 64 && K >= 1 && K <= 512 && p.K32 % 128 == 0 && vq_track_ok(K, D) && (B + 3) / 4 <= kVqMaxGrid &&
+           !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES | VQVAE_VQ_UNFUSED));
+}
+
+int vqvae::vq_prepare_impl(const float *codebook, int K, int D, int flags, void *workspace, size_t workspace_bytes, hipStream_t st) {
+    if (!codebook || !workspace) return VQVAE_ERR_NULL;
+    if (D != 64 || K < 1 || K > 16384) return VQVAE_ERR_UNSUPPORTED;
+    if (workspace_bytes < vqvae_vq_workspace_bytes(0, K, D)) return VQVAE_ERR_WORKSPACE;
+    if (flags & VQVAE_VQ_CODEBOOK_PREPARED) return VQVAE_OK;
+    return launch_vq_prepare<64>(codebook, K, static_cast<char *>(workspace), st);
+}
+
+vqvae::VqFuse vqvae::vq_fuse_args(const float *codebook, int K, void *workspace, float *z_q, int64_t *idx, int32_t *hist) {
+    const VqPlan p = vq_plan(K, 64);
+    char *ws = static_cast<char *>(workspace);
+    VqFuse f;
+    f.imgf = reinterpret_cast<const uint4 *>(ws + p.off_imgf);
+    f.seeds = reinterpret_cast<const float *>(ws + p.off_seeds);
+    f.ee = reinterpret_cast<const float *>(ws + p.off_ee);
+    f.flags = reinterpret_cast<const int *>(ws + p.off_flags);
+    f.cb = codebook;
+    f.K = K;
+    f.K32 = p.K32;
+    f.zq = z_q;
+    f.idx = reinterpret_cast<long long *>(idx);
+    f.hist = hist;
+    f.partials = reinterpret_cast<double *>(ws + p.off_partials);
+    return f;
+}
+
+int vqvae::vq_finalize_impl(void *workspace, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss,
+                            float *perplexity, hipStream_t st) {
+    const VqPlan p = vq_plan(K, D);
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<double *>(static_cast<char *>(workspace) + p.off_partials),
+                       grid, hist, K, (long long)n_rows, D, beta, loss, perplexity);
+    return (int)hipGetLastError();
+}
 
 int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W,
                            int K, float beta, int flags, float *z_q, int64_t *idx, int32_t *hist,

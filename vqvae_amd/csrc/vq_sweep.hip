@@ -61,7 +61,8 @@ constexpr float kPadSeed = -3.0e38f;          // padded codes: finite (a key mus
 template <int D>
 __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restrict__ cb, const float *__restrict__ ee,
                                                           int K, int K32, int *__restrict__ flags,
-                                                          unsigned short *__restrict__ img, float *__restrict__ seeds) {
+                                                          unsigned short *__restrict__ img, float *__restrict__ seeds,
+                                                          unsigned short *__restrict__ imgf) {
     const int k = blockIdx.x * 64 + threadIdx.x;
     if (k >= K32) return;
     const float emax = __int_as_float(flags[2]);
@@ -89,6 +90,13 @@ __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restric
         }
         unsigned short *dst = img + ((size_t)(ct * (D / 8) + c8) * 32 + i) * 8;
         for (int j = 0; j < 8; ++j) dst[j] = v[j];
+        if (imgf) {
+            // the fused conv kernels' channel order (conv.hip, acc_to_ksteps): k-step 2 n3 + t, half h holds channels
+            // 32 n3 + 16 h + 8 t + [0, 8) -- chunk c8 = 4 n3 + 2 h + t moves to position 4 n3 + 2 t + h
+            const int c8f = (c8 & ~3) | ((c8 & 1) << 1) | ((c8 >> 1) & 1);
+            unsigned short *dstf = imgf + ((size_t)(ct * (D / 8) + c8f) * 32 + i) * 8;
+            for (int j = 0; j < 8; ++j) dstf[j] = v[j];
+        }
     }
     float seed = kPadSeed;
     if (k < K) {
@@ -835,8 +843,10 @@ void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st
     int *fl = reinterpret_cast<int *>(ws + p.off_flags);
     unsigned short *img = reinterpret_cast<unsigned short *>(ws + p.off_imgh);
     float *seeds = reinterpret_cast<float *>(ws + p.off_seeds);
-    if (D == 64) hipLaunchKernelGGL(vq_prepare16_kernel<64>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds);
-    else hipLaunchKernelGGL(vq_prepare16_kernel<128>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds);
+    unsigned short *imgf = reinterpret_cast<unsigned short *>(ws + p.off_imgf);
+    if (D == 64) hipLaunchKernelGGL(vq_prepare16_kernel<64>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds, imgf);
+    else hipLaunchKernelGGL(vq_prepare16_kernel<128>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds,
+                            static_cast<unsigned short *>(nullptr));
 }
 
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,

@@ -15,6 +15,7 @@ VQ_EXACT_SWEEP = 0x4
 VQ_BF16_FILTER = 0x8
 VQ_TOP3_KEYS = 0x10
 VQ_SIXTEEN_WAVES = 0x20
+VQ_UNFUSED = 0x40
 
 
 def _stream_ptr(t: torch.Tensor) -> int:

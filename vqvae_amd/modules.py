@@ -261,8 +261,9 @@ class VQVAE(nn.Module):
         _cache.side(self)["c_weights"] = (key, cw, (keep, packed))
         return cw, (keep, packed)
 
-    def _forward_c(self, x, want_idx=False):
-        """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32)."""
+    def _forward_c(self, x, want_idx=False, vq_flags=0):
+        """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32).  vq_flags: extra quantizer flags for tests and
+        A/B runs (functional.VQ_UNFUSED: the quantizer as its own launch where the encoder's last kernel would quantize)."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
@@ -291,7 +292,7 @@ class VQVAE(nn.Module):
             x_hat = torch.empty_like(x)
             scal = torch.empty(2, dtype=torch.float32, device=dev)
             idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev) if want_idx else None
-            _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, F_hip.VQ_CODEBOOK_PREPARED if prepared else 0,
+            _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags,
                                            x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
                                            idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
                                            stream))
