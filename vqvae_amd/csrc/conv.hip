@@ -1089,6 +1089,218 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 }
 
 // ---------------------------------------------------------------------------
+// The tile-resident scheme of conv_tile8_bf3_kernel on maps LARGER than 8x8 (round 3; BASELINE configs 4 / 5: 56x56 and 64x64
+// latent maps): one wave owns one 8x8 TILE of one image's pixel grid plus a one-pixel halo -- a 10x10 input patch -- and NT
+// 32-channel output tiles.  Layers whose input is sampled at stride 1 on a grid that is a multiple of 8 both ways: the 3x3
+// conv, the 3x3 conv-transpose, the four phases of the 4x4 stride-2 conv-transpose, the 1x1 conv.  Per 32-channel chunk the
+// patch is loaded ONCE (128 contiguous bytes per pixel; pixels outside the image read as zero through the buffer
+// descriptor), ReLU'd, split once into its two fp16 terms and parked in the wave's LDS tile; every tap then reads its
+// operands at a shifted patch index -- no per-tap reload / re-split as in conv_igemm_bf3_kernel, no border masks.  Two-term
+// fp16 products only (split8_h): the scale is the image's maximum handed over by the producing layer (in_amax), or the
+// patch's own maximum where none is given (any power of two that covers the patch is exact).  Weights, accumulators, the
+// XCD-aware grid and the epilogue are conv_tile8_bf3_kernel's.
+template <int NT, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
+                                                                  const float *__restrict__ bias, float *__restrict__ out,
+                                                                  ConvGeom g, int ny, const int *__restrict__ whdr,
+                                                                  const int *__restrict__ in_amax, int *__restrict__ out_amax) {
+    constexpr int MT = 2, PW = 10, PP = PW * PW;                 // patch: 10 x 10 pixels
+    constexpr int HP = PP + 1, PLANE = HP * 2;                   // u32x4 per (k-step, term) plane: [half][patch pixel]
+    constexpr int TILE4 = 2 * 2 * PLANE;                         // [k-step 2][term 2][PLANE]
+    constexpr int CH4 = NT * 128 * 2;
+    __shared__ u32x4 Bs[2][CH4];
+    __shared__ u32x4 As_all[NW * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    unsigned bx, by;
+    {
+        const unsigned id = blockIdx.x, nxb = gridDim.x / (unsigned)ny;
+        if ((nxb & 7u) == 0) {
+            const unsigned slot = id >> 3;
+            by = slot % (unsigned)ny;
+            bx = (slot / (unsigned)ny) * 8 + (id & 7u);
+        } else {
+            by = id % (unsigned)ny;
+            bx = id / (unsigned)ny;
+        }
+    }
+    const int phase = by % g.nphase, nb = by / g.nphase;
+    const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
+    const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
+    const int ntaps = g.ntaps, cpt = g.cpt, nchunk = ntaps * cpt;
+
+    // this wave's tile
+    const int tx_n = g.Wg >> 3, ty_n = g.Hg >> 3;
+    const long long tile_id = (long long)bx * NW + wave;
+    const long long ntile_all = (long long)g.B * ty_n * tx_n;
+    const bool img_ok = tile_id < ntile_all;
+    const long long tq = img_ok ? tile_id : 0;
+    const long long img = tq / (ty_n * tx_n);
+    const int trem = (int)(tq - img * (ty_n * tx_n));
+    const int y0 = (trem / tx_n) * 8, x0 = (trem % tx_n) * 8;
+    // patch pixels of this lane: q = lane and q = 64 + lane (< 100); byte offset inside the image, out of range = zero
+    const auto rs = act_rsrc(in + (size_t)img * g.Hin * g.Win * g.Cin, img_ok ? (unsigned long long)g.Hin * g.Win * g.Cin * 4ull : 0ull);
+    unsigned poff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = 64 * k + lane;
+        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;
+        poff[k] = (q < PP && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (unsigned)((iy * g.Win + ix) * g.Cin) * 4u : kOobOffset;
+    }
+    int spx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = 32 * mt + l31;
+        spx[mt] = ((p >> 3) + 1) * PW + (p & 7) + 1;             // the tile pixel's place in the patch
+    }
+
+    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 256;
+    const size_t wchunk = (size_t)g.ntile * 256;
+    constexpr int NBQ = CH4 / (NW * 64);
+    static_assert(CH4 % (NW * 64) == 0, "weight chunk must divide over the workgroup");
+    u32x4 b_nxt[NBQ];
+    auto load_b = [&](int c) {
+        const u32x4 *p = wbase + (size_t)c * wchunk;
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) b_nxt[q] = p[tid + NW * 64 * q];
+    };
+    auto store_b = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + NW * 64 * q] = b_nxt[q];
+    };
+    float xscale = 1.0f, descale = 1.0f;
+    f32x4 raw[2][8];
+    auto load_raw = [&](int cc) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] == kOobOffset ? kOobOffset : poff[k] + (unsigned)(32 * cc + 4 * j) * 4u, 0, 0));
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && lane >= PP - 64) break;
+            if (relu_in) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) raw[k][j] = relu4(raw[k][j]);
+            }
+            u32x4 *dst = As + 64 * k + lane;
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    u32x4 t1, t2;
+                    split8_h(raw[k][4 * hh + 2 * t], raw[k][4 * hh + 2 * t + 1], xscale, t1, t2);
+                    dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
+                    dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
+                }
+        }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;        // the producer's maximum of this image, if any
+        if (given >= 0) m = __int_as_float(given);
+        else for (int c2 = 0; c2 < cpt; ++c2) {                           // else the patch's own (one more pass over it)
+            load_raw(c2);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    f32x4 v = raw[k][j];
+                    if (relu_in) v = relu4(v);
+                    m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+                }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        descale = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+    }
+
+    // iteration it = cc * ntaps + tap  ->  weight chunk tap * cpt + cc
+    const int niter = nchunk;
+    load_raw(0);
+    load_b(0);
+    store_b(0);
+    if (niter > 1) load_b(ntaps > 1 ? cpt : 1);
+    int cc = 0, tap = 0;
+    for (int it = 0; it < niter; ++it) {
+        if (tap == 0) {
+            stage();                                   // (wave-private tile, LDS operations of a wave execute in order)
+            if (cc + 1 < cpt) load_raw(cc + 1);
+        }
+        __syncthreads();                               // weights of this iteration + (tap 0) the fresh tile
+        const u32x4 *bs = Bs[it & 1];
+        const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            u32x4 A1[MT], A2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 *ap = As + (t * 2) * PLANE + h * HP + spx[mt] + shift;
+                A1[mt] = ap[0];
+                A2[mt] = ap[PLANE];
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const u32x4 *bp = bs + nt * 256 + (t * 2 + h) * 32 + l31;
+                prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], acc[0][nt], acc[1][nt]);
+            }
+        }
+        int ntap = tap + 1, ncc = cc;
+        if (ntap == ntaps) { ntap = 0; ++ncc; }
+        if (it + 1 < niter) {
+            store_b((it + 1) & 1);
+            int t2 = ntap + 1, c2 = ncc;
+            if (t2 == ntaps) { t2 = 0; ++c2; }
+            if (it + 2 < niter) load_b(t2 * cpt + c2);
+        }
+        tap = ntap; cc = ncc;
+    }
+
+    float bv[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nb * NT + nt) * 32 + l31;
+        bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+    }
+    float omax = 0.0f;
+    if (img_ok) {
+        // the operand tile is free now (wave-private): stage the outputs through it, 16-byte stores
+        float *tile = reinterpret_cast<float *>(As);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[mt][nt][r] * descale + bv[nt];
+                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                    omax = fmaxf(omax, __builtin_fabsf(v[r]));
+                }
+                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
+                    const int px = 32 * mt + p;
+                    const int gy = y0 + (px >> 3), gx = x0 + (px & 7);
+                    const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
+                                           g.opx[phase]) * (long long)g.Cout;
+                    if (n < g.Cout) *reinterpret_cast<f32x4 *>(out + off + n) = a;
+                });
+            }
+    }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+}
+
+// ---------------------------------------------------------------------------
 // Fused residual layer on the split-bf16 product path (same math and layout as res_layer_kernel below;
 // see conv_igemm_bf3_kernel for the split).  GEMM1 (3x3, C -> 32 hidden) is barrier-free: each wave
 // reads its 6-KiB weight chunk (three bf16 terms) straight from L1/L2 next to its A operands.
@@ -4002,6 +4214,12 @@ constexpr size_t kH2Header = 256;
 static size_t packed_h2_bytes(const ConvGeom &g) {
     return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 2048 * sizeof(unsigned short);
 }
+// conv_halo8_h2_kernel: stride-1-sampled layers on pixel grids that are multiples of 8 both ways and larger than one tile
+static bool conv_halo8_ok(const ConvGeom &g, int Cin, int flags) {
+    return !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32)) && g.istride == 1 && g.Hg == g.Hin && g.Wg == g.Win &&
+           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && g.ntaps <= 9 &&
+           (long long)g.Hin * g.Win * Cin * 4 < 0x7FFFFFF0ll;
+}
 // byte offset of the header from the start of a layer's packed weights
 static size_t packed_h2_offset(const ConvGeom &g, int kind) {
     return packed_floats(g) * sizeof(float) + packed_bf3_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
@@ -4118,6 +4336,19 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
                 else      { if (h2) TILE8_LAUNCH(2, false, 4, true, 256); else TILE8_LAUNCH(2, false, 4, false, 256); }
             }
 #undef TILE8_LAUNCH
+        }
+        else if (conv_halo8_ok(g, Cin, flags) && in_amax) {
+            // larger maps whose grid is a multiple of 8 both ways, inside the whole-path entry points (maxima handed over):
+            // 8x8 tiles with a one-pixel halo, one per wave (conv_halo8_h2_kernel)
+            const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
+            const int *whdr = reinterpret_cast<const int *>(h2base);
+            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + kH2Header);
+            const bool wide = g.ntile % 4 == 0;
+            const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
+            const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
+            const unsigned gxt = (unsigned)((tiles + 7) / 8) * ny;
+            if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
         }
         else {
             // generic maps: the two-term fp16 products need every image's maximum from the producing layer (in_amax); the
