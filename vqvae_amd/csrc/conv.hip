@@ -1760,6 +1760,219 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 }
 
 // ---------------------------------------------------------------------------
+// res_tile8_bf3_kernel<., true> on maps LARGER than 8x8 (round 3; BASELINE configs 4 / 5): one wave owns one 8x8 tile of
+// one image's map plus a one-pixel halo (a 10x10 patch).  Per 16-channel slice the patch is loaded once (pixels outside the
+// image read as zero through the buffer descriptor), ReLU'd, split once into its two fp16 terms and parked in the wave's
+// LDS tile; the nine taps read their operands at shifted patch indices, no masks.  Hidden tile, 1x1 GEMM, skip, ReLU and
+// the staged stores are res_tile8_bf3_kernel's (the skip re-reads the tile's 64 centre pixels).  Two-term fp16 products;
+// the scale of x is the image's maximum from the producing layer (in_amax), or the patch's own where none is given.
+template <int NT2>
+__global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w1img,
+                                                             const u32x4 *__restrict__ w2img, float *__restrict__ out, int B,
+                                                             int H, int W, int C, int flags, const int *__restrict__ hdr1,
+                                                             const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                             int *__restrict__ out_amax) {
+    constexpr int MT = 2, PW = 10, PP = PW * PW, HP = PP + 1, TILE4 = 4 * HP;      // [term 2][half 2][patch pixel]
+    static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
+    __shared__ u32x4 W2s[NT2 * 256];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+
+    const int tx_n = W >> 3, ty_n = H >> 3;
+    const long long tile_id = (long long)blockIdx.x * 4 + wave, ntile_all = (long long)B * ty_n * tx_n;
+    const bool img_ok = tile_id < ntile_all;
+    const long long tq = img_ok ? tile_id : 0;
+    const long long img = tq / (ty_n * tx_n);
+    const int trem = (int)(tq - img * (ty_n * tx_n));
+    const int y0 = (trem / tx_n) * 8, x0 = (trem % tx_n) * 8;
+    const float *img_base = in + (size_t)img * H * W * C;
+    const auto rs = act_rsrc(img_base, img_ok ? (unsigned long long)H * W * C * 4ull : 0ull);
+    unsigned poff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = 64 * k + lane;
+        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;
+        poff[k] = (q < PP && iy >= 0 && iy < H && ix >= 0 && ix < W) ? (unsigned)((iy * W + ix) * C) * 4u : kOobOffset;
+    }
+    int spx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = 32 * mt + l31;
+        spx[mt] = ((p >> 3) + 1) * PW + (p & 7) + 1;
+    }
+
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    // slice sl = k-step (sl & 1) of 32-channel chunk (sl >> 1): channels 32 chunk + 8 step + [0, 8) (h = 0), + 16 (h = 1)
+    f32x4 raw[2][4];
+    auto load_raw = [&](int sl) {
+        const unsigned co = (unsigned)(32 * (sl >> 1) + 8 * (sl & 1)) * 4u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const unsigned o = poff[k] == kOobOffset ? kOobOffset : poff[k] + co;
+            raw[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
+            raw[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 16u, 0, 0));
+            raw[k][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 64u, 0, 0));
+            raw[k][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 80u, 0, 0));
+        }
+    };
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[2]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+    };
+    u32x4 bw[2][2];
+    float xscale, d1;
+    {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = raw[k][j];
+                    if (relu_in) v = relu4(v);
+                    m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+                }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+    }
+    load_raw(0);
+    load_w(0, 0, bw[0]);
+    auto slice = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        {
+            u32x4 t1a[2], t2a[2], t1b[2], t2b[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (relu_in) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) raw[k][j] = relu4(raw[k][j]);
+                }
+                split8_h(raw[k][0], raw[k][1], xscale, t1a[k], t2a[k]);
+                split8_h(raw[k][2], raw[k][3], xscale, t1b[k], t2b[k]);
+            }
+            if (sl + 1 < nslice) load_raw(sl + 1);
+            __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && lane >= PP - 64) break;
+                u32x4 *dst = As + 64 * k + lane;
+                dst[0] = t1a[k]; dst[HP] = t1b[k];
+                dst[HP * 2] = t2a[k]; dst[HP * 3] = t2b[k];
+            }
+            lds_order_wave();
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
+            u32x4 S[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 *ap = As + h * HP + spx[mt] + shift;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+            }
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+        }
+    };
+    for (int sl = 0; sl < nslice; sl += 2) {
+        slice(sl, std::integral_constant<int, 0>{});
+        slice(sl + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete; operand tile no longer read
+
+    float *Hs = reinterpret_cast<float *>(As);
+    u32x4 H1[MT][2], Hb[MT][2];
+    float hscale, d2;
+    {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
+                m = fmaxf(m, acc1[mt][r]);
+            }
+        const int kh = wave_scale_exp(m);
+        hscale = __builtin_ldexpf(1.0f, kh);
+        d2 = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[prow * 33 + l31] = acc1[mt][r];
+        }
+        lds_order_wave();
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+        split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+        split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    float omax = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        f32x16 acc2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+            prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+        }
+        if (img_ok) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = acc2[mt][r] * d2;
+                // the four skip values of this lane are requested before the tile goes through LDS
+                f32x4 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int p = mt * 32 + (lane >> 3) + 8 * k;
+                    u[k] = *reinterpret_cast<const f32x4 *>(img_base + ((size_t)(y0 + (p >> 3)) * W + x0 + (p & 7)) * C + nt * 32 + 4 * (lane & 7));
+                }
+                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int k) {
+                    f32x4 u0 = u[k];
+                    if (relu_in) u0 = relu4(u0);
+                    f32x4 yv = u0 + a4;
+                    if (relu_out) yv = relu4(yv);
+                    omax = fmaxf(omax, fmaxf(fmaxf(__builtin_fabsf(yv.x), __builtin_fabsf(yv.y)), fmaxf(__builtin_fabsf(yv.z), __builtin_fabsf(yv.w))));
+                    const int px = mt * 32 + p;
+                    *reinterpret_cast<f32x4 *>(out + (((size_t)img * H + y0 + (px >> 3)) * W + x0 + (px & 7)) * C + n) = yv;
+                });
+            }
+        }
+    }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+}
+
+// ---------------------------------------------------------------------------
 // TWO residual layers of a stack in one kernel (models/residual.py:47-51: the layers of a stack share their weights), 8x8
 // maps, two-term fp16 products.  One wave owns one image; the first layer's output never leaves the chip:
 //   layer 1:  as res_tile8_bf3_kernel<., true>, but the skip relu(x) is added in the ACCUMULATOR layout (dword loads, 128
@@ -4217,7 +4430,7 @@ static size_t packed_h2_bytes(const ConvGeom &g) {
 // conv_halo8_h2_kernel: stride-1-sampled layers on pixel grids that are multiples of 8 both ways and larger than one tile
 static bool conv_halo8_ok(const ConvGeom &g, int Cin, int flags) {
     return !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32)) && g.istride == 1 && g.Hg == g.Hin && g.Wg == g.Win &&
-           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && g.ntaps <= 9 &&
+           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && g.ntaps > 1 && g.ntaps <= 9 &&
            (long long)g.Hin * g.Win * Cin * 4 < 0x7FFFFFF0ll;
 }
 // byte offset of the header from the start of a layer's packed weights
@@ -4425,6 +4638,20 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
                 case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
                 case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
                 case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
+            }
+        } else if (in_amax && !(flags & VQVAE_CONV_BF16_SPLIT) && H % 8 == 0 && W % 8 == 0 && C % 32 == 0 &&
+                   (long long)H * W * C * 4 < 0x7FFFFFF0ll) {
+            // larger maps that are multiples of 8 both ways, inside the whole-path entry points: 8x8 tiles with a halo
+            const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2p + kH2Header);
+            const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
+            const long long tiles = (long long)B * (H / 8) * (W / 8);
+            const unsigned gt = (unsigned)((tiles + 3) / 4);
+            switch (C / 32) {
+                case 1: hipLaunchKernelGGL((res_halo8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
+                case 2: hipLaunchKernelGGL((res_halo8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
+                case 4: hipLaunchKernelGGL((res_halo8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
             }
         } else {
             // generic maps: two-term fp16 products when the producing layer handed over the images' maxima
