@@ -268,6 +268,10 @@ BIG_SHAPES = {
     "c4_224_k1024_d64": (128, 32, 2, 1024, 64, 1, 224, 224),
     "c5_256_k8192_d128": (128, 32, 2, 8192, 128, 1, 256, 256),
     "odd_40x56_k100_d32": (64, 16, 2, 100, 32, 2, 40, 56),
+    # latent maps that are multiples of 8 both ways and larger than 8x8: the halo-tile kernels of round 3 (conv_halo8_h2 /
+    # res_halo8_h2), non-square, tile counts that leave waves of the last workgroup idle, both channel widths
+    "halo_64x96_k512_d64": (128, 32, 2, 512, 64, 3, 64, 96),
+    "halo_h64_64x128_k100_d32": (64, 16, 2, 100, 32, 5, 64, 128),
 }
 
 
@@ -318,7 +322,8 @@ def test_large_and_odd_shapes_stagewise_vs_oracle(name):
         assert x_hat2.shape == x.shape and torch.isfinite(x_hat2).all() and torch.isfinite(loss2)
 
 
-def test_whole_path_per_image_scales_on_generic_maps():
+@pytest.mark.parametrize("H,W", [(24, 40), (32, 64)], ids=["generic_6x10", "halo_tiles_8x16"])
+def test_whole_path_per_image_scales_on_generic_maps(H, W):
     """Images of very different magnitude in one batch through the whole-path encoder on maps that are NOT 8x8 (generic
     kernels: a wave's pixel rows can belong to two images, every row carries its own image's scale; the maxima are
     handed from layer to layer): every image against the oracle, tolerance relative to its own magnitude."""
@@ -326,7 +331,7 @@ def test_whole_path_per_image_scales_on_generic_maps():
     from vqvae_amd import _lib, conv
     from vqvae_amd.modules import VQVAE
     conv.set_conv_backend("hip")
-    h, rh, nl, K, D, B, H, W = 64, 16, 2, 100, 32, 7, 24, 40
+    h, rh, nl, K, D, B = 64, 16, 2, 100, 32, 7
     torch.manual_seed(3)
     m = VQVAE(h, rh, nl, K, D, 0.25).eval()
     with torch.no_grad():

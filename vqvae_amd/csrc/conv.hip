@@ -1099,7 +1099,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 // fp16 products only (split8_h): the scale is the image's maximum handed over by the producing layer (in_amax), or the
 // patch's own maximum where none is given (any power of two that covers the patch is exact).  Weights, accumulators, the
 // XCD-aware grid and the epilogue are conv_tile8_bf3_kernel's.
-template <int NT, int NW>
+template <int NT, int NW, bool S2D = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
                                                                   const float *__restrict__ bias, float *__restrict__ out,
                                                                   ConvGeom g, int ny, const int *__restrict__ whdr,
@@ -1128,7 +1128,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
     const int phase = by % g.nphase, nb = by / g.nphase;
     const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
-    const int ntaps = g.ntaps, cpt = g.cpt, nchunk = ntaps * cpt;
+    // S2D: the 4x4 stride-2 conv read as a conv over the grid of 2x2 input blocks (conv_tile8_bf3_kernel<., true>): a patch
+    // "pixel" is a block, a chunk = (sub-position of the block, 32-channel slice) meets four block offsets
+    const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt, nchunk = ntaps * cpt;
 
     // this wave's tile
     const int tx_n = g.Wg >> 3, ty_n = g.Hg >> 3;
@@ -1145,8 +1147,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int q = 64 * k + lane;
-        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;
-        poff[k] = (q < PP && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (unsigned)((iy * g.Win + ix) * g.Cin) * 4u : kOobOffset;
+        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;         // pixel (S2D: block) coordinates
+        if (S2D) poff[k] = (q < PP && iy >= 0 && 2 * iy < g.Hin && ix >= 0 && 2 * ix < g.Win) ? (unsigned)((2 * iy * g.Win + 2 * ix) * g.Cin) * 4u : kOobOffset;
+        else poff[k] = (q < PP && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (unsigned)((iy * g.Win + ix) * g.Cin) * 4u : kOobOffset;
     }
     int spx[MT];
 #pragma unroll
@@ -1172,11 +1175,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
     float xscale = 1.0f, descale = 1.0f;
     f32x4 raw[2][8];
     auto load_raw = [&](int cc) {
+        unsigned co = (unsigned)(32 * cc) * 4u;
+        if (S2D) {
+            const int sub = cc / g.cpt, sl = cc - sub * g.cpt;
+            co = (unsigned)(((sub >> 1) * g.Win + (sub & 1)) * g.Cin + 32 * sl) * 4u;
+        }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int j = 0; j < 8; ++j)
-                raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] == kOobOffset ? kOobOffset : poff[k] + (unsigned)(32 * cc + 4 * j) * 4u, 0, 0));
+                raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] == kOobOffset ? kOobOffset : poff[k] + co + (unsigned)(4 * j) * 4u, 0, 0));
     };
     auto stage = [&]() {
 #pragma unroll
@@ -1231,7 +1239,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
     load_raw(0);
     load_b(0);
     store_b(0);
-    if (niter > 1) load_b(ntaps > 1 ? cpt : 1);
+    if (niter > 1) load_b(S2D ? 1 : (ntaps > 1 ? cpt : 1));
     int cc = 0, tap = 0;
     for (int it = 0; it < niter; ++it) {
         if (tap == 0) {
@@ -1240,7 +1248,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
         }
         __syncthreads();                               // weights of this iteration + (tap 0) the fresh tile
         const u32x4 *bs = Bs[it & 1];
-        const int shift = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
+        int shift;
+        if (S2D) {
+            const int sub = cc / g.cpt;
+            shift = ((tap >> 1) - (sub >> 1)) * PW + ((tap & 1) - (sub & 1));
+        } else {
+            shift = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             u32x4 A1[MT], A2[MT];
@@ -1262,7 +1276,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
             store_b((it + 1) & 1);
             int t2 = ntap + 1, c2 = ncc;
             if (t2 == ntaps) { t2 = 0; ++c2; }
-            if (it + 2 < niter) load_b(t2 * cpt + c2);
+            if (it + 2 < niter) load_b(S2D ? c2 * 4 + t2 : t2 * cpt + c2);
         }
         tap = ntap; cc = ncc;
     }
@@ -4549,6 +4563,20 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
                 else      { if (h2) TILE8_LAUNCH(2, false, 4, true, 256); else TILE8_LAUNCH(2, false, 4, false, 256); }
             }
 #undef TILE8_LAUNCH
+        }
+        else if (in_amax && kind == VQVAE_CONV_4x4_S2 && !(flags & VQVAE_CONV_BF16_SPLIT) && g.Hg % 8 == 0 && g.Wg % 8 == 0 &&
+                 g.Hg * g.Wg > 64 && g.Hin == 2 * g.Hg && g.Win == 2 * g.Wg && Cin % 32 == 0 && g.ntile % 2 == 0 &&
+                 (long long)g.Hin * g.Win * Cin * 4 < 0x7FFFFFF0ll) {
+            // the 4x4 stride-2 conv on larger maps: 8x8 output tiles over the grid of 2x2 input blocks, with a one-block halo
+            const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
+            const int *whdr = reinterpret_cast<const int *>(h2base);
+            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + kH2Header + packed_h2_bytes(g));      // space-to-depth chunk order
+            const bool wide = g.ntile % 4 == 0;
+            const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
+            const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
+            const unsigned gxt = (unsigned)((tiles + 7) / 8) * ny;
+            if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 8, true>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 8, true>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
         }
         else if (conv_halo8_ok(g, Cin, flags) && in_amax) {
             // larger maps whose grid is a multiple of 8 both ways, inside the whole-path entry points (maxima handed over):
