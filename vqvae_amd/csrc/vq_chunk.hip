@@ -28,6 +28,7 @@
 // of config 5's step, against the ~70 ms the fp32 sweep costs.
 #include "common.h"
 #include "vq_device.h"
+#include "vq_track.h"
 
 namespace vqvae {
 
@@ -111,7 +112,7 @@ template <int D>
 __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
     const u32x4 *__restrict__ rows16, const float2 *__restrict__ stat, const u32x4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const int *__restrict__ flags, int nrows, long long row0, int K, int ntile,
-    long long *__restrict__ idx, uint2 *__restrict__ pair_list, unsigned *__restrict__ hard_list,
+    long long *__restrict__ idx, uint4 *__restrict__ open_list, unsigned *__restrict__ hard_list,
     unsigned long long *__restrict__ hard_best, int *__restrict__ counters) {
     constexpr int TC = ChunkCfg<D>::TC, NQ = D / 16, G = D / 8;
     constexpr int IMG_UNITS = TC * D * 4;                 // 16-byte units of image per chunk
@@ -136,8 +137,6 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
     const float EEh = 0.5f * EEmax * A, EEa = EEmax * A;
     constexpr float kGp = (float)(D + 1) * 1.1921e-7f * 1.001f;           // (D + 1) 2^-23: fp32 accumulation of the screen
     constexpr float kG = (float)D * 5.9605e-8f * 1.011f;                  // D 2^-24 * 1.01: the reference's fmaf chain
-    constexpr float kTrunc = 2.45e-4f;                                    // 2 * 2^-13: the 10 key bits
-    const unsigned keymask = 0xfffffc00u;
     const float inf = __builtin_inff();
 
     // chunk j of the codebook stream -> buffer j & 1 (LDS-DMA: every lane's 16 bytes land at piece base + 16 lane)
@@ -180,17 +179,21 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
             for (int q = 0; q < NQ; ++q)
                 zb[t][q] = __builtin_bit_cast(f16x8, rows16[((size_t)(tl0 + t) * G + 2 * q + h) * 32 + l31]);
 
+        // round 3: the stream tracker of vq_track.h.  Streams S[8] run over the WHOLE codebook; the three largest cell keys
+        // (cell = half of a 32-code tile, 6-bit field = cell within the 16-tile epoch) are folded at every epoch end into
+        // running (value, global cell) triples G / C, so the key field does not grow with K
         float G1[2], G2[2], G3[2];
         int C1[2], C2[2];
-        float m1[2], m2[2], m3[2];
+        trk::Lane L[2];
+        float pinf = inf, ninf = -inf;                      // opaque: see vq_track.h
+        unsigned keymask = trk::kKeyMask;
+        asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            G1[t] = G2[t] = G3[t] = -inf;
+            G1[t] = G2[t] = G3[t] = ninf;
             C1[t] = C2[t] = 0;
-            m1[t] = m2[t] = m3[t] = -inf;
+            trk::init(L[t], ninf);
         }
-        float pinf = inf;                                   // opaque +inf: see vq_sweep.hip
-        asm volatile("" : "+v"(pinf));
 
         const bool more_blocks = blk + (int)gridDim.x < nblk;
         for (int c = 0; c < nchunk; ++c, ++stream) {
@@ -224,26 +227,11 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[0][q], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[1][q], acc[1], 0, 0, 0);
                 }
-                if (lt + 1 < nt_here) fetch(lt + 1);       // lands under the ~170 vector ops below
-                const int f = kEpoch - ((c * TC + lt) & (kEpoch - 1));
-                const unsigned fix = (unsigned)(2 * f - 1);
+                if (lt + 1 < nt_here) fetch(lt + 1);       // lands under the vector ops below
+                unsigned cell0 = (unsigned)(2 * ((c * TC + lt) & (kEpoch - 1))), cell1 = cell0 + 1u;
+                asm volatile("" : "+s"(cell0), "+s"(cell1));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float key = __uint_as_float((__float_as_uint(acc[t][r]) & keymask) | (unsigned)(r | 16));
-                        m3[t] = __builtin_amdgcn_fmed3f(m2[t], m3[t], key);
-                        m2[t] = __builtin_amdgcn_fmed3f(m1[t], m2[t], key);
-                        m1[t] = __builtin_amdgcn_fmed3f(m1[t], key, pinf);
-                    }
-                    unsigned b1 = __float_as_uint(m1[t]), b2 = __float_as_uint(m2[t]), b3 = __float_as_uint(m3[t]);
-                    b1 += __umul24(b1 & 16u, fix);
-                    b2 += __umul24(b2 & 16u, fix);
-                    b3 += __umul24(b3 & 16u, fix);
-                    m1[t] = __uint_as_float(b1);
-                    m2[t] = __uint_as_float(b2);
-                    m3[t] = __uint_as_float(b3);
-                }
+                for (int t = 0; t < 2; ++t) trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
 #pragma unroll
                 for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(a[q]));
             }
@@ -253,12 +241,11 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                 const int ebase = ((c * TC) / kEpoch) * kEpoch;          // first tile of this epoch
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    const float mv[3] = {m1[t], m2[t], m3[t]};
+                    const float mv[3] = {L[t].m1, L[t].m2, L[t].m3};
 #pragma unroll
                     for (int i = 0; i < 3; ++i) {
                         const unsigned kb = __float_as_uint(mv[i]);
-                        const int code = (ebase + kEpoch - (int)((kb >> 5) & 31u)) * 32 +
-                                         (int)((kb & 3u) + 8u * ((kb >> 2) & 3u)) + 4 * h;
+                        const int code = 2 * ebase + (int)(kb & trk::kCellMask);      // GLOBAL cell id (2 * tile + half-tile)
                         const float v = mv[i];
                         const bool b1 = v > G1[t], b2 = v > G2[t], b3 = v > G3[t];
                         G3[t] = b2 ? G2[t] : (b3 ? v : G3[t]);
@@ -267,64 +254,69 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                         C1[t] = b1 ? code : C1[t];
                         G1[t] = b1 ? v : G1[t];
                     }
-                    m1[t] = m2[t] = m3[t] = -inf;
+                    L[t].m1 = L[t].m2 = L[t].m3 = ninf;
                 }
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next chunk have landed
             __syncthreads();                                       // everyone is done with this chunk; the next is visible
         }
 
-        // ---- merge the two lane halves of every row (x = half 0's triple, y = half 1's, identically in both lanes) ----
+        // ---- threshold per row, merge of the two lane halves, verdict (vq_track.h) ----
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-            const auto s1 = __builtin_amdgcn_permlane32_swap(__float_as_uint(G1[t]), __float_as_uint(G1[t]), false, false);
-            const auto s2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(G2[t]), __float_as_uint(G2[t]), false, false);
-            const auto s3 = __builtin_amdgcn_permlane32_swap(__float_as_uint(G3[t]), __float_as_uint(G3[t]), false, false);
-            const auto q1 = __builtin_amdgcn_permlane32_swap((unsigned)C1[t], (unsigned)C1[t], false, false);
-            const auto q2 = __builtin_amdgcn_permlane32_swap((unsigned)C2[t], (unsigned)C2[t], false, false);
-            const float o1 = __uint_as_float(h ? s1[0] : s1[1]), o2 = __uint_as_float(h ? s2[0] : s2[1]);
-            const float o3 = __uint_as_float(h ? s3[0] : s3[1]);
-            const int oc1 = (int)(h ? q1[0] : q1[1]), oc2 = (int)(h ? q2[0] : q2[1]);
-            const float x1 = h ? o1 : G1[t], x2 = h ? o2 : G2[t], x3 = h ? o3 : G3[t];
-            const float y1 = h ? G1[t] : o1, y2 = h ? G2[t] : o2, y3 = h ? G3[t] : o3;
-            const int xc1 = h ? oc1 : C1[t], xc2 = h ? oc2 : C2[t], yc1 = h ? C1[t] : oc1, yc2 = h ? C2[t] : oc2;
-            const bool xf = x1 >= y1;
-            const float v1 = xf ? x1 : y1;
-            int c1 = xf ? xc1 : yc1;
-            // second: the larger of the loser's first and the winner's second
-            const float la = xf ? y1 : x1, lb = xf ? x2 : y2;
-            const int lac = xf ? yc1 : xc1, lbc = xf ? xc2 : yc2;
-            const float v2 = la > lb ? la : lb;
-            int c2 = la > lb ? lac : lbc;
-            const float v3 = fmaxf(fmaxf(x3, y3), fmaxf(fminf(x2, y1), fminf(x1, y2)));
-
+            const float vA = trk::lane_max(L[t], ninf);
+            const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(vA), __float_as_uint(vA), false, false);
+            const float v1 = trk::max3(vA, __uint_as_float(h ? sv[0] : sv[1]), ninf);
             const int rrel = r0 + 32 * t + l31;
             const bool valid = rrel < nrows;
             const float2 st = stat[valid ? rrel : 0];
             const float zs = st.x * 1.0001f;                                       // |z^|^2
             const float errz = __builtin_sqrtf(st.y * 1.0001f) * 1.0001f;          // |z - z^|, measured at conversion
             const float zn = __builtin_sqrtf(zs) * 1.0001f + errz;                 // |z| <= |z^| + |z - z^|
-            const float eps = errz * Ehat + (zn + errz) * dE + kGp * (zn * Ehat + EEh);
+            const float mag = zn * Ehat + EEh;
+            const float eps = errz * Ehat + (zn + errz) * dE + kGp * mag;
             const float xi = kG * zn * EmaxS + 1.2e-7f * (A * zn * zn + EEa);
-            const float trunc = kTrunc * (zn * Ehat + EEh);
-            const float delta = (2.0f * eps + 2.0f * xi + trunc) * 1.001f;
-            const bool bad = cb_bad || !(zs < 1.0e30f) || !(st.y < 1.0e30f) || !(v1 > -1.0e37f) || !(delta < 1.0e37f);
-            const bool amb2 = !(v1 - v2 >= delta), amb3 = !(v1 - v3 >= delta);
-            const bool inr = c1 >= 0 && c1 < K && c2 >= 0 && c2 < K;
-            const bool hard = valid && (bad || c1 < 0 || c1 >= K || (amb2 && (amb3 || !inr)));
-            const bool pair = valid && !hard && amb2;
-            if (c1 < 0 || c1 >= K) c1 = 0;
-            if (c2 < 0 || c2 >= K) c2 = 0;
+            const float delta = (2.0f * eps + 2.0f * xi) * 1.001f;                 // no truncation term: the streams are exact
+            const float thr = v1 - delta, thrB = thr - 8.0e-6f * mag;              // cell keys: 2^6 ulp <= 2^-17 mag below their cell's maximum
+            const bool bad = cb_bad || !(zs < 1.0e30f) || !(st.y < 1.0e30f) || !(v1 > -1.0e37f) || !(v1 < 1.0e37f) || !(delta < 1.0e37f) ||
+                             (v1 > -1.0e-30f && v1 < 1.0e-30f);
+            const trk::Counts CN = trk::counts_of(L[t].S, G1[t], G2[t], G3[t], thr, thrB);
+            const trk::Products P = trk::products_of(CN, C1[t], C2[t], h, K);
+            // the two halves swap [popA : 4][nB : 2][k11 : 15]
+            const unsigned mine = (unsigned)CN.popA | ((unsigned)CN.nB << 4) | ((unsigned)P.k[0] << 6);
+            const auto so = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
+            const unsigned oth = h ? so[0] : so[1];
+            const int popO = (int)(oth & 15u), nBO = (int)((oth >> 4) & 3u), k11O = (int)(oth >> 6);
+            bool closed = (CN.popA + popO == 1) && (CN.nB + nBO == 1);
+            int c1 = CN.popA == 1 ? P.k[0] : k11O;
+            bool hard = bad || CN.popA > 2 || CN.nB > 2 || popO > 2 || nBO > 2;
+            if (closed && (c1 < 0 || c1 >= K)) { closed = false; hard = true; }
+            // open rows with no product at all on either side (cannot happen) -> every code exactly
+            const auto sn = __builtin_amdgcn_permlane32_swap((unsigned)P.n, (unsigned)P.n, false, false);
+            const int nO = (int)(h ? sn[0] : sn[1]);
+            if (!closed && !hard && P.n + nO == 0) hard = true;
+            hard = valid && hard;
+            const bool open = valid && !hard && !closed;
+            if (!closed || c1 < 0 || c1 >= K) c1 = 0;
             const bool writer = h == 0;
             if (valid && writer) idx[row0 + rrel] = c1;
-            const unsigned long long pm = __builtin_amdgcn_ballot_w64(pair && writer);
+            // open rows: one record per row, both halves' products (two uint4: {row, n0 | n1 << 8, k0 | k1 << 16, k2 | k3 << 16} of
+            // half 0 and {k0 | k1 << 16, k2 | k3 << 16, 0, 0} of half 1); the resolve kernel evaluates every code exactly
+            const unsigned long long om = __builtin_amdgcn_ballot_w64(open && writer);
             const unsigned long long hm = __builtin_amdgcn_ballot_w64(hard && writer);
             const unsigned long long below = (1ull << lane) - 1ull;
-            if (pm) {
+            if (om) {
                 int base = 0;
-                if (lane == 0) base = atomicAdd(&counters[0], __builtin_popcountll(pm));
+                if (lane == 0) base = atomicAdd(&counters[0], __builtin_popcountll(om));
                 base = __builtin_amdgcn_readfirstlane(base);
-                if (pair && writer) pair_list[base + __builtin_popcountll(pm & below)] = make_uint2((unsigned)rrel, (unsigned)c1 | ((unsigned)c2 << 16));
+                int slot = base + __builtin_popcountll(om & below);
+                const auto ss = __builtin_amdgcn_permlane32_swap((unsigned)slot, (unsigned)slot, false, false);
+                if (h) slot = (int)ss[0];                      // the row's slot, from its half-0 lane
+                if (open) {
+                    const unsigned k01 = (unsigned)P.k[0] | ((unsigned)P.k[1] << 16), k23 = (unsigned)P.k[2] | ((unsigned)P.k[3] << 16);
+                    if (h == 0) open_list[2 * slot] = make_uint4((unsigned)rrel, (unsigned)P.n | ((unsigned)nO << 8), k01, k23);
+                    else open_list[2 * slot + 1] = make_uint4(k01, k23, 0u, 0u);
+                }
             }
             if (hm) {
                 int base = 0;
@@ -403,35 +395,43 @@ constexpr int kHardRangeTiles = 8;                        // 32-code tiles per w
 template <int D>
 __global__ __launch_bounds__(256) void vq_stream_resolve_kernel(const float *__restrict__ z, const float *__restrict__ cb,
                                                                 const float *__restrict__ ee, const float *__restrict__ img32,
-                                                                int K, int KC, const uint2 *__restrict__ pair_list,
+                                                                int K, int KC, const uint4 *__restrict__ open_list,
                                                                 const unsigned *__restrict__ hard_list,
                                                                 unsigned long long *__restrict__ hard_best,
                                                                 int *__restrict__ batch_done,
                                                                 const int *__restrict__ counters, long long *__restrict__ idx) {
     const int npair = counters[0], nhard = counters[1];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // ---- pair tasks ----
+    // ---- open rows: one lane per row, every product of its streams and cells exactly (first-index rule among equals) ----
     for (int i = blockIdx.x + gridDim.x * tid; i < npair; i += gridDim.x * 256) {
-        const uint2 tk = pair_list[i];
-        const int ka = (int)(tk.y & 0xffffu), kb = (int)(tk.y >> 16);
-        const float *zr = z + (size_t)tk.x * D;
+        const uint4 r0 = open_list[2 * i], r1 = open_list[2 * i + 1];
+        const int n0 = (int)(r0.y & 0xffu), n1 = (int)((r0.y >> 8) & 0xffu);
+        const unsigned kk[4] = {r0.z, r0.w, r1.x, r1.y};
+        const float *zr = z + (size_t)r0.x * D;
         const float zz = aten_sqsum_stream<D>(zr);
-        const float *ea = cb + (size_t)ka * D, *eb = cb + (size_t)kb * D;
-        float ma = 0.0f, mb = 0.0f;
+        float bd = 0.0f;
+        int bk = 0x7fffffff;
+        for (int j = 0; j < 8; ++j) {
+            const int nj = j < 4 ? n0 : n1;
+            if ((j & 3) >= nj) continue;
+            const int k = (int)((kk[j >> 1] >> (16 * (j & 1))) & 0xffffu);
+            const float *ea = cb + (size_t)k * D;
+            float ma = 0.0f;
 #pragma unroll 4
-        for (int c4 = 0; c4 < D / 4; ++c4) {
-            const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + 4 * c4);
-            const f32x4 av = *reinterpret_cast<const f32x4 *>(ea + 4 * c4);
-            const f32x4 bv = *reinterpret_cast<const f32x4 *>(eb + 4 * c4);
-            ma = __builtin_fmaf(zv.x, av.x, ma); mb = __builtin_fmaf(zv.x, bv.x, mb);
-            ma = __builtin_fmaf(zv.y, av.y, ma); mb = __builtin_fmaf(zv.y, bv.y, mb);
-            ma = __builtin_fmaf(zv.z, av.z, ma); mb = __builtin_fmaf(zv.z, bv.z, mb);
-            ma = __builtin_fmaf(zv.w, av.w, ma); mb = __builtin_fmaf(zv.w, bv.w, mb);
+            for (int c4 = 0; c4 < D / 4; ++c4) {
+                const f32x4 zv = *reinterpret_cast<const f32x4 *>(zr + 4 * c4);
+                const f32x4 av = *reinterpret_cast<const f32x4 *>(ea + 4 * c4);
+                ma = __builtin_fmaf(zv.x, av.x, ma);
+                ma = __builtin_fmaf(zv.y, av.y, ma);
+                ma = __builtin_fmaf(zv.z, av.z, ma);
+                ma = __builtin_fmaf(zv.w, av.w, ma);
+            }
+            const float ta = zz + ee[k];
+            const float ua = 2.0f * ma;
+            const float da = ta - ua;
+            if (bk == 0x7fffffff || argmin_better(da, k, bd, bk)) { bd = da; bk = k; }
         }
-        const float ta = zz + ee[ka], tb = zz + ee[kb];
-        const float ua = 2.0f * ma, ub = 2.0f * mb;
-        const float da = ta - ua, db = tb - ub;
-        idx[tk.x] = argmin_better(da, ka, db, kb) ? ka : kb;
+        if (bk != 0x7fffffff) idx[r0.x] = bk;
     }
     // ---- hard rows ----
     if (nhard == 0) return;
@@ -563,7 +563,7 @@ bool vq_chunk_ok(int K, int D) { return (D == 64 || D == 128) && K >= 1 && K <= 
 
 size_t vq_chunk_scratch_bytes(int D) {
     return align_up((size_t)kVqSlabRows * D * 2, 256) + align_up((size_t)kVqSlabRows * 8, 256) +
-           align_up((size_t)kVqSlabRows * 8, 256) + align_up((size_t)kVqSlabRows * 4, 256) +
+           align_up((size_t)kVqSlabRows * 32, 256) + align_up((size_t)kVqSlabRows * 4, 256) +
            align_up((size_t)kVqSlabRows * 8, 256) + align_up((size_t)(kVqSlabRows / 32) * 4, 256) + 256;
 }
 
@@ -577,8 +577,8 @@ static int launch_chunked(const float *z, const float *cb, long long N, int K, f
     s += align_up((size_t)kVqSlabRows * D * 2, 256);
     float2 *stat = reinterpret_cast<float2 *>(s);
     s += align_up((size_t)kVqSlabRows * 8, 256);
-    uint2 *pairs = reinterpret_cast<uint2 *>(s);
-    s += align_up((size_t)kVqSlabRows * 8, 256);
+    uint4 *pairs = reinterpret_cast<uint4 *>(s);                 // one 32-byte record per open row
+    s += align_up((size_t)kVqSlabRows * 32, 256);
     unsigned *hards = reinterpret_cast<unsigned *>(s);
     s += align_up((size_t)kVqSlabRows * 4, 256);
     unsigned long long *hbest = reinterpret_cast<unsigned long long *>(s);

@@ -20,11 +20,11 @@
 // (only the cell keys are truncated, by 6 bits, and only the test of a key against the threshold pays for it).
 #pragma once
 
-#if defined(__HIP_DEVICE_COMPILE__)
-#define VQT_FN __device__ __forceinline__
-#else
 #include <cmath>
 #include <cstring>
+#if defined(__HIPCC__)
+#define VQT_FN __host__ __device__ __forceinline__      // (both passes of hipcc see the same declarations)
+#else
 #define VQT_FN inline
 #endif
 
@@ -34,20 +34,31 @@ namespace trk {
 VQT_FN unsigned f2u(float x) { return __builtin_bit_cast(unsigned, x); }
 VQT_FN float u2f(unsigned x) { return __builtin_bit_cast(float, x); }
 
+// three-operand forms only on the device: hipcc lowers a two-operand fmaxf to v_max_f32 plus a canonicalising v_max_f32 x, x
+// per input
+VQT_FN float max3(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-// three-operand forms only: hipcc lowers a two-operand fmaxf to v_max_f32 plus a canonicalising v_max_f32 x, x per input
-VQT_FN float max3(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
-VQT_FN float med3(float a, float b, float c) { return __builtin_amdgcn_fmed3f(a, b, c); }
-VQT_FN unsigned shl1_in(unsigned bits, float d) { return __builtin_amdgcn_alignbit(bits, f2u(d), 31); }
-VQT_FN int popc(unsigned x) { return __builtin_popcount(x); }
-VQT_FN int clz(unsigned x) { return __builtin_clz(x); }
+    return __builtin_fmaxf(__builtin_fmaxf(a, b), c);
 #else
-VQT_FN float max3(float a, float b, float c) { return std::fmax(std::fmax(a, b), c); }
-VQT_FN float med3(float a, float b, float c) { return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c)); }
-VQT_FN unsigned shl1_in(unsigned bits, float d) { return (bits << 1) | (f2u(d) >> 31); }
+    return std::fmax(std::fmax(a, b), c);
+#endif
+}
+VQT_FN float med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+    return std::fmax(std::fmin(a, b), std::fmin(std::fmax(a, b), c));
+#endif
+}
+VQT_FN unsigned shl1_in(unsigned bits, float d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(bits, f2u(d), 31);
+#else
+    return (bits << 1) | (f2u(d) >> 31);
+#endif
+}
 VQT_FN int popc(unsigned x) { return __builtin_popcount(x); }
 VQT_FN int clz(unsigned x) { return __builtin_clz(x); }
-#endif
 
 constexpr unsigned kCellBits = 6;                 // cell id = 2 * tile + s < 64  (K <= 1024)
 constexpr unsigned kCellMask = (1u << kCellBits) - 1u;
@@ -161,6 +172,50 @@ VQT_FN Cands cands_of(const Lane &L, const Half &H, int h, int K) {
     C.ta[0] = k11; C.tb[0] = k22;
     C.ta[1] = k12; C.tb[1] = k21;
     return C;
+}
+
+// ---- the same stage 1 / stage 2 for trackers that keep their three largest cell maxima OUTSIDE the keys' 6-bit field
+// (vq_chunk.hip: codebooks of up to 512 tiles; cell keys are folded every 16 tiles into running (value, global cell) triples)
+struct Counts {
+    unsigned ge;           // bit 7 - a: stream a at or above thr
+    int popA, nB;
+};
+
+VQT_FN Counts counts_of(const float (&S)[8], float k1, float k2, float k3, float thr, float thrB) {
+    unsigned lt = 0u;
+#pragma unroll
+    for (int a = 0; a < 8; ++a) lt = shl1_in(lt, S[a] - thr);
+    Counts C;
+    C.ge = ~lt & 0xffu;
+    C.popA = popc(C.ge);
+    C.nB = (k1 >= thrB ? 1 : 0) + (k2 >= thrB ? 1 : 0) + (k3 >= thrB ? 1 : 0);
+    return C;
+}
+
+// products of the (at most two) streams and cells at or above the threshold: n = popA * nB codes (0 when either is 0);
+// c1 / c2: GLOBAL cell ids (2 * tile + s) of the two largest cell maxima
+struct Products {
+    int n;
+    int k[4];
+};
+
+VQT_FN Products products_of(const Counts &C, int c1, int c2, int h, int K) {
+    const int p1 = 31 - clz(C.ge | 1u);
+    const unsigned ge2 = C.ge & ~(1u << p1);
+    const int p2 = ge2 ? 31 - clz(ge2) : p1;
+    const int a1 = (7 - p1) & 7, a2 = (7 - p2) & 7;
+    if (C.nB < 2) c2 = c1;
+    Products P;
+    P.k[0] = code_of(a1, c1, h); P.k[1] = code_of(a2, c2, h);      // the diagonal first: (1,1) and (2,2)
+    P.k[2] = code_of(a1, c2, h); P.k[3] = code_of(a2, c1, h);
+    const bool two = C.popA == 2 && C.nB == 2;
+    P.n = (C.popA >= 1 && C.nB >= 1) ? (two ? 4 : (C.popA == 2 || C.nB == 2 ? 2 : 1)) : 0;
+    // padding codes (k >= K) are phantoms: replace them by a product that is a real code
+    const int kv = P.k[0] < K ? P.k[0] : (P.k[1] < K ? P.k[1] : (P.k[2] < K ? P.k[2] : P.k[3]));
+    if (kv >= K) P.n = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) if (P.k[i] >= K) P.k[i] = kv;
+    return P;
 }
 
 // torch.argmin's order on (distance, index) as one unsigned 64-bit key (finite distances; -0 cannot occur: x - y of
