@@ -100,36 +100,70 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     f32x4 F[T][8];
     if (p < nunits) load_unit(p, F, tid & 63);
 
-    // codebook image and seeds -> LDS (eight 16-byte requests in flight per thread)
+    // codebook image -> LDS by LDS-DMA (1 KiB pieces, no staging registers), issued behind the first unit's row requests:
+    // the rows' HBM round trip, the image's L2 round trip and the first unit's fp16 conversion overlap; the workgroup meets once,
+    // in front of its first sweep.  (Inline assembly: for the builtin hipcc waits vmcnt(0) before every later LDS read.)
     {
         const u32x4 *src16 = reinterpret_cast<const u32x4 *>(img_g);
         u32x4 *dst16 = reinterpret_cast<u32x4 *>(Eimg);
-        const int n16 = ntile * 256;
-        // every workgroup reads the same 64 KiB: each starts at its own offset so the CUs do not queue on the same lines
-        const int rot = (int)((blockIdx.x * 97u) % (unsigned)ntile) * 256;
-        for (int i0 = 0; i0 < n16; i0 += 8 * NW * 64) {
-            u32x4 v[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * NW * 64 + tid;
-                v[j] = src16[i < n16 ? (i + rot) % n16 : 0];
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(v[j]));
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int i = i0 + j * NW * 64 + tid;
-                if (i < n16) dst16[(i + rot) % n16] = v[j];
-            }
+        const int npieces = ntile * 4, lane0 = tid & 63;
+        // every workgroup reads the same 64 KiB: each starts at its own piece so the CUs do not queue on the same lines
+        const int rot = (int)((blockIdx.x * 97u) % (unsigned)npieces);
+        for (int pc = wave_u; pc < npieces; pc += NW) {
+            const int sp = (pc + rot) % npieces;
+            const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)(dst16 + sp * 64));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src16 + sp * 64 + lane0), "s"(lds) : "memory", "m0");
         }
     }
     for (int i = tid; i < ntile * 32; i += NW * 64) seeds[i] = seeds_g[i];
     for (int k = tid; k < K; k += NW * 64) hist_s[k] = 0;
     if (tid == 0) ticket_s[0] = NW;                          // units 0 .. NW-1 of the workgroup are taken statically
+
+    // ---- fp32 rows -> fp16 B operands through the wave's LDS tile, |z^|^2 (of the unit whose rows are in F) ----
+    // tile: row r at 128 r, its 16-byte chunk c at slot c ^ ((r >> 1) & 7) (conflict-free for both access patterns);
+    // row 4 i + g4, chunk j16 >> 1: the slot is (j16 >> 1) ^ (g4 >> 1) ^ 2 (i & 3) -- one lane constant, one immediate
+    f16x8 zb[T][4];
+    float zn2[T];
+    auto convert = [&]() {
+        int lane_c = tid & 63;
+        asm volatile("" : "+v"(lane_c));
+        const int l31 = lane_c & 31, h = lane_c >> 5, j16 = lane_c & 15, g4 = lane_c >> 4;
+        const unsigned wbase = (unsigned)g4 * 128u + ((((unsigned)j16 >> 1) ^ ((unsigned)g4 >> 1)) << 4) + (((unsigned)j16 & 1u) << 3);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const f32x2 lo2 = {F[t][i].x, F[t][i].y}, hi2 = {F[t][i].z, F[t][i].w};
+                u32x2 w;
+                w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, f16x2));
+                w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, f16x2));
+                *reinterpret_cast<u32x2 *>(tile_s + t * 4096 + i * 512 + (wbase ^ ((unsigned)(2 * (i & 3)) << 4))) = w;
+            }
+        lds_order_wave();
+        const unsigned rbase = (unsigned)l31 * 128u + ((((unsigned)h ^ ((unsigned)l31 >> 1)) & 7u) << 4);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            float sq = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + (rbase ^ ((unsigned)(2 * q) << 4)));
+                zb[t][q] = __builtin_bit_cast(f16x8, v);
+                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), sq, false);
+                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), sq, false);
+                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), sq, false);
+                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), sq, false);
+            }
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
+            zn2[t] = sq + __uint_as_float(h ? sw[0] : sw[1]);
+        }
+    };
+    if (p < nunits) convert();                               // the first unit, while the codebook image is still landing
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the image
     __syncthreads();
 
     const float inf = __builtin_inff();
-    VQ_STAMP(0);                                               // codebook image copy + first row requests
+    VQ_STAMP(0);                                               // codebook image copy + first rows + first conversion
     float pinf = inf, ninf = -inf;                           // opaque: see vq_track.h
     unsigned keymask = trk::kKeyMask;
     asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
@@ -145,44 +179,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         const uint4 *ap0 = Eimg + h * 32 + l31;
         const float *sp0 = seeds + h * 16;
 
-        // ================= fp32 rows -> fp16 B operands through the wave's LDS tile, |z^|^2 ============================
-        // tile: row r at 128 r, its 16-byte chunk c at slot c ^ ((r >> 1) & 7) (conflict-free for both access patterns);
-        // row 4 i + g4, chunk j16 >> 1: the slot is (j16 >> 1) ^ (g4 >> 1) ^ 2 (i & 3) -- one lane constant, one immediate
-        f16x8 zb[T][4];
-        float zn2[T];
-        {
-            const unsigned wbase = (unsigned)g4 * 128u + ((((unsigned)j16 >> 1) ^ ((unsigned)g4 >> 1)) << 4) + (((unsigned)j16 & 1u) << 3);
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-#pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const f32x2 lo2 = {F[t][i].x, F[t][i].y}, hi2 = {F[t][i].z, F[t][i].w};
-                    u32x2 w;
-                    w.x = __builtin_bit_cast(unsigned, __builtin_convertvector(lo2, f16x2));
-                    w.y = __builtin_bit_cast(unsigned, __builtin_convertvector(hi2, f16x2));
-                    *reinterpret_cast<u32x2 *>(tile_s + t * 4096 + i * 512 + (wbase ^ ((unsigned)(2 * (i & 3)) << 4))) = w;
-                }
-            lds_order_wave();
-            const unsigned rbase = (unsigned)l31 * 128u + ((((unsigned)h ^ ((unsigned)l31 >> 1)) & 7u) << 4);
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                float s = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + (rbase ^ ((unsigned)(2 * q) << 4)));
-                    zb[t][q] = __builtin_bit_cast(f16x8, v);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), s, false);
-                    s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), s, false);
-                }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);
-                zn2[t] = s + __uint_as_float(h ? sw[0] : sw[1]);
-            }
-        }
-
-        VQ_STAMP(1);                                           // rows landed, fp16 conversion
         // ================= the sweep: 4 MFMAs per (code tile, row tile), stream / cell maxima per lane ====================
         trk::Lane L[T];
 #pragma unroll
@@ -308,8 +304,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             if (lane == 0) q = atomicAdd(ticket_s, 1);
             q = __builtin_amdgcn_readfirstlane(q);
             p = (long long)(q / NW) * pstride + (long long)blockIdx.x * NW + (q % NW);
-            if (p < nunits) load_unit(p, F, lane);
+            if (p < nunits) {
+                load_unit(p, F, lane);
+                convert();                                     // (waits for the rows; the next iteration starts with the sweep)
+            }
         }
+        VQ_STAMP(1);                                           // next rows landed, fp16 conversion
     }
 
 #ifdef VQ_SWEEP_TIMING
