@@ -495,7 +495,7 @@ def test_model_pickles_and_deepcopies_after_a_forward():
         assert torch.equal(out_s[1], ref[1])
 
 
-@pytest.mark.parametrize("B", [4096, 37, 1])
+@pytest.mark.parametrize("B", [4096, 37, 1, 5000])
 def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B):
     """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the
     encoder's last kernel (conv_res_pair8_h2_kernel<2, true>: z_e never leaves the chip).  Same z_e bits, same tracker,

@@ -142,8 +142,8 @@ void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *
 bool vq_fuse_ok(int K, int D, int64_t B, int flags);
 int vq_prepare_impl(const float *codebook, int K, int D, int flags, void *workspace, size_t workspace_bytes, hipStream_t st);
 VqFuse vq_fuse_args(const float *codebook, int K, void *workspace, float *z_q, int64_t *idx, int32_t *hist);
-int vq_finalize_impl(void *workspace, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss, float *perplexity,
-                     hipStream_t st);
+int vq_finalize_impl(const double *partials, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss,
+                     float *perplexity, hipStream_t st);
 int vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W, int K, float beta, int flags,
                     float *z_q, int64_t *idx, int32_t *hist, float *loss, float *perplexity, void *workspace,
                     size_t workspace_bytes, vqvae_stream_t stream, bool hist_zeroed);

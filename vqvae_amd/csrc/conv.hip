@@ -4799,7 +4799,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     ConvGeom g3;
     if (post && (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout) ||
                  make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK)) return VQVAE_ERR_UNSUPPORTED;
-    if (post && post->vq && (post->Cout != 64 || CRP_NW != 4 || post->vq->K32 % 128 || post->vq->K32 > 512 || gtc > (unsigned)kVqMaxGrid))
+    if (post && post->vq && (post->Cout != 64 || CRP_NW != 4 || post->vq->K32 % 128 || post->vq->K32 > 512 || !post->vq->partials))
         return VQVAE_ERR_UNSUPPORTED;
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {

@@ -362,9 +362,11 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         // vqvae.py:31-34 in TWO launches: the encoder's last kernel quantizes its own z_e (never written); the codebook's
         // images are prepared first, the histogram is cleared by the encoder's first kernel, loss / perplexity by the finalize
         if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, vqws, vqws_bytes, st)) != 0) return rc;
-        const VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, vqws, z_q, idx ? idx : idx_ws, hist);
+        VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, vqws, z_q, idx ? idx : idx_ws, hist);
+        // one loss partial per workgroup of four images: they go where z_e would have gone (any batch size)
+        vf.partials = reinterpret_cast<double *>(z_e);
         if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, hist, d->n_embeddings, &hist_zeroed, false, &vf)) != 0) return rc;
-        if ((rc = vq_finalize_impl(vqws, (int)((B + 3) / 4), hist, d->n_embeddings, (int64_t)rows, d->embedding_dim, d->beta, loss,
+        if ((rc = vq_finalize_impl(vf.partials, (int)((B + 3) / 4), hist, d->n_embeddings, (int64_t)rows, d->embedding_dim, d->beta, loss,
                                    perplexity, st)) != 0) return rc;
         return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                         // :36
     }

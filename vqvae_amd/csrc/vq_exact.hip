@@ -580,7 +580,8 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
 // ---- the quantizer inside the encoder's last kernel (conv.hip): what vqvae_forward_f32 does around that launch ---------
 bool vqvae::vq_fuse_ok(int K, int D, int64_t B, int flags) {
     const VqPlan p = vq_plan(K > 0 ? K : 1, 64);
-    return D == 64 && K >= 1 && K <= 512 && p.K32 % 128 == 0 && vq_track_ok(K, D) && (B + 3) / 4 <= kVqMaxGrid &&
+    (void)B;
+    return D == 64 && K >= 1 && K <= 512 && p.K32 % 128 == 0 && vq_track_ok(K, D) &&
            !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES | VQVAE_VQ_UNFUSED));
 }
 
@@ -610,11 +611,9 @@ vqvae::VqFuse vqvae::vq_fuse_args(const float *codebook, int K, void *workspace,
     return f;
 }
 
-int vqvae::vq_finalize_impl(void *workspace, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss,
+int vqvae::vq_finalize_impl(const double *partials, int grid, int32_t *hist, int K, int64_t n_rows, int D, float beta, float *loss,
                             float *perplexity, hipStream_t st) {
-    const VqPlan p = vq_plan(K, D);
-    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, reinterpret_cast<double *>(static_cast<char *>(workspace) + p.off_partials),
-                       grid, hist, K, (long long)n_rows, D, beta, loss, perplexity);
+    hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, grid, hist, K, (long long)n_rows, D, beta, loss, perplexity);
     return (int)hipGetLastError();
 }
 
