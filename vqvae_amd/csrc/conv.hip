@@ -3858,9 +3858,10 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
         }
 }
 
-// Same layer when a workgroup's 256 output pixels are whole output rows of one image (Wg | 256 and
-// 256 | Hg*Wg: 32x32 and 256x256 images): the 2R+2 input rows the band needs are staged once in LDS with
-// coalesced 16-byte loads and a zero border, and the 8*CIN gathers per pixel become LDS reads without
+// Same layer when a workgroup's 256 output pixels are an R x TW TILE of one image's output grid (TW a power of two that
+// divides Wg, R = 256 / TW rows that divide Hg: whole rows on 32x32 and 256x256 images, 16 x 16 tiles on 224x224): the
+// (2R+2) x (2TW+2) input patch the tile needs is staged once in LDS with coalesced 16-byte loads (zero outside the image),
+// and the 8*CIN gathers per pixel become LDS reads without
 // bounds checks (the plain kernel issues them as predicated 4-byte global loads).
 // BF3: the 8*CIN-deep reduction runs as CIN k-steps of exact three-term bf16 splits on the bf16 matrix cores
 // (weights split at pack time: [n_tile][k-step][term][half][n] x 16 B; the gathered pixels are split in
@@ -3871,42 +3872,40 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                                                            const float *__restrict__ wimg,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int B, int H, int W,
-                                                           int Cout, int flags, int *__restrict__ out_amax) {
+                                                           int Cout, int flags, int *__restrict__ out_amax, int tw_log2) {
     constexpr int MT = 2, S = CIN * 8, JG = (S + 3) / 4;
     constexpr int WF = BF3 ? NT * CIN * 768 : NT * JG * 256;     // floats of the weight image
     extern __shared__ __attribute__((aligned(16))) float smem_ci[];
     float *Ws = smem_ci;                                   // [WF]
-    float *Xs = smem_ci + WF;                              // [CIN][2R + 2][W + 8], column ix at 4 + ix
+    float *Xs = smem_ci + WF;                              // [CIN][2R + 2][2TW + 8], input column ix at 4 + ix - ix0
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int Hg = H / 2, Wg = W / 2;
-    const int R = 256 / Wg, NR = 2 * R + 2, XS = W + 8;
-    const long long band = blockIdx.x;                     // 256 consecutive output pixels = R output rows
-    const long long b = band / (Hg / R);
-    const int gy0 = (int)(band - b * (Hg / R)) * R;
-    const int iy0 = 2 * gy0 - 1;
+    const int TW = 1 << tw_log2, R = 256 >> tw_log2, NR = 2 * R + 2, XS = 2 * TW + 8;
+    const int ntx = Wg >> tw_log2, nty = Hg / R;
+    const long long band = blockIdx.x;                     // one R x TW tile of output pixels
+    const long long b = band / (nty * ntx);
+    const int trem = (int)(band - b * (nty * ntx));
+    const int gy0 = (trem / ntx) * R, gx0 = (trem % ntx) << tw_log2;
+    const int iy0 = 2 * gy0 - 1, ix0 = 2 * gx0;
     for (int i = tid; i < WF / 4; i += 256)
         reinterpret_cast<f32x4 *>(Ws)[i] = reinterpret_cast<const f32x4 *>(wimg)[i];
-    const int w4 = W / 4;
+    const int w4 = XS / 4;                                 // 16-byte groups ix0 - 4 + 4 x4 ... of a patch row (ix0 % 4 == 0)
     for (int i = tid; i < CIN * NR * w4; i += 256) {
         const int x4 = i % w4, q = i / w4;
         const int r = q % NR, ci = q / NR;
-        const int iy = iy0 + r;
+        const int iy = iy0 + r, ix = ix0 - 4 + 4 * x4;
         f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (iy >= 0 && iy < H) v = *reinterpret_cast<const f32x4 *>(x + ((b * CIN + ci) * H + iy) * (long long)W + 4 * x4);
-        *reinterpret_cast<f32x4 *>(Xs + (ci * NR + r) * XS + 4 + 4 * x4) = v;
-    }
-    for (int i = tid; i < CIN * NR; i += 256) {            // the ix = -1 and ix = W columns
-        Xs[i * XS + 3] = 0.0f;
-        Xs[i * XS + 4 + W] = 0.0f;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = *reinterpret_cast<const f32x4 *>(x + ((b * CIN + ci) * H + iy) * (long long)W + ix);
+        *reinterpret_cast<f32x4 *>(Xs + (ci * NR + r) * XS + 4 * x4) = v;
     }
     __syncthreads();
 
     float a[MT][JG * 4];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int p = wave * (32 * MT) + mt * 32 + l31;    // pixel within the band
-        const int ly = p / Wg, gx = p - ly * Wg;
+        const int p = wave * (32 * MT) + mt * 32 + l31;    // pixel within the tile
+        const int ly = p >> tw_log2, gx = p & (TW - 1);
         const float *base = Xs + (2 * ly) * XS + 2 * gx + 2 * h + 3;
 #pragma unroll
         for (int s = 0; s < JG * 4; ++s) {
@@ -3959,7 +3958,9 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
         }
     }
     const bool relu_out = flags & kFlagReluOut;
-    const long long wbase = band * 256 + wave * (32 * MT);
+    // output pixel (row-major NHWC) of the tile's pixel p
+    auto opix = [&](int p) { return (b * Hg + gy0 + (p >> tw_log2)) * (long long)Wg + gx0 + (p & (TW - 1)); };
+    const int wbase = wave * (32 * MT);
     float omax = 0.0f;
     float bv[NT];
 #pragma unroll
@@ -3979,7 +3980,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                     if (nt * 32 + l31 < Cout) omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
                 tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
-                    if (n < Cout) *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * Cout + n) = a4;
+                    if (n < Cout) *reinterpret_cast<f32x4 *>(out + opix(wbase + mt * 32 + p) * Cout + n) = a4;
                 });
             }
         if (out_amax) publish_amax(out_amax, b, omax, lane);       // the band's 256 pixels belong to image b
@@ -3989,7 +3990,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const long long prow = opix(wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = nt * 32 + l31;
@@ -4914,22 +4915,26 @@ int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const 
     prof_begin(VQVAE_PROF_CONV_IN, st);
     // whole output rows per workgroup -> LDS-staged input band (conv_in_rows_kernel)
     const int Hg = H / 2, Wg = W / 2;
-    const bool rows = Wg <= 256 && 256 % Wg == 0 && ((long long)Hg * Wg) % 256 == 0 && W % 4 == 0 &&
+    // tile: the widest power of two TW <= 256 that divides Wg with 256 / TW rows dividing Hg
+    int tw_log2 = -1;
+    for (int t = 8; t >= 1; --t)
+        if (Wg % (1 << t) == 0 && Hg % (256 >> t) == 0) { tw_log2 = t; break; }
+    const bool rows = tw_log2 > 0 && W % 4 == 0 &&
                       ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     const int jg = (Cin * 8 + 3) / 4;
     const bool bf3 = !(flags & VQVAE_CONV_EXACT_FP32);     // split-bf16 products unless the fp32 MFMA is asked for
     const float *packed3 = packed + (size_t)ntile * jg * 256;
-    size_t rows_lds = rows ? ((size_t)ntile * (bf3 ? Cin * 768 : jg * 256) + (size_t)Cin * (2 * (256 / Wg) + 2) * (W + 8)) *
-                                 sizeof(float) : 0;
+    size_t rows_lds = rows ? ((size_t)ntile * (bf3 ? Cin * 768 : jg * 256) +
+                              (size_t)Cin * (2 * (256 >> tw_log2) + 2) * (2 * (1 << tw_log2) + 8)) * sizeof(float) : 0;
     if (rows_lds < 4 * 32 * 36 * sizeof(float)) rows_lds = 4 * 32 * 36 * sizeof(float);   // the epilogue's output tiles
 #define CI_LAUNCH(CIN_, NT_)                                                                                       \
     do {                                                                                                           \
         if (rows && rows_lds <= 64 * 1024 && bf3)                                                                  \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, true>), dim3(gx), dim3(256), rows_lds, st, x_nchw,  \
-                               packed3, bias, y, (int)B, H, W, Cout, flags, out_amax);                             \
+                               packed3, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2);                    \
         else if (rows && rows_lds <= 64 * 1024)                                                                    \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, false>), dim3(gx), dim3(256), rows_lds, st, x_nchw, \
-                               packed, bias, y, (int)B, H, W, Cout, flags, out_amax);                              \
+                               packed, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2);                     \
         else                                                                                                       \
         {                                                                                                          \
             hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
