@@ -360,6 +360,48 @@ def test_whole_path_per_image_scales_on_generic_maps(H, W):
     assert np.all(got[3] == 0.0)
 
 
+@pytest.mark.parametrize("H,W,B", [(48, 48, 5), (64, 96, 3), (16, 16, 9)], ids=["generic_12x12", "halo_tiles_16x24", "rows_4x4"])
+def test_whole_path_zq_maxima_come_from_the_quantizer(H, W, B):
+    """Maps that are not 8x8 with a codebook too large for the LDS-resident screen (K = 700: vq_chunk.hip): the gather
+    kernel publishes max |z_q| per image for the decoder's first layer (two-term fp16 products need a power of two that
+    covers the image).  Codes whose magnitudes span five decades and images of very different scale, so that a maximum
+    filed under the wrong image (or a row missed) overflows fp16 or wrecks the small images: every image of the composed
+    forward against the oracle's decoder on the oracle's z_q of the DEVICE's z_e (same bits in, same indices out)."""
+    from oracle import torch_port
+    from vqvae_amd import _lib, conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    h, rh, nl, K, D = 64, 16, 2, 700, 64
+    torch.manual_seed(11)
+    m = VQVAE(h, rh, nl, K, D, 0.25).eval()
+    with torch.no_grad():
+        e = m.vector_quantization.embedding.weight
+        e.copy_(torch.randn(K, D) * (10.0 ** (-3.0 + 5.0 * torch.rand(K, 1))))
+    mags = (10.0 ** torch.linspace(-2.0, 3.0, B)).view(-1, 1, 1, 1)
+    x = torch.randn(B, 3, H, W) * mags
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    md = m.to(dev())
+    L = _lib.load()
+    cw, _keep = md._c_weights()
+    nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+    ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+    xd = x.to(dev()).contiguous()
+    z_e = torch.empty(B, H // 4, W // 4, D, device=dev())
+    _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, H, W, z_e.data_ptr(), ws.data_ptr(), nws,
+                                   torch.cuda.current_stream().cuda_stream))
+    with torch.no_grad():
+        _, z_q_ref, _, _, idx_ref = torch_port.quantize(z_e.permute(0, 3, 1, 2).cpu().contiguous(), sd["vector_quantization.embedding.weight"], 0.25)
+        x_hat_ref = torch_port.decode(sd, z_q_ref.clone(), nl)
+        _, x_hat, _ = md(xd)
+    zmax = z_q_ref.abs().amax(dim=(1, 2, 3))
+    assert zmax.max() / zmax.min() > 30.0, "the images' z_q maxima are meant to differ"
+    got = x_hat.cpu().numpy()
+    assert np.isfinite(got).all()
+    for i in range(B):
+        r = x_hat_ref[i].numpy()
+        np.testing.assert_allclose(got[i], r, atol=2e-5 * np.abs(r).max(), rtol=1e-4, err_msg=f"image {i}")
+
+
 def test_encoder_front_fusion_scales_and_borders():
     """enc_front8_h2_kernel (the encoder's first two layers in one launch: 32x32 RGB, h_dim 128) against the oracle on
     images chosen for its two risks: the image borders of the gathered 4x4 patches (single bright pixels in every corner

@@ -103,8 +103,10 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
                         char *ws, hipStream_t st, int *grid_out);
 void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);
 // vq_chunk.hip: the same screen with the codebook image streamed through LDS (D = 64 / 128, any K <= 16384)
+// zq_amax: NULL, or an array of N / hw ints (images of hw consecutive rows) that receives max |z_q| per image (atomicMax on the
+// bits of a non-negative float: the caller has filled it with -1)
 int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,
-                      char *ws, hipStream_t st, int *grid_out);
+                      char *ws, hipStream_t st, int *grid_out, int *zq_amax = nullptr, int hw = 1);
 int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out, bool sixteen);
 
@@ -146,7 +148,8 @@ int vq_finalize_impl(const double *partials, int grid, int32_t *hist, int K, int
                      float *perplexity, hipStream_t st);
 int vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W, int K, float beta, int flags,
                     float *z_q, int64_t *idx, int32_t *hist, float *loss, float *perplexity, void *workspace,
-                    size_t workspace_bytes, vqvae_stream_t stream, bool hist_zeroed);
+                    size_t workspace_bytes, vqvae_stream_t stream, bool hist_zeroed, int *zq_amax = nullptr,
+                    bool *zq_amax_done = nullptr);     // zq_amax: see launch_vq_chunked; *zq_amax_done = a kernel that publishes it ran
 bool enc_front_supported(int H, int W, int Cin, int C1, int C2);
 int enc_front_forward_impl(const float *x_nchw, const float *packed_in, const float *bias_in, const float *packed2,
                            const float *bias2, int64_t B, int H, int W, int Cin, int C1, int C2, float *y, hipStream_t st,

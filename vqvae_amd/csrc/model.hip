@@ -264,8 +264,16 @@ int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
                        w && dims_ok(&w->dims) && fused_c3_path(&w->dims, H, W));
 }
 
+// where z_q's per-image maxima go inside a maxima region (amax_bytes) for the decoder's first layer
+static int *zq_amax_slot(const VqvaeDims *d, int64_t B, int *am) { return am + (size_t)(2 + d->n_res_layers) * B; }
+// does the decoder's first layer want them (the generic / halo kernels do; the 8x8-map kernel measures its image itself)
+static bool zq_amax_wanted(const VqvaeDims *d, int h4, int w4) {
+    return vqvae_conv_term_products(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, d->h_dim, 0) != 3;
+}
+
+// zq_amax_given: the quantizer has already published z_q's maxima into the region's slot
 static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false) {
+                       size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false, bool zq_amax_given = false) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -284,9 +292,9 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     // z_q has no producer that publishes maxima: the 8x8-map kernel measures its image itself, the generic one gets them
     // from one more pass over z_q (array [2 + n_res_layers] of the region)
     int *amz = nullptr;
-    if (am && vqvae_conv_term_products(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, h, 0) != 3) {
-        amz = am + (size_t)(2 + d->n_res_layers) * B;
-        act_absmax_impl(z_q, B, (long long)h4 * w4 * d->embedding_dim, amz, st);
+    if (am && zq_amax_wanted(d, h4, w4)) {
+        amz = zq_amax_slot(d, B, am);
+        if (!zq_amax_given) act_absmax_impl(z_q, B, (long long)h4 * w4 * d->embedding_dim, amz, st);
     }
     const float *t = a;
     const int *amt = am;
@@ -370,13 +378,15 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
                                    perplexity, st)) != 0) return rc;
         return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                         // :36
     }
+    bool zq_amax_done = false;
     if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed)) != 0)
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                               (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
                                            VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)) | VQVAE_VQ_ROWMAJOR,
-                              z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed)) != 0) return rc;   // :34
-    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                             // :36
+                              z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
+                              zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
+    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done);        // :36
 }
 
 }  // extern "C"

@@ -505,7 +505,7 @@ template <int D>
 __global__ __launch_bounds__(1024) void vq_stream_gather_kernel(const float *__restrict__ z, const float *__restrict__ cb,
                                                                 const long long *__restrict__ idx, long long N, int K,
                                                                 float *__restrict__ zq, int *__restrict__ hist,
-                                                                double *__restrict__ partials) {
+                                                                double *__restrict__ partials, int *__restrict__ zq_amax, int hw) {
     constexpr int LPR = D / 4, RPB = 1024 / LPR;          // lanes per row, rows per block pass
     extern __shared__ int hist_s[];
     __shared__ double red[16];
@@ -513,36 +513,86 @@ __global__ __launch_bounds__(1024) void vq_stream_gather_kernel(const float *__r
     for (int k = tid; k < K; k += 1024) hist_s[k] = 0;
     __syncthreads();
     double dacc = 0.0;
-    const long long stride = (long long)gridDim.x * RPB;
-    for (long long r = (long long)blockIdx.x * RPB + rsub; r < N; r += 2 * stride) {
+    // a block takes a CONTIGUOUS run of row passes (RPB rows each), two passes per iteration
+    const long long npass = (N + RPB - 1) / RPB;
+    const long long per = (npass + gridDim.x - 1) / gridDim.x;
+    const long long p0 = (long long)blockIdx.x * per, p1 = p0 + per < npass ? p0 + per : npass;
+    // zq_amax: per-image maximum of |z_q| for the decoder's first layer (the two-term fp16 products' scale), images of hw
+    // consecutive rows: every lane keeps the running maximum of its current image and publishes it when any lane of the
+    // wave moves on to another image (one atomic per wave where the wave was inside one image, per lane otherwise)
+    int cur = -1;
+    float m = 0.0f;
+    long long img0 = 0;
+    int rem0 = 0;
+    const int q1 = RPB / hw, r1s = RPB % hw, q2 = (2 * RPB) / hw, r2s = (2 * RPB) % hw;
+    if (zq_amax && p0 < p1) {
+        const long long r = p0 * RPB + rsub;
+        img0 = r / hw;
+        rem0 = (int)(r - img0 * hw);
+    }
+    auto publish = [&]() {
+        const int c0 = __builtin_amdgcn_readfirstlane(cur);
+        if (__all(cur == c0)) {
+            float mm = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mm = fmaxf(mm, __shfl_xor(mm, o));
+            if ((tid & 63) == 0 && c0 >= 0) atomicMax(zq_amax + c0, __float_as_int(mm));
+        } else if (cur >= 0) {
+            atomicMax(zq_amax + cur, __float_as_int(m));
+        }
+    };
+    auto track = [&](bool valid, long long img, f32x4 v) {
+        const int im = valid ? (int)img : cur;
+        if (__any(im != cur)) {
+            publish();
+            cur = im;
+            m = 0.0f;
+        }
+        if (valid) m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+    };
+    for (long long ps = p0; ps < p1; ps += 2) {
         // two rows per iteration: two independent idx -> codebook chains in flight
-        const long long r1 = r + stride;
-        const bool two = r1 < N;
-        long long k0 = idx[r], k1 = two ? idx[r1] : 0;
+        const long long r = ps * RPB + rsub, r1 = r + RPB;
+        const bool one = r < N, two = ps + 1 < p1 && r1 < N;
+        long long k0 = one ? idx[r] : 0, k1 = two ? idx[r1] : 0;
         if (k0 < 0 || k0 >= K) k0 = 0;                     // cannot happen; never read out of bounds
         if (k1 < 0 || k1 >= K) k1 = 0;
-        const f32x4 z0 = *reinterpret_cast<const f32x4 *>(z + (size_t)r * D + 4 * j);
-        const f32x4 z1 = two ? *reinterpret_cast<const f32x4 *>(z + (size_t)r1 * D + 4 * j) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 zero4 = {0.0f, 0.0f, 0.0f, 0.0f};
+        const f32x4 z0 = one ? *reinterpret_cast<const f32x4 *>(z + (size_t)r * D + 4 * j) : zero4;
+        const f32x4 z1 = two ? *reinterpret_cast<const f32x4 *>(z + (size_t)r1 * D + 4 * j) : zero4;
         const f32x4 e0 = *reinterpret_cast<const f32x4 *>(cb + (size_t)k0 * D + 4 * j);
         const f32x4 e1 = *reinterpret_cast<const f32x4 *>(cb + (size_t)k1 * D + 4 * j);
         const f32x4 d0 = e0 - z0, d1 = e1 - z1;
-        float sq = d0.x * d0.x;
-        sq = sq + d0.y * d0.y;
-        sq = sq + d0.z * d0.z;
-        sq = sq + d0.w * d0.w;
-        dacc += (double)sq;
-        if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)r * D + 4 * j) = z0 + d0;
-        if (j == 0) atomicAdd(&hist_s[k0], 1);
+        const f32x4 o0 = z0 + d0, o1 = z1 + d1;
+        if (one) {
+            float sq = d0.x * d0.x;
+            sq = sq + d0.y * d0.y;
+            sq = sq + d0.z * d0.z;
+            sq = sq + d0.w * d0.w;
+            dacc += (double)sq;
+            if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)r * D + 4 * j) = o0;
+            if (j == 0) atomicAdd(&hist_s[k0], 1);
+        }
         if (two) {
             float sq1 = d1.x * d1.x;
             sq1 = sq1 + d1.y * d1.y;
             sq1 = sq1 + d1.z * d1.z;
             sq1 = sq1 + d1.w * d1.w;
             dacc += (double)sq1;
-            if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)r1 * D + 4 * j) = z1 + d1;
+            if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)r1 * D + 4 * j) = o1;
             if (j == 0) atomicAdd(&hist_s[k1], 1);
         }
+        if (zq_amax) {
+            track(one, img0, o0);
+            int rem1 = rem0 + r1s;
+            const long long img1 = img0 + q1 + (rem1 >= hw ? 1 : 0);
+            track(two, img1, o1);
+            rem0 += r2s;
+            img0 += q2;
+            if (rem0 >= hw) { rem0 -= hw; ++img0; }
+        }
     }
+    if (zq_amax) publish();
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
     if ((tid & 63) == 0) red[tid >> 6] = dacc;
@@ -569,7 +619,7 @@ size_t vq_chunk_scratch_bytes(int D) {
 
 template <int D>
 static int launch_chunked(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                          char *ws, hipStream_t st, int *grid_out) {
+                          char *ws, hipStream_t st, int *grid_out, int *zq_amax, int hw) {
     const VqPlan p = vq_plan(K, D);
     constexpr int TC = ChunkCfg<D>::TC;
     char *s = ws + p.off_chunk;
@@ -611,15 +661,15 @@ static int launch_chunked(const float *z, const float *cb, long long N, int K, f
     if (g > 2 * cus) g = 2 * cus;
     if (g > kVqMaxGrid) g = kVqMaxGrid;
     hipLaunchKernelGGL(vq_stream_gather_kernel<D>, dim3((unsigned)g), dim3(1024), (size_t)K * 4, st, z, cb, idx, N, K, zq,
-                       hist, reinterpret_cast<double *>(ws + p.off_partials));
+                       hist, reinterpret_cast<double *>(ws + p.off_partials), zq ? zq_amax : nullptr, hw > 0 ? hw : 1);
     *grid_out = (int)g;
     return (int)hipGetLastError();
 }
 
 int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,
-                      char *ws, hipStream_t st, int *grid_out) {
-    if (D == 64) return launch_chunked<64>(z, cb, N, K, zq, idx, hist, ws, st, grid_out);
-    if (D == 128) return launch_chunked<128>(z, cb, N, K, zq, idx, hist, ws, st, grid_out);
+                      char *ws, hipStream_t st, int *grid_out, int *zq_amax, int hw) {
+    if (D == 64) return launch_chunked<64>(z, cb, N, K, zq, idx, hist, ws, st, grid_out, zq_amax, hw);
+    if (D == 128) return launch_chunked<128>(z, cb, N, K, zq, idx, hist, ws, st, grid_out, zq_amax, hw);
     return VQVAE_ERR_UNSUPPORTED;
 }
 

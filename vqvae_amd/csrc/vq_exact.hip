@@ -451,7 +451,7 @@ static int launch_vq_prepare(const float *cb, int K, char *ws, hipStream_t st) {
 template <int D>
 static int launch_vq(const float *z, const float *cb, long long N, int HW, int K, float beta,
                      int flags, float *zq, long long *idx, int *hist, float *loss, float *ppl,
-                     char *ws, hipStream_t st, bool hist_zeroed) {
+                     char *ws, hipStream_t st, bool hist_zeroed, int *zq_amax, bool *zq_amax_done) {
     const VqPlan p = vq_plan(K, D);
     int *wflags = reinterpret_cast<int *>(ws + p.off_flags);
     float *ee = reinterpret_cast<float *>(ws + p.off_ee);
@@ -485,7 +485,8 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
         if (rowmajor && vq_chunk_ok(K, D) && !vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
-            const int rc = launch_vq_chunked(z, cb, N, K, D, zq, idx, hist, ws, st, &fgrid);
+            const int rc = launch_vq_chunked(z, cb, N, K, D, zq, idx, hist, ws, st, &fgrid, zq_amax, HW);
+            if (zq_amax_done) *zq_amax_done = zq_amax != nullptr && zq != nullptr;
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
             hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
@@ -620,7 +621,8 @@ int vqvae::vq_finalize_impl(const double *partials, int grid, int32_t *hist, int
 int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, int D, int H, int W,
                            int K, float beta, int flags, float *z_q, int64_t *idx, int32_t *hist,
                            float *loss, float *perplexity, void *workspace, size_t workspace_bytes,
-                           vqvae_stream_t stream, bool hist_zeroed) {
+                           vqvae_stream_t stream, bool hist_zeroed, int *zq_amax, bool *zq_amax_done) {
+    if (zq_amax_done) *zq_amax_done = false;
     if (!z_e || !codebook || !idx || !hist || !loss || !perplexity) return VQVAE_ERR_NULL;
     if (B < 1 || D < 1 || H < 1 || W < 1 || K < 1) return VQVAE_ERR_SHAPE;
     if (K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return VQVAE_ERR_UNSUPPORTED;
@@ -634,10 +636,10 @@ int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, i
     const int HW = H * W;
     long long *idx_ll = reinterpret_cast<long long *>(idx);
     switch (D) {
-        case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
-        case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
-        case 128: return launch_vq<128>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
-        case 256: return launch_vq<256>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed);
+        case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
+        case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
+        case 128: return launch_vq<128>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
+        case 256: return launch_vq<256>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
     }
     return VQVAE_ERR_UNSUPPORTED;
 }
