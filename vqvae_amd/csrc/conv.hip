@@ -1092,27 +1092,38 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 // The tile-resident scheme of conv_tile8_bf3_kernel on maps LARGER than 8x8 (round 3; BASELINE configs 4 / 5: 56x56 and 64x64
 // latent maps): one wave owns one 8x8 TILE of one image's pixel grid plus a one-pixel halo -- a 10x10 input patch -- and NT
 // 32-channel output tiles.  Layers whose input is sampled at stride 1 on a grid that is a multiple of 8 both ways: the 3x3
-// conv, the 3x3 conv-transpose, the four phases of the 4x4 stride-2 conv-transpose, the 1x1 conv.  Per 32-channel chunk the
-// patch is loaded ONCE (128 contiguous bytes per pixel; pixels outside the image read as zero through the buffer
-// descriptor), ReLU'd, split once into its two fp16 terms and parked in the wave's LDS tile; every tap then reads its
-// operands at a shifted patch index -- no per-tap reload / re-split as in conv_igemm_bf3_kernel, no border masks.  Two-term
-// fp16 products only (split8_h): the scale is the image's maximum handed over by the producing layer (in_amax), or the
-// patch's own maximum where none is given (any power of two that covers the patch is exact).  Weights, accumulators, the
-// XCD-aware grid and the epilogue are conv_tile8_bf3_kernel's.
-template <int NT, int NW, bool S2D = false>
-__global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
-                                                                  const float *__restrict__ bias, float *__restrict__ out,
-                                                                  ConvGeom g, int ny, const int *__restrict__ whdr,
-                                                                  const int *__restrict__ in_amax, int *__restrict__ out_amax) {
-    constexpr int MT = 2, PW = 10, PP = PW * PW;                 // patch: 10 x 10 pixels
-    constexpr int HP = PP + 1, PLANE = HP * 2;                   // u32x4 per (k-step, term) plane: [half][patch pixel]
-    constexpr int TILE4 = 2 * 2 * PLANE;                         // [k-step 2][term 2][PLANE]
-    constexpr int CH4 = NT * 128 * 2;
-    __shared__ u32x4 Bs[2][CH4];
-    __shared__ u32x4 As_all[NW * TILE4];
+// conv, the 3x3 conv-transpose, the four phases of the 4x4 stride-2 conv-transpose, and (S2D) the 4x4 stride-2 conv read
+// as a 2x2 conv over the grid of 2x2 input blocks.  Per SIXTEEN-channel slice the patch is loaded ONCE (64 contiguous bytes
+// per pixel; pixels outside the image read as zero through the buffer descriptor), ReLU'd, split once into its two fp16
+// terms and parked in the wave's LDS tile (6.5 KiB); every tap then reads its operands at a shifted patch index -- no
+// per-tap reload / re-split as in conv_igemm_bf3_kernel, no border masks.  Two-term fp16 products only (split8_h): the scale
+// is the image's maximum handed over by the producing layer (in_amax), or the patch's own maximum where none is given (any
+// power of two that covers the patch is exact).
+// Weights stream through two LDS buffers by LDS-DMA (no staging registers), one STAGE = TPS taps of one slice for the NT
+// output tiles (TPS * NT * 2 KiB), requested a stage ahead right behind the stage barrier; the DMA gathers the slice's
+// units out of the packed image's 32-channel chunks ([term][k-step t][half h][32 lanes]: the 16-channel slice s' is the
+// units (t = lane half, h = s')), so the image conv_igemm_bf3_kernel reads serves unchanged.  Four waves per workgroup and
+// TWO workgroups per CU (<= 75 KiB of LDS each): their prologues, conversions, barriers and epilogues fall into each
+// other's matrix phases -- with one eight-wave workgroup per CU these were 45 % of a wave's time with the CU's matrix
+// pipes idle (in-kernel stamps, profiles/r03_notes.txt).
+template <int NT, int TPS, bool S2D = false>
+__global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
+                                                              const float *__restrict__ bias, float *__restrict__ out,
+                                                              ConvGeom g, int ny, const int *__restrict__ whdr,
+                                                              const int *__restrict__ in_amax, int *__restrict__ out_amax) {
+    constexpr int NW = 4, MT = 2, PW = 10, PP = PW * PW;         // patch: 10 x 10 pixels
+    constexpr int HP = PP + 1, PLANE = HP * 2;                   // u32x4 per term plane: [half][patch pixel]
+    constexpr int TILE = 2 * PLANE;                              // [term 2][PLANE]: one 16-channel slice of the patch
+    constexpr int NPIECE = TPS * NT * 2;                         // 1 KiB pieces of a weight stage: [tap][nt][term]
+    constexpr int WST = NPIECE * 64;
+    static_assert(NPIECE % NW == 0, "a stage's pieces divide over the waves");
+    static_assert(TILE * 16 >= 32 * 32 * 4, "the epilogue stages a 32 x 32 float tile in the wave's operand tile");
+    __shared__ u32x4 Bs[2 * WST];
+    __shared__ u32x4 As_all[NW * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    u32x4 *As = As_all + wave * TILE4;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    u32x4 *As = As_all + wave * TILE;
     unsigned bx, by;
     {
         const unsigned id = blockIdx.x, nxb = gridDim.x / (unsigned)ny;
@@ -1129,8 +1140,9 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
     const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
     const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
     // S2D: the 4x4 stride-2 conv read as a conv over the grid of 2x2 input blocks (conv_tile8_bf3_kernel<., true>): a patch
-    // "pixel" is a block, a chunk = (sub-position of the block, 32-channel slice) meets four block offsets
-    const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt, nchunk = ntaps * cpt;
+    // "pixel" is a block, a 32-channel chunk = (sub-position of the block, 32-channel slice) meets four block offsets
+    const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt;
+    const int nslice = 2 * cpt, ngrp = ntaps / TPS, nstage = nslice * ngrp;
 
     // this wave's tile
     const int tx_n = g.Wg >> 3, ty_n = g.Hg >> 3;
@@ -1158,32 +1170,41 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
         spx[mt] = ((p >> 3) + 1) * PW + (p & 7) + 1;             // the tile pixel's place in the patch
     }
 
-    const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * 256;
+    // weight stage s = (slice s / ngrp, tap group s % ngrp): piece p = (tap of the group, nt, term), this wave's are
+    // p = wave + 4 j; unit of lane (h', l31) in the packed chunk (32-channel chunk sl >> 1, output tile): term * 128 + h' * 64 +
+    // (sl & 1) * 32 + l31
+    const u32x4 *wbase = wimg + ((size_t)phase * ntaps * cpt * g.ntile + (size_t)nb * NT) * 256 + (size_t)h * 64 + l31;
     const size_t wchunk = (size_t)g.ntile * 256;
-    constexpr int NBQ = CH4 / (NW * 64);
-    static_assert(CH4 % (NW * 64) == 0, "weight chunk must divide over the workgroup");
-    u32x4 b_nxt[NBQ];
-    auto load_b = [&](int c) {
-        const u32x4 *p = wbase + (size_t)c * wchunk;
-#pragma unroll
-        for (int q = 0; q < NBQ; ++q) b_nxt[q] = p[tid + NW * 64 * q];
+    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+        const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
+        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
     };
-    auto store_b = [&](int buf) {
+    auto dma_stage = [&](int s, int buf) {
+        const int sl = s / ngrp, grp = s - sl * ngrp;
+        const int c32 = sl >> 1;
 #pragma unroll
-        for (int q = 0; q < NBQ; ++q) Bs[buf][tid + NW * 64 * q] = b_nxt[q];
+        for (int j = 0; j < NPIECE / NW; ++j) {
+            const int p = wave_u + NW * j;
+            const int tl = p / (NT * 2), nt = (p >> 1) % NT, term = p & 1;
+            const int tap = grp * TPS + tl;
+            const size_t chunk = S2D ? (size_t)c32 * 4 + tap : (size_t)tap * cpt + c32;
+            dma(wbase + chunk * wchunk + (size_t)nt * 256 + term * 128 + (sl & 1) * 32, Bs + buf * WST + p * 64);
+        }
     };
+    dma_stage(0, 0);
+
     float xscale = 1.0f, descale = 1.0f;
-    f32x4 raw[2][8];
-    auto load_raw = [&](int cc) {
-        unsigned co = (unsigned)(32 * cc) * 4u;
+    f32x4 raw[2][4];
+    auto load_raw = [&](int sl) {                          // slice sl: 16 channels = 64 contiguous bytes per pixel
+        unsigned co = (unsigned)(16 * sl) * 4u;
         if (S2D) {
-            const int sub = cc / g.cpt, sl = cc - sub * g.cpt;
-            co = (unsigned)(((sub >> 1) * g.Win + (sub & 1)) * g.Cin + 32 * sl) * 4u;
+            const int c32 = sl >> 1, sub = c32 / g.cpt, s32 = c32 - sub * g.cpt;
+            co = (unsigned)(((sub >> 1) * g.Win + (sub & 1)) * g.Cin + 32 * s32 + 16 * (sl & 1)) * 4u;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
 #pragma unroll
-            for (int j = 0; j < 8; ++j)
+            for (int j = 0; j < 4; ++j)
                 raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] == kOobOffset ? kOobOffset : poff[k] + co + (unsigned)(4 * j) * 4u, 0, 0));
     };
     auto stage = [&]() {
@@ -1192,18 +1213,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
             if (k == 1 && lane >= PP - 64) break;
             if (relu_in) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) raw[k][j] = relu4(raw[k][j]);
+                for (int j = 0; j < 4; ++j) raw[k][j] = relu4(raw[k][j]);
             }
             u32x4 *dst = As + 64 * k + lane;
 #pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int hh = 0; hh < 2; ++hh) {
-                    u32x4 t1, t2;
-                    split8_h(raw[k][4 * hh + 2 * t], raw[k][4 * hh + 2 * t + 1], xscale, t1, t2);
-                    dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
-                    dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
-                }
+            for (int hh = 0; hh < 2; ++hh) {
+                u32x4 t1, t2;
+                split8_h(raw[k][2 * hh], raw[k][2 * hh + 1], xscale, t1, t2);
+                dst[hh * HP] = t1;
+                dst[PLANE + hh * HP] = t2;
+            }
         }
     };
 
@@ -1218,12 +1237,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
         float m = 0.0f;
         const int given = (in_amax && img_ok) ? in_amax[img] : -1;        // the producer's maximum of this image, if any
         if (given >= 0) m = __int_as_float(given);
-        else for (int c2 = 0; c2 < cpt; ++c2) {                           // else the patch's own (one more pass over it)
-            load_raw(c2);
+        else for (int s2 = 0; s2 < nslice; ++s2) {                        // else the patch's own (one more pass over it)
+            load_raw(s2);
 #pragma unroll
             for (int k = 0; k < 2; ++k)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
+                for (int j = 0; j < 4; ++j) {
                     f32x4 v = raw[k][j];
                     if (relu_in) v = relu4(v);
                     m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
@@ -1234,51 +1253,52 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_halo8_h2_kernel(const float *
         descale = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
     }
 
-    // iteration it = cc * ntaps + tap  ->  weight chunk tap * cpt + cc
-    const int niter = nchunk;
     load_raw(0);
-    load_b(0);
-    store_b(0);
-    if (niter > 1) load_b(S2D ? 1 : (ntaps > 1 ? cpt : 1));
-    int cc = 0, tap = 0;
-    for (int it = 0; it < niter; ++it) {
-        if (tap == 0) {
-            stage();                                   // (wave-private tile, LDS operations of a wave execute in order)
-            if (cc + 1 < cpt) load_raw(cc + 1);
-        }
-        __syncthreads();                               // weights of this iteration + (tap 0) the fresh tile
-        const u32x4 *bs = Bs[it & 1];
-        int shift;
-        if (S2D) {
-            const int sub = cc / g.cpt;
-            shift = ((tap >> 1) - (sub >> 1)) * PW + ((tap & 1) - (sub & 1));
-        } else {
-            shift = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
-        }
+    int sl = 0, grp = 0;
+#pragma unroll 1
+    for (int s = 0; s < nstage; ++s) {
+        if (grp == 0) stage();                         // (wave-private tile, LDS operations of a wave execute in order)
+        // operand offsets of the stage's taps; the first tap's operands are requested in front of the barrier
+        int shift[TPS];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            u32x4 A1[MT], A2[MT];
+        for (int tl = 0; tl < TPS; ++tl) {
+            const int tap = grp * TPS + tl;
+            if (S2D) {
+                const int sub = (sl >> 1) / g.cpt;
+                shift[tl] = ((tap >> 1) - (sub >> 1)) * PW + ((tap & 1) - (sub & 1));
+            } else {
+                shift[tl] = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
+            }
+        }
+        u32x4 A1[2][MT], A2[2][MT];
+        auto ldA = [&](int tl) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const u32x4 *ap = As + (t * 2) * PLANE + h * HP + spx[mt] + shift;
-                A1[mt] = ap[0];
-                A2[mt] = ap[PLANE];
+                const u32x4 *ap = As + h * HP + spx[mt] + shift[tl];
+                A1[tl & 1][mt] = ap[0];
+                A2[tl & 1][mt] = ap[PLANE];
             }
+        };
+        ldA(0);
+        // this stage's weights are in (a slice's load_raw behind the previous barrier may still be in flight: its eight
+        // loads are the youngest), everyone is done with the other buffer
+        const bool raw_behind = s > 0 && grp == (ngrp > 1 ? 1 : 0) && (ngrp > 1 ? sl : sl - 1) + 1 < nslice;
+        if (raw_behind) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (s + 1 < nstage) dma_stage(s + 1, (s + 1) & 1);
+        if (grp == 0 && sl + 1 < nslice) load_raw(sl + 1);
+        const u32x4 *bs = Bs + (s & 1) * WST + lane;
+#pragma unroll
+        for (int tl = 0; tl < TPS; ++tl) {
+            if (tl + 1 < TPS) ldA(tl + 1);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 *bp = bs + nt * 256 + (t * 2 + h) * 32 + l31;
-                prod3x2(A1[0], A2[0], A1[1], A2[1], bp[0], bp[128], acc[0][nt], acc[1][nt]);
+                const u32x4 *bp = bs + (tl * NT + nt) * 128;
+                prod3x2(A1[tl & 1][0], A2[tl & 1][0], A1[tl & 1][1], A2[tl & 1][1], bp[0], bp[64], acc[0][nt], acc[1][nt]);
             }
         }
-        int ntap = tap + 1, ncc = cc;
-        if (ntap == ntaps) { ntap = 0; ++ncc; }
-        if (it + 1 < niter) {
-            store_b((it + 1) & 1);
-            int t2 = ntap + 1, c2 = ncc;
-            if (t2 == ntaps) { t2 = 0; ++c2; }
-            if (it + 2 < niter) load_b(S2D ? c2 * 4 + t2 : t2 * cpt + c2);
-        }
-        tap = ntap; cc = ncc;
+        if (++grp == ngrp) { grp = 0; ++sl; }
     }
 
     float bv[NT];
@@ -4445,7 +4465,7 @@ static size_t packed_h2_bytes(const ConvGeom &g) {
 // conv_halo8_h2_kernel: stride-1-sampled layers on pixel grids that are multiples of 8 both ways and larger than one tile
 static bool conv_halo8_ok(const ConvGeom &g, int Cin, int flags) {
     return !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32)) && g.istride == 1 && g.Hg == g.Hin && g.Wg == g.Win &&
-           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && g.ntaps > 1 && g.ntaps <= 9 &&
+           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && (g.ntaps == 4 || g.ntaps == 9) &&
            (long long)g.Hin * g.Win * Cin * 4 < 0x7FFFFFF0ll;
 }
 // byte offset of the header from the start of a layer's packed weights
@@ -4575,9 +4595,9 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const bool wide = g.ntile % 4 == 0;
             const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
             const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
-            const unsigned gxt = (unsigned)((tiles + 7) / 8) * ny;
-            if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 8, true>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
-            else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 8, true>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            const unsigned gxt = (unsigned)((tiles + 3) / 4) * ny;
+            if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 2, true>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 4, true>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
         }
         else if (conv_halo8_ok(g, Cin, flags) && in_amax) {
             // larger maps whose grid is a multiple of 8 both ways, inside the whole-path entry points (maxima handed over):
@@ -4588,9 +4608,12 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const bool wide = g.ntile % 4 == 0;
             const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
             const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
-            const unsigned gxt = (unsigned)((tiles + 7) / 8) * ny;
-            if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
-            else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 8>), dim3(gxt), dim3(512), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            const unsigned gxt = (unsigned)((tiles + 3) / 4) * ny;
+            // taps per weight stage: a kernel row of the 3x3 layers; two (four) of a conv-transpose phase's four taps
+#define HALO_LAUNCH(NT_, TPS_) hipLaunchKernelGGL((conv_halo8_h2_kernel<NT_, TPS_>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax)
+            if (g.ntaps == 9) { if (wide) HALO_LAUNCH(4, 3); else HALO_LAUNCH(2, 3); }
+            else { if (wide) HALO_LAUNCH(4, 2); else HALO_LAUNCH(2, 4); }
+#undef HALO_LAUNCH
         }
         else {
             // generic maps: the two-term fp16 products need every image's maximum from the producing layer (in_amax); the
