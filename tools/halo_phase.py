@@ -19,7 +19,7 @@ m = VQVAE(128, 32, 2, 8192, 128, 0.25).eval().to(dev)
 x = torch.randn(B, 3, S, S, device=dev)
 raw = ctypes.CDLL(_lib.LIB_PATH)
 have = hasattr(raw, "vqvae_debug_conv_stamps")
-names = ["prologue", "stage+load_raw", "ldA0", "barrier", "mfma", "store_b+load_b", "epilogue"]
+names = ["prologue", "stage", "ldA0+dma wait", "barrier", "dma issue", "raw issue", "mfma", "epilogue"]
 with torch.no_grad():
     for _ in range(2):
         m(x)
@@ -38,5 +38,5 @@ if have:
     raw.vqvae_debug_conv_stamps(buf, 0)
     for v, vn in enumerate(["enc2 4x4s2 (S2D)", "enc4 3x3 128->128", "dec0 T3x3 D->128", "dec2 T4x4s2 128->64"]):
         n = max(buf[16 * v + 8], 1)
-        tot = sum(buf[16 * v + i] for i in range(7))
-        print(f"{vn:22s} per wave (cycles): " + "  ".join(f"{names[i]} {buf[16 * v + i] / n:.0f} ({100.0 * buf[16 * v + i] / max(tot, 1):.1f}%)" for i in range(7)) + f"   total {tot / n:.0f}")
+        tot = sum(buf[16 * v + i] for i in range(8))
+        print(f"{vn:22s} per wave (cycles): " + "  ".join(f"{names[i]} {buf[16 * v + i] / n:.0f} ({100.0 * buf[16 * v + i] / max(tot, 1):.1f}%)" for i in range(8)) + f"   total {tot / n:.0f}")
