@@ -1160,7 +1160,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 
     // this wave's tile
     const int tx_n = g.Wg >> 3, ty_n = g.Hg >> 3;
-    const long long tile_id = (long long)bx * NW + wave;
+    const long long tile_id = (long long)bx * NW + wave_u;       // (wave-uniform: a lane-derived one costs a waterfall loop per load)
     const long long ntile_all = (long long)g.B * ty_n * tx_n;
     const bool img_ok = tile_id < ntile_all;
     const long long tq = img_ok ? tile_id : 0;
@@ -1187,11 +1187,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     // weight stage s = (slice s / ngrp, tap group s % ngrp): piece p = (tap of the group, nt, term), this wave's are
     // p = wave + 4 j; unit of lane (h', l31) in the packed chunk (32-channel chunk sl >> 1, output tile): term * 128 + h' * 64 +
     // (sl & 1) * 32 + l31
-    const u32x4 *wbase = wimg + ((size_t)phase * ntaps * cpt * g.ntile + (size_t)nb * NT) * 256 + (size_t)h * 64 + l31;
+    // (scalar base + this lane's constant byte offset: no vector instruction per piece, no address register to wait for)
+    const u32x4 *wbase = wimg + ((size_t)phase * ntaps * cpt * g.ntile + (size_t)nb * NT) * 256;
+    const unsigned wlane = (unsigned)(h * 64 + l31) * 16u;
     const size_t wchunk = (size_t)g.ntile * 256;
-    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+    auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wlane), "s"(src_uniform), "s"(lds) : "memory", "m0");
     };
     auto dma_stage = [&](int s, int buf) {
         const int sl = s / ngrp, grp = s - sl * ngrp;
@@ -1219,7 +1221,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         for (int k = 0; k < 2; ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] == kOobOffset ? kOobOffset : poff[k] + co + (unsigned)(4 * j) * 4u, 0, 0));
+                raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + (unsigned)(4 * j) * 4u, co, 0));
     };
     auto stage = [&]() {
 #pragma unroll
@@ -1323,26 +1325,40 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     }
     float omax = 0.0f;
     if (img_ok) {
-        // the operand tile is free now (wave-private): stage the outputs through it, 16-byte stores
+        // the operand tile is free now (wave-private): the outputs go through it (accumulator layout in, whole 128-byte
+        // pixel rows out) and leave as 16-byte stores at a scalar row base + this lane's constant offset.  Few vector
+        // instructions on purpose: whatever a wave issues here waits behind the other workgroup's MFMAs.
         float *tile = reinterpret_cast<float *>(As);
+        const float lb = relu_out ? 0.0f : -__builtin_inff();
+        float *obase = out + ((img * g.Hout + (long long)y0 * g.ostride + g.opy[phase]) * g.Wout + (long long)x0 * g.ostride +
+                              g.opx[phase]) * (long long)g.Cout + (size_t)nb * NT * 32;
+        const size_t orow = (size_t)g.ostride * g.Wout * g.Cout;                  // floats from a tile row to the next
+        const unsigned olane = (unsigned)((lane >> 3) * g.ostride * g.Cout + 4 * (lane & 7)) * 4u;
+        const bool nok = (nb * NT) * 32 + 4 * (lane & 7) < g.Cout;               // Cout % 32 == 0 (ntile even): all tiles alike
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                float v[16];
+                const f32x2v d2 = {descale, descale}, b2 = {bv[nt], bv[nt]};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] = acc[mt][nt][r] * descale + bv[nt];
-                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
-                    omax = fmaxf(omax, __builtin_fabsf(v[r]));
+                for (int r = 0; r < 16; r += 2) {
+                    // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
+                    const f32x2v v = __builtin_elementwise_fma(f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]}, d2, b2);
+                    float v0, v1;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v.x), "v"(lb));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v.y), "v"(lb));
+                    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omax) : "v"(v0), "v"(v1));
+                    tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
+                    tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;
                 }
-                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
-                    const int px = 32 * mt + p;
-                    const int gy = y0 + (px >> 3), gx = x0 + (px & 7);
-                    const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
-                                           g.opx[phase]) * (long long)g.Cout;
-                    if (n < g.Cout) *reinterpret_cast<f32x4 *>(out + off + n) = a;
-                });
+                lds_order_wave();
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+                    float *urow = obase + (size_t)(4 * mt + k) * orow + nt * 32;      // wave-uniform
+                    if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(urow) + olane) = q;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
     }
     if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
