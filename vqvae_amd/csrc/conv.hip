@@ -68,8 +68,18 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float *p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n, 0x00020000);
 }
 
+// v_max_f32 / v_max3_f32 as ONE instruction each (fmaxf costs two: hipcc puts a canonicalising v_max in front; the
+// hardware instruction already returns the other operand for a NaN, which is fmaxf's rule)
+__device__ __forceinline__ float vmax(float a, float b) {
+    float o;
+    asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+__device__ __forceinline__ void vmax3_abs(float &m, float a, float b) {       // m = max(m, |a|, |b|)
+    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+    v.x = vmax(v.x, 0.0f); v.y = vmax(v.y, 0.0f); v.z = vmax(v.z, 0.0f); v.w = vmax(v.w, 0.0f);
     return v;
 }
 
@@ -1329,37 +1339,40 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         // pixel rows out) and leave as 16-byte stores at a scalar row base + this lane's constant offset.  Few vector
         // instructions on purpose: whatever a wave issues here waits behind the other workgroup's MFMAs.
         float *tile = reinterpret_cast<float *>(As);
-        const float lb = relu_out ? 0.0f : -__builtin_inff();
         float *obase = out + ((img * g.Hout + (long long)y0 * g.ostride + g.opy[phase]) * g.Wout + (long long)x0 * g.ostride +
                               g.opx[phase]) * (long long)g.Cout + (size_t)nb * NT * 32;
         const size_t orow = (size_t)g.ostride * g.Wout * g.Cout;                  // floats from a tile row to the next
         const unsigned olane = (unsigned)((lane >> 3) * g.ostride * g.Cout + 4 * (lane & 7)) * 4u;
         const bool nok = (nb * NT) * 32 + 4 * (lane & 7) < g.Cout;               // Cout % 32 == 0 (ntile even): all tiles alike
+        auto finish = [&](auto RO) {                       // (one straight-line copy per ReLU flag: no branches inside)
+            constexpr bool ro = decltype(RO)::value;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const f32x2v d2 = {descale, descale}, b2 = {bv[nt], bv[nt]};
+                for (int nt = 0; nt < NT; ++nt) {
+                    const f32x2v d2 = {descale, descale}, b2 = {bv[nt], bv[nt]};
 #pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
-                    const f32x2v v = __builtin_elementwise_fma(f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]}, d2, b2);
-                    float v0, v1;
-                    asm("v_max_f32 %0, %1, %2" : "=v"(v0) : "v"(v.x), "v"(lb));
-                    asm("v_max_f32 %0, %1, %2" : "=v"(v1) : "v"(v.y), "v"(lb));
-                    asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(omax) : "v"(v0), "v"(v1));
-                    tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
-                    tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;
+                    for (int r = 0; r < 16; r += 2) {
+                        // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
+                        const f32x2v v = __builtin_elementwise_fma(f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]}, d2, b2);
+                        float v0 = v.x, v1 = v.y;
+                        if (ro) { v0 = vmax(v0, 0.0f); v1 = vmax(v1, 0.0f); }
+                        vmax3_abs(omax, v0, v1);
+                        tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
+                        tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;
+                    }
+                    lds_order_wave();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+                        float *urow = obase + (size_t)(4 * mt + k) * orow + nt * 32;      // wave-uniform
+                        if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(urow) + olane) = q;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                lds_order_wave();
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
-                    float *urow = obase + (size_t)(4 * mt + k) * orow + nt * 32;      // wave-uniform
-                    if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(urow) + olane) = q;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
+        };
+        if (relu_out) finish(std::true_type{});
+        else finish(std::false_type{});
     }
     if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
 }
@@ -1842,6 +1855,7 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
     __shared__ u32x4 As_all[4 * TILE4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     u32x4 *As = As_all + wave * TILE4;
     const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
     const int cpt = C >> 5, nslice = C >> 4;
@@ -1849,7 +1863,8 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
     for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
 
     const int tx_n = W >> 3, ty_n = H >> 3;
-    const long long tile_id = (long long)blockIdx.x * 4 + wave, ntile_all = (long long)B * ty_n * tx_n;
+    // (wave-uniform: a lane-derived tile index costs a waterfall loop around every buffer load)
+    const long long tile_id = (long long)blockIdx.x * 4 + wave_u, ntile_all = (long long)B * ty_n * tx_n;
     const bool img_ok = tile_id < ntile_all;
     const long long tq = img_ok ? tile_id : 0;
     const long long img = tq / (ty_n * tx_n);
@@ -1882,12 +1897,11 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
     auto load_raw = [&](int sl) {
         const unsigned co = (unsigned)(32 * (sl >> 1) + 8 * (sl & 1)) * 4u;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const unsigned o = poff[k] == kOobOffset ? kOobOffset : poff[k] + co;
-            raw[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 0));
-            raw[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 16u, 0, 0));
-            raw[k][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 64u, 0, 0));
-            raw[k][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, o == kOobOffset ? o : o + 80u, 0, 0));
+        for (int k = 0; k < 2; ++k) {                      // (the slice's offset rides in the scalar offset: no vector instruction)
+            raw[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k], co, 0));
+            raw[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 16u, co, 0));
+            raw[k][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 64u, co, 0));
+            raw[k][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 80u, co, 0));
         }
     };
     const u32x4 *w1v = w1img + h * 32 + l31;
@@ -1972,8 +1986,8 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
-                m = fmaxf(m, acc1[mt][r]);
+                acc1[mt][r] = vmax(acc1[mt][r] * d1, 0.0f);
+                m = vmax(m, acc1[mt][r]);
             }
         const int kh = wave_scale_exp(m);
         hscale = __builtin_ldexpf(1.0f, kh);
@@ -2009,28 +2023,47 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
             prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
         }
         if (img_ok) {
+            // skip and output rows: a scalar row base + this lane's constant offset, packed multiplies, single-instruction
+            // max -- whatever a wave issues here waits behind the other waves' MFMAs.  (One straight-line copy per ReLU flag
+            // pair: branches inside would cut the epilogue into blocks with a full wait at every join.)
+            const unsigned olane = (unsigned)((lane >> 3) * C + 4 * (lane & 7)) * 4u;
+            auto finish = [&](auto RI, auto RO) {
+                constexpr bool ri = decltype(RI)::value, ro = decltype(RO)::value;
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                float v[16];
+                for (int mt = 0; mt < MT; ++mt) {
+                    const size_t urow0 = ((size_t)(y0 + 4 * mt) * W + x0) * C + nt * 32;         // wave-uniform
+                    // the four skip values of this lane are requested before the tile goes through LDS
+                    f32x4 u[4];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = acc2[mt][r] * d2;
-                // the four skip values of this lane are requested before the tile goes through LDS
-                f32x4 u[4];
+                    for (int k = 0; k < 4; ++k)
+                        u[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(img_base + urow0 + (size_t)k * W * C) + olane);
+                    const f32x2v dd = {d2, d2};
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int p = mt * 32 + (lane >> 3) + 8 * k;
-                    u[k] = *reinterpret_cast<const f32x4 *>(img_base + ((size_t)(y0 + (p >> 3)) * W + x0 + (p & 7)) * C + nt * 32 + 4 * (lane & 7));
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2v v = f32x2v{acc2[mt][r], acc2[mt][r + 1]} * dd;
+                        Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v.x;
+                        Hs[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v.y;
+                    }
+                    lds_order_wave();
+                    float *orow0 = out + (size_t)img * H * W * C + urow0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 q = *reinterpret_cast<const f32x4 *>(Hs + k * 256 + lane * 4);
+                        f32x4 uu = u[k];
+                        if (ri) uu = relu4(uu);
+                        f32x4 yv = uu + q;
+                        if (ro) yv = relu4(yv);
+                        vmax3_abs(omax, yv.x, yv.y);
+                        vmax3_abs(omax, yv.z, yv.w);
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(orow0 + (size_t)k * W * C) + olane) = yv;
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int k) {
-                    f32x4 u0 = u[k];
-                    if (relu_in) u0 = relu4(u0);
-                    f32x4 yv = u0 + a4;
-                    if (relu_out) yv = relu4(yv);
-                    omax = fmaxf(omax, fmaxf(fmaxf(__builtin_fabsf(yv.x), __builtin_fabsf(yv.y)), fmaxf(__builtin_fabsf(yv.z), __builtin_fabsf(yv.w))));
-                    const int px = mt * 32 + p;
-                    *reinterpret_cast<f32x4 *>(out + (((size_t)img * H + y0 + (px >> 3)) * W + x0 + (px & 7)) * C + n) = yv;
-                });
-            }
+            };
+            if (relu_in && relu_out) finish(std::true_type{}, std::true_type{});
+            else if (relu_in) finish(std::true_type{}, std::false_type{});
+            else if (relu_out) finish(std::false_type{}, std::true_type{});
+            else finish(std::false_type{}, std::false_type{});
         }
     }
     if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
