@@ -1130,7 +1130,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 // TWO workgroups per CU (<= 75 KiB of LDS each): their prologues, conversions, barriers and epilogues fall into each
 // other's matrix phases -- with one eight-wave workgroup per CU these were 45 % of a wave's time with the CU's matrix
 // pipes idle (in-kernel stamps, profiles/r03_notes.txt).
-template <int NT, int TPS, bool S2D = false>
+template <int NT, int TPS, bool S2D = false, int NPH = 1>
 __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               ConvGeom g, int ny, const int *__restrict__ whdr,
@@ -1138,8 +1138,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     constexpr int NW = 4, MT = 2, PW = 10, PP = PW * PW;         // patch: 10 x 10 pixels
     constexpr int HP = PP + 1, PLANE = HP * 2;                   // u32x4 per term plane: [half][patch pixel]
     constexpr int TILE = 2 * PLANE;                              // [term 2][PLANE]: one 16-channel slice of the patch
-    constexpr int NPIECE = TPS * NT * 2;                         // 1 KiB pieces of a weight stage: [tap][nt][term]
+    // NPH = 2: two output PHASES of the 4x4 stride-2 conv-transpose per wave, (py, 0) and (py, 1) (they read the same patch:
+    // one load / ReLU / split for both); a phase's NT channel tiles are then tiles i * NT .. of NV "virtual" ones
+    constexpr int NV = NPH * NT;
+    constexpr int NPIECE = TPS * NV * 2;                         // 1 KiB pieces of a weight stage: [tap][phase][nt][term]
     constexpr int WST = NPIECE * 64;
+    static_assert(NPH == 1 || (NPH == 2 && !S2D), "phase pairs are the conv-transpose's");
     static_assert(NPIECE % NW == 0, "a stage's pieces divide over the waves");
     static_assert(TILE * 16 >= 32 * 32 * 4, "the epilogue stages a 32 x 32 float tile in the wave's operand tile");
     __shared__ u32x4 Bs[2 * WST];
@@ -1160,9 +1164,15 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
             bx = id / (unsigned)ny;
         }
     }
-    const int phase = by % g.nphase, nb = by / g.nphase;
+    const int nps = g.nphase / NPH;                              // phase sets
+    const int phase0 = (int)(by % (unsigned)nps) * NPH, nb = by / nps;
     const bool relu_in = g.flags & kFlagReluIn, relu_out = g.flags & kFlagReluOut;
-    const unsigned long long dym = g.dymask[phase], dxm = g.dxmask[phase];
+    unsigned long long dym[NPH], dxm[NPH];
+#pragma unroll
+    for (int i = 0; i < NPH; ++i) {
+        dym[i] = g.dymask[phase0 + i];
+        dxm[i] = g.dxmask[phase0 + i];
+    }
     // S2D: the 4x4 stride-2 conv read as a conv over the grid of 2x2 input blocks (conv_tile8_bf3_kernel<., true>): a patch
     // "pixel" is a block, a 32-channel chunk = (sub-position of the block, 32-channel slice) meets four block offsets
     const int ntaps = S2D ? 4 : g.ntaps, cpt = S2D ? 4 * g.cpt : g.cpt;
@@ -1198,7 +1208,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     // p = wave + 4 j; unit of lane (h', l31) in the packed chunk (32-channel chunk sl >> 1, output tile): term * 128 + h' * 64 +
     // (sl & 1) * 32 + l31
     // (scalar base + this lane's constant byte offset: no vector instruction per piece, no address register to wait for)
-    const u32x4 *wbase = wimg + ((size_t)phase * ntaps * cpt * g.ntile + (size_t)nb * NT) * 256;
+    const u32x4 *wbase = wimg + ((size_t)phase0 * ntaps * cpt * g.ntile + (size_t)nb * NT) * 256;
+    const size_t wphase = (size_t)ntaps * cpt * g.ntile * 256;
     const unsigned wlane = (unsigned)(h * 64 + l31) * 16u;
     const size_t wchunk = (size_t)g.ntile * 256;
     auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
@@ -1211,10 +1222,10 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
         for (int j = 0; j < NPIECE / NW; ++j) {
             const int p = wave_u + NW * j;
-            const int tl = p / (NT * 2), nt = (p >> 1) % NT, term = p & 1;
+            const int tl = p / (NV * 2), ph = (p / (NT * 2)) % NPH, nt = (p >> 1) % NT, term = p & 1;
             const int tap = grp * TPS + tl;
             const size_t chunk = S2D ? (size_t)c32 * 4 + tap : (size_t)tap * cpt + c32;
-            dma(wbase + chunk * wchunk + (size_t)nt * 256 + term * 128 + (sl & 1) * 32, Bs + buf * WST + p * 64);
+            dma(wbase + ph * wphase + chunk * wchunk + (size_t)nt * 256 + term * 128 + (sl & 1) * 32, Bs + buf * WST + p * 64);
         }
     };
     dma_stage(0, 0);
@@ -1252,11 +1263,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         }
     };
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[MT][NV];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NV; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
     {
@@ -1285,25 +1296,32 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     for (int s = 0; s < nstage; ++s) {
         if (grp == 0) stage();                         // (wave-private tile, LDS operations of a wave execute in order)
         // operand offsets of the stage's taps; the first tap's operands are requested in front of the barrier
-        int shift[TPS];
+        int shift[TPS][NPH];
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl) {
             const int tap = grp * TPS + tl;
-            if (S2D) {
-                const int sub = (sl >> 1) / g.cpt;
-                shift[tl] = ((tap >> 1) - (sub >> 1)) * PW + ((tap & 1) - (sub & 1));
-            } else {
-                shift[tl] = ((int)((dym >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm >> (4 * tap)) & 15) - 8);
+#pragma unroll
+            for (int i = 0; i < NPH; ++i) {
+                if (S2D) {
+                    const int sub = (sl >> 1) / g.cpt;
+                    shift[tl][i] = ((tap >> 1) - (sub >> 1)) * PW + ((tap & 1) - (sub & 1));
+                } else {
+                    shift[tl][i] = ((int)((dym[i] >> (4 * tap)) & 15) - 8) * PW + ((int)((dxm[i] >> (4 * tap)) & 15) - 8);
+                }
             }
         }
-        u32x4 A1[2][MT], A2[2][MT];
+        // (one tap's operands ahead; with two phases per pass the registers allow the current tap's only)
+        constexpr int NAB = NPH == 1 ? 2 : 1;
+        u32x4 A1[NAB][NPH][MT], A2[NAB][NPH][MT];
         auto ldA = [&](int tl) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const u32x4 *ap = As + h * HP + spx[mt] + shift[tl];
-                A1[tl & 1][mt] = ap[0];
-                A2[tl & 1][mt] = ap[PLANE];
-            }
+            for (int i = 0; i < NPH; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const u32x4 *ap = As + h * HP + spx[mt] + shift[tl][i];
+                    A1[tl % NAB][i][mt] = ap[0];
+                    A2[tl % NAB][i][mt] = ap[PLANE];
+                }
         };
         ldA(0);
         // this stage's weights are in (a slice's load_raw behind the previous barrier may still be in flight: its eight
@@ -1317,11 +1335,13 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         const u32x4 *bs = Bs + (s & 1) * WST + lane;
 #pragma unroll
         for (int tl = 0; tl < TPS; ++tl) {
-            if (tl + 1 < TPS) ldA(tl + 1);
+            if (NAB == 2 && tl + 1 < TPS) ldA(tl + 1);
+            if (NAB == 1 && tl > 0) ldA(tl);
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const u32x4 *bp = bs + (tl * NT + nt) * 128;
-                prod3x2(A1[tl & 1][0], A2[tl & 1][0], A1[tl & 1][1], A2[tl & 1][1], bp[0], bp[64], acc[0][nt], acc[1][nt]);
+            for (int v = 0; v < NV; ++v) {
+                const u32x4 *bp = bs + (tl * NV + v) * 128;
+                const int i = v / NT;
+                prod3x2(A1[tl % NAB][i][0], A2[tl % NAB][i][0], A1[tl % NAB][i][1], A2[tl % NAB][i][1], bp[0], bp[64], acc[0][v], acc[1][v]);
             }
         }
         if (++grp == ngrp) { grp = 0; ++sl; }
@@ -1339,8 +1359,11 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         // pixel rows out) and leave as 16-byte stores at a scalar row base + this lane's constant offset.  Few vector
         // instructions on purpose: whatever a wave issues here waits behind the other workgroup's MFMAs.
         float *tile = reinterpret_cast<float *>(As);
-        float *obase = out + ((img * g.Hout + (long long)y0 * g.ostride + g.opy[phase]) * g.Wout + (long long)x0 * g.ostride +
-                              g.opx[phase]) * (long long)g.Cout + (size_t)nb * NT * 32;
+        float *obase[NPH];
+#pragma unroll
+        for (int i = 0; i < NPH; ++i)
+            obase[i] = out + ((img * g.Hout + (long long)y0 * g.ostride + g.opy[phase0 + i]) * g.Wout + (long long)x0 * g.ostride +
+                              g.opx[phase0 + i]) * (long long)g.Cout + (size_t)nb * NT * 32;
         const size_t orow = (size_t)g.ostride * g.Wout * g.Cout;                  // floats from a tile row to the next
         const unsigned olane = (unsigned)((lane >> 3) * g.ostride * g.Cout + 4 * (lane & 7)) * 4u;
         const bool nok = (nb * NT) * 32 + 4 * (lane & 7) < g.Cout;               // Cout % 32 == 0 (ntile even): all tiles alike
@@ -1349,13 +1372,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
+                for (int v = 0; v < NV; ++v) {
+                    const int nt = v % NT, i = v / NT;
                     const f32x2v d2 = {descale, descale}, b2 = {bv[nt], bv[nt]};
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
-                        const f32x2v v = __builtin_elementwise_fma(f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]}, d2, b2);
-                        float v0 = v.x, v1 = v.y;
+                        const f32x2v y = __builtin_elementwise_fma(f32x2v{acc[mt][v][r], acc[mt][v][r + 1]}, d2, b2);
+                        float v0 = y.x, v1 = y.y;
                         if (ro) { v0 = vmax(v0, 0.0f); v1 = vmax(v1, 0.0f); }
                         vmax3_abs(omax, v0, v1);
                         tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
@@ -1365,7 +1389,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
-                        float *urow = obase + (size_t)(4 * mt + k) * orow + nt * 32;      // wave-uniform
+                        float *urow = obase[i] + (size_t)(4 * mt + k) * orow + nt * 32;   // wave-uniform
                         if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(urow) + olane) = q;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -4670,12 +4694,15 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + kH2Header);
             const bool wide = g.ntile % 4 == 0;
             const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
-            const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
+            // 64-channel conv-transpose phases go in pairs (one patch load / split for two phases)
+            const bool pairs = !wide && g.nphase == 4;
+            const int ny = (pairs ? 2 : g.nphase) * (wide ? g.ntile / 4 : g.ntile / 2);
             const unsigned gxt = (unsigned)((tiles + 3) / 4) * ny;
-            // taps per weight stage: a kernel row of the 3x3 layers; two (four) of a conv-transpose phase's four taps
-#define HALO_LAUNCH(NT_, TPS_) hipLaunchKernelGGL((conv_halo8_h2_kernel<NT_, TPS_>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax)
-            if (g.ntaps == 9) { if (wide) HALO_LAUNCH(4, 3); else HALO_LAUNCH(2, 3); }
-            else { if (wide) HALO_LAUNCH(4, 2); else HALO_LAUNCH(2, 4); }
+            // taps per weight stage: a kernel row of the 3x3 layers; two of a conv-transpose phase's four taps
+#define HALO_LAUNCH(NT_, TPS_, NPH_) hipLaunchKernelGGL((conv_halo8_h2_kernel<NT_, TPS_, false, NPH_>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax)
+            if (g.ntaps == 9) { if (wide) HALO_LAUNCH(4, 3, 1); else HALO_LAUNCH(2, 3, 1); }
+            else if (pairs) HALO_LAUNCH(2, 2, 2);
+            else { if (wide) HALO_LAUNCH(4, 2, 1); else HALO_LAUNCH(2, 4, 1); }
 #undef HALO_LAUNCH
         }
         else {
