@@ -4166,13 +4166,13 @@ __global__ __launch_bounds__(256) void conv_in_pack_bf3_kernel(const float *__re
 // [chunk][n_tile][term][k-step][half][n] x 16 B; activations split in registers) instead of the fp32 MFMA.
 // MODE 0: exact fp32 MFMA, 1: three-term bf16 products, 2: two-term fp16 products (in_amax: the images' maxima, whdr: {kw})
 template <int NT, int MODE>
-__global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restrict__ in,
                                                         const float *__restrict__ wimg,
                                                         const float *__restrict__ bias,
                                                         float *__restrict__ out, int B, int H, int W,
                                                         int Cin, int Cout, int TH, int TW, int halo_y,
                                                         int halo_x, int tiles_y, int tiles_x, const int *__restrict__ whdr,
-                                                        const int *__restrict__ in_amax) {
+                                                        const int *__restrict__ in_amax, int ntiles) {
     constexpr int MT = 2;
     constexpr bool BF3 = MODE == 1, H2 = MODE == 2;
     const int STRIDE = 16 * Cout + 1;              // T row: the 16*Cout used columns (odd stride: conflict-free)
@@ -4186,12 +4186,11 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
 
-    int t = blockIdx.x;
-    const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y;
-    const long long b = t / tiles_y;
-    const int y0 = ty * TH, x0 = tx * TW;
-    const int ry = y0 - halo_y, rx = x0 - halo_x;
+    // PERSISTENT workgroups: tile blockIdx.x, + gridDim.x, ...; the next tile's input (both 32-channel chunks where there are
+    // two) is requested before the current tile's col2im, which has no global loads of its own -- the load latency that every
+    // one-tile workgroup used to sit out in front of its first MFMA now runs under the col2im of the tile before
+    long long b = 0;
+    int y0 = 0, x0 = 0, ry = 0, rx = 0;
 
     if constexpr (!H2)
         for (int i = tid; i < cpt * NT * (WCH / 4); i += 256)
@@ -4206,13 +4205,20 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
     bool ok[MT];
     const float *src[MT];
+    // tile t: its image / origin (kept by the caller where the previous tile's are still needed) and this lane's input rows
+    auto setup = [&](int t, long long &tb, int &ty0, int &tx0) {
+        const int tx = t % tiles_x; t /= tiles_x;
+        const int ty = t % tiles_y;
+        tb = t / tiles_y;
+        ty0 = ty * TH; tx0 = tx * TW;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int p = wave * 64 + mt * 32 + l31;
-        const int iy = ry + (p >> 4), ix = rx + (p & 15);
-        ok[mt] = iy >= 0 && iy < H && ix >= 0 && ix < W;
-        src[mt] = in + ((b * H + iy) * (long long)W + ix) * Cin + 16 * h;
-    }
+        for (int mt = 0; mt < MT; ++mt) {
+            const int p = wave * 64 + mt * 32 + l31;
+            const int iy = ty0 - halo_y + (p >> 4), ix = tx0 - halo_x + (p & 15);
+            ok[mt] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            src[mt] = in + ((tb * H + iy) * (long long)W + ix) * Cin + 16 * h;
+        }
+    };
     // A operands: chunk c+1 is in flight while chunk c multiplies (two register sets); chunk 0 is requested
     // before the barrier so its latency overlaps the weight copy
     auto load_a = [&](int c, f32x4(&a)[MT][4]) {
@@ -4227,15 +4233,17 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
             }
     };
     float xsc = 1.0f, dsc = 1.0f;                   // H2: the image's scale 2^kx and the accumulator scale 2^-(kx + kw)
-    if constexpr (H2) {
-        const float mx = __int_as_float(in_amax[b]);
-        int e = 15;
-        if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
-        int kx = 15 - e;
-        kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
-        xsc = __builtin_ldexpf(1.0f, kx);
-        dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
-    }
+    auto scales = [&]() {
+        if constexpr (H2) {
+            const float mx = __int_as_float(in_amax[b]);
+            int e = 15;
+            if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
+            int kx = 15 - e;
+            kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
+            xsc = __builtin_ldexpf(1.0f, kx);
+            dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+        }
+    };
     auto mma = [&](int c, const f32x4(&a)[MT][4]) {
         if constexpr (H2) {
             const u32x4 *wb = reinterpret_cast<const u32x4 *>(wimg + (size_t)c * NT * WCH);
@@ -4289,22 +4297,27 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         }
     };
     f32x4 a0[MT][4], a1[MT][4];
+    int tcur = blockIdx.x;
+    setup(tcur, b, y0, x0);
     load_a(0, a0);
+    if (cpt > 1) load_a(1, a1);
     __syncthreads();
+  for (;;) {
+    ry = y0 - halo_y; rx = x0 - halo_x;
+    scales();
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
+    // on entry chunks 0 and 1 are in a0 / a1 (requested a tile ago)
     for (int c = 0; c < cpt; c += 2) {
-        if (c + 1 < cpt) load_a(c + 1, a1);
-#if !defined(CTO_KNOB) || CTO_KNOB != 1          // timing-only knock-outs (wrong results): 1 = no MFMAs, 2 = no col2im
         mma(c, a0);
-#else
-        asm volatile("" :: "v"(a0[0][0]), "v"(a0[1][3]));
-#endif
+        if (c + 2 < cpt) load_a(c + 2, a0);
         if (c + 1 < cpt) {
-            if (c + 2 < cpt) load_a(c + 2, a0);
-#if !defined(CTO_KNOB) || CTO_KNOB != 1
             mma(c + 1, a1);
-#else
-            asm volatile("" :: "v"(a1[0][0]), "v"(a1[1][3]));
-#endif
+            if (c + 3 < cpt) load_a(c + 3, a1);
         }
     }
 #pragma unroll
@@ -4317,6 +4330,16 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
                 if (nt * 32 + l31 < STRIDE - 1) Ts[p * STRIDE + nt * 32 + l31] = H2 ? acc[mt][nt][r] * dsc : acc[mt][nt][r];
         }
     __syncthreads();
+    // the next tile's input goes on its way now
+    const int tnext = tcur + (int)gridDim.x;
+    const bool more = tnext < ntiles;
+    long long nb_ = b;
+    int ny0 = y0, nx0 = x0;
+    if (more) {
+        setup(tnext, nb_, ny0, nx0);
+        load_a(0, a0);
+        if (cpt > 1) load_a(1, a1);
+    }
 
     // col2im over the interior's outputs, ox fastest (coalesced NCHW rows)
     const int th = min(TH, H - y0), tw = min(TW, W - x0);
@@ -4346,14 +4369,6 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
         const bool pow2 = ((qw & (qw - 1)) | (OH & (OH - 1))) == 0;
         const int lq = 31 - __builtin_clz(qw), lh = 31 - __builtin_clz(OH);
         for (int e = tid; e < nquad; e += 256) {
-#if defined(CTO_KNOB) && CTO_KNOB == 2
-            {
-                const int xq0 = e % qw, q0 = e / qw, oyl0 = q0 % OH, co0 = q0 / OH;
-                *reinterpret_cast<f32x4 *>(out + ((b * Cout + co0) * Ho + 2 * y0 + oyl0) * (long long)Wo + 2 * x0 + 4 * xq0) =
-                    f32x4{Ts[e], Ts[e + 1], 0.0f, 0.0f};
-                continue;
-            }
-#endif
             int xq, oyl, co;
             if (pow2) { xq = e & (qw - 1); oyl = (e >> lq) & (OH - 1); co = e >> (lq + lh); }
             else { xq = e % qw; const int q = e / qw; oyl = q % OH; co = q / OH; }
@@ -4398,6 +4413,10 @@ __global__ __launch_bounds__(256) void convt_out_kernel(const float *__restrict_
             out[((b * Cout + co) * Ho + oy) * (long long)Wo + ox] = gather(co, oy, ox);
         }
     }
+    if (!more) break;
+    __syncthreads();                               // everyone is done with T
+    tcur = tnext; b = nb_; y0 = ny0; x0 = nx0;
+  }
 }
 
 __global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__restrict__ w, float *__restrict__ img,
@@ -5154,14 +5173,17 @@ int vqvae::convt_out_forward_impl(const float *x, const float *packed, const flo
     const char *h2base = reinterpret_cast<const char *>(packed) + (size_t)cpt * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const int *whdr = reinterpret_cast<const int *>(h2base);
     const float *wimg = h2 ? reinterpret_cast<const float *>(h2base + kH2Header) : (bf3 ? packed + (size_t)cpt * ntile * 1024 : packed);
+    // persistent workgroups, as many as fit on the chip at once (two per CU: ~230 registers per lane with a tile's input in flight)
+    const long long resident = (long long)num_cus() * (lds <= 80 * 1024 ? 2 : 1);
+    const long long grid = ntiles < resident ? ntiles : resident;
     prof_begin(VQVAE_PROF_CONV_OUT, st);
 #define CTO_LAUNCH(NT_, BF_)                                                                                          \
     do {                                                                                                              \
         auto k = convt_out_kernel<NT_, BF_>;                                                                          \
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,       \
                                   kLdsBytes);                                                                         \
-        hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(256), lds, st, x, wimg, bias, y_nchw, (int)B, H, W, Cin,   \
-                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x, whdr, in_amax);                            \
+        hipLaunchKernelGGL(k, dim3((unsigned)grid), dim3(256), lds, st, x, wimg, bias, y_nchw, (int)B, H, W, Cin,     \
+                           Cout, TH, TW, halo_y, halo_x, tiles_y, tiles_x, whdr, in_amax, (int)ntiles);               \
     } while (0)
     if (ntile == 1) { if (h2) CTO_LAUNCH(1, 2); else if (bf3) CTO_LAUNCH(1, 1); else CTO_LAUNCH(1, 0); }
     else { if (h2) CTO_LAUNCH(2, 2); else if (bf3) CTO_LAUNCH(2, 1); else CTO_LAUNCH(2, 0); }
