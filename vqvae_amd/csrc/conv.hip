@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
         bw[0] = p[0]; bw[1] = p[128];
     };
-    u32x4 bw[2][2];
+    u32x4 bw[3][2];                                    // three taps' weights: two in flight behind the one in use
     float xscale, d1;
     {
         float m = 0.0f;
@@ -1956,8 +1956,8 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
     }
     load_raw(0);
     load_w(0, 0, bw[0]);
-    auto slice = [&](int sl, auto PAR) {
-        constexpr int par = decltype(PAR)::value;
+    load_w(1, 0, bw[1]);
+    auto slice = [&](int sl) {
         {
             u32x4 t1a[2], t2a[2], t1b[2], t2b[2];
 #pragma unroll
@@ -1981,10 +1981,10 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
             lds_order_wave();
         }
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int cur = (tap + par) & 1;
-            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
-            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+        for (int tap = 0; tap < 9; ++tap) {            // (nine taps: the ring position of tap 0 is the same for every slice)
+            const int cur = tap % 3, nxt = (tap + 2) % 3;
+            if (tap + 2 < 9) load_w(tap + 2, sl, bw[nxt]);
+            else if (sl + 1 < nslice) load_w(tap + 2 - 9, sl + 1, bw[nxt]);
             const int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
             u32x4 S[MT][2];
 #pragma unroll
@@ -1995,10 +1995,8 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
             prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
         }
     };
-    for (int sl = 0; sl < nslice; sl += 2) {
-        slice(sl, std::integral_constant<int, 0>{});
-        slice(sl + 1, std::integral_constant<int, 1>{});
-    }
+#pragma unroll 1
+    for (int sl = 0; sl < nslice; ++sl) slice(sl);
     __syncthreads();          // W2 image (copied at kernel start) is complete; operand tile no longer read
 
     float *Hs = reinterpret_cast<float *>(As);
