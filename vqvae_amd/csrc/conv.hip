@@ -2032,33 +2032,38 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
     }
 
     float omax = 0.0f;
+    if (img_ok) {
+        // Per 32-channel tile: the 1x1 GEMM, then per pixel tile the skip and the output rows -- a scalar row base + this
+        // lane's constant offset, packed multiplies, single-instruction max: whatever a wave issues here waits behind the
+        // other waves' MFMAs.  The skip values of the NEXT (channel tile, pixel tile) step are requested a step ahead.  One
+        // straight-line copy per ReLU flag pair (branches inside would cut it into blocks with a full wait at every join).
+        const unsigned olane = (unsigned)((lane >> 3) * C + 4 * (lane & 7)) * 4u;
+        auto urow0 = [&](int step) { return ((size_t)(y0 + 4 * (step & 1)) * W + x0) * C + (step >> 1) * 32; };     // wave-uniform
+        auto skip_load = [&](int step, f32x4(&u)[4]) {
 #pragma unroll
-    for (int nt = 0; nt < NT2; ++nt) {
-        f32x16 acc2[MT];
+            for (int k = 0; k < 4; ++k)
+                u[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(img_base + urow0(step) + (size_t)k * W * C) + olane);
+        };
+        auto finish = [&](auto RI, auto RO) {
+            constexpr bool ri = decltype(RI)::value, ro = decltype(RO)::value;
+            f32x4 u[2][4];
+            skip_load(0, u[0]);
+#pragma unroll 1
+            for (int nt = 0; nt < NT2; ++nt) {
+                f32x16 acc2[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+                for (int m2 = 0; m2 < MT; ++m2)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+                    for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
-            prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
-        }
-        if (img_ok) {
-            // skip and output rows: a scalar row base + this lane's constant offset, packed multiplies, single-instruction
-            // max -- whatever a wave issues here waits behind the other waves' MFMAs.  (One straight-line copy per ReLU flag
-            // pair: branches inside would cut the epilogue into blocks with a full wait at every join.)
-            const unsigned olane = (unsigned)((lane >> 3) * C + 4 * (lane & 7)) * 4u;
-            auto finish = [&](auto RI, auto RO) {
-                constexpr bool ri = decltype(RI)::value, ro = decltype(RO)::value;
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+                    prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const size_t urow0 = ((size_t)(y0 + 4 * mt) * W + x0) * C + nt * 32;         // wave-uniform
-                    // the four skip values of this lane are requested before the tile goes through LDS
-                    f32x4 u[4];
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        u[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(img_base + urow0 + (size_t)k * W * C) + olane);
+                    const int step = 2 * nt + mt;
+                    if (step + 1 < 2 * NT2) skip_load(step + 1, u[mt ^ 1]);
                     const f32x2v dd = {d2, d2};
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
@@ -2067,11 +2072,11 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
                         Hs[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v.y;
                     }
                     lds_order_wave();
-                    float *orow0 = out + (size_t)img * H * W * C + urow0;
+                    float *orow0 = out + (size_t)img * H * W * C + urow0(step);
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
                         const f32x4 q = *reinterpret_cast<const f32x4 *>(Hs + k * 256 + lane * 4);
-                        f32x4 uu = u[k];
+                        f32x4 uu = u[mt][k];
                         if (ri) uu = relu4(uu);
                         f32x4 yv = uu + q;
                         if (ro) yv = relu4(yv);
@@ -2081,12 +2086,12 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
-            };
-            if (relu_in && relu_out) finish(std::true_type{}, std::true_type{});
-            else if (relu_in) finish(std::true_type{}, std::false_type{});
-            else if (relu_out) finish(std::false_type{}, std::true_type{});
-            else finish(std::false_type{}, std::false_type{});
-        }
+            }
+        };
+        if (relu_in && relu_out) finish(std::true_type{}, std::true_type{});
+        else if (relu_in) finish(std::true_type{}, std::false_type{});
+        else if (relu_out) finish(std::false_type{}, std::true_type{});
+        else finish(std::false_type{}, std::false_type{});
     }
     if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
 }
