@@ -1130,12 +1130,13 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 // TWO workgroups per CU (<= 75 KiB of LDS each): their prologues, conversions, barriers and epilogues fall into each
 // other's matrix phases -- with one eight-wave workgroup per CU these were 45 % of a wave's time with the CU's matrix
 // pipes idle (in-kernel stamps, profiles/r03_notes.txt).
-template <int NT, int TPS, bool S2D = false, int NPH = 1>
+template <int NT, int TPS, bool S2D = false, int NPH = 1, int HALO = 1>
 __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ wimg,
                                                               const float *__restrict__ bias, float *__restrict__ out,
                                                               ConvGeom g, int ny, const int *__restrict__ whdr,
                                                               const int *__restrict__ in_amax, int *__restrict__ out_amax) {
-    constexpr int NW = 4, MT = 2, PW = 10, PP = PW * PW;         // patch: 10 x 10 pixels
+    // HALO = 0: the 1x1 conv (one tap, no border): the patch is the tile itself
+    constexpr int NW = 4, MT = 2, PW = 8 + 2 * HALO, PP = PW * PW;         // patch: 10 x 10 pixels
     constexpr int HP = PP + 1, PLANE = HP * 2;                   // u32x4 per term plane: [half][patch pixel]
     constexpr int TILE = 2 * PLANE;                              // [term 2][PLANE]: one 16-channel slice of the patch
     // NPH = 2: two output PHASES of the 4x4 stride-2 conv-transpose per wave, (py, 0) and (py, 1) (they read the same patch:
@@ -1193,7 +1194,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int q = 64 * k + lane;
-        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;         // pixel (S2D: block) coordinates
+        const int iy = y0 - HALO + q / PW, ix = x0 - HALO + q % PW;   // pixel (S2D: block) coordinates
         if (S2D) poff[k] = (q < PP && iy >= 0 && 2 * iy < g.Hin && ix >= 0 && 2 * ix < g.Win) ? (unsigned)((2 * iy * g.Win + 2 * ix) * g.Cin) * 4u : kOobOffset;
         else poff[k] = (q < PP && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? (unsigned)((iy * g.Win + ix) * g.Cin) * 4u : kOobOffset;
     }
@@ -1201,7 +1202,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const int p = 32 * mt + l31;
-        spx[mt] = ((p >> 3) + 1) * PW + (p & 7) + 1;             // the tile pixel's place in the patch
+        spx[mt] = ((p >> 3) + HALO) * PW + (p & 7) + HALO;       // the tile pixel's place in the patch
     }
 
     // weight stage s = (slice s / ngrp, tap group s % ngrp): piece p = (tap of the group, nt, term), this wave's are
@@ -1239,14 +1240,14 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
             co = (unsigned)(((sub >> 1) * g.Win + (sub & 1)) * g.Cin + 32 * s32 + 16 * (sl & 1)) * 4u;
         }
 #pragma unroll
-        for (int k = 0; k < 2; ++k)
+        for (int k = 0; k < (PP > 64 ? 2 : 1); ++k)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 raw[k][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + (unsigned)(4 * j) * 4u, co, 0));
     };
     auto stage = [&]() {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < (PP > 64 ? 2 : 1); ++k) {
             if (k == 1 && lane >= PP - 64) break;
             if (relu_in) {
 #pragma unroll
@@ -1277,7 +1278,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         else for (int s2 = 0; s2 < nslice; ++s2) {                        // else the patch's own (one more pass over it)
             load_raw(s2);
 #pragma unroll
-            for (int k = 0; k < 2; ++k)
+            for (int k = 0; k < (PP > 64 ? 2 : 1); ++k)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     f32x4 v = raw[k][j];
@@ -1327,7 +1328,8 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         // this stage's weights are in (a slice's load_raw behind the previous barrier may still be in flight: its eight
         // loads are the youngest), everyone is done with the other buffer
         const bool raw_behind = s > 0 && grp == (ngrp > 1 ? 1 : 0) && (ngrp > 1 ? sl : sl - 1) + 1 < nslice;
-        if (raw_behind) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        if (raw_behind && PP > 64) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (raw_behind) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (s + 1 < nstage) dma_stage(s + 1, (s + 1) & 1);
@@ -4574,7 +4576,7 @@ static size_t packed_h2_bytes(const ConvGeom &g) {
 // conv_halo8_h2_kernel: stride-1-sampled layers on pixel grids that are multiples of 8 both ways and larger than one tile
 static bool conv_halo8_ok(const ConvGeom &g, int Cin, int flags) {
     return !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32)) && g.istride == 1 && g.Hg == g.Hin && g.Wg == g.Win &&
-           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && (g.ntaps == 4 || g.ntaps == 9) &&
+           g.Hg % 8 == 0 && g.Wg % 8 == 0 && g.Hg * g.Wg > 64 && Cin % 32 == 0 && g.ntile % 2 == 0 && (g.ntaps == 1 || g.ntaps == 4 || g.ntaps == 9) &&
            (long long)g.Hin * g.Win * Cin * 4 < 0x7FFFFFF0ll;
 }
 // byte offset of the header from the start of a layer's packed weights
@@ -4722,7 +4724,11 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const unsigned gxt = (unsigned)((tiles + 3) / 4) * ny;
             // taps per weight stage: a kernel row of the 3x3 layers; two of a conv-transpose phase's four taps
 #define HALO_LAUNCH(NT_, TPS_, NPH_) hipLaunchKernelGGL((conv_halo8_h2_kernel<NT_, TPS_, false, NPH_>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax)
-            if (g.ntaps == 9) { if (wide) HALO_LAUNCH(4, 3, 1); else HALO_LAUNCH(2, 3, 1); }
+            if (g.ntaps == 1) {                        // 1x1: the tile without a border
+                if (wide) hipLaunchKernelGGL((conv_halo8_h2_kernel<4, 1, false, 1, 0>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+                else hipLaunchKernelGGL((conv_halo8_h2_kernel<2, 1, false, 1, 0>), dim3(gxt), dim3(256), 0, st, x, wsel, bias, y, g, ny, whdr, in_amax, out_amax);
+            }
+            else if (g.ntaps == 9) { if (wide) HALO_LAUNCH(4, 3, 1); else HALO_LAUNCH(2, 3, 1); }
             else if (pairs) HALO_LAUNCH(2, 2, 2);
             else { if (wide) HALO_LAUNCH(4, 2, 1); else HALO_LAUNCH(2, 4, 1); }
 #undef HALO_LAUNCH
