@@ -4080,21 +4080,45 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
     if ((Cout & 7) == 0) {
         __syncthreads();                                   // every wave is done with Ws / Xs: reuse them as output tiles
         float *tile = smem_ci + wave * (32 * 36);
+        // the image's base is scalar, this lane's eight output pixels (two pixel tiles x four row groups of the staged tile)
+        // are byte offsets inside the image: no address arithmetic per store
+        float *obase = out + (size_t)b * Hg * Wg * Cout;
+        unsigned ooff[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                float v[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    v[r] = acc[mt][nt][r] + bv[nt];
-                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
-                    if (nt * 32 + l31 < Cout) omax = fmaxf(omax, __builtin_fabsf(v[r]));
-                }
-                tile_epilogue(tile, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
-                    if (n < Cout) *reinterpret_cast<f32x4 *>(out + opix(wbase + mt * 32 + p) * Cout + n) = a4;
-                });
+            for (int k = 0; k < 4; ++k) {
+                const int p = wbase + mt * 32 + (lane >> 3) + 8 * k;
+                ooff[mt][k] = (unsigned)((((gy0 + (p >> tw_log2)) * Wg + gx0 + (p & (TW - 1))) * Cout + 4 * (lane & 7)) * 4);
             }
+        auto finish = [&](auto RO) {                       // (one straight-line copy per ReLU flag)
+            constexpr bool ro = decltype(RO)::value;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bool nok = nt * 32 + 4 * (lane & 7) < Cout, cok = nt * 32 + l31 < Cout;
+                    const f32x2v b2 = {bv[nt], bv[nt]};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2v y = f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]} + b2;
+                        float v0 = y.x, v1 = y.y;
+                        if (ro) { v0 = vmax(v0, 0.0f); v1 = vmax(v1, 0.0f); }
+                        if (cok) vmax3_abs(omax, v0, v1);
+                        tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
+                        tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;
+                    }
+                    lds_order_wave();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+                        if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(obase + nt * 32) + ooff[mt][k]) = q;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+        };
+        if (relu_out) finish(std::true_type{});
+        else finish(std::false_type{});
         if (out_amax) publish_amax(out_amax, b, omax, lane);       // the band's 256 pixels belong to image b
         return;
     }
