@@ -36,7 +36,7 @@ with torch.no_grad():
 print(f"forward B={B} {S}x{S}: {e0.elapsed_time(e1) / 3:.2f} ms")
 if have:
     raw.vqvae_debug_conv_stamps(buf, 0)
-    for v, vn in enumerate(["enc2 4x4s2 (S2D)", "enc4 3x3 128->128", "dec0 T3x3 D->128", "dec2 T4x4s2 128->64"]):
+    for v, vn in enumerate(["enc2 4x4s2 (S2D)", "enc4 + dec0 3x3", "1x1 (no halo)", "dec2 T4x4s2 128->64"]):
         n = max(buf[16 * v + 8], 1)
         tot = sum(buf[16 * v + i] for i in range(8))
         print(f"{vn:22s} per wave (cycles): " + "  ".join(f"{names[i]} {buf[16 * v + i] / n:.0f} ({100.0 * buf[16 * v + i] / max(tot, 1):.1f}%)" for i in range(8)) + f"   total {tot / n:.0f}")

@@ -1213,23 +1213,28 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     const size_t wphase = (size_t)ntaps * cpt * g.ntile * 256;
     const unsigned wlane = (unsigned)(h * 64 + l31) * 16u;
     const size_t wchunk = (size_t)g.ntile * 256;
-    auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
-        const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
+    const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)Bs);
+    auto dma = [&](const u32x4 *src_uniform, unsigned lds) {      // lds: byte address of the 1 KiB piece
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wlane), "s"(src_uniform), "s"(lds) : "memory", "m0");
     };
-    auto dma_stage = [&](int s, int buf) {
-        const int sl = s / ngrp, grp = s - sl * ngrp;
-        const int c32 = sl >> 1;
+    // this wave's pieces p = wave + 4 j: their part of the source offset that does not depend on the stage (tap within the
+    // group, phase, channel tile, term) is worked out ONCE -- scalar instructions have a shared issue slot too
+    const size_t wtap = (S2D ? (size_t)1 : (size_t)cpt) * wchunk;            // units from a tap to the next
+    size_t wpiece[NPIECE / NW];
 #pragma unroll
-        for (int j = 0; j < NPIECE / NW; ++j) {
-            const int p = wave_u + NW * j;
-            const int tl = p / (NV * 2), ph = (p / (NT * 2)) % NPH, nt = (p >> 1) % NT, term = p & 1;
-            const int tap = grp * TPS + tl;
-            const size_t chunk = S2D ? (size_t)c32 * 4 + tap : (size_t)tap * cpt + c32;
-            dma(wbase + ph * wphase + chunk * wchunk + (size_t)nt * 256 + term * 128 + (sl & 1) * 32, Bs + buf * WST + p * 64);
-        }
+    for (int j = 0; j < NPIECE / NW; ++j) {
+        const int p = wave_u + NW * j;
+        const int tl = p / (NV * 2), ph = (p / (NT * 2)) % NPH, nt = (p >> 1) % NT, term = p & 1;
+        wpiece[j] = (size_t)tl * wtap + (size_t)ph * wphase + (size_t)nt * 256 + term * 128;
+    }
+    auto dma_stage = [&](int sl, int grp, int buf) {
+        // stage (slice sl, tap group grp): chunk = tap * cpt + (sl >> 1) (S2D: (sl >> 1) * 4 + tap), k-step half sl & 1
+        const u32x4 *sp = wbase + (size_t)(sl >> 1) * (S2D ? 4 * wchunk : wchunk) + (size_t)(grp * TPS) * wtap + (sl & 1) * 32;
+        const unsigned dp = bs_lds + (unsigned)(buf * WST + wave_u * 64) * 16u;
+#pragma unroll
+        for (int j = 0; j < NPIECE / NW; ++j) dma(sp + wpiece[j], dp + (unsigned)(j * NW * 64) * 16u);
     };
-    dma_stage(0, 0);
+    dma_stage(0, 0, 0);
 
     float xscale = 1.0f, descale = 1.0f;
     f32x4 raw[2][4];
@@ -1332,7 +1337,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         else if (raw_behind) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        if (s + 1 < nstage) dma_stage(s + 1, (s + 1) & 1);
+        if (s + 1 < nstage) dma_stage(grp + 1 == ngrp ? sl + 1 : sl, grp + 1 == ngrp ? 0 : grp + 1, (s + 1) & 1);
         if (grp == 0 && sl + 1 < nslice) load_raw(sl + 1);
         const u32x4 *bs = Bs + (s & 1) * WST + lane;
 #pragma unroll
