@@ -277,6 +277,29 @@ def test_vq_stream_two_slabs_ragged_vs_oracle():
     assert a[0].tobytes() == loss.tobytes() and a[2].tobytes() == ppl.tobytes()        # run-to-run bitwise
 
 
+def test_vq_stream_more_than_one_group_of_slabs_equals_the_exhaustive_kernel():
+    """The streamed kernels resolve the open / hard rows of sixteen slabs (2^22 rows) in one launch and start over for the
+    next group: 17 slabs + a ragged tail, on the device only (1.1 GB of rows), indices / z_q / histogram / loss bits
+    against the exhaustive fp32 kernel.  A few rows are made hard (many codes within the bound) in BOTH groups."""
+    from vqvae_amd import functional as F
+    g = torch.Generator(device=_dev()).manual_seed(5)
+    K, D = 640, 64
+    n = 17 * (1 << 18) + 333
+    cb = ((torch.rand(K, D, generator=g, device=_dev()) * 2 - 1) / K)
+    z = torch.randn(n // 3, 1, 3, D, generator=g, device=_dev()) * 0.066              # (B, H, W, D) row-major, 3 rows per "image"
+    rows = z.view(-1, D)
+    rows[12345] = cb[3:13].mean(0)                          # near-ties among many codes
+    rows[(1 << 22) + 77] = cb[100:110].mean(0)
+    rows[(1 << 22) + (1 << 18) + 5] = 0.0
+    a = F.vq_forward(z, cb, 0.25, rowmajor=True)
+    b = F.vq_forward(z, cb, 0.25, rowmajor=True, exact_sweep=True)
+    torch.cuda.synchronize()
+    assert torch.equal(a[3], b[3]), "indices"
+    assert torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)), "z_q bits"
+    assert torch.equal(a[4], b[4]), "histogram"
+    assert a[0].item() == b[0].item() and a[2].item() == b[2].item()
+
+
 def test_vq_nonfinite_codebook_forces_slow_path():
     """A codebook norm that is not < 1e38 routes EVERY row through the scalar torch.argmin path."""
     from oracle import c_oracle

@@ -52,6 +52,7 @@ constexpr int kVqCandCap = 8;   // per lane half (16 per row), unsigned short en
 constexpr int kVqTilesPerWave = 2;   // 32-row tiles a wave of the filter kernel walks per iteration
 constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many workgroups
 constexpr int kVqSlabRows = 1 << 18; // rows per pass of the streamed-codebook kernels (vq_chunk.hip): bounds their scratch
+constexpr int kVqGroupSlabs = 16;    // slabs whose open / hard rows are resolved by ONE launch (their records' scratch: 44.1 B per row of a group)
 
 bool vq_sweep_ok(int K, int D);
 bool vq_chunk_ok(int K, int D);

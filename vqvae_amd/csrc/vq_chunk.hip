@@ -52,14 +52,15 @@ template <> struct ChunkCfg<128> { static constexpr int TC = VQS_TC128; };
 template <int D>
 __global__ __launch_bounds__(256) void vq_stream_rows16_kernel(const float *__restrict__ z, long long nrows,
                                                          u32x4 *__restrict__ img, float2 *__restrict__ stat,
-                                                         int *__restrict__ counters, int *__restrict__ batch_done) {
+                                                         int *__restrict__ counters, int *__restrict__ batch_done,
+                                                         int zero_counters) {
     constexpr int G = D / 8;                              // 8-channel groups per row
     __shared__ float part[32][G][2];
     __shared__ int badrow[32];
     const int tid = threadIdx.x, n = tid & 31, g0 = tid >> 5;
     const long long tile = blockIdx.x;
     const long long row = tile * 32 + n;
-    if (blockIdx.x == 0 && tid < 2) counters[tid] = 0;
+    if (zero_counters && blockIdx.x == 0 && tid < 2) counters[tid] = 0;        // first slab of a group (see launch_chunked)
     if (tid == 0) batch_done[blockIdx.x] = 0;             // one possible batch of 32 hard rows per row tile
     if (tid < 32) badrow[tid] = 0;
     __syncthreads();
@@ -113,7 +114,9 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
     const u32x4 *__restrict__ rows16, const float2 *__restrict__ stat, const u32x4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const int *__restrict__ flags, int nrows, long long row0, int K, int ntile,
     long long *__restrict__ idx, uint4 *__restrict__ open_list, unsigned *__restrict__ hard_list,
-    unsigned long long *__restrict__ hard_best, int *__restrict__ counters) {
+    unsigned long long *__restrict__ hard_best, int *__restrict__ counters, unsigned rel0) {
+    // rel0: this slab's first row relative to its group's (the records of a group of slabs carry group-relative rows and
+    // share the counters: one resolve launch per group)
     constexpr int TC = ChunkCfg<D>::TC, NQ = D / 16, G = D / 8;
     constexpr int IMG_UNITS = TC * D * 4;                 // 16-byte units of image per chunk
     constexpr int SEED_PIECES = (TC * 8 + 63) / 64;       // 1 KiB pieces of seeds per chunk (TC * 128 B, rounded up)
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                 if (h) slot = (int)ss[0];                      // the row's slot, from its half-0 lane
                 if (open) {
                     const unsigned k01 = (unsigned)P.k[0] | ((unsigned)P.k[1] << 16), k23 = (unsigned)P.k[2] | ((unsigned)P.k[3] << 16);
-                    if (h == 0) open_list[2 * slot] = make_uint4((unsigned)rrel, (unsigned)P.n | ((unsigned)nO << 8), k01, k23);
+                    if (h == 0) open_list[2 * slot] = make_uint4(rel0 + (unsigned)rrel, (unsigned)P.n | ((unsigned)nO << 8), k01, k23);
                     else open_list[2 * slot + 1] = make_uint4(k01, k23, 0u, 0u);
                 }
             }
@@ -324,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                 base = __builtin_amdgcn_readfirstlane(base);
                 if (hard && writer) {
                     const int slot = base + __builtin_popcountll(hm & below);
-                    hard_list[slot] = (unsigned)rrel;
+                    hard_list[slot] = rel0 + (unsigned)rrel;
                     hard_best[slot] = ~0ull;
                 }
             }
@@ -612,9 +615,11 @@ __global__ __launch_bounds__(1024) void vq_stream_gather_kernel(const float *__r
 bool vq_chunk_ok(int K, int D) { return (D == 64 || D == 128) && K >= 1 && K <= 16384; }
 
 size_t vq_chunk_scratch_bytes(int D) {
+    // per slab: the rows' fp16 image + statistics; per GROUP of slabs: the open rows' records (32 B per row), the hard rows'
+    // list + running best (4 + 8 B per row), one batch counter per 32 rows, the two task counters
+    const size_t grows = (size_t)kVqGroupSlabs * kVqSlabRows;
     return align_up((size_t)kVqSlabRows * D * 2, 256) + align_up((size_t)kVqSlabRows * 8, 256) +
-           align_up((size_t)kVqSlabRows * 32, 256) + align_up((size_t)kVqSlabRows * 4, 256) +
-           align_up((size_t)kVqSlabRows * 8, 256) + align_up((size_t)(kVqSlabRows / 32) * 4, 256) + 256;
+           align_up(grows * 32, 256) + align_up(grows * 4, 256) + align_up(grows * 8, 256) + align_up((grows / 32) * 4, 256) + 256;
 }
 
 template <int D>
@@ -627,14 +632,15 @@ static int launch_chunked(const float *z, const float *cb, long long N, int K, f
     s += align_up((size_t)kVqSlabRows * D * 2, 256);
     float2 *stat = reinterpret_cast<float2 *>(s);
     s += align_up((size_t)kVqSlabRows * 8, 256);
+    const size_t grows = (size_t)kVqGroupSlabs * kVqSlabRows;
     uint4 *pairs = reinterpret_cast<uint4 *>(s);                 // one 32-byte record per open row
-    s += align_up((size_t)kVqSlabRows * 32, 256);
+    s += align_up(grows * 32, 256);
     unsigned *hards = reinterpret_cast<unsigned *>(s);
-    s += align_up((size_t)kVqSlabRows * 4, 256);
+    s += align_up(grows * 4, 256);
     unsigned long long *hbest = reinterpret_cast<unsigned long long *>(s);
-    s += align_up((size_t)kVqSlabRows * 8, 256);
+    s += align_up(grows * 8, 256);
     int *bdone = reinterpret_cast<int *>(s);
-    s += align_up((size_t)(kVqSlabRows / 32) * 4, 256);
+    s += align_up((grows / 32) * 4, 256);
     int *counters = reinterpret_cast<int *>(s);
     const int *flags = reinterpret_cast<const int *>(ws + p.off_flags);
     const float *ee = reinterpret_cast<const float *>(ws + p.off_ee);
@@ -645,16 +651,23 @@ static int launch_chunked(const float *z, const float *cb, long long N, int K, f
     const size_t lds = 2 * (size_t)(TC * D * 4 + 64 * ((TC * 8 + 63) / 64)) * 16;
     auto sweep = vq_stream_sweep_kernel<D>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(sweep), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    for (long long row0 = 0; row0 < N; row0 += kVqSlabRows) {
-        const int nrows = (int)((N - row0) < kVqSlabRows ? (N - row0) : kVqSlabRows);
-        const int nblk = (nrows + 511) / 512;
-        const float *zs = z + (size_t)row0 * D;
-        hipLaunchKernelGGL(vq_stream_rows16_kernel<D>, dim3(nblk * 16), dim3(256), 0, st, zs, (long long)nrows, rows16, stat, counters, bdone);
-        hipLaunchKernelGGL(sweep, dim3(nblk < cus ? nblk : cus), dim3(512), lds, st, rows16, stat, img, seeds, flags, nrows,
-                           row0, K, ntile, idx, pairs, hards, hbest, counters);
-        hipLaunchKernelGGL(vq_stream_resolve_kernel<D>, dim3(4 * cus), dim3(256), 0, st, zs, cb, ee,
+    // slabs of 2^18 rows (their fp16 image stays cache-sized); the open and hard rows of up to sixteen slabs are resolved by
+    // ONE launch -- a slab leaves ~7 000 of them, which a launch of its own turns into 90 us of latency (1.46 ms of config 5's
+    // 35, round 3)
+    for (long long g0 = 0; g0 < N; g0 += (long long)grows) {
+        const long long gn = (N - g0) < (long long)grows ? (N - g0) : (long long)grows;
+        for (long long row0 = g0; row0 < g0 + gn; row0 += kVqSlabRows) {
+            const int nrows = (int)((g0 + gn - row0) < kVqSlabRows ? (g0 + gn - row0) : kVqSlabRows);
+            const int nblk = (nrows + 511) / 512;
+            const float *zs = z + (size_t)row0 * D;
+            hipLaunchKernelGGL(vq_stream_rows16_kernel<D>, dim3(nblk * 16), dim3(256), 0, st, zs, (long long)nrows, rows16, stat, counters,
+                               bdone + (row0 - g0) / 32, row0 == g0 ? 1 : 0);
+            hipLaunchKernelGGL(sweep, dim3(nblk < cus ? nblk : cus), dim3(512), lds, st, rows16, stat, img, seeds, flags, nrows,
+                               row0, K, ntile, idx, pairs, hards, hbest, counters, (unsigned)(row0 - g0));
+        }
+        hipLaunchKernelGGL(vq_stream_resolve_kernel<D>, dim3(4 * cus), dim3(256), 0, st, z + (size_t)g0 * D, cb, ee,
                            reinterpret_cast<const float *>(ws + p.off_img), K, p.KC, pairs, hards, hbest, bdone, counters,
-                           idx + row0);
+                           idx + g0);
     }
     constexpr int kRowsPerPass = 1024 / (D / 4);
     long long g = (N + 2 * kRowsPerPass - 1) / (2 * kRowsPerPass);
