@@ -2577,20 +2577,22 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     // cannot prove disjoint from the destination -- i.e. it waits for the NEXT stage's pieces before reading this stage's.
     // The waits are explicit here (dma_wait_sync); the compiler's own vmcnt waits stay correct (loads return in order and an
     // uncounted outstanding load only makes a counted wait longer).
-    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+    // (scalar source base + this lane's constant byte offset: no vector instruction and no address register per piece)
+    const unsigned dma_lane = (unsigned)lane * 16u;
+    auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
     };
     // the nine taps of slice sl of the residual 3x3 -> buffer `buf`: piece p = tap * 2 + term
     auto dma_slice = [&](int sl, int buf) {
-        const u32x4 *base = w1img + (size_t)(sl >> 1) * 256 + (sl & 1) * 64 + lane;
+        const u32x4 *base = w1img + (size_t)(sl >> 1) * 256 + (sl & 1) * 64;
         for (int p = wave_u; p < 18; p += CRP_NW)
             dma(base + (size_t)(p >> 1) * cpt * 256 + (p & 1) * 128, Wb_all + buf * WBUF + p * 64);
     };
     // 16 KiB of an image as it lies (the 1x1 GEMMs): four pieces per wave
     auto dma_linear = [&](const u32x4 *src, int buf) {
 #pragma unroll
-        for (int j = 0; j < 16 / CRP_NW; ++j) dma(src + (wave_u * (16 / CRP_NW) + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * (16 / CRP_NW) + j) * 64);
+        for (int j = 0; j < 16 / CRP_NW; ++j) dma(src + (wave_u * (16 / CRP_NW) + j) * 64, Wb_all + buf * WBUF + (wave_u * (16 / CRP_NW) + j) * 64);
     };
     // stage k after the front conv: 9 LI + slice (3x3 of layer LI), 9 LI + 8 (its 1x1), 18 + j (part j of the post conv)
     auto dma_stage = [&](int k, int buf) {
@@ -2598,7 +2600,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
             // four 32-code tiles of the codebook's fp16 image (16 pieces) + their seeds -A ee / 2 (512 bytes of piece 16)
             const int j = k - (18 + NT3);
             dma_linear(reinterpret_cast<const u32x4 *>(vq.imgf) + (size_t)j * 1024, buf);
-            if (wave_u == 0) dma(reinterpret_cast<const u32x4 *>(vq.seeds) + (size_t)j * 32 + lane, Wb_all + buf * WBUF + 16 * 64);
+            if (wave_u == 0) dma(reinterpret_cast<const u32x4 *>(vq.seeds) + (size_t)j * 32, Wb_all + buf * WBUF + 16 * 64);
         }
         else if (k >= 18) dma_linear(w3img + (size_t)(k - 18) * 1024, buf);
         else if (k % 9 == 8) dma_linear(w2img, buf);
@@ -2640,7 +2642,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
         if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};
         // stage (cc, tap) = 16 pieces: piece p = nt * 4 + t * 2 + term, four per wave
         auto dma_front = [&](int cc, int tap, int buf) {
-            const u32x4 *base = fc.wimg + (size_t)(tap * cpt0 + cc) * (NT2 * 256) + lane;
+            const u32x4 *base = fc.wimg + (size_t)(tap * cpt0 + cc) * (NT2 * 256);
 #pragma unroll
             for (int j = 0; j < 16 / CRP_NW; ++j) {
                 const int p = wave_u * (16 / CRP_NW) + j;
@@ -3125,15 +3127,17 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
 
-    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+    // (scalar source base + this lane's constant byte offset: no vector instruction and no address register per piece)
+    const unsigned dma_lane = (unsigned)lane * 16u;
+    auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
     };
     // stage k = chunk * 4 + tap, chunk = 2 s + slice: 16 KiB as it lies in the space-to-depth image
     auto dma_stage = [&](int k, int buf) {
         const u32x4 *src = w2img + (size_t)k * 1024;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma(src + (wave_u * 4 + j) * 64 + lane, Wb_all + buf * WBUF + (wave_u * 4 + j) * 64);
+        for (int j = 0; j < 4; ++j) dma(src + (wave_u * 4 + j) * 64, Wb_all + buf * WBUF + (wave_u * 4 + j) * 64);
     };
     auto dma_wait_sync = [&]() {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -3434,9 +3438,11 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
 
-    auto dma = [&](const u32x4 *src_lane, u32x4 *dst_piece) {
+    // (scalar source base + this lane's constant byte offset: no vector instruction and no address register per piece)
+    const unsigned dma_lane = (unsigned)lane * 16u;
+    auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src_lane), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
     };
     // A PASS covers the two phases (py, 0) and (py, 1): they share the parked planes, and where their taps read the same
     // input offset (dx = 0) also the operand reads.  stage k = 17 py + i: i < 16: chunk i >> 2, tap pair i & 3 = (ty, kind) of
@@ -3450,7 +3456,7 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
             const int ty = (i >> 1) & 1, kind = i & 1, tap = ty * 2 + (half ? 1 - kind : kind);
             const u32x4 *src = i == 16 ? w4img + p * 64
                                        : w2img + (size_t)((2 * py + half) * 16 + tap * CPT + (i >> 2)) * 512 + (p & 7) * 64;
-            dma(src + lane, Wb_all + buf * WBUF + p * 64);
+            dma(src, Wb_all + buf * WBUF + p * 64);
         }
     };
     auto dma_wait_sync = [&]() {
