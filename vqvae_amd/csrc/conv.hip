@@ -2664,7 +2664,6 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
                     dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
                 }
-            if (cc + 1 < cpt0) load_raw0(cc + 1);
             lds_order_wave();
 #pragma unroll 1
             for (int tap = 0; tap < 9; ++tap, ++wstage) {
@@ -2680,10 +2679,17 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                         X[t][mt][0] = ap[0];
                         X[t][mt][1] = ap[PLANE];
                     }
-                dma_wait_sync();                               // this stage's weights are in; everyone is done with the other buffer
+                // this stage's weights are in; everyone is done with the other buffer.  The next chunk's eight activation loads
+                // go out BEHIND tap 1's weights and may stay in flight across tap 1's wait (they are its youngest requests):
+                // in front of tap 0's wait, as before, every chunk sat out their whole latency at that barrier
+                if (tap == 1 && cc + 1 < cpt0) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __syncthreads();
+                } else dma_wait_sync();
                 if (tap + 1 < 9) dma_front(cc, tap + 1, (wstage + 1) & 1);
                 else if (cc + 1 < cpt0) dma_front(cc + 1, 0, (wstage + 1) & 1);
                 else dma_stage(0, (wstage + 1) & 1);           // the first slice of the first residual layer
+                if (tap == 0 && cc + 1 < cpt0) load_raw0(cc + 1);
                 const u32x4 *wt = Wb_all + (wstage & 1) * WBUF + lane;
                 // group g = (t, nt): weights one group ahead of the matrix instructions
                 u32x4 Wc0 = wt[0], Wc1 = wt[64];
@@ -3535,7 +3541,6 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                     dst[(t * 2 + 0) * PLANE + hh * HP] = t1;
                     dst[(t * 2 + 1) * PLANE + hh * HP] = t2;
                 }
-            load_raw(cc + 1 < CPT ? cc + 1 : 0);           // (the next pass starts over at chunk 0)
             lds_order_wave();
 #pragma unroll 1
             for (int i = 0; i < 4; ++i) {
@@ -3557,8 +3562,14 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                 };
                 ldX(0, 0, tapA);
                 ldX(1, 0, tapA);
-                dma_wait_sync();                           // this stage's weights are in; everyone is done with the other buffer
+                // this stage's weights are in; everyone is done with the other buffer.  (The next chunk's eight activation loads
+                // go out behind stage i = 1's weights and may stay in flight across its wait: see conv_res_pair8_h2_kernel.)
+                if (i == 1) {
+                    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                    __syncthreads();
+                } else dma_wait_sync();
                 dma_stage(k + 1, (k + 1) & 1);
+                if (i == 0) load_raw(cc + 1 < CPT ? cc + 1 : 0);       // (the next pass starts over at chunk 0)
                 const u32x4 *wt = Wb_all + (k & 1) * WBUF + lane;      // [phase of the pair][nt][term][k-step] x 64 units
                 u32x4 Wc0 = wt[0], Wc1 = wt[128];
 #pragma unroll
