@@ -68,6 +68,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t act_rsrc(const float *p, unsig
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, n, 0x00020000);
 }
 
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 // v_max_f32 / v_max3_f32 as ONE instruction each (fmaxf costs two: hipcc puts a canonicalising v_max in front; the
 // hardware instruction already returns the other operand for a NaN, which is fmaxf's rule)
 __device__ __forceinline__ float vmax(float a, float b) {
@@ -78,6 +79,25 @@ __device__ __forceinline__ float vmax(float a, float b) {
 __device__ __forceinline__ void vmax3_abs(float &m, float a, float b) {       // m = max(m, |a|, |b|)
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
 }
+__device__ __forceinline__ void vmax3(float &m, float a, float b) {           // m = max(m, a, b)
+    asm("v_max3_f32 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b));
+}
+// (a0, a1) <- max((a0, a1) * d + (b0, b1), 0), m <- max(m, a0, a1): one packed FMA (d a power of two: the product is exact, so
+// the fused form rounds once like the separate add), two v_max, one v_max3 for the pair -- five instructions; twelve as hipcc
+// emits the C form (multiply, add, two canonicalising v_max in front of the two maxima, per value)
+__device__ __forceinline__ f32x2v scale_bias_relu2(float a0, float a1, float d, float b0, float b1, float &m) {
+    // (two scalar FMAs, not a packed one: v_pk_fma_f32 wants aligned register pairs, and with 128 accumulator registers live
+    // that constraint cost conv_res_pair8_h2_kernel<2, true> 500 spilled registers)
+    const f32x2v r = {vmax(__builtin_fmaf(a0, d, b0), 0.0f), vmax(__builtin_fmaf(a1, d, b1), 0.0f)};
+    vmax3(m, r.x, r.y);
+    return r;
+}
+#define SCALE_BIAS_RELU2(A0, A1, D, B0, B1, M)                                   \
+    do {                                                                         \
+        const f32x2v r_ = scale_bias_relu2((A0), (A1), (D), (B0), (B1), (M));    \
+        (A0) = r_.x;                                                             \
+        (A1) = r_.y;                                                             \
+    } while (0)
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
     v.x = vmax(v.x, 0.0f); v.y = vmax(v.y, 0.0f); v.z = vmax(v.z, 0.0f); v.w = vmax(v.w, 0.0f);
     return v;
@@ -392,7 +412,6 @@ __device__ __forceinline__ void prod6x2(const u32x4 &s1, const u32x4 &s2, const 
 // error 2^-25 in scaled units = 2^-40 of the maximum), which is invisible next to the fp32 accumulation itself.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void split2_h(float a, float b, unsigned &p1, unsigned &p2) {
     const f16x2 h = {(_Float16)a, (_Float16)b};                      // v_cvt_pk_f16_f32, round to nearest even
@@ -1791,10 +1810,7 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
-                m = fmaxf(m, acc1[mt][r]);
-            }
+            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
         const int kh = wave_scale_exp(m);
         hscale = __builtin_ldexpf(1.0f, kh);
         d2 = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
@@ -2188,10 +2204,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
-                m = fmaxf(m, acc1[mt][r]);
-            }
+            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
         const int kh = wave_scale_exp(m);
         const float hscale = __builtin_ldexpf(1.0f, kh);
 #pragma unroll
@@ -2720,11 +2733,8 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float v = fmaxf(Y[mt][nt][4 * g + q] * d0 + bv[q], 0.0f);
-                        Y[mt][nt][4 * g + q] = v;
-                        ymax = fmaxf(ymax, v);
-                    }
+                    for (int q = 0; q < 4; q += 2)
+                        SCALE_BIAS_RELU2(Y[mt][nt][4 * g + q], Y[mt][nt][4 * g + q + 1], d0, bv[q], bv[q + 1], ymax);
             }
     }
     lds_order_wave();
@@ -2814,10 +2824,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                acc1[mt][r] = fmaxf(acc1[mt][r] * d1, 0.0f);
-                m = fmaxf(m, acc1[mt][r]);
-            }
+            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
         const int kh = wave_scale_exp(m);
         const float hscale = __builtin_ldexpf(1.0f, kh), d2 = __builtin_ldexpf(1.0f, -(kh + kw2));
         u32x4 H1[MT][2], Hb[MT][2];
@@ -2839,15 +2846,30 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
             for (int t = 0; t < 2; ++t)
                 prod3x2t(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], Wc[t][0], Wc[t][1], acc2[0], acc2[1]);
+            // Y <- [relu](Y + acc2 * 2^-k), nmax: FMA (exact product), single-instruction max; the ReLU flag is wave-uniform and
+            // decided once per tile, not per value
+            if (relu_after) {
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float v = Y[mt][nt][r] + acc2[mt][r] * d2;
-                    if (relu_after) v = fmaxf(v, 0.0f);
-                    Y[mt][nt][r] = v;
-                    nmax = fmaxf(nmax, __builtin_fabsf(v));
-                }
+                    for (int r = 0; r < 16; r += 2) {
+                        const float y0 = vmax(__builtin_fmaf(acc2[mt][r], d2, Y[mt][nt][r]), 0.0f);
+                        const float y1 = vmax(__builtin_fmaf(acc2[mt][r + 1], d2, Y[mt][nt][r + 1]), 0.0f);
+                        Y[mt][nt][r] = y0;
+                        Y[mt][nt][r + 1] = y1;
+                        vmax3(nmax, y0, y1);
+                    }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const float y0 = __builtin_fmaf(acc2[mt][r], d2, Y[mt][nt][r]), y1 = __builtin_fmaf(acc2[mt][r + 1], d2, Y[mt][nt][r + 1]);
+                        Y[mt][nt][r] = y0;
+                        Y[mt][nt][r + 1] = y1;
+                        vmax3_abs(nmax, y0, y1);
+                    }
+            }
         }
         ymax = nmax;
     };
@@ -3265,7 +3287,10 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc0[mt][4 * g + q] = fmaxf(acc0[mt][4 * g + q] * d0 + bv[q], 0.0f);
+                for (int q = 0; q < 4; q += 2) {
+                    float unused = 0.0f;
+                    SCALE_BIAS_RELU2(acc0[mt][4 * g + q], acc0[mt][4 * g + q + 1], d0, bv[q], bv[q + 1], unused);
+                }
         }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(acc0[mt], xs1, T1[mt], T2[mt]);
@@ -3327,9 +3352,10 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
                 f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    v[4 * g + q] = fmaxf(Y[mt][nt][4 * g + q] * d2 + bv[q], 0.0f);
-                    ymax = fmaxf(ymax, v[4 * g + q]);
+                for (int q = 0; q < 4; q += 2) {
+                    v[4 * g + q] = Y[mt][nt][4 * g + q];
+                    v[4 * g + q + 1] = Y[mt][nt][4 * g + q + 1];
+                    SCALE_BIAS_RELU2(v[4 * g + q], v[4 * g + q + 1], d2, bv[q], bv[q + 1], ymax);
                 }
             }
             if (img_ok) {
@@ -3610,11 +3636,8 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float v = fmaxf(acc[px][mt][nt][4 * g + q] * d1 + bv[q], 0.0f);
-                            acc[px][mt][nt][4 * g + q] = v;
-                            um = fmaxf(um, v);
-                        }
+                        for (int q = 0; q < 4; q += 2)
+                            SCALE_BIAS_RELU2(acc[px][mt][nt][4 * g + q], acc[px][mt][nt][4 * g + q + 1], d1, bv[q], bv[q + 1], um);
                 }
             const int ku = wave_scale_exp(img_ok ? um : 0.0f);
             const float us = __builtin_ldexpf(1.0f, ku);
