@@ -1234,7 +1234,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
     const size_t wchunk = (size_t)g.ntile * 256;
     const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)Bs);
     auto dma = [&](const u32x4 *src_uniform, unsigned lds) {      // lds: byte address of the 1 KiB piece
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wlane), "s"(src_uniform), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(wlane), "s"(src_uniform), "s"(lds) : "memory");
     };
     // this wave's pieces p = wave + 4 j: their part of the source offset that does not depend on the stage (tap within the
     // group, phase, channel tile, term) is worked out ONCE -- scalar instructions have a shared issue slot too
@@ -2594,7 +2594,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     const unsigned dma_lane = (unsigned)lane * 16u;
     auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory");
     };
     // the nine taps of slice sl of the residual 3x3 -> buffer `buf`: piece p = tap * 2 + term
     auto dma_slice = [&](int sl, int buf) {
@@ -3159,7 +3159,7 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
     const unsigned dma_lane = (unsigned)lane * 16u;
     auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory");
     };
     // stage k = chunk * 4 + tap, chunk = 2 s + slice: 16 KiB as it lies in the space-to-depth image
     auto dma_stage = [&](int k, int buf) {
@@ -3474,7 +3474,7 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
     const unsigned dma_lane = (unsigned)lane * 16u;
     auto dma = [&](const u32x4 *src_uniform, u32x4 *dst_piece) {
         const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)dst_piece);
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory", "m0");
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(dma_lane), "s"(src_uniform), "s"(lds) : "memory");
     };
     // A PASS covers the two phases (py, 0) and (py, 1): they share the parked planes, and where their taps read the same
     // input offset (dx = 0) also the operand reads.  stage k = 17 py + i: i < 16: chunk i >> 2, tap pair i & 3 = (ty, kind) of
@@ -5005,7 +5005,6 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
     const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
     const unsigned gtc = (unsigned)((B + CRP_NW - 1) / CRP_NW);
-    const unsigned gt = (unsigned)((B + 3) / 4);
     // the checks that can refuse come BEFORE prof_begin: an early return behind it would leave an unmatched begin event
     ConvGeom g3;
     if (post && (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout) ||

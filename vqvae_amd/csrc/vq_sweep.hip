@@ -133,8 +133,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
     int *ticket_s = reinterpret_cast<int *>(red + NW);                                  // next pair of this workgroup (+ pad)
     unsigned char *wave_base = reinterpret_cast<unsigned char *>(red + NW + 2);             // per wave: 4 KiB per tile (the unit's fp16 rows, later 16 fp32 row slots) + 1.5 KiB task tables
 
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
-    const int j16 = lane & 15, g4 = lane >> 4;                 // coalesced layout: 16 lanes per row, 4 rows per instruction
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int RU = 32 * T;                                  // rows per unit
     constexpr int TILEB = 4096 * T, TABB = 1552;

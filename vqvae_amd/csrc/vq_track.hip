@@ -112,7 +112,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         for (int pc = wave_u; pc < npieces; pc += NW) {
             const int sp = (pc + rot) % npieces;
             const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)(dst16 + sp * 64));
-            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src16 + sp * 64 + lane0), "s"(lds) : "memory", "m0");
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src16 + sp * 64 + lane0), "s"(lds) : "memory");
         }
     }
     for (int i = tid; i < ntile * 32; i += NW * 64) seeds[i] = seeds_g[i];
@@ -175,7 +175,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         // out of this loop, spills them and reloads them from scratch inside it
         int lane_v = tid & 63;
         asm volatile("" : "+v"(lane_v));
-        const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5, j16 = lane_v & 15, g4 = lane_v >> 4;
+        const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5;
         const uint4 *ap0 = Eimg + h * 32 + l31;
         const float *sp0 = seeds + h * 16;
 
