@@ -101,7 +101,8 @@ VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);
 VQVAE_API int vqvae_vq_screen_sweeps(int K, int D, int flags);
 
 /* Bytes of workspace vqvae_vq_forward_f32 needs (any number of rows: the streamed-codebook kernels work through the rows
- * in slabs of 2^18, so their scratch -- 39 MB at D = 64, 72 MB at D = 128 -- does not grow with n_rows). */
+ * in slabs of 2^18 and resolve the open rows of up to sixteen slabs per launch, so their scratch -- 221 MB at D = 64,
+ * 254 MB at D = 128: a slab's fp16 rows + 44 bytes of records per row of a sixteen-slab group -- does not grow with n_rows). */
 VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);
 
 /*
