@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Per-phase cycle breakdown of conv_halo8_h2_kernel from a -DCONV_STAMP build (tools/build_variant.py stamp -DCONV_STAMP;
-VQVAE_BENCH_LIB=<that library>): the whole-path encoder + decoder entries at BASELINE config 5's (or 4's) shape."""
+"""Per-phase cycle breakdown of conv_halo8_h2_kernel from a build with phase stamps (tools/conv_stamp_patch.py;
+VQVAE_BENCH_LIB=<that library>): the whole forward at BASELINE config 5's shape, batch and image size from the command line."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
