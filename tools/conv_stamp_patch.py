@@ -34,12 +34,12 @@ rep('''        if (grp == 0) stage();                         // (wave-private t
 ''','''        if (grp == 0) { stage(); CST(1); }
 ''')
 rep('''        __syncthreads();
-        if (s + 1 < nstage) dma_stage(s + 1, (s + 1) & 1);
+        if (s + 1 < nstage) dma_stage(grp + 1 == ngrp ? sl + 1 : sl, grp + 1 == ngrp ? 0 : grp + 1, (s + 1) & 1);
         if (grp == 0 && sl + 1 < nslice) load_raw(sl + 1);
 ''','''        CST(2);
         __syncthreads();
         CST(3);
-        if (s + 1 < nstage) dma_stage(s + 1, (s + 1) & 1);
+        if (s + 1 < nstage) dma_stage(grp + 1 == ngrp ? sl + 1 : sl, grp + 1 == ngrp ? 0 : grp + 1, (s + 1) & 1);
         CST(4);
         if (grp == 0 && sl + 1 < nslice) load_raw(sl + 1);
         CST(5);
