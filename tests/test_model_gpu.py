@@ -537,6 +537,32 @@ def test_model_pickles_and_deepcopies_after_a_forward():
         assert torch.equal(out_s[1], ref[1])
 
 
+@pytest.mark.parametrize("name,B,S,K,D", [("c4", 512, 224, 1024, 64), ("c5", 1024, 256, 8192, 128)])
+def test_baseline_configs_4_and_5_at_full_size_properties(name, B, S, K, D):
+    """BASELINE configs 4 / 5 at their FULL per-GPU batch (1.6 M / 4.2 M latent rows: sixteen slabs = one group of the
+    streamed-codebook quantizer, every halo-tile kernel with its full grid), properties that need no CPU reference:
+    run-to-run bitwise determinism, perplexity = the histogram of the returned indices, and x_hat = the decoder applied to
+    the codebook rows of those indices (VQVAE.decode_indices: the z_q the forward used is exactly that gather)."""
+    from vqvae_amd import conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    torch.manual_seed(8)
+    m = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev())
+    x = torch.randn(B, 3, S, S, device=dev())
+    with torch.no_grad():
+        loss, x_hat, ppl, idx = m._forward_c(x, want_idx=True)
+        loss2, x_hat2, ppl2, idx2 = m._forward_c(x, want_idx=True)
+        torch.cuda.synchronize()
+        assert torch.equal(idx, idx2) and torch.equal(x_hat.view(torch.int32), x_hat2.view(torch.int32))
+        assert loss.item() == loss2.item() and ppl.item() == ppl2.item()
+        assert torch.isfinite(x_hat).all() and torch.isfinite(loss)
+        assert int(idx.min()) >= 0 and int(idx.max()) < K and idx.numel() == B * (S // 4) ** 2
+        p = torch.bincount(idx.view(-1), minlength=K).double() / idx.numel()
+        np.testing.assert_allclose(ppl.item(), float(torch.exp(-(p * torch.log(p + 1e-10)).sum())), rtol=1e-5)
+        x_dec = m.decode_indices(idx, B, S // 4, S // 4)
+        np.testing.assert_allclose(x_dec.cpu().numpy(), x_hat.cpu().numpy(), atol=1e-6, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B", [4096, 37, 1, 5000])
 def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B):
     """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the
