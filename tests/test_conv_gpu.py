@@ -152,7 +152,9 @@ def test_conv_vs_c_oracle():
 
 
 @pytest.mark.parametrize("Cin,Cout,B,H,W", [(3, 64, 5, 32, 32), (3, 32, 2, 16, 24), (1, 16, 2, 8, 8), (4, 128, 1, 12, 12),
-                                            (3, 64, 2, 64, 64), (3, 32, 1, 256, 256), (1, 96, 3, 32, 32)])
+                                            (3, 64, 2, 64, 64), (3, 32, 1, 256, 256), (1, 96, 3, 32, 32),
+                                            # R x TW output tiles that are not whole rows (interior tile borders read real neighbours)
+                                            (3, 64, 2, 224, 224), (3, 64, 3, 32, 96), (4, 32, 2, 96, 64)])
 def test_conv_in_vs_torch_cpu(Cin, Cout, B, H, W):
     from vqvae_amd.modules import Encoder
     torch.manual_seed(Cin * 10 + Cout)
