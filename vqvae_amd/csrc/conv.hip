@@ -3668,64 +3668,64 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                              T[px][m2][0], T[px][m2][1]);
                 }
         }
-        // ----------------------------- col2im of the pass -----------------------------
-        // through a wave-private LDS tile (the operand planes are free until the next pass): per output channel the two phases'
-        // terms land at row Y + 1, column slot ((X + 4) & 3) * 10 + ((X + 4) >> 2) of a zeroed 34 x 42 tile (the four
-        // column residues side by side and a row stride of 42: the scatter's lanes, 4 floats apart in x and 4 rows apart
-        // in y, then hit 32 different banks; in plain [Y][X] order they share 8) -- phase (py, 0) stores (every element at most once), phase (py, 1)
-        // adds -- and leave as whole 128-byte rows: out = bias + tile in pass 0, out += tile in pass 1
-        f32x4 ov[CO][4];                                   // this lane's 16-byte pieces of the image after pass 0
+        // ----------------------------- col2im of the pass, in registers -----------------------------
+        // Lane (pixel (y, x), half h) holds for every output channel the eight terms of its pixel's two phases for the two
+        // output rows oy = 4y + 2py - 1 + h (kernel row ky = h) and oy + 2 (ky = h + 2): a[kx] of phase (py, 0) lands at column
+        // 4x - 1 + kx, b[kx] of phase (py, 1) at 4x + 1 + kx.  The lane's own 16-byte quad of a row, columns 4x .. 4x + 3, is
+        //     { a1 + b3 of the LEFT pixel,  a2 + b0,  a3 + b1,  b2 + a0 of the RIGHT pixel }
+        // -- the two neighbour terms come by DPP row shifts inside the 8-lane pixel row (nothing at the image's left / right
+        // edge: those taps fall outside) -- so the eight lanes of a pixel row write one whole 128-byte output row straight
+        // from registers: pass 0 stores bias + quad, pass 1 adds to what pass 0 stored (row 31 gets its only term in pass 1).
+        // Same terms in the same order as the LDS-tile form this replaces (phase 0's term first, pass 0 first): same bits; no
+        // LDS tile to zero, scatter into and read back (420 LDS operations per image), 28 % of a wave's time before.
+        const bool xl = (lane & 7) != 0, xr = (lane & 7) != 7;
+        unsigned roff[MT][2];                              // byte offset of the lane's quad in rows oy / oy + 2 of channel 0, or out of range
+        bool only1[MT][2];                                 // pass 1: the row got nothing in pass 0 (row 31)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int row = 4 * (spx[mt] >> 3) + 2 * py - 1 + h + 2 * g;
+                roff[mt][g] = (row >= 0 && row < 32) ? (unsigned)((row * 32 + 4 * (lane & 7)) * 4) : kOobOffset;
+                only1[mt][g] = row == 31;
+            }
+        f32x4 ov[CO][MT][2];
         if (py > 0) {
 #pragma unroll
             for (int co = 0; co < CO; ++co)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    ov[co][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0));
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g)
+                        ov[co][mt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, roff[mt][g], (unsigned)co * 4096u, 0));
         }
-        float *tile = reinterpret_cast<float *>(As);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                if (lane + 64 * i < 357) reinterpret_cast<f32x4 *>(tile)[lane + 64 * i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-            lds_order_wave();
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-                // phase (py, 0) stores; phase (py, 1) reads, adds and stores (no two lanes of one instruction meet, the wave's
-                // LDS operations execute in order; ds_add_f32 does the same 110 us per step slower, measured)
-                float old[MT][8];
-                if (px == 1) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) {
-                        const int y = spx[mt] >> 3, x = spx[mt] & 7;
-                        const float *tp = tile + (4 * y + 2 * py + h) * 42 + x;
-#pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) old[mt][rr] = tp[((rr >> 2) & 1) * 84 + ((2 * px + 3 + (rr & 3)) & 3) * 10 + ((2 * px + 3 + (rr & 3)) >> 2)];
-                    }
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const int y = spx[mt] >> 3, x = spx[mt] & 7;
-                    float *tp = tile + (4 * y + 2 * py + h) * 42 + x;
-#pragma unroll
-                    for (int rr = 0; rr < 8; ++rr) {
-                        const float v = T[px][co >> 1][mt][8 * (co & 1) + rr] * d4[px];
-                        tp[((rr >> 2) & 1) * 84 + ((2 * px + 3 + (rr & 3)) & 3) * 10 + ((2 * px + 3 + (rr & 3)) >> 2)] = px == 0 ? v : old[mt][rr] + v;
-                    }
-                }
-                lds_order_wave();
-            }
             const float bv = bias4 ? bias4[co] : 0.0f;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = (lane >> 3) + 8 * i;
-                const float *rp = tile + (row + 1) * 42 + (lane & 7) + 1;
-                f32x4 v = {rp[0], rp[10], rp[20], rp[30]};
-                if (py > 0) v = ov[co][i] + v;
-                else v = f32x4{bv, bv, bv, bv} + v;
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, (unsigned)lane * 16u, (unsigned)(co * 4 + i) * 1024u, 0);
-            }
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    const f32x16 &T0 = T[0][co >> 1][mt], &T1 = T[1][co >> 1][mt];
+                    const int r0 = 8 * (co & 1) + 4 * g;
+                    const float a0 = T0[r0] * d4[0], b0 = T1[r0] * d4[1], b1 = T1[r0 + 1] * d4[1], b2 = T1[r0 + 2] * d4[1], b3 = T1[r0 + 3] * d4[1];
+                    // neighbours: row_shr:1 hands lane i the value of lane i - 1, row_shl:1 that of lane i + 1 (16-lane rows = two pixel rows)
+                    float lb3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b3), 0x111, 0xf, 0xf, true));
+                    float ra0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x101, 0xf, 0xf, true));
+                    lb3 = xl ? lb3 : 0.0f;
+                    ra0 = xr ? ra0 : 0.0f;
+                    f32x4 e;
+                    e.x = __builtin_fmaf(T0[r0 + 1], d4[0], lb3);          // (the products by 2^-k are exact: one rounding, as mul + add)
+                    e.y = __builtin_fmaf(T0[r0 + 2], d4[0], b0);
+                    e.z = __builtin_fmaf(T0[r0 + 3], d4[0], b1);
+                    e.w = ra0 + b2;
+                    f32x4 base = {bv, bv, bv, bv};
+                    if (py > 0 && !only1[mt][g]) base = ov[co][mt][g];
+                    const f32x4 v = base + e;
+                    // (the channel's offset in the VECTOR offset: a scalar-offset store followed by an overwrite of its data registers is the
+                    // hazard hipcc leaves unguarded, tools/hazard_scan.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, roff[mt][g] == kOobOffset ? kOobOffset : roff[mt][g] + (unsigned)co * 4096u, 0, 0);
+                }
         }
         __builtin_amdgcn_wave_barrier();
         if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};   // the planes' padding pixels again
