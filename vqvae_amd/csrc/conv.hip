@@ -3438,14 +3438,16 @@ __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__res
 //       layer's B operands by half-wave swaps (acc_to_ksteps), scaled by the phase tile's own maximum;
 //   layer 2 in its GEMM + col2im form: T[co * 16 + tap][pixel] = sum_c w4[c][co][tap] u[pixel][c] (48 rows = two A tiles),
 //       and out[co][4y + 2py - 1 + ky][4x + 2px - 1 + kx] += T: every output element receives exactly ONE term per phase.
-//       Per output channel the phase's terms are scattered into a zeroed wave-private 34 x 42 LDS tile (the operand planes
-//       are free then; the second phase of a pass reads, adds and stores) and leave as whole 128-byte rows: out = bias + tile
-//       in pass 0, out += tile in pass 1 with
-//       16-byte read-modify-writes of the wave's own 12 KiB image (L2-resident; plain accesses: the same lanes of the same wave
-//       on the same CU re-read what they wrote, its write-through L1 does not keep a stale copy, and a phase's stores are
-//       complete -- eight s_waitcnt vmcnt(0) later -- before the next phase's loads are issued): a fixed summation order,
-//       no atomics, no 12 KiB accumulation tile per wave.  (Scattered 4-byte read-modify-writes straight from the
-//       accumulator layout were measured first: 570 us instead of 330 for the two separate kernels -- L2 request bound.)
+//       The two phases of a pass are combined in REGISTERS: a lane holds its pixel's terms of both phases for the output
+//       rows 4y + 2py - 1 + h and + 2; its own 16-byte quad of such a row (columns 4x .. 4x + 3) is its six inner terms plus one
+//       term each of its left and right pixel, fetched by DPP row shifts -- eight lanes then store one whole 128-byte output
+//       row straight from registers: out = bias + quad in pass 0, out += quad in pass 1 with 16-byte read-modify-writes of
+//       the wave's own 12 KiB image (L2-resident; plain accesses by the wave that wrote them, its write-through L1 keeps no
+//       stale copy, and a pass's stores are complete -- sixteen s_waitcnt vmcnt(0) later -- before the next pass's loads are
+//       issued): a fixed summation order, no atomics, no accumulation tile.  (Round 2 scattered the terms into a zeroed
+//       wave-private 34 x 42 LDS tile per channel and read it back: 420 LDS operations per image, 28 % of a wave's time;
+//       scattered 4-byte read-modify-writes straight from the accumulator layout were measured first: 570 us instead of 330
+//       for the two separate kernels -- L2 request bound.)
 struct TailGeom {
     unsigned long long dym[4], dxm[4];             // 4 bits per tap: dy + 8, dx + 8 (ConvGeom) of each phase
 };
