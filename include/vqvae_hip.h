@@ -370,6 +370,28 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
                                 size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
                                 vqvae_stream_t stream);
 
+/* The same step in PARTS, for callers that spread a large batch over several streams (the default shapes' path only: 32x32
+ * images, h_dim 128, two residual layers, K = 512, D = 64; VQVAE_ERR_UNSUPPORTED otherwise -- use vqvae_forward_f32):
+ *   vqvae_forward_begin_f32   codebook images + cleared histogram, on `stream`;
+ *   vqvae_forward_part_f32    images [b0, b0 + Bc) of the batch of B, on ANY stream ordered behind the begin (b0 and every Bc
+ *                             but the last multiples of 64); x, x_hat, idx and both workspaces are the WHOLE batch's, as
+ *                             vqvae_forward_f32 would get them; parts must not overlap;
+ *   vqvae_forward_end_f32     loss and perplexity of the whole batch, on a stream ordered behind every part.
+ * Results are bit-identical to one vqvae_forward_f32 call.  Why: with the four kernels of the whole batch one after the other,
+ * 10-15 % of every kernel's workgroup slots stand empty while it ramps up and while its last workgroups finish; kernels of
+ * different parts on different streams can fill those ends -- measured between -7 % and +9 % per step depending on the box
+ * (profiles/r03_notes.txt section 11), which is why the Python host layer does not do it by default.
+ * The library creates no streams or events: ordering between the streams is the caller's (hipStreamWaitEvent / torch
+ * wait_stream). */
+VQVAE_API int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int vq_flags, void *workspace,
+                                      size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
+                                      vqvae_stream_t stream);
+VQVAE_API int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int64_t B, int64_t b0, int64_t Bc, int H, int W,
+                                     int vq_flags, float *x_hat, int64_t *idx, void *workspace, size_t workspace_bytes,
+                                     void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream);
+VQVAE_API int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float *loss, float *perplexity,
+                                    void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

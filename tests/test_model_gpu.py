@@ -563,6 +563,30 @@ def test_baseline_configs_4_and_5_at_full_size_properties(name, B, S, K, D):
         np.testing.assert_allclose(x_dec.cpu().numpy(), x_hat.cpu().numpy(), atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("B,parts", [(4096, 4), (4096, 3), (1000, 4), (2112, 2), (4097, 4), (200, 8)])
+def test_step_in_parts_on_side_streams_equals_the_single_call(B, parts):
+    """vqvae_forward_begin / part / end (the batch in parts on side streams: `_forward_c(x, parts=n)`) against
+    one vqvae_forward_f32 call: loss, perplexity, x_hat and the indices bit for bit, ragged batches and part counts that do
+    not divide the batch included; twice in a row (histogram cleared per call, stream ordering across steps)."""
+    from vqvae_amd import conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    torch.manual_seed(31)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    for rep in range(2):
+        x = torch.randn(B, 3, 32, 32, device=dev()) * (1.0 + rep)
+        with torch.no_grad():
+            a = m._forward_c(x, want_idx=True, parts=1)
+            b = m._forward_c(x, want_idx=True, parts=parts)
+        torch.cuda.synchronize()
+        assert a[0].item() == b[0].item() and a[2].item() == b[2].item(), "loss / perplexity"
+        assert torch.equal(a[1].view(torch.int32), b[1].view(torch.int32)), "x_hat bits"
+        assert torch.equal(a[3], b[3]), "indices"
+    with torch.no_grad():                              # and VQVAE.forward (the default policy) gives the same again
+        c = m(x)
+    assert c[0].item() == a[0].item() and torch.equal(c[1].view(torch.int32), a[1].view(torch.int32))
+
+
 @pytest.mark.parametrize("B", [4096, 37, 1, 5000])
 def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B):
     """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the

@@ -332,31 +332,59 @@ int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4
                        w && dims_ok(&w->dims) && fused_c3_path(&w->dims, 4 * h4, 4 * w4));
 }
 
+}  // extern "C"
+
+namespace {
+// The whole-batch workspace of the forward entry points (vqvae_workspace_bytes), carved the same way by all of them
+struct FwdWs {
+    void *acts; size_t act, rows; int *am2; float *z_e, *z_q; int64_t *idx_ws; int32_t *hist; void *vqws; size_t vqws_bytes;
+};
+int carve_forward(const VqvaeDims *d, int64_t B, int H, int W, void *workspace, size_t workspace_bytes, void *vq_workspace,
+                  size_t vq_workspace_bytes, int &vq_flags, FwdWs &f) {
+    const size_t need = vqvae_workspace_bytes(d, B, H, W);
+    if (need == 0) return VQVAE_ERR_UNSUPPORTED;
+    if (workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
+    Carve c{static_cast<char *>(workspace), workspace_bytes};
+    f.act = act_elems(d, B, H, W);
+    f.rows = (size_t)B * (H / 4) * (W / 4);
+    f.acts = c.raw(2 * align_up(f.act * sizeof(float), 256));
+    f.am2 = static_cast<int *>(c.raw(2 * amax_bytes(d, B)));          // encoder's and decoder's maxima: one fill for both
+    f.z_e = c.f32(f.rows * d->embedding_dim);
+    f.z_q = c.f32(f.rows * d->embedding_dim);
+    f.idx_ws = static_cast<int64_t *>(c.raw(f.rows * sizeof(int64_t)));
+    f.hist = static_cast<int32_t *>(c.raw((size_t)d->n_embeddings * sizeof(int32_t)));
+    const size_t vqb = vqvae_vq_workspace_bytes((int64_t)f.rows, d->n_embeddings, d->embedding_dim);
+    f.vqws = vq_workspace;
+    f.vqws_bytes = vq_workspace_bytes;
+    if (!f.vqws) {                                     // no persistent codebook workspace: use (and re-prepare) ours
+        f.vqws = c.raw(vqb);
+        f.vqws_bytes = vqb;
+        vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
+    }
+    return c.ok ? VQVAE_OK : VQVAE_ERR_WORKSPACE;
+}
+}  // namespace
+
+extern "C" {
+
 int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, float *x_hat,
                       float *loss, float *perplexity, int64_t *idx, void *workspace, size_t workspace_bytes,
                       void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream) {
     if (!w || !x || !x_hat || !loss || !perplexity || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
-    const size_t need = vqvae_workspace_bytes(d, B, H, W);
-    if (need == 0) return VQVAE_ERR_UNSUPPORTED;
-    if (workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
-    Carve c{static_cast<char *>(workspace), workspace_bytes};
-    const size_t act = act_elems(d, B, H, W);
-    const size_t rows = (size_t)B * (H / 4) * (W / 4);
-    void *acts = c.raw(2 * align_up(act * sizeof(float), 256));
-    int *am2 = static_cast<int *>(c.raw(2 * amax_bytes(d, B)));            // encoder's and decoder's maxima: one fill for both
-    float *z_e = c.f32(rows * d->embedding_dim), *z_q = c.f32(rows * d->embedding_dim);
-    int64_t *idx_ws = static_cast<int64_t *>(c.raw(rows * sizeof(int64_t)));
-    int32_t *hist = static_cast<int32_t *>(c.raw((size_t)d->n_embeddings * sizeof(int32_t)));
-    const size_t vqb = vqvae_vq_workspace_bytes((int64_t)rows, d->n_embeddings, d->embedding_dim);
-    void *vqws = vq_workspace;
-    size_t vqws_bytes = vq_workspace_bytes;
-    if (!vqws) {                                       // no persistent codebook workspace: use (and re-prepare) ours
-        vqws = c.raw(vqb);
-        vqws_bytes = vqb;
-        vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
+    FwdWs f;
+    {
+        const int crc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
+        if (crc != VQVAE_OK) return crc;
     }
-    if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    const size_t act = f.act, rows = f.rows;
+    void *acts = f.acts;
+    int *am2 = f.am2;
+    float *z_e = f.z_e, *z_q = f.z_q;
+    int64_t *idx_ws = f.idx_ws;
+    int32_t *hist = f.hist;
+    void *vqws = f.vqws;
+    const size_t vqws_bytes = f.vqws_bytes;
     const size_t acts_bytes = 2 * align_up(act * sizeof(float), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
     // two fill launches per step saved on the fused 32x32 path: the maxima need none there, and the quantizer's histogram
@@ -387,6 +415,69 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
                               z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
                               zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
     return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done);        // :36
+}
+
+
+// ---- the same step in PARTS (the default shapes' fused path only) -----------------------------------------------------------
+// vqvae_forward_begin_f32 (codebook images, histogram cleared) -> vqvae_forward_part_f32 for disjoint image ranges, each on
+// ANY stream ordered behind the begin -> vqvae_forward_end_f32 ordered behind all parts (loss, perplexity of the whole batch).
+// Buffers and workspaces are the whole batch's, exactly vqvae_forward_f32's; results are bit-identical to it (a workgroup
+// quantizes the same four images and leaves the same loss partial; the histogram is integer).  Why: run on several streams,
+// the kernels of different parts fill each other's ramp-up and tail -- 10-15 % of a kernel's workgroup slots stand empty there
+// when the four kernels of the whole batch run one after the other (profiles/r03_notes.txt sections 9, 11).
+int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int vq_flags, void *workspace, size_t workspace_bytes,
+                            void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    FwdWs f;
+    int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
+    if (rc != VQVAE_OK) return rc;
+    if (!fused_c3_path(d, H, W) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, f.vqws, f.vqws_bytes, st)) != 0) return rc;
+    if (hipMemsetAsync(f.hist, 0, (size_t)d->n_embeddings * sizeof(int32_t), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    return VQVAE_OK;
+}
+
+int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int64_t B, int64_t b0, int64_t Bc, int H, int W, int vq_flags,
+                           float *x_hat, int64_t *idx, void *workspace, size_t workspace_bytes, void *vq_workspace,
+                           size_t vq_workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !x || !x_hat || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    // whole 64-image blocks per part (the last part takes what is left): the parts' slices of the maxima region stay aligned
+    if (B < 1 || b0 < 0 || Bc < 1 || b0 + Bc > B || b0 % 64 || (b0 + Bc < B && Bc % 64)) return VQVAE_ERR_SHAPE;
+    FwdWs f;
+    int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
+    if (rc != VQVAE_OK) return rc;
+    if (!fused_c3_path(d, H, W) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t per_img = f.act / (size_t)B, lat = (size_t)(H / 4) * (W / 4);
+    // this part's own two activation buffers and maxima regions inside the whole batch's
+    char *acts_p = static_cast<char *>(f.acts) + 2 * (size_t)b0 * per_img * sizeof(float);
+    const size_t acts_p_bytes = 2 * align_up((size_t)Bc * per_img * sizeof(float), 256);
+    const size_t am_ints = (size_t)(4 + d->n_res_layers);
+    int *am_p = f.am2 + 2 * am_ints * (size_t)b0;
+    int *am_dec_p = reinterpret_cast<int *>(reinterpret_cast<char *>(am_p) + amax_bytes(d, Bc));
+    float *z_q_p = f.z_q + (size_t)b0 * lat * d->embedding_dim;
+    int64_t *idx_p = (idx ? idx : f.idx_ws) + (size_t)b0 * lat;
+    VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, f.vqws, z_q_p, idx_p, f.hist);
+    vf.partials = reinterpret_cast<double *>(f.z_e) + b0 / 4;
+    const float *x_p = x + (size_t)b0 * d->in_ch * H * W;
+    if ((rc = encoder_run(w, x_p, Bc, H, W, f.z_e, acts_p, acts_p_bytes, st, am_p, nullptr, 0, nullptr, false, &vf)) != 0) return rc;
+    return decoder_run(w, z_q_p, Bc, H / 4, W / 4, x_hat + (size_t)b0 * d->in_ch * H * W, acts_p, acts_p_bytes, st, am_dec_p);
+}
+
+int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float *loss, float *perplexity, void *workspace,
+                          size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !loss || !perplexity || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    FwdWs f;
+    int flags = 0;
+    char dummy = 0;                                    // (the quantizer workspace is not touched here)
+    int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, &dummy, 0, flags, f);
+    if (rc != VQVAE_OK) return rc;
+    return vq_finalize_impl(reinterpret_cast<const double *>(f.z_e), (int)((B + 3) / 4), f.hist, d->n_embeddings, (int64_t)f.rows,
+                            d->embedding_dim, d->beta, loss, perplexity, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -261,9 +261,51 @@ class VQVAE(nn.Module):
         _cache.side(self)["c_weights"] = (key, cw, (keep, packed))
         return cw, (keep, packed)
 
-    def _forward_c(self, x, want_idx=False, vq_flags=0):
+    # The step can run as n parts on n side streams (vqvae_forward_begin / part / end; _forward_c(x, parts=n)): the kernels of
+    # different parts fill each other's ramp-up and tail.  NOT the default: measured -2 % per step on one MI355X box and +9 % on
+    # another (profiles/r03_notes.txt section 11), so FORWARD_PARTS stays 1 = one vqvae_forward_f32 call on the current stream.
+    FORWARD_PARTS = 1
+    FORWARD_PARTS_MIN_BATCH = 2048
+
+    def _forward_parts(self, L, cw, x, B, H, W, flags, x_hat, scal, idx, ws, nws, vws, dev, stream, parts):
+        """The step in parts on side streams; False = not applicable here (the caller makes the single call).  Outputs are
+        bit-identical to the single call; the current stream waits for the side streams before this returns."""
+        from . import _lib
+        n = self.FORWARD_PARTS if parts is None else parts
+        if n < 2 or B < (self.FORWARD_PARTS_MIN_BATCH if parts is None else 128) or (H, W) != (32, 32):
+            return False
+        rc = L.vqvae_forward_begin_f32(cw, B, H, W, flags, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(), stream)
+        if rc == -3:                                   # VQVAE_ERR_UNSUPPORTED: another architecture / codebook shape / quantizer flags
+            return False
+        _lib.check(rc)
+        pool = _cache.side(self).setdefault("part_streams", {})
+        streams = pool.get(str(dev))
+        if streams is None or len(streams) < n:
+            streams = pool[str(dev)] = [torch.cuda.Stream(device=dev) for _ in range(n)]
+        cur = torch.cuda.current_stream(dev)
+        per = -(-B // n)
+        per = -(-per // 64) * 64                        # whole 64-image blocks per part
+        b0 = 0
+        used = []
+        for s in streams[:n]:
+            if b0 >= B:
+                break
+            bc = min(per, B - b0)
+            s.wait_stream(cur)
+            _lib.check(L.vqvae_forward_part_f32(cw, x.data_ptr(), B, b0, bc, H, W, flags, x_hat.data_ptr(),
+                                                idx.data_ptr() if idx is not None else None, ws.data_ptr(), nws, vws.data_ptr(),
+                                                vws.numel(), s.cuda_stream))
+            used.append(s)
+            b0 += bc
+        for s in used:
+            cur.wait_stream(s)
+        _lib.check(L.vqvae_forward_end_f32(cw, B, H, W, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), nws, stream))
+        return True
+
+    def _forward_c(self, x, want_idx=False, vq_flags=0, parts=None):
         """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32).  vq_flags: extra quantizer flags for tests and
-        A/B runs (functional.VQ_UNFUSED: the quantizer as its own launch where the encoder's last kernel would quantize)."""
+        A/B runs (functional.VQ_UNFUSED: the quantizer as its own launch where the encoder's last kernel would quantize).
+        parts: None = the default policy (FORWARD_PARTS side streams for large batches), 1 = always the single call, n = n parts."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
@@ -292,10 +334,11 @@ class VQVAE(nn.Module):
             x_hat = torch.empty_like(x)
             scal = torch.empty(2, dtype=torch.float32, device=dev)
             idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev) if want_idx else None
-            _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags,
-                                           x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
-                                           idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
-                                           stream))
+            flags = (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags
+            if not self._forward_parts(L, cw, x, B, H, W, flags, x_hat, scal, idx, ws, nws, vws, dev, stream, parts):
+                _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, flags, x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
+                                               idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
+                                               stream))
             slot[1] = key
         return (scal[0], x_hat, scal[1]) + ((idx,) if want_idx else ())
 
