@@ -339,8 +339,10 @@ namespace {
 struct FwdWs {
     void *acts; size_t act, rows; int *am2; float *z_e, *z_q; int64_t *idx_ws; int32_t *hist; void *vqws; size_t vqws_bytes;
 };
+// with_vq = false: the caller does not touch the quantizer's workspace (vqvae_forward_end_f32); everything in front of it
+// lies where the other entry points put it
 int carve_forward(const VqvaeDims *d, int64_t B, int H, int W, void *workspace, size_t workspace_bytes, void *vq_workspace,
-                  size_t vq_workspace_bytes, int &vq_flags, FwdWs &f) {
+                  size_t vq_workspace_bytes, int &vq_flags, FwdWs &f, bool with_vq = true) {
     const size_t need = vqvae_workspace_bytes(d, B, H, W);
     if (need == 0) return VQVAE_ERR_UNSUPPORTED;
     if (workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
@@ -356,7 +358,7 @@ int carve_forward(const VqvaeDims *d, int64_t B, int H, int W, void *workspace, 
     const size_t vqb = vqvae_vq_workspace_bytes((int64_t)f.rows, d->n_embeddings, d->embedding_dim);
     f.vqws = vq_workspace;
     f.vqws_bytes = vq_workspace_bytes;
-    if (!f.vqws) {                                     // no persistent codebook workspace: use (and re-prepare) ours
+    if (!f.vqws && with_vq) {                          // no persistent codebook workspace: use (and re-prepare) ours
         f.vqws = c.raw(vqb);
         f.vqws_bytes = vqb;
         vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
@@ -473,8 +475,7 @@ int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float 
     const VqvaeDims *d = &w->dims;
     FwdWs f;
     int flags = 0;
-    char dummy = 0;                                    // (the quantizer workspace is not touched here)
-    int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, &dummy, 0, flags, f);
+    int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, nullptr, 0, flags, f, false);
     if (rc != VQVAE_OK) return rc;
     return vq_finalize_impl(reinterpret_cast<const double *>(f.z_e), (int)((B + 3) / 4), f.hist, d->n_embeddings, (int64_t)f.rows,
                             d->embedding_dim, d->beta, loss, perplexity, static_cast<hipStream_t>(stream));
