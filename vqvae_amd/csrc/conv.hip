@@ -5130,7 +5130,7 @@ int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const 
     int tw_log2 = -1;
     for (int t = 8; t >= 1; --t)
         if (Wg % (1 << t) == 0 && Hg % (256 >> t) == 0) { tw_log2 = t; break; }
-    const bool rows = tw_log2 > 0 && W % 4 == 0 &&
+    const bool rows = tw_log2 > 0 && W % 4 == 0 && (long long)Hg * Wg * Cout * 4 < 0xFFFFFFF0ll &&      // 32-bit byte offsets inside an image
                       ((reinterpret_cast<uintptr_t>(x_nchw) | reinterpret_cast<uintptr_t>(y)) & 15) == 0;
     const int jg = (Cin * 8 + 3) / 4;
     const bool bf3 = !(flags & VQVAE_CONV_EXACT_FP32);     // split-bf16 products unless the fp32 MFMA is asked for
