@@ -219,10 +219,9 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                     seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
                 }
             };
-            fetch(0);
-#pragma unroll 1
-            for (int lt = 0; lt < nt_here; ++lt) {
-                f32x16 acc[2];
+            // Two accumulator sets: tile lt+1's matrix ops are issued before tile lt's tracker runs, so the tracker never
+            // waits for the results it reads and the matrix pipe has work queued while the vector ops issue.
+            auto mm = [&](f32x16 (&acc)[2]) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[0][0], seed, 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[1][0], seed, 0, 0, 0);
 #pragma unroll
@@ -230,15 +229,34 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[0][q], acc[0], 0, 0, 0);
                     acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[1][q], acc[1], 0, 0, 0);
                 }
-                if (lt + 1 < nt_here) fetch(lt + 1);       // lands under the vector ops below
+            };
+            auto track = [&](f32x16 (&acc)[2], int lt) {
                 unsigned cell0 = (unsigned)(2 * ((c * TC + lt) & (kEpoch - 1))), cell1 = cell0 + 1u;
                 asm volatile("" : "+s"(cell0), "+s"(cell1));
 #pragma unroll
                 for (int t = 0; t < 2; ++t) trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
+            };
+            if (nt_here == TC) {                            // every chunk but a ragged last one: straight-line, two sets
+                f32x16 acc[2][2];
+                fetch(0);
+                mm(acc[0]);
 #pragma unroll
-                for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(a[q]));
+                for (int lt = 0; lt < TC; ++lt) {
+                    if (lt + 1 < TC) { fetch(lt + 1); mm(acc[(lt + 1) & 1]); }
+                    track(acc[lt & 1], lt);
+                }
+            } else {
+                fetch(0);
+#pragma unroll 1
+                for (int lt = 0; lt < nt_here; ++lt) {
+                    f32x16 acc[2];
+                    mm(acc);
+                    if (lt + 1 < nt_here) fetch(lt + 1);
+                    track(acc, lt);
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(a[q]));
+                }
             }
-
             // end of a key epoch (16 tiles) or of the codebook: fold the lane's three keys into its running top-3
             if ((((c + 1) * TC) & (kEpoch - 1)) == 0 || c + 1 == nchunk) {
                 const int ebase = ((c * TC) / kEpoch) * kEpoch;          // first tile of this epoch
