@@ -199,6 +199,24 @@ def test_conv_backward_vs_torch_autograd(case, relu_out):
         _close_grad(md.bias.grad, m.bias.grad, "grad_b")
 
 
+# the map-resident weight-gradient kernel (8x8 A maps), every wave layout it is built for, more images than image ranges
+# (131 images -> 66 ranges of two, the last one of one) against the defining sum in fp64
+@pytest.mark.parametrize("k,s,CA,CB", [(3, 1, 128, 128), (3, 1, 64, 128), (3, 1, 32, 128), (3, 1, 128, 32), (4, 2, 128, 64),
+                                       (4, 2, 64, 32), (1, 1, 64, 128), (1, 1, 32, 128), (1, 1, 128, 32), (1, 1, 128, 96)])
+def test_map_resident_weight_gradient_vs_fp64_sum(k, s, CA, CB):
+    from vqvae_amd import autograd_conv as A
+    dev = torch.device("cuda:0")
+    torch.manual_seed(k * 1000 + CA + CB)
+    B, pad = 131, (0 if k == 1 else 1)
+    a = torch.randn(B, 8, 8, CA)
+    bt = torch.randn(B, 8 * s, 8 * s, CB)
+    ref = torch.nn.grad.conv2d_weight(bt.permute(0, 3, 1, 2).double(), (CA, CB, k, k), a.permute(0, 3, 1, 2).double(),
+                                      stride=s, padding=pad)
+    got = A.conv_wgrad(a.to(dev), bt.to(dev), k, s, pad)
+    _close_grad(got, ref.float(), "grad_w")
+    assert torch.equal(got, A.conv_wgrad(a.to(dev), bt.to(dev), k, s, pad))          # fixed-order sums: bit-reproducible
+
+
 @pytest.mark.parametrize("C,Rh,B,H,W,relu_in,relu_out", [(128, 32, 3, 8, 8, False, True), (128, 32, 2, 8, 8, True, True),
                                                        (64, 16, 2, 5, 7, True, False), (32, 8, 1, 4, 4, False, False)])
 def test_res_layer_backward_vs_torch_autograd(C, Rh, B, H, W, relu_in, relu_out):

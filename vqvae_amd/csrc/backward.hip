@@ -17,7 +17,7 @@
 
 namespace vqvae {
 
-constexpr int kWgMaxSplit = 64;       // pixel-range splits across workgroups
+constexpr int kWgMaxSplit = 128;      // pixel-range (or image-range) splits across workgroups
 constexpr int kWgImgSplit = 512;      // workgroups (= partials) of the image-operand kernel
 
 struct WgradGeom {
@@ -180,6 +180,93 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_kernel(const float *__restr
                     const int c = tb * 64 + nt * 32 + l31;
                     if (a < g.CA && c < g.CB) dst[(size_t)a * g.CB + c] = acc[mt][nt][r];
                 }
+    }
+}
+
+// Weight gradient with both maps resident in LDS, for 8x8 A maps (the body of the path at 32x32 images: every conv,
+// conv-transpose and residual layer between the first and the last one).  The kernel above reads A once per tap and
+// per 64 columns of Bt (16 flops per byte: it runs at the L2's pace, not the matrix pipe's); here a workgroup
+// parks one image's A tile (64 pixels x 32 WA channels) and the zero-framed Bt tile (PH x PH pixels x 32 WB channels)
+// in LDS -- LDS-DMA, 1 KiB pieces of 8 pixels x 32 channels, the frame is zeroed once and never written again --
+// and every tap reads its operand from there at a constant offset: one ds_read_b32 per 64-cycle MFMA, no address
+// arithmetic.  A wave owns a 32 x 32 tile of (ca, cb) for NTW taps (K = 4: the 16 taps are split over two waves),
+// so its accumulators are final for its split: no reduction across waves.  Two workgroups per CU: one loads while the
+// other multiplies.  Partials [split][tap][ca][cb] as above, combined in a fixed order by conv_wgrad_reduce_kernel.
+template <int K, int S, int WA, int WB>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_map8_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                 float *__restrict__ partial, WgradGeom g, int imgs_per_split) {
+    constexpr int TG = 4 / (WA * WB), NTW = K * K / TG, PH = 7 * S + K, HB = 8 * S, PAD = K == 1 ? 0 : 1;
+    static_assert(WA * WB * TG == 4 && NTW * TG == K * K && NTW % K == 0, "wave layout");
+    constexpr int ASZ = WA * 64 * 32, BSZ = WB * PH * PH * 32;                  // floats
+    constexpr int NPA = WA * 8, NPB = WB * HB * S, NPIECE = NPA + NPB;         // 1 KiB pieces per image
+    __shared__ __attribute__((aligned(128))) float smem[ASZ + BSZ];
+    float *As = smem, *Bs = smem + ASZ;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qa = wave_u % WA, qb = (wave_u / WA) % WB, tg = wave_u / (WA * WB);
+    const int tiles_b = g.CB / (32 * WB);
+    const int tb = blockIdx.x % tiles_b, ta = blockIdx.x / tiles_b;
+    const int ca0 = ta * 32 * WA, cb0 = tb * 32 * WB;
+    const int split = blockIdx.y;
+    const long long b_lo = (long long)split * imgs_per_split;
+    long long b_hi = b_lo + imgs_per_split;
+    if (b_hi > g.B) b_hi = g.B;
+
+    for (int i = tid; i < BSZ / 4; i += 256) reinterpret_cast<f32x4 *>(Bs)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // a piece = 8 pixels x 32 channels: lane -> pixel lane / 8, channels 4 (lane % 8) ..+3 (scalar base + lane offset)
+    const unsigned la = (unsigned)((lane >> 3) * g.CA + (lane & 7) * 4) * 4u;
+    const unsigned lb = (unsigned)((lane >> 3) * g.CB + (lane & 7) * 4) * 4u;
+    const unsigned as_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)As);
+    const unsigned bs_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)Bs);
+    auto dma = [&](unsigned lane_off, const float *src_uniform, unsigned lds) {
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_off), "s"(src_uniform), "s"(lds) : "memory");
+    };
+    // operand addresses of this lane: pixel pair q = pixels 2q + h = (q >> 2, 2 (q & 3) + h) of the 8x8 map
+    const float *ar = As + (qa * 64 + h) * 32 + l31;                                       // + q * 64
+    const float *br = Bs + (qb * PH * PH + h * S + tg * (NTW / K) * PH) * 32 + l31;       // + (pixel, tap) offset
+
+    for (long long b = b_lo; b < b_hi; ++b) {
+        __syncthreads();                                    // the previous image's operands have been read (first: the zero fill)
+#pragma unroll
+        for (int j = 0; j < (NPIECE + 3) / 4; ++j) {
+            const int p = wave_u + 4 * j;
+            if (p < NPA) {
+                const int ct = p >> 3, px = (p & 7) * 8;
+                dma(la, A + ((size_t)(b * 64 + px) * g.CA + ca0 + 32 * ct), as_lds + (unsigned)((ct * 64 + px) * 128));
+            } else if (p < NPIECE) {
+                const int r = p - NPA, ct = r / (HB * S), rr = r - ct * (HB * S), y = rr / S, u = rr - y * S;
+                dma(lb, Bt + ((size_t)((b * HB + y) * HB + 8 * u) * g.CB + cb0 + 32 * ct),
+                    bs_lds + (unsigned)((ct * PH * PH + (y + PAD) * PH + PAD + 8 * u) * 128));
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            const float av = ar[q * 64];
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int ky = t / K, kx = t % K;
+                const float bv = br[(((q >> 2) * S + ky) * PH + 2 * (q & 3) * S + kx) * 32];
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    float *dst = partial + (size_t)split * K * K * g.CA * g.CB;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tap = tg * NTW + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int a = ca0 + qa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[((size_t)tap * g.CA + a) * g.CB + cb0 + qb * 32 + l31] = acc[t][r];
+        }
     }
 }
 
@@ -450,12 +537,39 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
                            (int)nwg, k * k, CA, CB, grad_w);
         return (int)hipGetLastError();
     }
+    const long long total = (long long)k * k * CA * CB;
+    long long rgrid = (total + 255) / 256;
+    if (rgrid > 4096) rgrid = 4096;
+    // 8x8 A maps with whole 32-channel tiles: both maps resident in LDS, all taps from one staging
+    if (!bt_nchw && HA == 8 && WA == 8 && HB == 8 * stride && WB == 8 * stride && pad == (k == 1 ? 0 : 1) &&
+        ((k == 4 && stride == 2) || ((k == 3 || k == 1) && stride == 1))) {
+        int wa = 0, wb = 0;
+        if (k == 4) { if (CA % 64 == 0 && CB % 32 == 0) wa = 2, wb = 1; }
+        else if (CA % 64 == 0 && CB % 64 == 0) wa = 2, wb = 2;
+        else if (CA % 32 == 0 && CB % 128 == 0) wa = 1, wb = 4;
+        else if (CA % 128 == 0 && CB % 32 == 0) wa = 4, wb = 1;
+        if (wa) {
+            const long long tiles = (long long)(CA / (32 * wa)) * (CB / (32 * wb));
+            long long ns = (2LL * num_cus() + tiles - 1) / tiles;          // two workgroups per CU
+            if (ns > kWgMaxSplit) ns = kWgMaxSplit;
+            if (ns > B) ns = B;
+            const int ips = (int)((B + ns - 1) / ns);
+            ns = (B + ips - 1) / ips;
+            const dim3 grid((unsigned)tiles, (unsigned)ns);
+            if (k == 4) hipLaunchKernelGGL((conv_wgrad_map8_kernel<4, 2, 2, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else if (k == 3 && wa == 2) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 2, 2>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else if (k == 3 && wa == 1) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 1, 4>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else if (k == 3) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 4, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else if (wa == 2) hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else if (wa == 1) hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            else hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+            hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, st, partial, (int)ns, k * k, CA, CB, grad_w);
+            return (int)hipGetLastError();
+        }
+    }
     const unsigned gx = (unsigned)(((CA + 63) / 64) * ((CB + 63) / 64) * k * k);
     hipLaunchKernelGGL(conv_wgrad_kernel, dim3(gx, (unsigned)g.nsplit), dim3(256), 0, st, a, bt, partial, g);
-    const long long total = (long long)k * k * CA * CB;
-    long long grid = (total + 255) / 256;
-    if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)grid), dim3(256), 0, st, partial, g.nsplit, k * k, CA,
+    hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, st, partial, g.nsplit, k * k, CA,
                        CB, grad_w);
     return (int)hipGetLastError();
 }
