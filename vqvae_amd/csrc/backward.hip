@@ -17,7 +17,8 @@
 
 namespace vqvae {
 
-constexpr int kWgMaxSplit = 128;      // pixel-range (or image-range) splits across workgroups
+constexpr int kWgMaxSplit = 64;       // pixel-range splits across workgroups
+constexpr int kWgMapSplit = 512;      // image ranges of the map-resident kernel (two workgroups per CU when one tile covers dW)
 constexpr int kWgImgSplit = 512;      // workgroups (= partials) of the image-operand kernel
 
 struct WgradGeom {
@@ -383,8 +384,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float *__r
                                                                 int CA, int CB, float *__restrict__ dw) {
     const long long total = (long long)ntap * CA * CB;
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        float s = 0.0f;
-        for (int sp = 0; sp < nsplit; ++sp) s += partial[(size_t)sp * total + e];
+        // eight interleaved running sums (loads in flight instead of one dependent add per load), combined in a fixed order
+        float s8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+        int sp = 0;
+        for (; sp + 8 <= nsplit; sp += 8)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8[j] += partial[(size_t)(sp + j) * total + e];
+        for (int j = 0; sp < nsplit; ++sp, ++j) s8[j] += partial[(size_t)sp * total + e];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         const int tap = (int)(e / ((long long)CA * CB));
         const long long rem = e - (long long)tap * CA * CB;          // ca * CB + cb
         dw[rem * ntap + tap] = s;
@@ -502,8 +509,16 @@ extern "C" {
 
 size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k) {
     if (CA < 1 || CB < 1 || k < 1 || k > 4) return 0;
-    const int splits = (k * k * CB <= 64 && CA <= 64) ? kWgImgSplit : kWgMaxSplit;      // image-operand kernel
-    return (size_t)splits * k * k * CA * CB * sizeof(float);
+    // image-operand kernel: kWgImgSplit partials; map-resident kernel: two workgroups per CU over its (ca, cb) tiles
+    // (a tile is 64 x 64 or 32 x 128 channels, 64 x 32 for k = 4), capped; generic kernel: kWgMaxSplit
+    size_t splits = (k * k * CB <= 64 && CA <= 64) ? kWgImgSplit : kWgMaxSplit;
+    if (CA % 32 == 0 && CB % 32 == 0) {
+        const size_t tiles = k == 4 ? (size_t)((CA + 63) / 64) * (CB / 32) : ((size_t)CA * CB + 4095) / 4096;
+        size_t ns = (2 * (size_t)num_cus() + tiles - 1) / tiles;
+        if (ns > (size_t)kWgMapSplit) ns = kWgMapSplit;
+        if (ns > splits) splits = ns;
+    }
+    return splits * k * k * CA * CB * sizeof(float);
 }
 
 int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA, int HB, int WB, int CB,
@@ -551,7 +566,7 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
         if (wa) {
             const long long tiles = (long long)(CA / (32 * wa)) * (CB / (32 * wb));
             long long ns = (2LL * num_cus() + tiles - 1) / tiles;          // two workgroups per CU
-            if (ns > kWgMaxSplit) ns = kWgMaxSplit;
+            if (ns > kWgMapSplit) ns = kWgMapSplit;
             if (ns > B) ns = B;
             const int ips = (int)((B + ns - 1) / ns);
             ns = (B + ips - 1) / ips;
