@@ -206,6 +206,15 @@ VQVAE_API int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1
                                           const float *packed_w2, int64_t B, int H, int W, int C,
                                           int Rh, int flags, float *y, vqvae_stream_t stream);
 
+/* The same layer for a training step (main.py:74-78 through models/residual.py:27-29): also writes the hidden
+ * activation relu(W1 (*) r(x)) as hidden (B,H,W,Rh) row-major, which the backward pass needs for the ReLU mask and the
+ * 1x1 weight gradient -- instead of recomputing the 3x3 conv there.  Only where a wave owns whole images:
+ * H = W = 8, Rh = 32 (VQVAE_ERR_UNSUPPORTED otherwise: the caller recomputes with vqvae_conv_forward_f32).     */
+VQVAE_API int vqvae_res_layer_forward_hidden_f32(const float *x, const float *packed_w1,
+                                                 const float *packed_w2, int64_t B, int H, int W, int C,
+                                                 int Rh, int flags, float *y, float *hidden,
+                                                 vqvae_stream_t stream);
+
 /* First encoder conv, nn.Conv2d(Cin,Cout,k=4,s=2,p=1) (models/encoder.py:29-31), reading the NCHW
  * image x (B,Cin,H,W) and writing row-major (B,H/2,W/2,Cout).  Cin in {1,3,4}, Cout <= 128.
  * flags: VQVAE_CONV_RELU_OUT, VQVAE_CONV_EXACT_FP32 (fp32 MFMA instead of the split-bf16 products).
@@ -274,7 +283,10 @@ VQVAE_API int vqvae_recon_loss_backward_f32(const float *x_hat, const float *x, 
  *   nn.Conv2d:          a = grad_y (B,Ho,Wo,Cout), bt = x (B,H,W,Cin)        -> grad_w is (Cout,Cin,k,k)
  *   nn.ConvTranspose2d: a = x (B,H,W,Cin),         bt = grad_y (B,Ho,Wo,Cout) -> grad_w is (Cin,Cout,k,k)
  *   a is row-major; bt is row-major, or an NCHW image tensor when bt_nchw != 0 (first / last layer).
- *   Exact fp32 products (fp32 MFMA), fixed-order reduction: bit-reproducible.  k <= 4.                       */
+ *   Exact fp32 products (fp32 MFMA), fixed-order reduction: bit-reproducible.  k <= 4.
+ *   8x8 a maps with 32-channel multiples (every layer of the path between the first and the last at 32x32 images):
+ *   both maps of an image resident in LDS, all taps from one staging (conv_wgrad_map8_kernel); else pixel blocks
+ *   per tap.  The workspace holds the per-range partial sums ([range][tap][ca][cb]).                          */
 VQVAE_API size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k);
 VQVAE_API int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA,
                                    int HB, int WB, int CB, int k, int stride, int pad, int bt_nchw,

@@ -89,7 +89,8 @@ def test_conv_and_training_argument_errors_without_gpu():
     assert L.vqvae_recon_loss_f32(a, a + 4, 16, 1.0, None, None, a, a, 1 << 20, None) == -3
     assert L.vqvae_recon_loss_f32(a, a, 16, 1.0, None, None, a, a, 8, None) == -4
     assert L.vqvae_transpose_f32(None, 1, 8, 8, a, None) == -1
-    assert L.vqvae_conv_wgrad_workspace_bytes(128, 128, 3) == 64 * 9 * 128 * 128 * 4
+    assert L.vqvae_conv_wgrad_workspace_bytes(128, 128, 3) == 128 * 9 * 128 * 128 * 4      # 512 workgroups over four 64 x 64 tiles
+    assert L.vqvae_conv_wgrad_workspace_bytes(100, 60, 3) == 64 * 9 * 100 * 60 * 4           # generic kernel: 64 pixel ranges
     assert L.vqvae_conv_wgrad_workspace_bytes(128, 128, 5) == 0
     assert L.vqvae_conv_wgrad_f32(a, None, 1, 8, 8, 128, 8, 8, 128, 3, 1, 1, 0, a, a, 1 << 30, None) == -1
     assert L.vqvae_conv_wgrad_f32(a, a, 1, 8, 8, 128, 8, 8, 128, 5, 1, 1, 0, a, a, 1 << 30, None) == -3

@@ -7,7 +7,8 @@ conv-transpose and residual layer on libvqvae_hip.so, forward AND backward.
   bias gradients    vqvae_bias_grad_f32;   ReLU masks  vqvae_relu_backward_f32
 
 Activations are row-major (B,H,W,C) between layers, as in the forward-only path.  ResidualLayer keeps its
-fused forward kernel and recomputes the hidden activation in backward.  No CPU path, no fallback.
+fused forward kernel, which also writes the hidden activation for backward on 8x8 maps (other shapes: recomputed in
+backward).  No CPU path, no fallback.
 """
 from __future__ import annotations
 
@@ -176,26 +177,27 @@ class ConvTOutFn(torch.autograd.Function):
 
 
 class ResLayerFn(torch.autograd.Function):
-    """One ResidualLayer (models/residual.py:18-29): fused forward kernel, hidden activation recomputed in
-    backward.  y = [relu](r + W2 * relu(W1 * r)),  r = relu(x) if relu_in else x."""
+    """One ResidualLayer (models/residual.py:18-29): fused forward kernel; it also writes the hidden activation for
+    backward on 8x8 maps (recomputed in backward elsewhere).  y = [relu](r + W2 * relu(W1 * r)),  r = relu(x) if relu_in else x."""
 
     @staticmethod
     def forward(ctx, x, w1, w2, layer, relu_in, relu_out):
         flags = (RELU_IN if relu_in else 0) | (RELU_OUT if relu_out else 0)
-        y = conv_hip.res_layer(x.detach().contiguous(), layer, flags)
-        ctx.save_for_backward(x.detach(), w1.detach(), w2.detach(), y if relu_out else None)
+        y, hid = conv_hip.res_layer(x.detach().contiguous(), layer, flags, want_hidden=True)
+        ctx.save_for_backward(x.detach(), w1.detach(), w2.detach(), y if relu_out else None, hid)
         ctx.layer, ctx.relu_in, ctx.relu_out = layer, relu_in, relu_out
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        x, w1, w2, y = ctx.saved_tensors
+        x, w1, w2, y, h = ctx.saved_tensors
         c1, c2 = ctx.layer.res_block[1], ctx.layer.res_block[3]
         C, Rh = w1.shape[1], w1.shape[0]
         g = relu_backward(gy, y) if ctx.relu_out else gy.contiguous()
-        # recompute h = relu(W1 * r) with the plain conv kernel (the fused forward does not keep it)
-        h = conv_hip.conv(CONV_3x3_S1, x, _holder(ctx.layer, "w1_fwd"), w1, None, C, Rh,
-                          (RELU_IN if ctx.relu_in else 0) | RELU_OUT)
+        if h is None:
+            # h = relu(W1 * r) again with the plain conv kernel (shapes whose fused forward kernel does not write it)
+            h = conv_hip.conv(CONV_3x3_S1, x, _holder(ctx.layer, "w1_fwd"), w1, None, C, Rh,
+                              (RELU_IN if ctx.relu_in else 0) | RELU_OUT)
         gh = conv_hip.conv(CONVT_1x1, g, _holder(ctx.layer, "w2_dgrad"), w2, None, C, Rh, 0)   # (B,H,W,Rh)
         gh = relu_backward(gh, h)
         gx = gw1 = gw2 = None

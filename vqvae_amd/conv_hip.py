@@ -73,8 +73,9 @@ def conv(kind, x, mod, weight, bias, Cin, Cout, flags):
     return y
 
 
-def res_layer(x, layer, flags):
-    """One ResidualLayer on row-major activations (fused kernel)."""
+def res_layer(x, layer, flags, want_hidden=False):
+    """One ResidualLayer on row-major activations (fused kernel).  want_hidden: also return relu(W1 * r(x)) as
+    (B,H,W,Rh) where the kernel can write it (8x8 maps, res_h = 32), else None -- a training step keeps it for backward."""
     c1, c2 = layer.res_block[1], layer.res_block[3]
     B, H, W, C = x.shape
     Rh = c1.weight.shape[0]
@@ -86,9 +87,14 @@ def res_layer(x, layer, flags):
     p1 = _pack_conv(c1, CONV_3x3_S1, c1.weight, C, Rh)
     p2 = _pack_conv(c2, CONV_1x1, c2.weight, Rh, C)
     y = torch.empty_like(x)
+    if want_hidden and H == 8 and W == 8 and Rh == 32:
+        hid = torch.empty((B, H, W, Rh), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().vqvae_res_layer_forward_hidden_f32(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, H, W, C, Rh,
+                                                                  flags, y.data_ptr(), hid.data_ptr(), _sp(x)))
+        return y, hid
     _lib.check(_lib.load().vqvae_res_layer_forward_f32(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, H, W, C, Rh,
                                                        flags, y.data_ptr(), _sp(x)))
-    return y
+    return (y, None) if want_hidden else y
 
 
 def transpose(x, batch, R, Cc):

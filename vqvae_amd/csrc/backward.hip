@@ -18,7 +18,7 @@
 namespace vqvae {
 
 constexpr int kWgMaxSplit = 64;       // pixel-range splits across workgroups
-constexpr int kWgMapSplit = 512;      // image ranges of the map-resident kernel (two workgroups per CU when one tile covers dW)
+constexpr int kWgMapSplit = 512;      // workgroups of the map-resident kernel (two per CU): image ranges = 512 / (ca, cb) tiles
 constexpr int kWgImgSplit = 512;      // workgroups (= partials) of the image-operand kernel
 
 struct WgradGeom {
@@ -509,13 +509,12 @@ extern "C" {
 
 size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k) {
     if (CA < 1 || CB < 1 || k < 1 || k > 4) return 0;
-    // image-operand kernel: kWgImgSplit partials; map-resident kernel: two workgroups per CU over its (ca, cb) tiles
-    // (a tile is 64 x 64 or 32 x 128 channels, 64 x 32 for k = 4), capped; generic kernel: kWgMaxSplit
+    // image-operand kernel: kWgImgSplit partials; map-resident kernel: kWgMapSplit workgroups over its (ca, cb) tiles
+    // (a tile is 64 x 64 or 32 x 128 channels, 64 x 32 for k = 4); generic kernel: kWgMaxSplit
     size_t splits = (k * k * CB <= 64 && CA <= 64) ? kWgImgSplit : kWgMaxSplit;
     if (CA % 32 == 0 && CB % 32 == 0) {
         const size_t tiles = k == 4 ? (size_t)((CA + 63) / 64) * (CB / 32) : ((size_t)CA * CB + 4095) / 4096;
-        size_t ns = (2 * (size_t)num_cus() + tiles - 1) / tiles;
-        if (ns > (size_t)kWgMapSplit) ns = kWgMapSplit;
+        const size_t ns = ((size_t)kWgMapSplit + tiles - 1) / tiles;
         if (ns > splits) splits = ns;
     }
     return splits * k * k * CA * CB * sizeof(float);
@@ -565,8 +564,7 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
         else if (CA % 128 == 0 && CB % 32 == 0) wa = 4, wb = 1;
         if (wa) {
             const long long tiles = (long long)(CA / (32 * wa)) * (CB / (32 * wb));
-            long long ns = (2LL * num_cus() + tiles - 1) / tiles;          // two workgroups per CU
-            if (ns > kWgMapSplit) ns = kWgMapSplit;
+            long long ns = (kWgMapSplit + tiles - 1) / tiles;              // two workgroups per CU of the 256
             if (ns > B) ns = B;
             const int ips = (int)((B + ns - 1) / ns);
             ns = (B + ips - 1) / ips;

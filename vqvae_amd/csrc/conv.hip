@@ -1663,7 +1663,8 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
                                                                const u32x4 *__restrict__ w2img,
                                                                float *__restrict__ out, int B, int C, int flags,
                                                                const int *__restrict__ hdr1, const int *__restrict__ hdr2,
-                                                               const int *__restrict__ in_amax, int *__restrict__ out_amax) {
+                                                               const int *__restrict__ in_amax, int *__restrict__ out_amax,
+                                                               float *__restrict__ hid_out) {
     constexpr int TERMS = H2 ? 2 : 3;
     // u32x4 per wave tile: [term][half][pixel + zero], at least the 32 x 33 floats of the hidden tile that aliases it.
     // H2: 4.1 KiB per wave + 16 KiB of W2 = 33 KiB per workgroup -> four workgroups (16 waves) per CU, and the 1024
@@ -1826,6 +1827,11 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
         float a2[16];
 #pragma unroll
         for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+        if (hid_out && img_ok) {                            // training: the hidden activation (B, 8, 8, 32) for backward
+            f32x4 *hp = reinterpret_cast<f32x4 *>(hid_out + ((size_t)img * PX + mt * 32 + l31) * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hp[q] = f32x4{a2[4 * q], a2[4 * q + 1], a2[4 * q + 2], a2[4 * q + 3]};
+        }
         if constexpr (H2) {
             split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
             split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
@@ -4843,11 +4849,22 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
                                 int H, int W, int C, int Rh, int flags, float *y, vqvae_stream_t stream) {
     return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
+
+int vqvae_res_layer_forward_hidden_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B,
+                                       int H, int W, int C, int Rh, int flags, float *y, float *hidden,
+                                       vqvae_stream_t stream) {
+    if (!hidden) return VQVAE_ERR_NULL;
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr, hidden);
+}
 }  // extern "C"
 
 int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
-                                  int C, int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax) {
+                                  int C, int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
+                                  float *hidden) {
     if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
+    // the hidden activation is written by the kernels that own whole 8x8 images only (full 32-wide hidden tile)
+    if (hidden && (H != 8 || W != 8 || Rh != 32 || (flags & VQVAE_CONV_EXACT_FP32) || (reinterpret_cast<uintptr_t>(hidden) & 15)))
+        return VQVAE_ERR_UNSUPPORTED;
     if (B < 1 || H < 1 || W < 1 || C < 1 || Rh < 1) return VQVAE_ERR_SHAPE;
     if (Rh > 32 || C % 4 || !(C == 32 || C == 64 || C == 128)) return VQVAE_ERR_UNSUPPORTED;
     if (x == y) return VQVAE_ERR_UNSUPPORTED;           // 3x3 halo: not in place
@@ -4871,14 +4888,14 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
                 const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
                 const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
                 switch (C / 32) {
-                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
-                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
-                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax); break;
+                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
+                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
+                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
                 }
             } else switch (C / 32) {
-                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
-                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
-                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax); break;
+                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
+                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
+                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
             }
         } else if (in_amax && !(flags & VQVAE_CONV_BF16_SPLIT) && H % 8 == 0 && W % 8 == 0 && C % 32 == 0 &&
                    (long long)H * W * C * 4 < 0x7FFFFFF0ll) {
