@@ -316,27 +316,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const float *ab = A + (size_t)b * npx * g.CA;
-        for (int p0 = 0; p0 < npx; p0 += 2) {
-            const int p = p0 + h;
-            const bool pok = p < npx;
-            const int yA = p / g.WA, xA = p - yA * g.WA;
-            float av[MT], bv[NT];
+        // eight pixel pairs per round: their A values are requested together (one memory latency per round, not per pair)
+        for (int p0 = 0; p0 < npx; p0 += 16) {
+            float av[8][MT];
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int c = mt * 32 + l31;
-                av[mt] = (pok && c < g.CA) ? ab[(size_t)p * g.CA + c] : 0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const int p = p0 + 2 * j + h;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int c = mt * 32 + l31;
+                    av[j][mt] = (p < npx && c < g.CA) ? ab[(size_t)p * g.CA + c] : 0.0f;
+                }
             }
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int yB = yA * g.stride + ky[nt] - g.pad, xB = xA * g.stride + kx[nt] - g.pad;
-                const bool ok = pok && nok[nt] && yB >= 0 && yB < g.HB && xB >= 0 && xB < g.WB;
-                bv[nt] = ok ? img[cbo[nt] + yB * g.WB + xB] : 0.0f;
+            for (int j = 0; j < 8; ++j) {
+                const int p = p0 + 2 * j + h;
+                const bool pok = p < npx;
+                const int yA = p / g.WA, xA = p - yA * g.WA;
+                float bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int yB = yA * g.stride + ky[nt] - g.pad, xB = xA * g.stride + kx[nt] - g.pad;
+                    const bool ok = pok && nok[nt] && yB >= 0 && yB < g.HB && xB >= 0 && xB < g.WB;
+                    bv[nt] = ok ? img[cbo[nt] + yB * g.WB + xB] : 0.0f;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j][mt], bv[nt], acc[mt][nt], 0, 0, 0);
             }
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
         }
     }
     float *red = smem_img;                                   // 4096 floats (the launch sizes LDS for it)
@@ -415,7 +424,15 @@ __global__ __launch_bounds__(256) void bias_grad_partial_kernel(const float *__r
         const int grp = tid / c4, q = tid - grp * c4;
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
         if (grp < G) {
-            for (long long p = lo + grp; p < hi; p += G) {
+            long long p = lo + grp;
+            for (; p + 3 * G < hi; p += 4 * G) {             // four rows in flight; the sums keep their row order
+                f32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4 *>(g + (size_t)(p + j * G) * C + 4 * q);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { a0 += (double)v[j].x; a1 += (double)v[j].y; a2 += (double)v[j].z; a3 += (double)v[j].w; }
+            }
+            for (; p < hi; p += G) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(g + (size_t)p * C + 4 * q);
                 a0 += (double)v.x; a1 += (double)v.y; a2 += (double)v.z; a3 += (double)v.w;
             }
