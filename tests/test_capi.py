@@ -78,6 +78,9 @@ def test_conv_and_training_argument_errors_without_gpu():
     assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 96, 32, 0, a + 4096, None) == -3   # C not in {32,64,128}
     assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 128, 64, 0, a + 4096, None) == -3  # res_h > 32
     assert L.vqvae_res_layer_forward_f32(a, a, a, 1, 8, 8, 128, 32, 0, a, None) == -3         # in place
+    assert L.vqvae_res_layer_forward_hidden_f32(a, a, a, 1, 8, 8, 128, 32, 0, a + 4096, None, None) == -1     # no hidden buffer
+    assert L.vqvae_res_layer_forward_hidden_f32(a, a, a, 1, 16, 16, 128, 32, 0, a + 4096, a + 8192, None) == -3   # only 8x8 maps
+    assert L.vqvae_res_layer_forward_hidden_f32(a, a, a, 1, 8, 8, 128, 16, 0, a + 4096, a + 8192, None) == -3     # only res_h = 32
     assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 31, 32, 3, 64, 0, a, None) == -3
     assert L.vqvae_conv_in_forward_f32(a, a, a, 1, 32, 32, 2, 64, 0, a, None) == -3           # Cin not in {1,3,4}
     assert L.vqvae_convt_out_forward_f32(a, a, a, 1, 16, 16, 64, 5, 0, a, None) == -3            # Cout > 4

@@ -217,6 +217,28 @@ def test_map_resident_weight_gradient_vs_fp64_sum(k, s, CA, CB):
     assert torch.equal(got, A.conv_wgrad(a.to(dev), bt.to(dev), k, s, pad))          # fixed-order sums: bit-reproducible
 
 
+@pytest.mark.parametrize("C,flags", [(128, 2), (64, 3), (32, 0)])
+def test_res_layer_hidden_activation_for_backward(C, flags):
+    """vqvae_res_layer_forward_hidden_f32: y bit-identical to the forward-only entry, hidden = relu(W1 * r(x)) of
+    models/residual.py:20-23 (fp32 reference on the CPU; two-term fp16 products: 1e-5 + 1e-4 rel)."""
+    from vqvae_amd import conv_hip
+    from vqvae_amd.modules import ResidualLayer
+    import torch.nn.functional as F
+    dev = torch.device("cuda:0")
+    torch.manual_seed(C + flags)
+    layer = ResidualLayer(C, C, 32)
+    x = torch.randn(7, C, 8, 8)
+    ld = ResidualLayer(C, C, 32).to(dev)
+    ld.load_state_dict(layer.state_dict())
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    y, hid = conv_hip.res_layer(xd, ld, flags, want_hidden=True)
+    assert hid is not None and hid.shape == (7, 8, 8, 32)
+    assert torch.equal(y, conv_hip.res_layer(xd, ld, flags))
+    r = torch.relu(x) if flags & 1 else x
+    ref = torch.relu(F.conv2d(r, layer.res_block[1].weight, None, 1, 1))
+    np.testing.assert_allclose(hid.permute(0, 3, 1, 2).cpu().numpy(), ref.detach().numpy(), atol=1e-5, rtol=1e-4)
+
+
 @pytest.mark.parametrize("C,Rh,B,H,W,relu_in,relu_out", [(128, 32, 3, 8, 8, False, True), (128, 32, 2, 8, 8, True, True),
                                                        (64, 16, 2, 5, 7, True, False), (32, 8, 1, 4, 4, False, False)])
 def test_res_layer_backward_vs_torch_autograd(C, Rh, B, H, W, relu_in, relu_out):
