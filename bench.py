@@ -26,7 +26,8 @@ launch stream (vqvae_profile_* hooks) in extra steps after the timed region -- t
 overhead, so the per-kernel figures sum to slightly more than one un-instrumented step.  On the default shapes the step's
 quantizer runs inside the encoder's last kernel; `roofline` then times the standalone quantizer kernel on the same z_e.
 `index_flips_vs_reference` = every index of this batch against the reference's algorithm on the host;
-`other_workloads` = BASELINE configs 2 / 4 / 5 on this GPU, >= 1 s timed each.  `roofline.traffic` is
+`other_workloads` = BASELINE configs 2 / 4 / 5 on this GPU, >= 1 s timed each; `training_step` = SURVEY 8(f) row 2
+(main.py:74-78: forward + losses + backward on the HIP kernels, no optimizer) at the same batch.  `roofline.traffic` is
 HBM bytes per launch from rocprofv3 PMC passes recorded in the file named by `traffic_source` (null when no
 such file is committed for the workload); it is never a constant in this script.  `cpu_baseline` is the reference's
 algorithm on the host cores (oracle/torch_port.py, same ATen ops as the reference, bounded sample).
@@ -47,6 +48,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 HBM_ACHIEVABLE_GBPS = 6290.0
 MFMA_16BIT_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
+MFMA_FP32_PEAK_TFLOPS = 157.3     # fp32 MFMA (256 flop / clk / CU x 256 CUs x 2.4 GHz)
 MFMA_F32_PEAK_TFLOPS = 157.3      # exact-fp32 MFMA = vector rate
 
 # name -> (description, per-GPU batch, H = W, K, D, conv backend)
@@ -202,6 +204,60 @@ def index_flips(model, x, torch):
     n = int((got != want).sum())
     return {"flips": n, "rows": int(got.numel()), "rate": n / got.numel(), "expected_at_most": 1e-4,
             "reference": "oracle/torch_port.py (bitwise the imported reference) on the same batch, host CPU"}
+
+
+def training_step(torch, dev, seconds=1.0):
+    """SURVEY.md 8(f) row 2, the reference's main.py:74-78 without the optimizer: forward (saving activations), the fused
+    losses, backward -- every conv, quantizer and gradient on libvqvae_hip.so.  Plus the dominant backward kernel alone:
+    the weight gradient of the 3x3 128 -> 128 layer (exact fp32 products on the fp32 matrix cores) against that pipe's peak."""
+    import statistics
+    from vqvae_amd import autograd_conv, conv as conv_mod, training as T
+    from vqvae_amd.modules import VQVAE
+    desc, B, HW, K, D, _ = WORKLOADS["c3"]
+    conv_mod.set_conv_backend("hip")
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, K, D, 0.25).to(dev).train()
+    x = torch.randn(B, 3, HW, HW, generator=torch.Generator().manual_seed(1000)).to(dev)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model.zero_grad(set_to_none=True)
+            el, xh, pp = model(x)
+            T.step_losses(el, xh, pp, x, 0.06)[1].backward()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(3)
+    steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
+    times = [run(steps) for _ in range(5)]
+    el = statistics.median(times)
+    res = {"workload": "main.py:74-78 (forward + recon/embedding losses + backward, no optimizer), 32x32x3, K=512, D=64",
+           "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps}
+    model.zero_grad(set_to_none=True)
+    del model, x
+    a = torch.randn(B, 8, 8, 128, device=dev)
+    bt = torch.randn(B, 8, 8, 128, device=dev)
+    for _ in range(2):
+        autograd_conv.conv_wgrad(a, bt, 3, 1, 1)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 10
+    e0.record()                                        # the kernels run on torch's current stream (conv_hip._sp)
+    for _ in range(n):
+        autograd_conv.conv_wgrad(a, bt, 3, 1, 1)
+    e1.record()
+    torch.cuda.synchronize()
+    t = e0.elapsed_time(e1) / n * 1e-3
+    flops = 2.0 * B * 64 * 9 * 128 * 128
+    res["weight_gradient_3x3_128"] = {"kernels": "conv_wgrad_map8_kernel<3, 1, 2, 2> + conv_wgrad_reduce_kernel", "us": round(t * 1e6, 1),
+                                      "bound": "mfma", "dtype": "f32", "achieved": round(flops / t / 1e12, 1),
+                                      "peak": MFMA_FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": round(flops / t / 1e12 / MFMA_FP32_PEAK_TFLOPS, 4)}
+    del a, bt
+    torch.cuda.empty_cache()
+    return res
 
 
 def other_workload(name, torch, dev, seconds=1.0):
@@ -506,6 +562,7 @@ def main():
             if n_gpus == 1 and args.workload == "c3" and not args.no_other_workloads and not args.batch:
                 del out
                 line["other_workloads"] = {w: other_workload(w, torch, dev) for w in ("c2", "c4", "c5")}
+                line["training_step"] = training_step(torch, dev)
                 conv_mod.set_conv_backend(conv_backend)
         print(json.dumps(line), flush=True)
     if dist:
