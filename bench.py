@@ -562,7 +562,10 @@ def main():
             if n_gpus == 1 and args.workload == "c3" and not args.no_other_workloads and not args.batch:
                 del out
                 line["other_workloads"] = {w: other_workload(w, torch, dev) for w in ("c2", "c4", "c5")}
-                line["training_step"] = training_step(torch, dev)
+                try:                                   # a next-row figure: its failure must not take the headline line with it
+                    line["training_step"] = training_step(torch, dev)
+                except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)
+                    line["training_step"] = {"error": f"{type(e).__name__}: {e}"}
                 conv_mod.set_conv_backend(conv_backend)
         print(json.dumps(line), flush=True)
     if dist:
