@@ -539,6 +539,10 @@ def main():
                     "traffic": int(pmc["conv_bytes_per_image"] * B) if pmc and "conv_bytes_per_image" in pmc else None,
                     "traffic_source": pmc["_path"] if pmc and "conv_bytes_per_image" in pmc else None,
                     "flops_per_image": flops_img, "ms_per_step": round(t_conv * 1e3, 4),
+                    # the same flop count over the TIMED region's step (no event brackets; on the fused 32x32 path the step is
+                    # these kernels + a 5 us finalize, the quantizer's work inside the second one included in the time)
+                    "frac_over_timed_step": (round(terms * B * flops_img / (elapsed / args.steps) / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4)
+                                             if ends and vq_in_step is False else None),
                     "note": f"achieved = 16-bit MFMA flop ISSUED ({terms} term products per fp32 product) / live HIP-event "
                             "time; achieved_algorithmic_tflops = 2*MAC of the layers / the same time (what a plain fp32 conv "
                             f"would be credited with): its ceiling on this path is 2500/{terms} = {2500 // terms} TF",
