@@ -9,8 +9,11 @@
 //      (the same index formula serves both: y_Bt = y_A * stride + ky - pad).  Exact fp32 products on the fp32
 //      matrix cores (v_mfma_f32_32x32x2_f32: the reduction index is the PIXEL, two pixels per MFMA step, and
 //      with row-major activations both operands are plain coalesced 128-byte reads -- no transposition);
-//      the pixel range is split over workgroups and waves, partial sums are combined in a fixed order
-//      (no floating-point atomics: gradients are bit-reproducible run to run).
+//      the pixel (or image) range is split over workgroups, partial sums are combined in a fixed order
+//      (no floating-point atomics: gradients are bit-reproducible run to run).  Three kernels: 8x8 maps with both
+//      maps of an image resident in LDS and all taps from one staging (conv_wgrad_map8_kernel: the path's layers at
+//      32x32 images, 80-90 % of the fp32 matrix peak); any map, per tap (conv_wgrad_kernel); image operand with the
+//      taps folded into the MFMA N dimension (conv_wgrad_img_kernel: first / last layer).
 //   vqvae_bias_grad_f32    db[c] = sum over pixels of grad_y[pixel][c]   (fixed-order two-stage reduction, fp64)
 //   vqvae_relu_backward_f32  g_in = g_out * (y > 0)
 #include "common.h"

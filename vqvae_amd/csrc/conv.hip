@@ -4285,20 +4285,24 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.0f;
-    bool ok[MT];
-    const float *src[MT];
+    // this lane's input rows as byte offsets into the tile's IMAGE (descriptor per image: one image is below 2 GiB, the
+    // tensor need not be); pixels outside the image get kOobOffset and read as zero -- no branch around any load
+    unsigned aoff[MT];
+    __amdgpu_buffer_rsrc_t img_rs = act_rsrc(in, 0);
+    const unsigned long long img_bytes = (unsigned long long)H * W * Cin * 4;
     // tile t: its image / origin (kept by the caller where the previous tile's are still needed) and this lane's input rows
     auto setup = [&](int t, long long &tb, int &ty0, int &tx0) {
         const int tx = t % tiles_x; t /= tiles_x;
         const int ty = t % tiles_y;
         tb = t / tiles_y;
         ty0 = ty * TH; tx0 = tx * TW;
+        img_rs = act_rsrc(in + (size_t)tb * H * W * Cin, img_bytes);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const int p = wave * 64 + mt * 32 + l31;
             const int iy = ty0 - halo_y + (p >> 4), ix = tx0 - halo_x + (p & 15);
-            ok[mt] = iy >= 0 && iy < H && ix >= 0 && ix < W;
-            src[mt] = in + ((tb * H + iy) * (long long)W + ix) * Cin + 16 * h;
+            const bool ok = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            aoff[mt] = ok ? (unsigned)((iy * W + ix) * Cin + 16 * h) * 4u : kOobOffset;
         }
     };
     // A operands: chunk c+1 is in flight while chunk c multiplies (two register sets); chunk 0 is requested
@@ -4308,10 +4312,8 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-                if (ok[mt] && c * 32 + 16 * h + 4 * j < Cin)
-                    v = *reinterpret_cast<const f32x4 *>(src[mt] + c * 32 + 4 * j);
-                a[mt][j] = v;
+                const unsigned vo = c * 32 + 16 * h + 4 * j < Cin ? aoff[mt] : kOobOffset;     // channel tail of a partial chunk
+                a[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img_rs, vo + (unsigned)((c * 32 + 4 * j) * 4), 0, 0));
             }
     };
     float xsc = 1.0f, dsc = 1.0f;                   // H2: the image's scale 2^kx and the accumulator scale 2^-(kx + kw)
@@ -5262,6 +5264,7 @@ int vqvae::convt_out_forward_impl(const float *x, const float *packed, const flo
     const int tiles_y = (H + TH - 1) / TH, tiles_x = (W + TW - 1) / TW;
     const long long ntiles = B * (long long)tiles_y * tiles_x;
     if (ntiles > INT32_MAX) return VQVAE_ERR_OVERFLOW;
+    if ((long long)H * W * Cin * 4 >= 0x7FFFFFF0ll) return VQVAE_ERR_OVERFLOW;          // one image per buffer descriptor
     const int ntile = (16 * Cout + 31) / 32, cpt = (Cin + 31) / 32;
     const bool h2 = in_amax && !(flags & (VQVAE_CONV_EXACT_FP32 | VQVAE_CONV_BF16_SPLIT));
     const bool bf3 = !h2 && !(flags & VQVAE_CONV_EXACT_FP32);     // split products unless the fp32 MFMA is asked for
