@@ -4404,14 +4404,16 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
             if (c + 3 < cpt) load_a(c + 3, a1);
         }
     }
+    // (column test outermost: one exec mask per n-tile instead of one branch per store)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
+    for (int nt = 0; nt < NT; ++nt)
+        if (nt * 32 + l31 < STRIDE - 1) {
+            float *tcol = Ts + (wave * 64 + 4 * h) * STRIDE + nt * 32 + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int p = wave * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                if (nt * 32 + l31 < STRIDE - 1) Ts[p * STRIDE + nt * 32 + l31] = H2 ? acc[mt][nt][r] * dsc : acc[mt][nt][r];
+                for (int r = 0; r < 16; ++r)
+                    tcol[(mt * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE] = H2 ? acc[mt][nt][r] * dsc : acc[mt][nt][r];
         }
     __syncthreads();
     // the next tile's input goes on its way now
@@ -4468,16 +4470,16 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
             const int om = (vm ? ixc - 1 : ixc) * STRIDE, o0 = ixc * STRIDE, o1 = (v1 ? ixc + 1 : ixc) * STRIDE,
                       o2 = (v2 ? ixc + 2 : ixc) * STRIDE;
             // one output: row A taps (kx0 at column ca, kx0 + 2 at column cb), then row B taps
+            // (every address is inside T -- rows and columns are clamped above -- so the sixteen reads are unconditional and a
+            // term outside the image enters as + 0.0f: no branch per read)
             auto one = [&](int kx0, int ca, bool va, int cb, bool vb) -> float {
+                const float a0 = TA[ca + kx0 * Cout], a1 = TA[cb + (kx0 + 2) * Cout];
+                const float b0 = TB[ca + kx0 * Cout], b1 = TB[cb + (kx0 + 2) * Cout];
                 float acc = bsv;
-                if (vA) {
-                    if (va) acc += TA[ca + kx0 * Cout];
-                    if (vb) acc += TA[cb + (kx0 + 2) * Cout];
-                }
-                if (vB) {
-                    if (va) acc += TB[ca + kx0 * Cout];
-                    if (vb) acc += TB[cb + (kx0 + 2) * Cout];
-                }
+                acc += vA && va ? a0 : 0.0f;
+                acc += vA && vb ? a1 : 0.0f;
+                acc += vB && va ? b0 : 0.0f;
+                acc += vB && vb ? b1 : 0.0f;
                 return acc;
             };
             f32x4 v;
