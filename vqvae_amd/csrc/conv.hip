@@ -4451,43 +4451,45 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
         // four consecutive ox per thread: one 16-byte store per quad.  The quad (ox = 4 xq .. 4 xq + 3, ox even first)
         // reads input columns ixc - 1 .. ixc + 2 of two input rows; per output the taps are added in gather()'s
         // order (ky, then kx), with the index arithmetic hoisted out of the sixteen LDS reads.
-        const int qw = OW >> 2, nquad = Cout * OH * qw;
-        const bool pow2 = ((qw & (qw - 1)) | (OH & (OH - 1))) == 0;
-        const int lq = 31 - __builtin_clz(qw), lh = 31 - __builtin_clz(OH);
-        for (int e = tid; e < nquad; e += 256) {
-            int xq, oyl, co;
-            if (pow2) { xq = e & (qw - 1); oyl = (e >> lq) & (OH - 1); co = e >> (lq + lh); }
-            else { xq = e % qw; const int q = e / qw; oyl = q % OH; co = q / OH; }
+        // thread -> (output row oyl = tid / 8 < OH <= 32, quad xq = tid % 8 < OW / 4 <= 8), channels in a loop: no division
+        // per quad, and everything but the channel offset is worked out once per thread
+        const int qw = OW >> 2;
+        const int xq = tid & 7, oyl = tid >> 3;
+        if (xq < qw && oyl < OH) {
             const int oy = 2 * y0 + oyl, ox = 2 * x0 + 4 * xq;
-            const float bsv = bias ? bias[co] : 0.0f;
             const int ky0 = (oy + 1) & 1;
             const int iyA = (oy + 1 - ky0) >> 1, iyB = iyA - 1;            // rows of ky = ky0 and ky0 + 2
             const bool vA = iyA < H, vB = iyB >= 0;
-            const float *TA = Ts + ((vA ? iyA - ry : 0) * 16 - rx) * STRIDE + (ky0 * 4) * Cout + co;
-            const float *TB = Ts + ((vB ? iyB - ry : 0) * 16 - rx) * STRIDE + ((ky0 + 2) * 4) * Cout + co;
+            const float *TA0 = Ts + ((vA ? iyA - ry : 0) * 16 - rx) * STRIDE + (ky0 * 4) * Cout;
+            const float *TB0 = Ts + ((vB ? iyB - ry : 0) * 16 - rx) * STRIDE + ((ky0 + 2) * 4) * Cout;
             const int ixc = ox >> 1;
             const bool vm = ixc - 1 >= 0, v1 = ixc + 1 < W, v2 = ixc + 2 < W;
             const int om = (vm ? ixc - 1 : ixc) * STRIDE, o0 = ixc * STRIDE, o1 = (v1 ? ixc + 1 : ixc) * STRIDE,
                       o2 = (v2 ? ixc + 2 : ixc) * STRIDE;
-            // one output: row A taps (kx0 at column ca, kx0 + 2 at column cb), then row B taps
-            // (every address is inside T -- rows and columns are clamped above -- so the sixteen reads are unconditional and a
-            // term outside the image enters as + 0.0f: no branch per read)
-            auto one = [&](int kx0, int ca, bool va, int cb, bool vb) -> float {
-                const float a0 = TA[ca + kx0 * Cout], a1 = TA[cb + (kx0 + 2) * Cout];
-                const float b0 = TB[ca + kx0 * Cout], b1 = TB[cb + (kx0 + 2) * Cout];
-                float acc = bsv;
-                acc += vA && va ? a0 : 0.0f;
-                acc += vA && vb ? a1 : 0.0f;
-                acc += vB && va ? b0 : 0.0f;
-                acc += vB && vb ? b1 : 0.0f;
-                return acc;
-            };
-            f32x4 v;
-            v.x = one(1, o0, true, om, vm);
-            v.y = one(0, o1, v1, o0, true);
-            v.z = one(1, o1, v1, o0, true);
-            v.w = one(0, o2, v2, o1, v1);
-            *reinterpret_cast<f32x4 *>(out + ((b * Cout + co) * Ho + oy) * (long long)Wo + ox) = v;
+            float *orow = out + (b * Cout * Ho + oy) * (long long)Wo + ox;
+            for (int co = 0; co < Cout; ++co) {
+                const float bsv = bias ? bias[co] : 0.0f;
+                const float *TA = TA0 + co, *TB = TB0 + co;
+                // one output: row A taps (kx0 at column ca, kx0 + 2 at column cb), then row B taps.  Every address is inside
+                // T -- rows and columns are clamped above -- so the sixteen reads are unconditional and a term outside the
+                // image enters as + 0.0f: no branch per read
+                auto one = [&](int kx0, int ca, bool va, int cb, bool vb) -> float {
+                    const float a0 = TA[ca + kx0 * Cout], a1 = TA[cb + (kx0 + 2) * Cout];
+                    const float b0 = TB[ca + kx0 * Cout], b1 = TB[cb + (kx0 + 2) * Cout];
+                    float acc = bsv;
+                    acc += vA && va ? a0 : 0.0f;
+                    acc += vA && vb ? a1 : 0.0f;
+                    acc += vB && va ? b0 : 0.0f;
+                    acc += vB && vb ? b1 : 0.0f;
+                    return acc;
+                };
+                f32x4 v;
+                v.x = one(1, o0, true, om, vm);
+                v.y = one(0, o1, v1, o0, true);
+                v.z = one(1, o1, v1, o0, true);
+                v.w = one(0, o2, v2, o1, v1);
+                *reinterpret_cast<f32x4 *>(orow + (long long)co * Ho * Wo) = v;
+            }
         }
     } else {
         const int total = Cout * OH * OW;
