@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__rest
     const int ntap = g.k * g.k, ncol = ntap * g.CB;
 
     // this lane's B columns: n = nt*32 + l31 -> (tap, cb)
-    int ky[NT], kx[NT], cbo[NT];
+    int ky[NT], kx[NT], kyp[NT], kxp[NT], cbo[NT];
     bool nok[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -299,6 +299,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__rest
         const int tap = nok[nt] ? n / g.CB : 0;
         cbo[nt] = (nok[nt] ? n - tap * g.CB : 0) * plane;
         ky[nt] = tap / g.k; kx[nt] = tap - ky[nt] * g.k;
+        kyp[nt] = ky[nt] - g.pad; kxp[nt] = kx[nt] - g.pad;
     }
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__rest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const float *ab = A + (size_t)b * npx * g.CA;
+        int yA = h / g.WA, xA = h - yA * g.WA;               // pixel h of the image
         // eight pixel pairs per round: their A values are requested together (one memory latency per round, not per pair)
         for (int p0 = 0; p0 < npx; p0 += 16) {
             float av[8][MT];
@@ -335,14 +337,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_img_kernel(const float *__rest
             for (int j = 0; j < 8; ++j) {
                 const int p = p0 + 2 * j + h;
                 const bool pok = p < npx;
-                const int yA = p / g.WA, xA = p - yA * g.WA;
+                // (yA, xA) of pixel p, carried along instead of divided out: two pixels further per step
+                const int ys = yA * g.stride, xs = xA * g.stride;
                 float bv[NT];
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const int yB = yA * g.stride + ky[nt] - g.pad, xB = xA * g.stride + kx[nt] - g.pad;
-                    const bool ok = pok && nok[nt] && yB >= 0 && yB < g.HB && xB >= 0 && xB < g.WB;
+                    const int yB = ys + kyp[nt], xB = xs + kxp[nt];
+                    const bool ok = pok && nok[nt] && (unsigned)yB < (unsigned)g.HB && (unsigned)xB < (unsigned)g.WB;
                     bv[nt] = ok ? img[cbo[nt] + yB * g.WB + xB] : 0.0f;
                 }
+                xA += 2;
+                while (xA >= g.WA) { xA -= g.WA; ++yA; }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
