@@ -122,18 +122,24 @@ __global__ __launch_bounds__(256) void vqb_segsum_kernel(const float *__restrict
     const int g = tid / D, c = tid - g * D;
     double acc = 0.0;
     if (g < G) {
-        for (int j = a + g; j < b; j += G) {
-            const long long r = rows[j];
-            float v;
-            if (rowmajor) {
-                v = z[(size_t)r * D + c];
-            } else {
-                const long long bb = r / HW;
-                const int hw = (int)(r - bb * HW);
-                v = z[((size_t)bb * D + c) * HW + hw];
-            }
-            acc += (double)v;
+        auto zat = [&](long long r) {
+            if (rowmajor) return z[(size_t)r * D + c];
+            const long long bb = r / HW;
+            const int hw = (int)(r - bb * HW);
+            return z[((size_t)bb * D + c) * HW + hw];
+        };
+        int j = a + g;
+        for (; j + 3 * G < b; j += 4 * G) {                 // four rows' (index, value) loads in flight; same summation order
+            long long r[4];
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = rows[j + q * G];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = zat(r[q]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc += (double)v[q];
         }
+        for (; j < b; j += G) acc += (double)zat(rows[j]);
     }
     red[tid] = acc;
     __syncthreads();
@@ -153,8 +159,16 @@ __global__ __launch_bounds__(256) void vqb_codebook_grad_kernel(const float *__r
     const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
     if (e >= (long long)K * D) return;
     const int k = (int)(e / D), c = (int)(e - (long long)k * D);
-    double zsum = 0.0;
-    for (int u = unit_start[k]; u < unit_start[k + 1]; ++u) zsum += partial[(size_t)u * D + c];
+    // four interleaved running sums (a code that owns many rows has many units: their loads are in flight together
+    // instead of one dependent add per load), combined in a fixed order
+    double z4[4] = {0.0, 0.0, 0.0, 0.0};
+    int u = unit_start[k];
+    const int u1 = unit_start[k + 1];
+    for (; u + 4 <= u1; u += 4)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) z4[j] += partial[(size_t)(u + j) * D + c];
+    for (int j = 0; u < u1; ++u, ++j) z4[j] += partial[(size_t)u * D + c];
+    const double zsum = (z4[0] + z4[1]) + (z4[2] + z4[3]);
     const double cnt = (double)(offsets[k + 1] - offsets[k]);
     const double gl = g_loss ? (double)g_loss[0] : 1.0;
     grad_cb[e] = (float)(gl * scale * (cnt * (double)cb[e] - zsum));
@@ -168,6 +182,23 @@ __global__ __launch_bounds__(256) void vqb_gradz_kernel(const float *__restrict_
                                                         int HW, int rowmajor, float scale,
                                                         float *__restrict__ grad_z) {
     const float gs = (g_loss ? g_loss[0] : 1.0f) * scale;
+    if (rowmajor < 0) {
+        // row-major rows with D % 4 == 0 and 16-byte aligned tensors (the launch checks): four channels per thread
+        for (long long e4 = (long long)blockIdx.x * 256 + threadIdx.x; e4 < (total >> 2); e4 += (long long)gridDim.x * 256) {
+            const long long e = e4 << 2, row = e / D;
+            const int c = (int)(e - row * D);
+            const f32x4 zv = *reinterpret_cast<const f32x4 *>(z + e);
+            const f32x4 ev = *reinterpret_cast<const f32x4 *>(cb + (size_t)idx[row] * D + c);
+            f32x4 o;
+            o.x = gs * (zv.x - ev.x); o.y = gs * (zv.y - ev.y); o.z = gs * (zv.z - ev.z); o.w = gs * (zv.w - ev.w);
+            if (g_zq) {
+                const f32x4 gv = *reinterpret_cast<const f32x4 *>(g_zq + e);
+                o.x = gv.x + o.x; o.y = gv.y + o.y; o.z = gv.z + o.z; o.w = gv.w + o.w;
+            }
+            *reinterpret_cast<f32x4 *>(grad_z + e) = o;
+        }
+        return;
+    }
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
         long long row;
         int c;
@@ -269,10 +300,13 @@ int vqvae_vq_backward_f32(const float *z_e, const float *codebook, const int64_t
     const double nd = (double)N * (double)D;
     if (grad_z) {
         const long long total = N * D;
-        long long grid = (total + 255) / 256;
+        const bool vec4 = rowmajor && (D & 3) == 0 &&
+                          !((reinterpret_cast<uintptr_t>(z_e) | reinterpret_cast<uintptr_t>(codebook) | reinterpret_cast<uintptr_t>(grad_z) |
+                             reinterpret_cast<uintptr_t>(grad_zq)) & 15);
+        long long grid = ((vec4 ? total >> 2 : total) + 255) / 256;
         if (grid > 65536) grid = 65536;
         hipLaunchKernelGGL(vqb_gradz_kernel, dim3((unsigned)grid), dim3(256), 0, st, z_e, codebook,
-                           reinterpret_cast<const long long *>(idx), grad_zq, grad_loss, total, D, (int)HW, rowmajor,
+                           reinterpret_cast<const long long *>(idx), grad_zq, grad_loss, total, D, (int)HW, vec4 ? -1 : rowmajor,
                            (float)(2.0 / nd), grad_z);
     }
     if (grad_codebook) {
