@@ -487,7 +487,23 @@ __device__ __forceinline__ void publish_amax_exclusive(int *out_amax, long long 
 __global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, long long n, int *__restrict__ hdr) {
     __shared__ float red[256];
     float m = 0.0f;
-    for (long long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(w[i]));
+    // (a training step packs every layer's weights again: 16-byte loads, four of them in flight per thread)
+    const long long n4 = (reinterpret_cast<uintptr_t>(w) & 15) == 0 ? n >> 2 : 0;
+    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w);
+    long long i4 = threadIdx.x;
+    for (; i4 + 768 < n4; i4 += 1024) {
+        f32x4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = w4[i4 + 256 * q];
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[q].x), __builtin_fabsf(v[q].y)), fmaxf(__builtin_fabsf(v[q].z), __builtin_fabsf(v[q].w))));
+    }
+    for (; i4 < n4; i4 += 256) {
+        const f32x4 v = w4[i4];
+        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+    }
+    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(w[i]));
     red[threadIdx.x] = m;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
