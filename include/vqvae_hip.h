@@ -30,7 +30,9 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 3   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS */
+#define VQVAE_HIP_ABI_VERSION 4   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+                                    4: forward in parts (begin / part / end), residual layer with hidden output, larger
+                                       weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions) */
 
 #define VQVAE_OK               0
 #define VQVAE_ERR_NULL        -1   /* a required pointer is NULL                       */

@@ -111,7 +111,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
-    if lib.vqvae_abi_version() != 3:
+    if lib.vqvae_abi_version() != 4:
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
