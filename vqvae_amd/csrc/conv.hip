@@ -124,27 +124,7 @@ __device__ __forceinline__ void tile_epilogue(float *tile, const float (&v)[16],
 }
 
 // ---------------------------------------------------------------------------
-// Weight packing (once per layer / weight version).
-__global__ __launch_bounds__(256) void conv_pack_kernel(const float *__restrict__ w, float *__restrict__ img,
-                                                        ConvGeom g, long long total) {
-    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
-        const int i = e & 3, n = (e >> 2) & 31, h = (e >> 7) & 1, j = (e >> 8) & 3;
-        long long t = e >> 10;
-        const int nt = (int)(t % g.ntile); t /= g.ntile;
-        const int nchunk = g.ntaps * g.cpt;
-        const int chunk = (int)(t % nchunk);
-        const int phase = (int)(t / nchunk);
-        const int tap = chunk / g.cpt, cc = chunk - tap * g.cpt;
-        const int ci = cc * 32 + 16 * h + 4 * j + i, co = nt * 32 + n;
-        float v = 0.0f;
-        if (ci < g.Cin && co < g.Cout) {
-            const int kyx = g.kyx[phase][tap];
-            v = g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx]
-                             : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
-        }
-        img[e] = v;
-    }
-}
+// Weight packing (once per layer / weight version): conv_pack_images_kernel, below the split helpers.
 
 // ---------------------------------------------------------------------------
 // Generic implicit-GEMM kernel.  Workgroup = 4 waves x (MT x 32 pixels) x (NT x 32 channels).
@@ -540,18 +520,36 @@ __global__ __launch_bounds__(256) void act_absmax_kernel(const float *__restrict
     if (threadIdx.x == 0) atomicMax(amax + blockIdx.y, __float_as_int(fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]))));
 }
 
-// H2 = false: three bf16 terms per element; H2 = true: two fp16 terms of w * 2^kw (kw from conv_wscale_kernel)
-template <bool H2>
-__global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restrict__ w,
-                                                            unsigned short *__restrict__ img, ConvGeom g,
-                                                            long long total, const int *__restrict__ hdr) {
-    const float wsc = H2 ? __builtin_ldexpf(1.0f, hdr[0]) : 1.0f;
-    // one thread per (phase, chunk, ntile, step, half, n, i) element; writes the three term images
+// Every image of a layer's weights in ONE launch (a training step packs every layer again after the optimizer, and again for
+// its data-gradient conv: the launches, not the bytes, are what that costs): element e of
+//   img32   the fp32 B-operand image ([(phase, chunk, n_tile)][k-group 4][half][n 32][4]; NULL: not in this pass),
+//   img_bf  three bf16 terms per element,
+//   img_h   two fp16 terms of w * 2^kw (kw from conv_wscale_kernel, which runs first),
+// the two 16-bit images in the chunk order g.s2d selects.
+__global__ __launch_bounds__(256) void conv_pack_images_kernel(const float *__restrict__ w, float *__restrict__ img32,
+                                                               unsigned short *__restrict__ img_bf,
+                                                               unsigned short *__restrict__ img_h, ConvGeom g,
+                                                               long long total, const int *__restrict__ hdr) {
+    const float wsc = __builtin_ldexpf(1.0f, hdr[0]);
+    const int nchunk = g.ntaps * g.cpt;
+    auto wat = [&](int ci, int co, int kyx) {
+        return g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx] : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
+    };
+    // one thread per (phase, chunk, ntile, step, half, n, i) element
     for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        if (img32) {
+            const int i = e & 3, n = (e >> 2) & 31, h = (e >> 7) & 1, j = (e >> 8) & 3;
+            long long t = e >> 10;
+            const int nt = (int)(t % g.ntile); t /= g.ntile;
+            const int chunk = (int)(t % nchunk);
+            const int phase = (int)(t / nchunk);
+            const int tap = chunk / g.cpt, cc = chunk - tap * g.cpt;
+            const int ci = cc * 32 + 16 * h + 4 * j + i, co = nt * 32 + n;
+            img32[e] = (ci < g.Cin && co < g.Cout) ? wat(ci, co, g.kyx[phase][tap]) : 0.0f;
+        }
         const int i = e & 7, n = (e >> 3) & 31, hh = (e >> 8) & 1, t = (e >> 9) & 1;
         long long r = e >> 10;
         const int nt = (int)(r % g.ntile); r /= g.ntile;
-        const int nchunk = g.ntaps * g.cpt;
         const int chunk = (int)(r % nchunk);
         const int phase = (int)(r / nchunk);
         int ci, kyx;
@@ -570,29 +568,26 @@ __global__ __launch_bounds__(256) void conv_pack_bf3_kernel(const float *__restr
             ci = cc * 32 + 16 * hh + 8 * t + i;
             kyx = g.kyx[phase][tap];
         }
-        float v = 0.0f;
-        if (ci < g.Cin && co < g.Cout)
-            v = g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx]
-                             : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
+        const float v = (ci < g.Cin && co < g.Cout) ? wat(ci, co, kyx) : 0.0f;
         const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
-        if (H2) {
+        const size_t cell = (size_t)(phase * nchunk + chunk) * g.ntile + nt;
+        {
             const float vs = v * wsc;
             const _Float16 g1 = (_Float16)vs;
             const _Float16 g2 = (_Float16)(vs - (float)g1);
-            const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 2048;
-            img[base + pos] = __builtin_bit_cast(unsigned short, g1);
-            img[base + 1024 + pos] = __builtin_bit_cast(unsigned short, g2);
-        } else {
+            img_h[cell * 2048 + pos] = __builtin_bit_cast(unsigned short, g1);
+            img_h[cell * 2048 + 1024 + pos] = __builtin_bit_cast(unsigned short, g2);
+        }
+        {
             const unsigned short b1 = f32_to_bf16_rne(v);
             const float r1 = v - __uint_as_float((unsigned)b1 << 16);
             const unsigned short b2 = f32_to_bf16_rne(r1);
             const float r2 = r1 - __uint_as_float((unsigned)b2 << 16);
             const unsigned short b3 = f32_to_bf16_rne(r2);
             // image: [(phase*nchunk + chunk)*ntile + nt][term][t][hh][n][i]
-            const size_t base = ((size_t)(phase * nchunk + chunk) * g.ntile + nt) * 3072;
-            img[base + pos] = b1;
-            img[base + 1024 + pos] = b2;
-            img[base + 2048 + pos] = b3;
+            img_bf[cell * 3072 + pos] = b1;
+            img_bf[cell * 3072 + 1024 + pos] = b2;
+            img_bf[cell * 3072 + 2048 + pos] = b3;
         }
     }
 }
@@ -845,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
 // of taps (9x / 4x), and the per-load tap decode disappears.
 // S2D: the 4x4 stride-2 conv on a 16x16 map, read as a conv over the 8x8 grid of 2x2 input blocks: a chunk is
 // (sub-position (py,px) of the block, 32-channel slice) and meets four block offsets ("virtual taps"), so every
-// input element is still split once and used four times (weights in the s2d chunk order, conv_pack_bf3_kernel).
+// input element is still split once and used four times (weights in the s2d chunk order, conv_pack_images_kernel).
 // H2: two-term fp16 products with per-image activation scale and per-layer weight scale (see split8_h) instead of the
 // three-term bf16 products; whdr = the weight image's header {kw}.
 template <int NT, bool S2D, int NW, int WB = 2, bool H2 = false>
@@ -4706,26 +4701,20 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
     const long long total = (long long)packed_floats(g);
     long long grid = (total + 255) / 256;
     if (grid > 4096) grid = 4096;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3((unsigned)grid), dim3(256), 0, static_cast<hipStream_t>(stream), w,
-                       packed, g, total);
-    // split-bf16 image right behind it (1024 bf16 elements per term per (phase, chunk, n_tile))
-    const long long total3 = total;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(conv_pack_bf3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, w,
-                       reinterpret_cast<unsigned short *>(packed + total), g, total3, (const int *)nullptr);
-    // two-term fp16 image of w * 2^kw behind its header
+    // [fp32 image][split-bf16 image (1024 bf16 per term per (phase, chunk, n_tile))] ... [header {kw}][two-term fp16 image of w * 2^kw]:
+    // the weight scale first, then every image in one launch (4x4 stride 2: one more for the space-to-depth chunk order)
     char *h2 = reinterpret_cast<char *>(packed) + packed_h2_offset(g, kind);
     int *hdr = reinterpret_cast<int *>(h2);
     hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * g.kk, hdr);
-    hipLaunchKernelGGL(conv_pack_bf3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, w,
-                       reinterpret_cast<unsigned short *>(h2 + kH2Header), g, total3, hdr);
+    hipLaunchKernelGGL(conv_pack_images_kernel, dim3((unsigned)grid), dim3(256), 0, st, w, packed,
+                       reinterpret_cast<unsigned short *>(packed + total), reinterpret_cast<unsigned short *>(h2 + kH2Header), g,
+                       total, hdr);
     if (kind == VQVAE_CONV_4x4_S2) {
         g.s2d = 1;
-        hipLaunchKernelGGL(conv_pack_bf3_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, w,
-                           reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2, g, total3,
-                           (const int *)nullptr);
-        hipLaunchKernelGGL(conv_pack_bf3_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, w,
-                           reinterpret_cast<unsigned short *>(h2 + kH2Header + packed_h2_bytes(g)), g, total3, hdr);
+        hipLaunchKernelGGL(conv_pack_images_kernel, dim3((unsigned)grid), dim3(256), 0, st, w, (float *)nullptr,
+                           reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2,
+                           reinterpret_cast<unsigned short *>(h2 + kH2Header + packed_h2_bytes(g)), g, total, hdr);
     }
     return (int)hipGetLastError();
 }
