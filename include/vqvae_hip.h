@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 4   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+#define VQVAE_HIP_ABI_VERSION 5   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
                                     4: forward in parts (begin / part / end), residual layer with hidden output, larger
                                        weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions) */
 
@@ -375,10 +375,29 @@ VQVAE_API int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B
 /* Decoder: z_q (B,h,w,D) row-major -> x_hat (B,in_ch,4h,4w) NCHW. */
 VQVAE_API int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h, int w_, float *x_hat,
                                 void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* The same two with a product-scheme selector (flags: 0, VQVAE_FWD_CONV_BF16_SPLIT or VQVAE_FWD_CONV_EXACT_FP32, below). */
+VQVAE_API int vqvae_encoder_ex_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int flags, float *z_e,
+                                   void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+VQVAE_API int vqvae_decoder_ex_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h, int w_, int flags, float *x_hat,
+                                   void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+
+/* Whole-path product scheme (round 4), OR-ed into vqvae_forward_f32's vq_flags / the flags of the _ex_ entries above:
+ *   default (neither bit)       two-term fp16 products (3 MFMAs per fp32 product, <= 2^-21 relative per product) with one
+ *                               power-of-two scale per OUTPUT CHANNEL of every weight tensor and one per image for the
+ *                               activations; on the reference's default shapes the four fused kernels;
+ *   VQVAE_FWD_CONV_BF16_SPLIT   every layer through the per-layer kernels with three-term bf16 products (6 MFMAs per fp32
+ *                               product, <= 3 * 2^-24 relative per product, fp32's exponent range: no operand scales at all);
+ *   VQVAE_FWD_CONV_EXACT_FP32   every layer through the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32: fp32 products,
+ *                               fp32 accumulation -- the reference's own arithmetic up to summation order).
+ * The two selectors are the escape hatch for callers whose data defeats the fp16 scheme's range assumptions (DESIGN.md section 5,
+ * "error bound per output channel") and the honest side-by-side legs of bench.py.  Both at once: VQVAE_ERR_UNSUPPORTED.   */
+#define VQVAE_FWD_CONV_BF16_SPLIT 0x1000
+#define VQVAE_FWD_CONV_EXACT_FP32 0x2000
+
 /* VQVAE.forward: x -> (embedding_loss, x_hat, perplexity) (models/vqvae.py:44); idx (B*H/4*W/4 int64) is optional.
  * vq_flags: VQVAE_VQ_CODEBOOK_PREPARED (only meaningful with a persistent vq_workspace of vqvae_vq_workspace_bytes),
- * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _TOP3_KEYS / _SIXTEEN_WAVES.  vq_workspace may be NULL (then the codebook images are
- * rebuilt inside `workspace` on every call).                                                                         */
+ * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _TOP3_KEYS / _SIXTEEN_WAVES, VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32.  vq_workspace may
+ * be NULL (then the codebook images are rebuilt inside `workspace` on every call).                                                                       */
 VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags,
                                 float *x_hat, float *loss, float *perplexity, int64_t *idx, void *workspace,
                                 size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,

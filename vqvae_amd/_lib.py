@@ -82,6 +82,8 @@ SIGNATURES = {
     "vqvae_resstack_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vqvae_encoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_decoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqvae_encoder_ex_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
+    "vqvae_decoder_ex_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_forward_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_begin_f32": (_i32, [_wp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_part_f32": (_i32, [_wp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
@@ -111,7 +113,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
-    if lib.vqvae_abi_version() != 4:
+    if lib.vqvae_abi_version() != 5:
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -92,6 +92,15 @@ __device__ __forceinline__ f32x2v scale_bias_relu2(float a0, float a1, float d, 
     vmax3(m, r.x, r.y);
     return r;
 }
+// the same with one scale per value (round 4: the weight rows' own powers of two)
+#define SCALE2_BIAS_RELU2(A0, A1, D0, D1, B0, B1, M)                             \
+    do {                                                                         \
+        const float r0_ = vmax(__builtin_fmaf((A0), (D0), (B0)), 0.0f);          \
+        const float r1_ = vmax(__builtin_fmaf((A1), (D1), (B1)), 0.0f);          \
+        vmax3((M), r0_, r1_);                                                    \
+        (A0) = r0_;                                                              \
+        (A1) = r1_;                                                              \
+    } while (0)
 #define SCALE_BIAS_RELU2(A0, A1, D, B0, B1, M)                                   \
     do {                                                                         \
         const f32x2v r_ = scale_bias_relu2((A0), (A1), (D), (B0), (B1), (M));    \
@@ -463,39 +472,52 @@ __device__ __forceinline__ void publish_amax_exclusive(int *out_amax, long long 
     if (lane == 0) out_amax[img] = __float_as_int(om);
 }
 
-// Weight scale of a layer: header {int kw} in front of its two-term fp16 image (one block).
-__global__ __launch_bounds__(256) void conv_wscale_kernel(const float *__restrict__ w, long long n, int *__restrict__ hdr) {
-    __shared__ float red[256];
+// Weight scales of a layer (round 4: one power of two per OUTPUT CHANNEL -- a trained checkpoint's channel norms differ by
+// orders of magnitude, and a row 2^17 below the tensor's maximum would lose the bits fp32 keeps).  Header in
+// front of the layer's two-term fp16 image, h2_header_bytes(ntile) long:
+//   int   [0 .. 63]              misc ([1]: the first layer's L1 bound, conv_in_hdr_kernel)
+//   float [64 + c]               dw[c] = 2^-kw[c]: what an accumulator of output channel c is multiplied with (1.0 for the
+//                                padding channels of the last 32-channel tile)
+//   int   [64 + 32 ntile + c]    kw[c]: row c of the weights is packed as fp16 terms of w * 2^kw[c], largest |w| of the row
+//                                -> [2^14, 2^15)
+// One block per output channel (the row's Cin * kh * kw elements; `transposed`: the tensor is (Cin, Cout, kh, kw)).
+__device__ __forceinline__ const float *h2_dw(const int *hdr) { return reinterpret_cast<const float *>(hdr) + 64; }
+// TRANSPOSED accumulator tiles (lane = pixel, register 4 g + q = channel c0 + 8 g + 4 h + q): the four channel scales
+// 2^-kw[.] of registers 4 g .. 4 g + 3, times d (the activation side's 2^-kx)
+// (tab: the dw table, in the fused kernels a copy in LDS -- one address register (h) and an immediate offset per read, no
+// pointer pair kept live next to 128 accumulator registers)
+__device__ __forceinline__ f32x4 h2_dw4(const float *tab, int c0, int g, int h, float d) {
+    __builtin_amdgcn_sched_barrier(0);     // hipcc otherwise hoists every group's read to the top of the epilogue: 16+ more live registers
+    const f32x4 t = *reinterpret_cast<const f32x4 *>(tab + c0 + 8 * g + 4 * h);
+    return f32x4{t.x * d, t.y * d, t.z * d, t.w * d};
+}
+__device__ __forceinline__ int h2_scale_exp(float mm) {
+    int e = 15;
+    if (mm > 0.0f && mm < 3.0e38f) (void)__builtin_frexpf(mm, &e);
+    e = 15 - e;
+    return e > 100 ? 100 : (e < -100 ? -100 : e);
+}
+__global__ __launch_bounds__(64) void conv_wscale_kernel(const float *__restrict__ w, int Cin, int Cout, int kk, int transposed,
+                                                         int ntile, int *__restrict__ hdr) {
+    const int co = blockIdx.x, lane = threadIdx.x;
     float m = 0.0f;
-    // (a training step packs every layer's weights again: 16-byte loads, four of them in flight per thread)
-    const long long n4 = (reinterpret_cast<uintptr_t>(w) & 15) == 0 ? n >> 2 : 0;
-    const f32x4 *w4 = reinterpret_cast<const f32x4 *>(w);
-    long long i4 = threadIdx.x;
-    for (; i4 + 768 < n4; i4 += 1024) {
-        f32x4 v[4];
+    if (co < Cout) {
+        if (!transposed) {
+            const float *row = w + (size_t)co * Cin * kk;
+            for (int i = lane; i < Cin * kk; i += 64) m = fmaxf(m, __builtin_fabsf(row[i]));
+        } else {
+            for (int i = lane; i < Cin * kk; i += 64) {
+                const int ci = i / kk, k = i - ci * kk;
+                m = fmaxf(m, __builtin_fabsf(w[((size_t)ci * Cout + co) * kk + k]));
+            }
+        }
+    }
 #pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = w4[i4 + 256 * q];
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-            m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v[q].x), __builtin_fabsf(v[q].y)), fmaxf(__builtin_fabsf(v[q].z), __builtin_fabsf(v[q].w))));
-    }
-    for (; i4 < n4; i4 += 256) {
-        const f32x4 v = w4[i4];
-        m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
-    }
-    for (long long i = (n4 << 2) + threadIdx.x; i < n; i += 256) m = fmaxf(m, __builtin_fabsf(w[i]));
-    red[threadIdx.x] = m;
-    __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        int e = 15;
-        const float mm = red[0];
-        if (mm > 0.0f && mm < 3.0e38f) (void)__builtin_frexpf(mm, &e);
-        e = 15 - e;
-        hdr[0] = e > 100 ? 100 : (e < -100 ? -100 : e);
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) {
+        const int e = co < Cout ? h2_scale_exp(m) : 0;
+        reinterpret_cast<float *>(hdr)[64 + co] = __builtin_ldexpf(1.0f, -e);
+        hdr[64 + 32 * ntile + co] = e;
     }
 }
 
@@ -524,13 +546,13 @@ __global__ __launch_bounds__(256) void act_absmax_kernel(const float *__restrict
 // its data-gradient conv: the launches, not the bytes, are what that costs): element e of
 //   img32   the fp32 B-operand image ([(phase, chunk, n_tile)][k-group 4][half][n 32][4]; NULL: not in this pass),
 //   img_bf  three bf16 terms per element,
-//   img_h   two fp16 terms of w * 2^kw (kw from conv_wscale_kernel, which runs first),
+//   img_h   two fp16 terms of w * 2^kw[co] (kw per output channel from conv_wscale_kernel, which runs first),
 // the two 16-bit images in the chunk order g.s2d selects.
 __global__ __launch_bounds__(256) void conv_pack_images_kernel(const float *__restrict__ w, float *__restrict__ img32,
                                                                unsigned short *__restrict__ img_bf,
                                                                unsigned short *__restrict__ img_h, ConvGeom g,
                                                                long long total, const int *__restrict__ hdr) {
-    const float wsc = __builtin_ldexpf(1.0f, hdr[0]);
+    const int *kwtab = hdr + 64 + 32 * g.ntile;
     const int nchunk = g.ntaps * g.cpt;
     auto wat = [&](int ci, int co, int kyx) {
         return g.transposed ? w[((size_t)ci * g.Cout + co) * g.kk + kyx] : w[((size_t)co * g.Cin + ci) * g.kk + kyx];
@@ -572,7 +594,7 @@ __global__ __launch_bounds__(256) void conv_pack_images_kernel(const float *__re
         const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
         const size_t cell = (size_t)(phase * nchunk + chunk) * g.ntile + nt;
         {
-            const float vs = v * wsc;
+            const float vs = v * __builtin_ldexpf(1.0f, kwtab[co]);
             const _Float16 g1 = (_Float16)vs;
             const _Float16 g2 = (_Float16)(vs - (float)g1);
             img_h[cell * 2048 + pos] = __builtin_bit_cast(unsigned short, g1);
@@ -622,7 +644,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
     unsigned pbase, tapmask;
     long long myoff;
     long long myimg = -1;                              // image of this lane's pixel row (-1: past the end)
-    float xsc = 1.0f, dsc = 1.0f;                      // H2: the image's scale 2^kx and the accumulator scale 2^-(kx + kw)
+    float xsc = 1.0f, dsc = 1.0f;                      // H2: the image's scale 2^kx and its inverse (the weight rows' 2^-kw[n] join in the epilogue)
     {
         const long long p = (long long)blockIdx.x * 128 + wave * 32 + l31;
         const bool valid = p < M;
@@ -649,7 +671,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
             int kx = 15 - e;
             kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
             xsc = __builtin_ldexpf(1.0f, kx);
-            dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+            dsc = __builtin_ldexpf(1.0f, -kx);
         }
     }
     const u32x4 *wbase = wimg + ((size_t)phase * nchunk * g.ntile + (size_t)nb * NT) * (128 * TERMS);
@@ -785,11 +807,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
     }
 
     const bool relu_out = g.flags & kFlagReluOut;
-    float bv[NT];
+    float bv[NT], wd[NT];                              // bias and (H2) weight-row scale 2^-kw[n] of this lane's output channels
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+        wd[nt] = H2 ? h2_dw(whdr)[n] : 1.0f;
     }
     // maxima for the next layer: one image per wave in the common case (one wave-wide reduction), per pixel row otherwise
     const long long img0 = __shfl(myimg, 0);
@@ -806,7 +829,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
             for (int nt = 0; nt < NT; ++nt) {
                 const int n = (nb * NT + nt) * 32 + l31;
                 if (n < g.Cout) {
-                    float v = (H2 ? acc[nt][r] * drow : acc[nt][r]) + bv[nt];
+                    float v = (H2 ? acc[nt][r] * drow * wd[nt] : acc[nt][r]) + bv[nt];
                     if (relu_out) v = fmaxf(v, 0.0f);
                     rmax = fmaxf(rmax, __builtin_fabsf(v));
                     out[off + n] = v;
@@ -923,7 +946,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 #pragma unroll
         for (int q = 0; q < NBQ; ++q) Bs[buf][tid + NW * 64 * q] = b_nxt[q];
     };
-    float xscale = 1.0f, descale = 1.0f;             // H2: image scale 2^kx, accumulator scale 2^-(kx + kw)
+    float xscale = 1.0f, descale = 1.0f;             // H2: image scale 2^kx and its inverse (x the weight row's 2^-kw[n] in the epilogue)
     f32x4 raw[8];
     auto load_raw = [&](int cc) {
         const float *q = src + 32 * cc;
@@ -984,7 +1007,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
         xscale = __builtin_ldexpf(1.0f, kx);
-        descale = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+        descale = __builtin_ldexpf(1.0f, -kx);
     }
 
     // iteration it = cc * ntaps + tap  ->  weight chunk tap * cpt + cc
@@ -1088,11 +1111,12 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
         tap = ntap; cc = ncc;
     }
 
-    float bv[NT];
+    float bv[NT], wd[NT];                            // bias, (H2) accumulator scale 2^-(kx + kw[n]) of this lane's output channels
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+        wd[nt] = H2 ? descale * h2_dw(whdr)[n] : 1.0f;
     }
     float omax = 0.0f;
     if (img_ok && (g.Cout & 7) == 0) {
@@ -1105,7 +1129,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    v[r] = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
+                    v[r] = (H2 ? acc[mt][nt][r] * wd[nt] : acc[mt][nt][r]) + bv[nt];
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                     omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
@@ -1131,7 +1155,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                 for (int nt = 0; nt < NT; ++nt) {
                     const int n = (nb * NT + nt) * 32 + l31;
                     if (n < g.Cout) {
-                        float v = (H2 ? acc[mt][nt][r] * descale : acc[mt][nt][r]) + bv[nt];
+                        float v = (H2 ? acc[mt][nt][r] * wd[nt] : acc[mt][nt][r]) + bv[nt];
                         if (relu_out) v = fmaxf(v, 0.0f);
                         omax = fmaxf(omax, __builtin_fabsf(v));
                         out[off + n] = v;
@@ -1323,7 +1347,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
         xscale = __builtin_ldexpf(1.0f, kx);
-        descale = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+        descale = __builtin_ldexpf(1.0f, -kx);
     }
 
     load_raw(0);
@@ -1384,11 +1408,12 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
         if (++grp == ngrp) { grp = 0; ++sl; }
     }
 
-    float bv[NT];
+    float bv[NT], wd[NT];                              // bias and accumulator scale 2^-(kx + kw[n]) of this lane's output channels
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int n = (nb * NT + nt) * 32 + l31;
         bv[nt] = (bias && n < g.Cout) ? bias[n] : 0.0f;
+        wd[nt] = descale * h2_dw(whdr)[n];
     }
     float omax = 0.0f;
     if (img_ok) {
@@ -1411,7 +1436,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
                     const int nt = v % NT, i = v / NT;
-                    const f32x2v d2 = {descale, descale}, b2 = {bv[nt], bv[nt]};
+                    const f32x2v d2 = {wd[nt], wd[nt]}, b2 = {bv[nt], bv[nt]};
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
@@ -1472,7 +1497,8 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
     const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
     unsigned pbase[MT], tapmask[MT];
     long long myimg[MT];
-    float xsc[MT], d1[MT];                              // H2: image scale 2^kx and 3x3 accumulator scale 2^-(kx + kw1) of this lane's pixel rows
+    float xsc[MT], d1[MT];                              // H2: image scale 2^kx and its inverse of this lane's pixel rows
+    const float w1d = H2 ? h2_dw(hdr1)[l31] : 1.0f;     // H2: 2^-kw1[n] of this lane's hidden channel
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         const long long p = wbase + mt * 32 + l31;
@@ -1498,7 +1524,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
             int kx = 15 - e;
             kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
             xsc[mt] = __builtin_ldexpf(1.0f, kx);
-            d1[mt] = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+            d1[mt] = __builtin_ldexpf(1.0f, -kx);
         }
     }
 
@@ -1572,7 +1598,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-            const float dr = H2 ? __shfl(d1[mt], prow) : 1.0f;       // the row's 3x3 accumulator scale
+            const float dr = H2 ? __shfl(d1[mt], prow) * w1d : 1.0f;  // the row's 3x3 accumulator scale 2^-(kx + kw1[n])
             Hs[wave][mt][prow * 33 + l31] = fmaxf(H2 ? acc1[mt][r] * dr : acc1[mt][r], 0.0f);
         }
     lds_order_wave();
@@ -1594,7 +1620,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
             int kh = 15 - e;
             kh = kh > 100 ? 100 : (kh < -100 ? -100 : kh);
             const float hsc = __builtin_ldexpf(1.0f, kh);
-            d2[mt] = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+            d2[mt] = __builtin_ldexpf(1.0f, -kh);
             split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hsc, H1[mt][0], Hb[mt][0]);
             split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hsc, H1[mt][1], Hb[mt][1]);
         } else {
@@ -1633,7 +1659,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
                 const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
                 const long long prow = wbase + mt * 32 + src;
                 const int n = nt * 32 + l31;
-                const float dr = H2 ? __shfl(d2[mt], src) : 1.0f;
+                const float dr = H2 ? __shfl(d2[mt], src) * h2_dw(hdr2)[n] : 1.0f;     // 2^-(kh + kw2[n])
                 float rmax = 0.0f;
                 if (prow < M && n < C) {
                     float u = in[prow * C + n];
@@ -1756,7 +1782,7 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
         xscale = __builtin_ldexpf(1.0f, kx);
-        d1 = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+        d1 = __builtin_ldexpf(1.0f, -kx) * h2_dw(hdr1)[l31];          // this lane's hidden channel: 2^-(kx + kw1[n])
     }
     load_raw(0, raw);
     load_w(0, 0, bw[0]);
@@ -1825,7 +1851,7 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
             for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
         const int kh = wave_scale_exp(m);
         hscale = __builtin_ldexpf(1.0f, kh);
-        d2 = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+        d2 = __builtin_ldexpf(1.0f, -kh);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -1878,8 +1904,9 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 float v[16];
+                const float d2n = H2 ? d2 * h2_dw(hdr2)[nt * 32 + l31] : 1.0f;       // 2^-(kh + kw2[n]) of this lane's channel
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = H2 ? acc2[mt][r] * d2 : acc2[mt][r];
+                for (int r = 0; r < 16; ++r) v[r] = H2 ? acc2[mt][r] * d2n : acc2[mt][r];
                 // the four skip values of this lane are requested before the tile goes through LDS
                 f32x4 u[4];
 #pragma unroll
@@ -1992,7 +2019,7 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
         xscale = __builtin_ldexpf(1.0f, kx);
-        d1 = __builtin_ldexpf(1.0f, -(kx + hdr1[0]));
+        d1 = __builtin_ldexpf(1.0f, -kx) * h2_dw(hdr1)[l31];          // this lane's hidden channel: 2^-(kx + kw1[n])
     }
     load_raw(0);
     load_w(0, 0, bw[0]);
@@ -2053,7 +2080,7 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
             }
         const int kh = wave_scale_exp(m);
         hscale = __builtin_ldexpf(1.0f, kh);
-        d2 = __builtin_ldexpf(1.0f, -(kh + hdr2[0]));
+        d2 = __builtin_ldexpf(1.0f, -kh);
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -2104,7 +2131,8 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
                 for (int mt = 0; mt < MT; ++mt) {
                     const int step = 2 * nt + mt;
                     if (step + 1 < 2 * NT2) skip_load(step + 1, u[mt ^ 1]);
-                    const f32x2v dd = {d2, d2};
+                    const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];                // 2^-(kh + kw2[n]) of this lane's channel
+                    const f32x2v dd = {d2n, d2n};
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const f32x2v v = f32x2v{acc2[mt][r], acc2[mt][r + 1]} * dd;
@@ -2172,7 +2200,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
     const long long img = (long long)blockIdx.x * 4 + wave;
     const bool img_ok = img < B;
     const float *src = in + (size_t)(img_ok ? img : 0) * PX * C + (size_t)lane * C;   // this lane's pixel row
-    const int kw1 = hdr1[0], kw2 = hdr2[0];
+    const float w1d = h2_dw(hdr1)[l31];                  // 2^-kw1[n] of this lane's hidden channel
 
     int spx[MT];
     unsigned tapok[MT];
@@ -2236,7 +2264,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
             split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
             __builtin_amdgcn_wave_barrier();
         }
-        return __builtin_ldexpf(1.0f, -(kh + kw2));
+        return __builtin_ldexpf(1.0f, -kh);               // (x the 1x1 rows' 2^-kw2[n] at the use)
     };
     auto gemm2 = [&](int nt, f32x16(&acc2)[MT]) {
 #pragma unroll
@@ -2275,7 +2303,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
         xscale = __builtin_ldexpf(1.0f, kx);
-        d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+        d1 = __builtin_ldexpf(1.0f, -kx) * w1d;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -2317,12 +2345,13 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
 #pragma unroll
             for (int r = 0; r < 16; ++r) u[r] = xb[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * C + nt * 32 + l31];
             gemm2(nt, acc2);
+            const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];            // 2^-(kh + kw2[n]) of this lane's channel
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float u0 = relu_in ? fmaxf(u[r], 0.0f) : u[r];
-                    Y[mt][nt][r] = fmaxf(u0 + acc2[mt][r] * d2, 0.0f);       // + the second layer's in-place ReLU
+                    Y[mt][nt][r] = fmaxf(u0 + acc2[mt][r] * d2n, 0.0f);      // + the second layer's in-place ReLU
                 }
                 if (mt + 1 < MT) {
 #pragma unroll
@@ -2343,7 +2372,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
                 for (int r = 0; r < 16; ++r) m = fmaxf(m, Y[mt][nt][r]);
         const int kx = wave_scale_exp(m);
         xscale = __builtin_ldexpf(1.0f, kx);
-        d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+        d1 = __builtin_ldexpf(1.0f, -kx) * w1d;
     }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -2389,13 +2418,14 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
         for (int nt = 0; nt < NT2; ++nt) {
             f32x16 acc2[MT];
             gemm2(nt, acc2);
+            const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];
             if (img_ok) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     float v[16];
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        v[r] = Y[mt][nt][r] + acc2[mt][r] * d2;
+                        v[r] = Y[mt][nt][r] + acc2[mt][r] * d2n;
                         if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                         omax = fmaxf(omax, __builtin_fabsf(v[r]));
                     }
@@ -2415,7 +2445,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
         if constexpr (NT3 > 0) {
             // ================================ 1x1 conv on y2 (same operand order as conv_tile8_bf3_kernel) ================
             const int kx3 = wave_scale_exp(img_ok ? omax : 0.0f);
-            const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -(kx3 + hdr3[0]));
+            const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -kx3);
             f32x16 acc3[MT][NT3];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -2453,10 +2483,10 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int n3 = 0; n3 < NT3; ++n3) {
-                        const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f;
+                        const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f, d3n = d3 * h2_dw(hdr3)[n3 * 32 + l31];
                         float v[16];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3 + bv;
+                        for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3n + bv;
                         __builtin_amdgcn_wave_barrier();
                         tile_epilogue(Hs, v, lane, n3 * 32, [&](int p, int n, f32x4 a4, int) {
                             *reinterpret_cast<f32x4 *>(out3 + (wbase + mt * 32 + p) * (32 * NT3) + n) = a4;
@@ -2562,6 +2592,11 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     // fused quantizer: per-wave tables (vq_unit.h), the workgroup's histogram and loss partials
     __shared__ __attribute__((aligned(16))) unsigned char vq_tab_all[VQ ? CRP_NW * 1040 : 16];
     __shared__ int vq_hist_s[VQ ? 512 : 1];
+    // the four weight tensors' per-output-channel scales 2^-kw[c]: front conv [0, 128), residual 3x3 [128, 160), residual 1x1
+    // [160, 288), post conv [288, 288 + 32 NT3) (a stage barrier precedes every use)
+    __shared__ __attribute__((aligned(16))) float dw_s[288 + 32 * (NT3 > 0 ? NT3 : 1)];
+    for (int i = threadIdx.x; i < 288 + 32 * NT3; i += CRP_NW * 64)
+        dw_s[i] = i < 128 ? h2_dw(fc.hdr)[i] : (i < 160 ? h2_dw(hdr1)[i - 128] : (i < 288 ? h2_dw(hdr2)[i - 160] : h2_dw(hdr3)[i - 288]));
     __shared__ double vq_red_s[VQ ? CRP_NW : 1];
     if constexpr (VQ) {
         for (int i = threadIdx.x; i < vq.K; i += CRP_NW * 64) vq_hist_s[i] = 0;        // (a stage barrier precedes every use)
@@ -2575,7 +2610,6 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 
     const long long img = (long long)blockIdx.x * CRP_NW + wave;
     const bool img_ok = img < B;
-    const int kw1 = hdr1[0], kw2 = hdr2[0];
     // a buffer the NEXT kernel of the stream wants zeroed (the quantizer's histogram: saves a fill launch per step)
     if (zero_buf && blockIdx.x == 0)
         for (int i = tid; i < zero_n; i += CRP_NW * 64) zero_buf[i] = 0;
@@ -2661,7 +2695,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                 m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(raw[j].x), __builtin_fabsf(raw[j].y)), fmaxf(__builtin_fabsf(raw[j].z), __builtin_fabsf(raw[j].w))));
         }
         const int kx = wave_scale_exp(img_ok ? m : 0.0f);
-        const float xs = __builtin_ldexpf(1.0f, kx), d0 = __builtin_ldexpf(1.0f, -(kx + fc.hdr[0]));
+        const float xs = __builtin_ldexpf(1.0f, kx), d0 = __builtin_ldexpf(1.0f, -kx);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -2747,11 +2781,12 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
             for (int g = 0; g < 4; ++g) {
                 f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (fc.bias) bv = *reinterpret_cast<const f32x4 *>(fc.bias + nt * 32 + 8 * g + 4 * h);
+                const f32x4 dv = h2_dw4(dw_s, nt * 32, g, h, d0);          // 2^-(kx + kw[c]) of registers 4 g .. 4 g + 3
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int q = 0; q < 4; q += 2)
-                        SCALE_BIAS_RELU2(Y[mt][nt][4 * g + q], Y[mt][nt][4 * g + q + 1], d0, bv[q], bv[q + 1], ymax);
+                        SCALE2_BIAS_RELU2(Y[mt][nt][4 * g + q], Y[mt][nt][4 * g + q + 1], dv[q], dv[q + 1], bv[q], bv[q + 1], ymax);
             }
     }
     lds_order_wave();
@@ -2809,7 +2844,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     auto layer = [&](auto LT, bool relu_after) __attribute__((always_inline)) {
         constexpr int LI = decltype(LT)::value;                // 0 or 1: stages 9 LI ..
         const int kx = wave_scale_exp(img_ok ? ymax : 0.0f);
-        const float xscale = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + kw1));
+        const float xscale = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -kx);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -2839,11 +2874,16 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
         // hidden tile -> B operands of the 1x1 GEMM, in registers
         float m = 0.0f;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 dv = h2_dw4(dw_s + 128, 0, g, h, d1);            // 2^-(kx + kw1[j]) of the hidden channels 8 g + 4 h + [0, 4)
 #pragma unroll
-            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int q = 0; q < 4; q += 2)
+                    SCALE2_BIAS_RELU2(acc1[mt][4 * g + q], acc1[mt][4 * g + q + 1], dv[q], dv[q + 1], 0.0f, 0.0f, m);
+        }
         const int kh = wave_scale_exp(m);
-        const float hscale = __builtin_ldexpf(1.0f, kh), d2 = __builtin_ldexpf(1.0f, -(kh + kw2));
+        const float hscale = __builtin_ldexpf(1.0f, kh), d2 = __builtin_ldexpf(1.0f, -kh);
         u32x4 H1[MT][2], Hb[MT][2];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc_to_ksteps(acc1[mt], hscale, H1[mt], Hb[mt]);
@@ -2865,27 +2905,38 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                 prod3x2t(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], Wc[t][0], Wc[t][1], acc2[0], acc2[1]);
             // Y <- [relu](Y + acc2 * 2^-k), nmax: FMA (exact product), single-instruction max; the ReLU flag is wave-uniform and
             // decided once per tile, not per value
+            // (the 1x1 rows' own scales: 2^-(kh + kw2[c]) of registers 4 g .. 4 g + 3, four at a time)
             if (relu_after) {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dv = h2_dw4(dw_s + 160, nt * 32, g, h, d2);
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float y0 = vmax(__builtin_fmaf(acc2[mt][r], d2, Y[mt][nt][r]), 0.0f);
-                        const float y1 = vmax(__builtin_fmaf(acc2[mt][r + 1], d2, Y[mt][nt][r + 1]), 0.0f);
-                        Y[mt][nt][r] = y0;
-                        Y[mt][nt][r + 1] = y1;
-                        vmax3(nmax, y0, y1);
-                    }
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const int r = 4 * g + q;
+                            const float y0 = vmax(__builtin_fmaf(acc2[mt][r], dv[q], Y[mt][nt][r]), 0.0f);
+                            const float y1 = vmax(__builtin_fmaf(acc2[mt][r + 1], dv[q + 1], Y[mt][nt][r + 1]), 0.0f);
+                            Y[mt][nt][r] = y0;
+                            Y[mt][nt][r + 1] = y1;
+                            vmax3(nmax, y0, y1);
+                        }
+                }
             } else {
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 dv = h2_dw4(dw_s + 160, nt * 32, g, h, d2);
 #pragma unroll
-                    for (int r = 0; r < 16; r += 2) {
-                        const float y0 = __builtin_fmaf(acc2[mt][r], d2, Y[mt][nt][r]), y1 = __builtin_fmaf(acc2[mt][r + 1], d2, Y[mt][nt][r + 1]);
-                        Y[mt][nt][r] = y0;
-                        Y[mt][nt][r + 1] = y1;
-                        vmax3_abs(nmax, y0, y1);
-                    }
+                    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                        for (int q = 0; q < 4; q += 2) {
+                            const int r = 4 * g + q;
+                            const float y0 = __builtin_fmaf(acc2[mt][r], dv[q], Y[mt][nt][r]), y1 = __builtin_fmaf(acc2[mt][r + 1], dv[q + 1], Y[mt][nt][r + 1]);
+                            Y[mt][nt][r] = y0;
+                            Y[mt][nt][r + 1] = y1;
+                            vmax3_abs(nmax, y0, y1);
+                        }
+                }
             }
         }
         ymax = nmax;
@@ -2911,7 +2962,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     const long long wbase = img * PX;
     if constexpr (NT3 > 0) {
         const int kx3 = wave_scale_exp(img_ok ? ymax : 0.0f);
-        const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -(kx3 + hdr3[0]));
+        const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -kx3);
         f32x16 acc3[MT][NT3];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -2949,8 +3000,9 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     for (int g = 0; g < 4; ++g) {
                         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                         if (bias3) bv = *reinterpret_cast<const f32x4 *>(bias3 + n3 * 32 + 8 * g + 4 * h);
+                        const f32x4 dv = h2_dw4(dw_s + 288, n3 * 32, g, h, d3);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc3[mt][n3][4 * g + q] = acc3[mt][n3][4 * g + q] * d3 + bv[q];
+                        for (int q = 0; q < 4; ++q) acc3[mt][n3][4 * g + q] = acc3[mt][n3][4 * g + q] * dv[q] + bv[q];
                     }
             // fp16 B operands of the screen: k-step ks = 2 n3 + t, this half's channels 32 n3 + 16 h + 8 t + [0, 8)
             u32x4 zb[MT][4];
@@ -3114,8 +3166,9 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     for (int g = 0; g < 4; ++g) {
                         f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                         if (bias3) bv = *reinterpret_cast<const f32x4 *>(bias3 + n3 * 32 + 8 * g + 4 * h);
+                        const f32x4 dv = h2_dw4(dw_s + 288, n3 * 32, g, h, d3);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) v[4 * g + q] = acc3[mt][n3][4 * g + q] * d3 + bv[q];
+                        for (int q = 0; q < 4; ++q) v[4 * g + q] = acc3[mt][n3][4 * g + q] * dv[q] + bv[q];
                     }
                     store_tile(v, out3 + (wbase + mt * 32) * (32 * NT3) + n3 * 32, 32 * NT3);
                 }
@@ -3164,6 +3217,7 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
     __shared__ u32x4 As_all[4 * TILE4];
     __shared__ u32x4 Wb_all[2 * WBUF];
     __shared__ u32x4 W0s[2 * CIN * 2 * 64];                // first layer: [slice 2][ci][term 2] x 64 lanes
+    __shared__ __attribute__((aligned(16))) float dw_s[64 + 128];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -3190,6 +3244,8 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
     };
     dma_stage(0, 0);
     for (int i = tid; i < 2 * CIN * 2 * 64; i += 256) W0s[i] = w0img[i];
+    // both layers' per-output-channel weight scales 2^-kw[c]: first layer [0, 64), second [64, 192) (behind the W0s barrier)
+    if (tid < C0 + C) dw_s[tid] = tid < C0 ? h2_dw(hdr0)[tid] : h2_dw(hdr2)[tid - C0];
     if (lane < 8) As[(lane >> 1) * PLANE + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};       // padding pixels of the four planes
 
     // block-pixel bookkeeping: bit sub * 4 + tap of tapok = block offset ((tap >> 1) - (sub >> 1), (tap & 1) - (sub & 1)) is inside
@@ -3218,11 +3274,11 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) xm = fmaxf(xm, __shfl_xor(xm, o));
     const int kx0 = wave_scale_exp(img_ok ? xm : 0.0f);
-    const float xs0 = __builtin_ldexpf(1.0f, kx0), d0 = __builtin_ldexpf(1.0f, -(kx0 + hdr0[0]));
+    const float xs0 = __builtin_ldexpf(1.0f, kx0), d0 = __builtin_ldexpf(1.0f, -kx0);       // (x the weight rows' 2^-kw[c] at the use)
     float bm = bias0 ? __builtin_fabsf(bias0[lane]) : 0.0f;                                 // C0 = 64 channels
     const float bound = (__int_as_float(hdr0[1]) * xm + bm) * 1.0001f;
     const int k1 = wave_scale_exp(img_ok ? bound : 0.0f);                                     // (reduces bm over the wave)
-    const float xs1 = __builtin_ldexpf(1.0f, k1), d2 = __builtin_ldexpf(1.0f, -(k1 + hdr2[0]));
+    const float xs1 = __builtin_ldexpf(1.0f, k1), d2 = __builtin_ldexpf(1.0f, -k1);
 
     f32x16 Y[MT][NT];
 #pragma unroll
@@ -3301,12 +3357,13 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
         for (int g = 0; g < 4; ++g) {
             f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
             if (bias0) bv = *reinterpret_cast<const f32x4 *>(bias0 + sl * 32 + 8 * g + 4 * h);
+            const f32x4 dv = h2_dw4(dw_s, sl * 32, g, h, d0);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int q = 0; q < 4; q += 2) {
                     float unused = 0.0f;
-                    SCALE_BIAS_RELU2(acc0[mt][4 * g + q], acc0[mt][4 * g + q + 1], d0, bv[q], bv[q + 1], unused);
+                    SCALE2_BIAS_RELU2(acc0[mt][4 * g + q], acc0[mt][4 * g + q + 1], dv[q], dv[q + 1], bv[q], bv[q + 1], unused);
                 }
         }
 #pragma unroll
@@ -3368,11 +3425,12 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
             for (int g = 0; g < 4; ++g) {
                 f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                 if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+                const f32x4 dv = h2_dw4(dw_s + C0, nt * 32, g, h, d2);
 #pragma unroll
                 for (int q = 0; q < 4; q += 2) {
                     v[4 * g + q] = Y[mt][nt][4 * g + q];
                     v[4 * g + q + 1] = Y[mt][nt][4 * g + q + 1];
-                    SCALE_BIAS_RELU2(v[4 * g + q], v[4 * g + q + 1], d2, bv[q], bv[q + 1], ymax);
+                    SCALE2_BIAS_RELU2(v[4 * g + q], v[4 * g + q + 1], dv[q], dv[q + 1], bv[q], bv[q + 1], ymax);
                 }
             }
             if (img_ok) {
@@ -3393,48 +3451,35 @@ __global__ __launch_bounds__(256, EF_MINW) void enc_front8_h2_kernel(const float
     (void)C0;
 }
 
-// header of the first layer's two-term image: {kw, float bits of the largest absolute row sum of w} (one block)
+// header of the first layer's two-term image, slot [1]: float bits of the largest absolute row sum of w (one block; the
+// per-channel scales come from conv_wscale_kernel)
 __global__ __launch_bounds__(256) void conv_in_hdr_kernel(const float *__restrict__ w, int per, int Cout, int *__restrict__ hdr) {
-    __shared__ float red[256], red1[256];
-    float m = 0.0f, l1 = 0.0f;
+    __shared__ float red1[256];
+    float l1 = 0.0f;
     for (int co = threadIdx.x; co < Cout; co += 256) {
         float s = 0.0f;
-        for (int i = 0; i < per; ++i) {
-            const float a = __builtin_fabsf(w[(size_t)co * per + i]);
-            m = fmaxf(m, a);
-            s += a;
-        }
+        for (int i = 0; i < per; ++i) s += __builtin_fabsf(w[(size_t)co * per + i]);
         l1 = fmaxf(l1, s);
     }
-    red[threadIdx.x] = m;
     red1[threadIdx.x] = l1;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
-            red1[threadIdx.x] = fmaxf(red1[threadIdx.x], red1[threadIdx.x + o]);
-        }
+        if ((int)threadIdx.x < o) red1[threadIdx.x] = fmaxf(red1[threadIdx.x], red1[threadIdx.x + o]);
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
-        int e = 15;
-        const float mm = red[0];
-        if (mm > 0.0f && mm < 3.0e38f) (void)__builtin_frexpf(mm, &e);
-        e = 15 - e;
-        hdr[0] = e > 100 ? 100 : (e < -100 ? -100 : e);
-        hdr[1] = __float_as_int(red1[0] * 1.0001f);
-    }
+    if (threadIdx.x == 0) hdr[1] = __float_as_int(red1[0] * 1.0001f);
 }
-// two-term fp16 A-operand image of the first layer's weights * 2^kw: [n_tile][ci][term] x 64 lanes x 16 B; lane (n, h),
+// two-term fp16 A-operand image of the first layer's weights * 2^kw[co]: [n_tile][ci][term] x 64 lanes x 16 B; lane (n, h),
 // element q = tap (ky = 2h + (q >> 2), kx = q & 3)
 template <int CIN>
 __global__ __launch_bounds__(256) void conv_in_pack_h2_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int Cout,
                                                               int ntile, const int *__restrict__ hdr) {
-    const float sc = __builtin_ldexpf(1.0f, hdr[0]);
+    const int *kwtab = hdr + 64 + 32 * ntile;
     const int total = ntile * CIN * 64;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
         const int lane = e & 63, t = e >> 6, ci = t % CIN, n = t / CIN;
         const int co = n * 32 + (lane & 31), hh = lane >> 5;
+        const float sc = __builtin_ldexpf(1.0f, kwtab[co]);
         float v[8];
         for (int q = 0; q < 8; ++q) v[q] = co < Cout ? w[((co * CIN + ci) * 4 + 2 * hh + (q >> 2)) * 4 + (q & 3)] : 0.0f;
         u32x4 t1, t2;
@@ -3482,6 +3527,8 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
     constexpr int WBUF = 16 * 64, NSTAGE = 34;             // per pass: 4 chunks x 4 tap pairs (16 pieces each) + the second layer's image
     __shared__ u32x4 As_all[4 * TILE4];
     __shared__ u32x4 Wb_all[2 * WBUF];
+    __shared__ __attribute__((aligned(16))) float dw_s[64];      // the first layer's per-output-channel weight scales 2^-kw[c]
+    if (threadIdx.x < 64) dw_s[threadIdx.x] = h2_dw(hdr2)[threadIdx.x];      // (stage barriers precede every use)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     u32x4 *As = As_all + wave * TILE4;
@@ -3539,8 +3586,7 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
             m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(raw[j].x), __builtin_fabsf(raw[j].y)), fmaxf(__builtin_fabsf(raw[j].z), __builtin_fabsf(raw[j].w))));
     }
     const int kx = wave_scale_exp(img_ok ? m : 0.0f);
-    const float xs = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -(kx + hdr2[0]));
-    const int kw4 = hdr4[0];
+    const float xs = __builtin_ldexpf(1.0f, kx), d1 = __builtin_ldexpf(1.0f, -kx);      // (x the weight rows' 2^-kw[c] at the use)
     load_raw(0);
 
 #pragma unroll 1
@@ -3652,15 +3698,16 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                 for (int g = 0; g < 4; ++g) {
                     f32x4 bv = {0.0f, 0.0f, 0.0f, 0.0f};
                     if (bias2) bv = *reinterpret_cast<const f32x4 *>(bias2 + nt * 32 + 8 * g + 4 * h);
+                    const f32x4 dv = h2_dw4(dw_s, nt * 32, g, h, d1);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                         for (int q = 0; q < 4; q += 2)
-                            SCALE_BIAS_RELU2(acc[px][mt][nt][4 * g + q], acc[px][mt][nt][4 * g + q + 1], d1, bv[q], bv[q + 1], um);
+                            SCALE2_BIAS_RELU2(acc[px][mt][nt][4 * g + q], acc[px][mt][nt][4 * g + q + 1], dv[q], dv[q + 1], bv[q], bv[q + 1], um);
                 }
             const int ku = wave_scale_exp(img_ok ? um : 0.0f);
             const float us = __builtin_ldexpf(1.0f, ku);
-            d4[px] = __builtin_ldexpf(1.0f, -(ku + kw4));
+            d4[px] = __builtin_ldexpf(1.0f, -ku);
             u32x4 U1[MT][NT][2], U2[MT][NT][2];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -3721,22 +3768,24 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
             const float bv = bias4 ? bias4[co] : 0.0f;
+            const float w4d = h2_dw(hdr4)[co];                  // the output channel's own weight scale 2^-kw4[co] (wave-uniform)
+            const float d40 = d4[0] * w4d, d41 = d4[1] * w4d;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     const f32x16 &T0 = T[0][co >> 1][mt], &T1 = T[1][co >> 1][mt];
                     const int r0 = 8 * (co & 1) + 4 * g;
-                    const float a0 = T0[r0] * d4[0], b0 = T1[r0] * d4[1], b1 = T1[r0 + 1] * d4[1], b2 = T1[r0 + 2] * d4[1], b3 = T1[r0 + 3] * d4[1];
+                    const float a0 = T0[r0] * d40, b0 = T1[r0] * d41, b1 = T1[r0 + 1] * d41, b2 = T1[r0 + 2] * d41, b3 = T1[r0 + 3] * d41;
                     // neighbours: row_shr:1 hands lane i the value of lane i - 1, row_shl:1 that of lane i + 1 (16-lane rows = two pixel rows)
                     float lb3 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, b3), 0x111, 0xf, 0xf, true));
                     float ra0 = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, a0), 0x101, 0xf, 0xf, true));
                     lb3 = xl ? lb3 : 0.0f;
                     ra0 = xr ? ra0 : 0.0f;
                     f32x4 e;
-                    e.x = __builtin_fmaf(T0[r0 + 1], d4[0], lb3);          // (the products by 2^-k are exact: one rounding, as mul + add)
-                    e.y = __builtin_fmaf(T0[r0 + 2], d4[0], b0);
-                    e.z = __builtin_fmaf(T0[r0 + 3], d4[0], b1);
+                    e.x = __builtin_fmaf(T0[r0 + 1], d40, lb3);            // (the products by 2^-k are exact: one rounding, as mul + add)
+                    e.y = __builtin_fmaf(T0[r0 + 2], d40, b0);
+                    e.z = __builtin_fmaf(T0[r0 + 3], d40, b1);
                     e.w = ra0 + b2;
                     f32x4 base = {bv, bv, bv, bv};
                     if (py > 0 && !only1[mt][g]) base = ov[co][mt][g];
@@ -3755,10 +3804,11 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
 // lane (row rho - 32 m with rho = co * 16 + tap, h), element q = input channel 32 (k >> 1) + 16 h + 8 (k & 1) + q (acc_to_ksteps' order)
 __global__ __launch_bounds__(256) void convt_out_pack_a_kernel(const float *__restrict__ w, u32x4 *__restrict__ img, int Cin, int Cout,
                                                                const int *__restrict__ hdr) {
-    const float sc = __builtin_ldexpf(1.0f, hdr[0]);
+    const int *kwtab = hdr + 64 + 32;                       // header of one 32-channel tile: kw[co], co < Cout <= 4
     for (int e = blockIdx.x * 256 + threadIdx.x; e < 8 * 64; e += gridDim.x * 256) {
         const int lane = e & 63, kk = (e >> 6) & 3, m2 = e >> 8;
         const int rho = 32 * m2 + (lane & 31), hh = lane >> 5;
+        const float sc = __builtin_ldexpf(1.0f, kwtab[rho < 16 * Cout ? (rho >> 4) : 0]);
         float v[8];
         for (int q = 0; q < 8; ++q) {
             const int c = 32 * (kk >> 1) + 16 * hh + 8 * (kk & 1) + q;
@@ -4336,7 +4386,7 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
             int kx = 15 - e;
             kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
             xsc = __builtin_ldexpf(1.0f, kx);
-            dsc = __builtin_ldexpf(1.0f, -(kx + whdr[0]));
+            dsc = __builtin_ldexpf(1.0f, -kx);
         }
     };
     auto mma = [&](int c, const f32x4(&a)[MT][4]) {
@@ -4420,11 +4470,13 @@ __global__ __launch_bounds__(256, 2) void convt_out_kernel(const float *__restri
     for (int nt = 0; nt < NT; ++nt)
         if (nt * 32 + l31 < STRIDE - 1) {
             float *tcol = Ts + (wave * 64 + 4 * h) * STRIDE + nt * 32 + l31;
+            // H2: column = tap * Cout + co -> the output channel's own weight scale 2^-kw[co] beside the image's 2^-kx
+            const float dcol = H2 ? dsc * h2_dw(whdr)[(nt * 32 + l31) % Cout] : 1.0f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
-                    tcol[(mt * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE] = H2 ? acc[mt][nt][r] * dsc : acc[mt][nt][r];
+                    tcol[(mt * 32 + (r & 3) + 8 * (r >> 2)) * STRIDE] = H2 ? acc[mt][nt][r] * dcol : acc[mt][nt][r];
         }
     __syncthreads();
     // the next tile's input goes on its way now
@@ -4537,7 +4589,7 @@ __global__ __launch_bounds__(256) void convt_out_pack_kernel(const float *__rest
 template <bool H2>
 __global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__restrict__ w, unsigned short *__restrict__ img,
                                                                  int Cin, int Cout, int ntile, const int *__restrict__ hdr) {
-    const float wsc = H2 ? __builtin_ldexpf(1.0f, hdr[0]) : 1.0f;
+    const int *kwtab = H2 ? hdr + 64 + 32 : nullptr;       // kw[co] of the (single-tile) header, co < Cout <= 4
     const int cpt = (Cin + 31) / 32;
     const int total = cpt * ntile * 1024;
     for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
@@ -4549,7 +4601,7 @@ __global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__
         const float v = (ci < Cin && tap < 16) ? w[((size_t)ci * Cout + co) * 16 + tap] : 0.0f;
         const size_t pos = (size_t)((t * 2 + hh) * 32 + n) * 8 + i;
         if (H2) {
-            const float vs = v * wsc;
+            const float vs = v * __builtin_ldexpf(1.0f, kwtab[co]);
             const _Float16 g1 = (_Float16)vs;
             const _Float16 g2 = (_Float16)(vs - (float)g1);
             const size_t base = (size_t)(chunk * ntile + nt) * 2048;
@@ -4662,8 +4714,9 @@ static size_t packed_floats(const ConvGeom &g) {
 static size_t packed_bf3_bytes(const ConvGeom &g) {
     return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 3072 * sizeof(unsigned short);
 }
-// two-term fp16 image: 2 terms x 32x32 fp16 per (phase, chunk, n_tile) = 4 KiB, behind a 256-byte header {int kw}
-constexpr size_t kH2Header = 256;
+// two-term fp16 image: 2 terms x 32x32 fp16 per (phase, chunk, n_tile) = 4 KiB, behind the header of conv_wscale_kernel
+// (64 ints + one float and one int per output channel of the ntile 32-channel tiles)
+static size_t h2_header_bytes(int ntile) { return 256 + (size_t)ntile * 256; }
 static size_t packed_h2_bytes(const ConvGeom &g) {
     return (size_t)g.nphase * g.ntaps * g.cpt * g.ntile * 2048 * sizeof(unsigned short);
 }
@@ -4689,7 +4742,7 @@ size_t vqvae_conv_packed_bytes(int kind, int Cin, int Cout) {
     if (Cin < 1 || Cout < 1 || make_geom(kind, 1, 4, 4, Cin, Cout, 0, g) != VQVAE_OK) return 0;
     // [fp32 B-operand image][split-bf16 image][4x4 s2 only: split-bf16 image in space-to-depth chunk order]
     // [header {kw}][two-term fp16 image][4x4 s2 only: the same in space-to-depth chunk order]
-    return packed_h2_offset(g, kind) + kH2Header + packed_h2_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
+    return packed_h2_offset(g, kind) + h2_header_bytes(g.ntile) + packed_h2_bytes(g) * (kind == VQVAE_CONV_4x4_S2 ? 2 : 1);
 }
 
 int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *packed, vqvae_stream_t stream) {
@@ -4706,15 +4759,15 @@ int vqvae_conv_pack_f32(int kind, const float *w, int Cin, int Cout, float *pack
     // the weight scale first, then every image in one launch (4x4 stride 2: one more for the space-to-depth chunk order)
     char *h2 = reinterpret_cast<char *>(packed) + packed_h2_offset(g, kind);
     int *hdr = reinterpret_cast<int *>(h2);
-    hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * g.kk, hdr);
+    hipLaunchKernelGGL(conv_wscale_kernel, dim3(32 * g.ntile), dim3(64), 0, st, w, Cin, Cout, g.kk, g.transposed, g.ntile, hdr);
     hipLaunchKernelGGL(conv_pack_images_kernel, dim3((unsigned)grid), dim3(256), 0, st, w, packed,
-                       reinterpret_cast<unsigned short *>(packed + total), reinterpret_cast<unsigned short *>(h2 + kH2Header), g,
+                       reinterpret_cast<unsigned short *>(packed + total), reinterpret_cast<unsigned short *>(h2 + h2_header_bytes(g.ntile)), g,
                        total, hdr);
     if (kind == VQVAE_CONV_4x4_S2) {
         g.s2d = 1;
         hipLaunchKernelGGL(conv_pack_images_kernel, dim3((unsigned)grid), dim3(256), 0, st, w, (float *)nullptr,
                            reinterpret_cast<unsigned short *>(packed + total) + packed_bf3_bytes(g) / 2,
-                           reinterpret_cast<unsigned short *>(h2 + kH2Header + packed_h2_bytes(g)), g, total, hdr);
+                           reinterpret_cast<unsigned short *>(h2 + h2_header_bytes(g.ntile) + packed_h2_bytes(g)), g, total, hdr);
     }
     return (int)hipGetLastError();
 }
@@ -4770,7 +4823,7 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const bool h2 = !(flags & VQVAE_CONV_BF16_SPLIT);
             const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
             const int *whdr = reinterpret_cast<const int *>(h2base);
-            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + kH2Header + (S2D_ ? packed_h2_bytes(g) : 0))
+            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + h2_header_bytes(g.ntile) + (S2D_ ? packed_h2_bytes(g) : 0))
                                    : (S2D_ ? img3 + packed_bf3_bytes(g) / sizeof(u32x4) : img3);
 #define TILE8_LAUNCH(NT_, S2D__, NW_, H2_, THREADS_)                                                                   \
     hipLaunchKernelGGL((conv_tile8_bf3_kernel<NT_, S2D__, NW_, 2, H2_>), dim3(gxt), dim3(THREADS_), 0, st, x, wsel, bias, y, \
@@ -4790,7 +4843,7 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             // the 4x4 stride-2 conv on larger maps: 8x8 output tiles over the grid of 2x2 input blocks, with a one-block halo
             const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
             const int *whdr = reinterpret_cast<const int *>(h2base);
-            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + kH2Header + packed_h2_bytes(g));      // space-to-depth chunk order
+            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + h2_header_bytes(g.ntile) + packed_h2_bytes(g));      // space-to-depth chunk order
             const bool wide = g.ntile % 4 == 0;
             const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
             const int ny = g.nphase * (wide ? g.ntile / 4 : g.ntile / 2);
@@ -4803,7 +4856,7 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             // 8x8 tiles with a one-pixel halo, one per wave (conv_halo8_h2_kernel)
             const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
             const int *whdr = reinterpret_cast<const int *>(h2base);
-            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + kH2Header);
+            const u32x4 *wsel = reinterpret_cast<const u32x4 *>(h2base + h2_header_bytes(g.ntile));
             const bool wide = g.ntile % 4 == 0;
             const long long tiles = (long long)B * (g.Hg / 8) * (g.Wg / 8);
             // 64-channel conv-transpose phases go in pairs (one patch load / split for two phases)
@@ -4827,7 +4880,7 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             const bool h2 = in_amax && !(flags & VQVAE_CONV_BF16_SPLIT);
             const char *h2base = reinterpret_cast<const char *>(packed) + packed_h2_offset(g, kind);
             const int *whdr = reinterpret_cast<const int *>(h2base);
-            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + kH2Header) : img3;
+            const u32x4 *wsel = h2 ? reinterpret_cast<const u32x4 *>(h2base + h2_header_bytes(g.ntile)) : img3;
 #define IGEMM_LAUNCH(NT_, H2_, GY_)                                                                                     \
     hipLaunchKernelGGL((conv_igemm_bf3_kernel<NT_, H2_>), dim3(gx, GY_), dim3(256), 0, st, x, wsel, bias, y, g, whdr, in_amax, \
                        out_amax)
@@ -4896,7 +4949,7 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
                 // two-term fp16 images: [header {kw}][image] behind the bf16 ones (vqvae_conv_pack_f32)
                 const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
                 const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
-                const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+                const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes((C + 31) / 32));
                 const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
                 switch (C / 32) {
                     case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
@@ -4913,7 +4966,7 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
             // larger maps that are multiples of 8 both ways, inside the whole-path entry points: 8x8 tiles with a halo
             const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
             const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
-            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2p + kH2Header);
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2p + h2_header_bytes((C + 31) / 32));
             const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
             const long long tiles = (long long)B * (H / 8) * (W / 8);
             const unsigned gt = (unsigned)((tiles + 3) / 4);
@@ -4927,7 +4980,7 @@ int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const 
             const bool h2 = in_amax && !(flags & VQVAE_CONV_BF16_SPLIT);
             const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
             const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
-            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2p + kH2Header);
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2p + h2_header_bytes((C + 31) / 32));
             const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
 #define RES_GEN(NT_)                                                                                                             \
     do {                                                                                                                         \
@@ -4974,7 +5027,7 @@ int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const f
     const int cpt = (C + 31) / 32;
     const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
-    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes((C + 31) / 32));
     const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
     const unsigned gt = (unsigned)((B + 3) / 4);
     // the checks that can refuse come BEFORE prof_begin: an early return behind it would leave an unmatched begin event
@@ -4984,7 +5037,7 @@ int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const f
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {
         const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
-        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + kH2Header);
+        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + h2_header_bytes(g3.ntile));
         const int *hd3 = reinterpret_cast<const int *>(h3);
 #define PAIR_POST(NT3_)                                                                                                         \
     hipLaunchKernelGGL((res_pair8_h2_kernel<4, NT3_>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2,  \
@@ -5023,7 +5076,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     if (make_geom(kind, B, H, W, Cin, C, 0, g) != VQVAE_OK || g.nphase != 1 || g.ntaps != 9) return VQVAE_ERR_UNSUPPORTED;
     const char *hf = reinterpret_cast<const char *>(packed_front) + packed_h2_offset(g, kind);
     FrontConv fc;
-    fc.wimg = reinterpret_cast<const u32x4 *>(hf + kH2Header);
+    fc.wimg = reinterpret_cast<const u32x4 *>(hf + h2_header_bytes(g.ntile));
     fc.hdr = reinterpret_cast<const int *>(hf);
     fc.bias = bias_front;
     fc.dym = g.dymask[0];
@@ -5032,7 +5085,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     const int cpt = C / 32;
     const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
-    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + kH2Header), *w2h = reinterpret_cast<const u32x4 *>(h2 + kH2Header);
+    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes((C + 31) / 32));
     const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
     const unsigned gtc = (unsigned)((B + CRP_NW - 1) / CRP_NW);
     // the checks that can refuse come BEFORE prof_begin: an early return behind it would leave an unmatched begin event
@@ -5044,7 +5097,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {
         const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
-        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + kH2Header);
+        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + h2_header_bytes(g3.ntile));
         const int *hd3 = reinterpret_cast<const int *>(h3);
 #define CRP_POST(NT3_)                                                                                                          \
     hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
@@ -5073,8 +5126,8 @@ extern "C" {
 size_t vqvae_conv_in_packed_bytes(int Cin, int Cout) {
     if (!(Cin == 1 || Cin == 3 || Cin == 4) || Cout < 1 || Cout > 128) return 0;
     const int S = Cin * 8, JG = (S + 3) / 4;
-    // [fp32 B-operand image][split-bf16 image][header {kw, L1}][two-term fp16 A-operand image (enc_front8_h2_kernel)]
-    return (size_t)((Cout + 31) / 32) * ((size_t)JG * 256 + (size_t)Cin * 768) * sizeof(float) + kH2Header +
+    // [fp32 B-operand image][split-bf16 image][header (kw per output channel, [1] = L1)][two-term fp16 A-operand image (enc_front8_h2_kernel)]
+    return (size_t)((Cout + 31) / 32) * ((size_t)JG * 256 + (size_t)Cin * 768) * sizeof(float) + h2_header_bytes((Cout + 31) / 32) +
            (size_t)((Cout + 31) / 32) * Cin * 2048;
 }
 
@@ -5096,7 +5149,8 @@ int vqvae_conv_in_pack_f32(const float *w, int Cin, int Cout, float *packed, vqv
     }
     char *h2 = reinterpret_cast<char *>(packed) + (size_t)ntile * ((size_t)((Cin * 8 + 3) / 4) * 256 + (size_t)Cin * 768) * sizeof(float);
     int *hdr = reinterpret_cast<int *>(h2);
-    u32x4 *img16 = reinterpret_cast<u32x4 *>(h2 + kH2Header);
+    u32x4 *img16 = reinterpret_cast<u32x4 *>(h2 + h2_header_bytes(ntile));
+    hipLaunchKernelGGL(conv_wscale_kernel, dim3(32 * ntile), dim3(64), 0, st, w, Cin, Cout, 16, 0, ntile, hdr);
     hipLaunchKernelGGL(conv_in_hdr_kernel, dim3(1), dim3(256), 0, st, w, Cin * 16, Cout, hdr);
     switch (Cin) {
         case 1: hipLaunchKernelGGL((conv_in_pack_h2_kernel<1>), dim3(4), dim3(256), 0, st, w, img16, Cout, ntile, hdr); break;
@@ -5127,10 +5181,10 @@ int vqvae::enc_front_forward_impl(const float *x_nchw, const float *packed_in, c
     ConvGeom g;
     if (make_geom(VQVAE_CONV_4x4_S2, B, H / 2, W / 2, C1, C2, 0, g) != VQVAE_OK) return VQVAE_ERR_UNSUPPORTED;
     const char *h2 = reinterpret_cast<const char *>(packed2) + packed_h2_offset(g, VQVAE_CONV_4x4_S2);
-    const u32x4 *w2s2d = reinterpret_cast<const u32x4 *>(h2 + kH2Header + packed_h2_bytes(g));     // space-to-depth chunk order
+    const u32x4 *w2s2d = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes(g.ntile) + packed_h2_bytes(g));     // space-to-depth chunk order
     prof_begin(VQVAE_PROF_CONV_IGEMM, st);
     hipLaunchKernelGGL((enc_front8_h2_kernel<3>), dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x_nchw,
-                       reinterpret_cast<const u32x4 *>(h0 + kH2Header), reinterpret_cast<const int *>(h0), bias_in, w2s2d,
+                       reinterpret_cast<const u32x4 *>(h0 + h2_header_bytes(ntile0)), reinterpret_cast<const int *>(h0), bias_in, w2s2d,
                        reinterpret_cast<const int *>(h2), bias2, y, (int)B, out_amax, zero_buf, zero_n);
     prof_end(VQVAE_PROF_CONV_IGEMM, st);
     return (int)hipGetLastError();
@@ -5204,9 +5258,9 @@ extern "C" {
 size_t vqvae_convt_out_packed_bytes(int Cin, int Cout) {
     if (Cin < 4 || Cin % 4 || Cin > 256 || Cout < 1 || Cout > 4) return 0;
     const int ntile = (16 * Cout + 31) / 32;
-    // [fp32 B-operand image][three-term bf16 image][header {kw}][two-term fp16 image]
+    // [fp32 B-operand image][three-term bf16 image][header (one tile: kw per output channel)][two-term fp16 image]
     // ... [A-operand image of dec_tail8_h2_kernel: 16 KiB]
-    return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short)) + kH2Header +
+    return (size_t)((Cin + 31) / 32) * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short)) + h2_header_bytes(1) +
            (size_t)((Cin + 31) / 32) * ntile * 2048 * sizeof(unsigned short) + 16384;
 }
 
@@ -5222,11 +5276,11 @@ int vqvae_convt_out_pack_f32(const float *w, int Cin, int Cout, float *packed, v
                        reinterpret_cast<unsigned short *>(packed + cells * 1024), Cin, Cout, ntile_p, (const int *)nullptr);
     char *h2 = reinterpret_cast<char *>(packed) + cells * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     int *hdr = reinterpret_cast<int *>(h2);
-    hipLaunchKernelGGL(conv_wscale_kernel, dim3(1), dim3(256), 0, st, w, (long long)Cin * Cout * 16, hdr);
+    hipLaunchKernelGGL(conv_wscale_kernel, dim3(32), dim3(64), 0, st, w, Cin, Cout, 16, 1, 1, hdr);
     hipLaunchKernelGGL(convt_out_pack_bf3_kernel<true>, dim3(32), dim3(256), 0, st, w,
-                       reinterpret_cast<unsigned short *>(h2 + kH2Header), Cin, Cout, ntile_p, hdr);
+                       reinterpret_cast<unsigned short *>(h2 + h2_header_bytes(1)), Cin, Cout, ntile_p, hdr);
     hipLaunchKernelGGL(convt_out_pack_a_kernel, dim3(2), dim3(256), 0, st, w,
-                       reinterpret_cast<u32x4 *>(h2 + kH2Header + cells * 2048 * sizeof(unsigned short)), Cin, Cout, hdr);
+                       reinterpret_cast<u32x4 *>(h2 + h2_header_bytes(1) + cells * 2048 * sizeof(unsigned short)), Cin, Cout, hdr);
     return (int)hipGetLastError();
 }
 
@@ -5254,8 +5308,8 @@ int vqvae::dec_tail_forward_impl(const float *x, const float *packed2, const flo
     const char *h4p = reinterpret_cast<const char *>(packed4) + cells * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     prof_begin(VQVAE_PROF_CONV_OUT, st);
     hipLaunchKernelGGL(dec_tail8_h2_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, st, x,
-                       reinterpret_cast<const u32x4 *>(h2 + kH2Header), reinterpret_cast<const int *>(h2), bias2, tg,
-                       reinterpret_cast<const u32x4 *>(h4p + kH2Header + cells * 2048 * sizeof(unsigned short)),
+                       reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes(g.ntile)), reinterpret_cast<const int *>(h2), bias2, tg,
+                       reinterpret_cast<const u32x4 *>(h4p + h2_header_bytes(1) + cells * 2048 * sizeof(unsigned short)),
                        reinterpret_cast<const int *>(h4p), bias4, y_nchw, (int)B, in_amax);
     prof_end(VQVAE_PROF_CONV_OUT, st);
     return (int)hipGetLastError();
@@ -5280,7 +5334,7 @@ int vqvae::convt_out_forward_impl(const float *x, const float *packed, const flo
     const size_t lds = ((h2 ? 0 : (size_t)cpt * ntile * (bf3 ? 1536 : 1024)) + 256 * (16 * Cout + 1)) * sizeof(float);
     const char *h2base = reinterpret_cast<const char *>(packed) + (size_t)cpt * ntile * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
     const int *whdr = reinterpret_cast<const int *>(h2base);
-    const float *wimg = h2 ? reinterpret_cast<const float *>(h2base + kH2Header) : (bf3 ? packed + (size_t)cpt * ntile * 1024 : packed);
+    const float *wimg = h2 ? reinterpret_cast<const float *>(h2base + h2_header_bytes(1)) : (bf3 ? packed + (size_t)cpt * ntile * 1024 : packed);
     // persistent workgroups, as many as fit on the chip at once (two per CU: ~230 registers per lane with a tile's input in flight)
     const long long resident = (long long)num_cus() * (lds <= 80 * 1024 ? 2 : 1);
     const long long grid = ntiles < resident ? ntiles : resident;

@@ -38,7 +38,7 @@ size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
 // amax: NULL, or (n_layers + 1) arrays of B ints (-1 = not provided): [0] belongs to x, [i + 1] to layer i's output
 int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
               bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr,
-              const ResPairPost *post = nullptr, bool *post_done = nullptr) {
+              const ResPairPost *post = nullptr, bool *post_done = nullptr, int conv_flags = 0) {
     // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
     // the producer applies it.  Layers run in PAIRS where the fused two-layer kernel applies (8x8 maps, two-term fp16
     // products; the intermediate map stays on chip), a trailing odd layer alone; buffers alternate so that the result of
@@ -46,13 +46,13 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
     // never has to.
     const float *cur = x;
     *out = x;
-    const bool pairs = n_layers >= 2 && res_pair_supported(H, W, C, Rh, 0);
+    const bool pairs = n_layers >= 2 && res_pair_supported(H, W, C, Rh, conv_flags);
     const int nsteps = pairs ? n_layers / 2 + (n_layers & 1) : n_layers;
     int i = 0;
     for (int j = 0; j < nsteps; ++j) {
         const bool pair = pairs && i + 1 < n_layers;
         const int last = pair ? i + 1 : i;
-        int flags = (i == 0 && first_relu_in) ? VQVAE_CONV_RELU_IN : 0;
+        int flags = ((i == 0 && first_relu_in) ? VQVAE_CONV_RELU_IN : 0) | conv_flags;
         if (last < n_layers - 1 || final_relu) flags |= VQVAE_CONV_RELU_OUT;
         float *dst = ((nsteps - 1 - j) % 2 == 0) ? y : tmp;
         const int *ain = amax ? amax + (size_t)i * B : nullptr;
@@ -181,7 +181,9 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
 // vq: quantize inside the last kernel (fused 32x32 path only; z_e is then NOT written and zero_buf is cleared by the FIRST kernel)
 static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, int *zero_buf = nullptr, int zero_n = 0,
-                       bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr) {
+                       bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr, int cf = 0) {
+    // cf: 0 = the default product scheme (two-term fp16 where the kernels have it), VQVAE_CONV_BF16_SPLIT / VQVAE_CONV_EXACT_FP32 =
+    // every layer through the per-layer kernels of that scheme (no fused kernels: they exist for the fp16 products only)
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return VQVAE_ERR_SHAPE;
@@ -203,19 +205,19 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     // encoder.py:29-31, :32-34, :35-36 (+ the residual stack's first in-place ReLU, residual.py:19)
 #ifndef VQVAE_NO_ENC_FRONT_FUSION    // A/B builds (tools/build_variant.py)
     // encoder.py:29-34 in ONE launch on 32x32 RGB images: the 16x16 x h/2 map between the two stride-2 convs is never written
-    if (enc_front_supported(H, W, d->in_ch, h / 2, h)) {
+    if (!cf && enc_front_supported(H, W, d->in_ch, h / 2, h)) {
         if ((rc = enc_front_forward_impl(x, w->enc0, w->enc0_b, w->enc2, w->enc2_b, B, H, W, d->in_ch, h / 2, h, b, st, am1,
                                          vq ? zero_buf : nullptr, vq ? zero_n : 0)) != 0) return rc;
     } else
 #endif
     {
-        if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT, a, st, am0)) != 0) return rc;
-        if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT, b, st, am0, am1)) != 0) return rc;
+        if ((rc = conv_in_forward_impl(x, w->enc0, w->enc0_b, B, H, W, d->in_ch, h / 2, VQVAE_CONV_RELU_OUT | cf, a, st, am0)) != 0) return rc;
+        if ((rc = conv_forward_impl(VQVAE_CONV_4x4_S2, a, w->enc2, w->enc2_b, B, H / 2, W / 2, h / 2, h, VQVAE_CONV_RELU_OUT | cf, b, st, am0, am1)) != 0) return rc;
     }
 #ifndef VQVAE_NO_FRONT_FUSION    // A/B builds (tools/build_variant.py)
     // encoder.py:35-38 + vqvae.py:33 in ONE launch where the shapes allow (8x8 latent maps, h_dim 128, two residual layers):
     // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
-    if (d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
+    if (!cf && d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
         res_pair_post_supported(h, d->embedding_dim)) {
         const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, vq ? nullptr : zero_buf, vq ? 0 : zero_n, vq};
         if (zeroed) *zeroed = zero_buf != nullptr;
@@ -223,7 +225,7 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
                                           d->res_h_dim, VQVAE_CONV_RELU_OUT, nullptr, st, am1, nullptr, &post);
     }
 #endif
-    if ((rc = conv_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT, a, st, am1, am2)) != 0) return rc;
+    if ((rc = conv_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, B, H / 4, W / 4, h, h, VQVAE_CONV_RELU_OUT | cf, a, st, am1, am2)) != 0) return rc;
     const float *t = a;
     const int *amt = am2;
     if (d->n_res_layers > 0) {                                                                  // encoder.py:37-38
@@ -234,18 +236,19 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
         const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e};
         bool post_done = false;
         if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am2,
-                            &post, &post_done)) != 0)
+                            &post, &post_done, cf)) != 0)
             return rc;
         if (post_done) return 0;
         if (am2) amt = am2 + (size_t)d->n_res_layers * B;
     }
     // n_res_layers == 0: F.relu of an already ReLU'd tensor is the identity
-    return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, 0, z_e, st, amt, nullptr);   // vqvae.py:33
+    return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, cf, z_e, st, amt, nullptr);   // vqvae.py:33
 }
 
 // 32x32 RGB images, h_dim 128, two residual layers: the step is four fused conv kernels (+ the quantizer), every per-image
 // maximum that is read has ONE producing wave that stores it plainly -- the maxima arrays need no fill
-static bool fused_c3_path(const VqvaeDims *d, int H, int W) {
+static bool fused_c3_path(const VqvaeDims *d, int H, int W, int cf = 0) {
+    if (cf) return false;
 #if defined(VQVAE_NO_FRONT_FUSION) || defined(VQVAE_NO_ENC_FRONT_FUSION) || defined(VQVAE_NO_DEC_TAIL_FUSION)
     (void)d; (void)H; (void)W;
     return false;
@@ -258,10 +261,24 @@ static bool fused_c3_path(const VqvaeDims *d, int H, int W) {
 #endif
 }
 
+// VQVAE_FWD_CONV_* -> the per-layer product-scheme flag; -1: both at once / unknown bits
+static int conv_scheme(int flags) {
+    const int sel = flags & (VQVAE_FWD_CONV_BF16_SPLIT | VQVAE_FWD_CONV_EXACT_FP32);
+    if (sel == (VQVAE_FWD_CONV_BF16_SPLIT | VQVAE_FWD_CONV_EXACT_FP32)) return -1;
+    return sel == VQVAE_FWD_CONV_BF16_SPLIT ? VQVAE_CONV_BF16_SPLIT : (sel == VQVAE_FWD_CONV_EXACT_FP32 ? VQVAE_CONV_EXACT_FP32 : 0);
+}
+
+int vqvae_encoder_ex_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int flags, float *z_e, void *workspace,
+                         size_t workspace_bytes, vqvae_stream_t stream) {
+    const int cf = conv_scheme(flags);
+    if (cf < 0 || (flags & ~(VQVAE_FWD_CONV_BF16_SPLIT | VQVAE_FWD_CONV_EXACT_FP32))) return VQVAE_ERR_UNSUPPORTED;
+    return encoder_run(w, x, B, H, W, z_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, 0, nullptr,
+                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, H, W, cf), nullptr, cf);
+}
+
 int vqvae_encoder_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                       size_t workspace_bytes, vqvae_stream_t stream) {
-    return encoder_run(w, x, B, H, W, z_e, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr, nullptr, 0, nullptr,
-                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, H, W));
+    return vqvae_encoder_ex_f32(w, x, B, H, W, 0, z_e, workspace, workspace_bytes, stream);
 }
 
 // where z_q's per-image maxima go inside a maxima region (amax_bytes) for the decoder's first layer
@@ -273,7 +290,8 @@ static bool zq_amax_wanted(const VqvaeDims *d, int h4, int w4) {
 
 // zq_amax_given: the quantizer has already published z_q's maxima into the region's slot
 static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
-                       size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false, bool zq_amax_given = false) {
+                       size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false, bool zq_amax_given = false,
+                       int cf = 0) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -300,7 +318,7 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     const int *amt = am;
 #ifndef VQVAE_NO_FRONT_FUSION
     // decoder.py:28-30 in one launch where the shapes allow: conv-transpose 3x3 (+ the stack's first ReLU) and both residual layers
-    const bool front = d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, h, d->res_h_dim);
+    const bool front = !cf && d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, h, d->res_h_dim);
 #else
     const bool front = false;
 #endif
@@ -309,27 +327,35 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
         if ((rc = conv_res_pair_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, d->embedding_dim, w->dec_res_w1, w->dec_res_w2, B, h4,
                                              w4, h, d->res_h_dim, VQVAE_CONV_RELU_OUT, a, st, amz, aout)) != 0) return rc;
         amt = aout;
-    } else if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT, a, st, amz, am)) != 0) return rc;
+    } else if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT | cf, a, st, amz, am)) != 0) return rc;
     if (!front && d->n_res_layers > 0) {
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
-        if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am)) != 0) return rc;
+        if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am,
+                            nullptr, nullptr, cf)) != 0) return rc;
         if (am) amt = am + (size_t)d->n_res_layers * B;
     }
 #ifndef VQVAE_NO_DEC_TAIL_FUSION    // A/B builds (tools/build_variant.py)
     // decoder.py:31-35 in ONE launch on 8x8 latent maps: the 16x16 x h/2 map between the two stride-2 transposed convs is never written
-    if (dec_tail_supported(h4, w4, h, h / 2, d->in_ch))
+    if (!cf && dec_tail_supported(h4, w4, h, h / 2, d->in_ch))
         return dec_tail_forward_impl(t, w->dec2, w->dec2_b, w->dec4, w->dec4_b, B, h4, w4, h, h / 2, d->in_ch, x_hat, st, amt);
 #endif
     float *u = (t == a) ? b : a;
     int *am_u = am ? am + (size_t)(3 + d->n_res_layers) * B : nullptr;       // dec2's output maxima for the last layer
-    if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT, u, st, amt, am_u)) != 0) return rc;
-    return convt_out_forward_impl(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, 0, x_hat, st, am_u);
+    if ((rc = conv_forward_impl(VQVAE_CONVT_4x4_S2, t, w->dec2, w->dec2_b, B, h4, w4, h, h / 2, VQVAE_CONV_RELU_OUT | cf, u, st, amt, am_u)) != 0) return rc;
+    return convt_out_forward_impl(u, w->dec4, w->dec4_b, B, 2 * h4, 2 * w4, h / 2, d->in_ch, cf, x_hat, st, am_u);
+}
+
+int vqvae_decoder_ex_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, int flags, float *x_hat, void *workspace,
+                         size_t workspace_bytes, vqvae_stream_t stream) {
+    const int cf = conv_scheme(flags);
+    if (cf < 0 || (flags & ~(VQVAE_FWD_CONV_BF16_SPLIT | VQVAE_FWD_CONV_EXACT_FP32))) return VQVAE_ERR_UNSUPPORTED;
+    return decoder_run(w, z_q, B, h4, w4, x_hat, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr,
+                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, 4 * h4, 4 * w4, cf), false, cf);
 }
 
 int vqvae_decoder_f32(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
                       size_t workspace_bytes, vqvae_stream_t stream) {
-    return decoder_run(w, z_q, B, h4, w4, x_hat, workspace, workspace_bytes, static_cast<hipStream_t>(stream), nullptr,
-                       w && dims_ok(&w->dims) && fused_c3_path(&w->dims, 4 * h4, 4 * w4));
+    return vqvae_decoder_ex_f32(w, z_q, B, h4, w4, 0, x_hat, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"
@@ -391,7 +417,9 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     hipStream_t st = static_cast<hipStream_t>(stream);
     // two fill launches per step saved on the fused 32x32 path: the maxima need none there, and the quantizer's histogram
     // is cleared by the encoder's last kernel
-    const bool fused = fused_c3_path(d, H, W);
+    const int cf = conv_scheme(vq_flags);
+    if (cf < 0) return VQVAE_ERR_UNSUPPORTED;
+    const bool fused = fused_c3_path(d, H, W, cf);
     if (!fused && hipMemsetAsync(am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
     int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(am2) + amax_bytes(d, B));
     int rc;
@@ -409,14 +437,15 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                         // :36
     }
     bool zq_amax_done = false;
-    if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed)) != 0)
+    if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed, false,
+                          nullptr, cf)) != 0)
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                               (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
                                            VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)) | VQVAE_VQ_ROWMAJOR,
                               z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
                               zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
-    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done);        // :36
+    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf);    // :36
 }
 
 
@@ -434,7 +463,7 @@ int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int 
     FwdWs f;
     int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
     if (rc != VQVAE_OK) return rc;
-    if (!fused_c3_path(d, H, W) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
+    if (!fused_c3_path(d, H, W, conv_scheme(vq_flags)) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, f.vqws, f.vqws_bytes, st)) != 0) return rc;
     if (hipMemsetAsync(f.hist, 0, (size_t)d->n_embeddings * sizeof(int32_t), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
@@ -451,7 +480,7 @@ int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int64_t B, int
     FwdWs f;
     int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
     if (rc != VQVAE_OK) return rc;
-    if (!fused_c3_path(d, H, W) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
+    if (!fused_c3_path(d, H, W, conv_scheme(vq_flags)) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t per_img = f.act / (size_t)B, lat = (size_t)(H / 4) * (W / 4);
     // this part's own two activation buffers and maxima regions inside the whole batch's

@@ -16,6 +16,9 @@ VQ_BF16_FILTER = 0x8
 VQ_TOP3_KEYS = 0x10
 VQ_SIXTEEN_WAVES = 0x20
 VQ_UNFUSED = 0x40
+# whole-path product scheme (vqvae_forward_f32 / vqvae_encoder_ex_f32 / vqvae_decoder_ex_f32)
+FWD_CONV_BF16_SPLIT = 0x1000
+FWD_CONV_EXACT_FP32 = 0x2000
 
 
 def _stream_ptr(t: torch.Tensor) -> int:

@@ -302,10 +302,12 @@ class VQVAE(nn.Module):
         _lib.check(L.vqvae_forward_end_f32(cw, B, H, W, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), nws, stream))
         return True
 
-    def _forward_c(self, x, want_idx=False, vq_flags=0, parts=None):
+    def _forward_c(self, x, want_idx=False, vq_flags=0, parts=None, fwd_flags=0):
         """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32).  vq_flags: extra quantizer flags for tests and
         A/B runs (functional.VQ_UNFUSED: the quantizer as its own launch where the encoder's last kernel would quantize).
-        parts: None = the default policy (FORWARD_PARTS side streams for large batches), 1 = always the single call, n = n parts."""
+        parts: None = the default policy (FORWARD_PARTS side streams for large batches), 1 = always the single call, n = n parts.
+        fwd_flags: functional.FWD_CONV_BF16_SPLIT / FWD_CONV_EXACT_FP32 = the whole path on the three-term bf16 / exact-fp32 MFMA
+        kernels instead of the default two-term fp16 products."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
@@ -334,7 +336,7 @@ class VQVAE(nn.Module):
             x_hat = torch.empty_like(x)
             scal = torch.empty(2, dtype=torch.float32, device=dev)
             idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev) if want_idx else None
-            flags = (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags
+            flags = (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags | fwd_flags
             if not self._forward_parts(L, cw, x, B, H, W, flags, x_hat, scal, idx, ws, nws, vws, dev, stream, parts):
                 _lib.check(L.vqvae_forward_f32(cw, x.data_ptr(), B, H, W, flags, x_hat.data_ptr(), scal.data_ptr(), scal.data_ptr() + 4,
                                                idx.data_ptr() if want_idx else None, ws.data_ptr(), nws, vws.data_ptr(), vws.numel(),
