@@ -50,6 +50,7 @@ HBM_ACHIEVABLE_GBPS = 6290.0
 MFMA_16BIT_PEAK_TFLOPS = 2500.0   # dense bf16 / fp16 MFMA
 MFMA_FP32_PEAK_TFLOPS = 157.3     # fp32 MFMA (256 flop / clk / CU x 256 CUs x 2.4 GHz)
 MFMA_F32_PEAK_TFLOPS = 157.3      # exact-fp32 MFMA = vector rate
+CALIB_REFERENCE_TFLOPS = 1700.0   # what the calibration stream sustained on the box of profiles/r03_mfma_power.txt (1 701 TF at 1.69 GHz)
 
 # name -> (description, per-GPU batch, H = W, K, D, conv backend)
 WORKLOADS = {
@@ -148,8 +149,45 @@ def cpu_baseline(seconds: float, torch):
     except OSError:
         pass
     return {"value": round(best, 1), "unit": "images/s", "cores": best_t, "kind": "port",
+            "kind_detail": "port (oracle/torch_port.py = the reference's ATen ops); BEST of a threads x batch sweep, not SURVEY 8d's "
+                           "single B=32 / nproc-threads point: generous to the CPU",
             "sample": "VQVAE.forward 32x32x3 K=512 D=64 fp32 eval/no_grad on the host CPU (" + cpu +
                       f", {ncpu} logical cpus); ~{per:.1f}s per (threads,batch) point, img/s: " + " ".join(detail)}
+
+
+def calibrate(torch, dev, seconds=0.6):
+    """Box calibration: a bare fp16 MFMA stream on random operands (vqvae_calibration_mfma_f16, the kernel
+    of tools/ubench/mfma_power.hip) for ~`seconds` right before the timed region.  The sustained rate of that stream is set by
+    the clock the chip holds at its power limit, which differs from box to box by more than a round's kernel work does
+    (profiles/r03_notes.txt section 10: 0.905 ... 1.09 ms per step for one build); with it in the line a reader can tell
+    "box" from "build".  Returns TFLOP/s and the in-kernel shader clock of the LAST launch (the clock needs ~1 s of load to settle;
+    the earlier launches bring the chip there)."""
+    import ctypes
+    from vqvae_amd import _lib
+    L = _lib.load()
+    nb = L.vqvae_calibration_scratch_bytes()
+    scratch = torch.empty(nb, dtype=torch.uint8, device=dev)
+    iters = 20000
+    st = torch.cuda.current_stream(dev).cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0, ms, launches = time.perf_counter(), 0.0, 0
+    while True:
+        e0.record()
+        _lib.check(L.vqvae_calibration_mfma_f16(iters, scratch.data_ptr(), nb, st))
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        launches += 1
+        if time.perf_counter() - t0 >= seconds:
+            break
+    clk = scratch[:512 * 16].view(torch.int64).view(512, 2).double().cpu()
+    ghz = float((clk[:, 0] / (clk[:, 1] * 10e-9)).mean() / 1e9)
+    tf = L.vqvae_calibration_flops(iters) / (ms * 1e-3) / 1e12
+    del scratch
+    return {"mfma_fp16_random_tflops": round(tf, 1), "sclk_ghz": round(ghz, 3), "launches": launches,
+            "seconds": round(time.perf_counter() - t0, 2), "reference_tflops": CALIB_REFERENCE_TFLOPS,
+            "kernel": "vqvae_calibration_mfma_f16: bare v_mfma_f32_32x32x16_f16 stream, random operands, 2 waves/SIMD on every CU "
+                      "(tools/ubench/mfma_power.hip); figures of the last launch"}
 
 
 def source_sha():
@@ -186,14 +224,14 @@ def pmc_traffic(workload: str, vq_kernel: str):
     return d, None
 
 
-def index_flips(model, x, torch):
+def index_flips(model, x, torch, fwd_flags=0):
     """min_encoding_indices of the HIP path against the reference's algorithm (oracle/torch_port.py) on THIS batch: every
     row compared, the flips counted (z_e differs by conv rounding noise, so rows whose two best codes are closer than that
     may flip: SURVEY.md 8c expects <= 1e-4).  Checker only; runs after the timed region."""
     from oracle import torch_port
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     with torch.no_grad():
-        out = model._forward_c(x, want_idx=True)
+        out = model._forward_c(x, want_idx=True, fwd_flags=fwd_flags)
         got = out[3].view(-1).cpu()
         xc = x.cpu()
         want = []
@@ -300,7 +338,9 @@ def other_workload(name, torch, dev, seconds=1.0):
            "ms_per_step": round(el / steps * 1e3, 4), "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps}
     if vq_n:
         t_vq = vq_ms / vq_n * 1e-3
-        res["vq"] = {"kernel": _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0), "avg_kernel_us": round(t_vq * 1e6, 2),
+        # (VQVAE.forward hands the quantizer row-major rows with BOTH conv backends -- the torch backend permutes z_e itself,
+        # vqvae_amd/conv.py -- so the kernel is the row-major one; round 3 printed the NCHW kernel's name here by mistake)
+        res["vq"] = {"kernel": _lib.vq_kernel_name(K, D, 0x1), "avg_kernel_us": round(t_vq * 1e6, 2),
                      "hbm_GBps": round(rows * (8 * D + 8) / t_vq / 1e9, 1),
                      "hbm_frac": round(rows * (8 * D + 8) / t_vq / 1e9 / HBM_PEAK_GBPS, 4),
                      # at K >= 1024 the screen is matrix-bound, not HBM-bound
@@ -314,6 +354,45 @@ def other_workload(name, torch, dev, seconds=1.0):
         res["conv"] = {"ms_per_step": round(t_conv * 1e3, 4), "term_products_per_mac": terms,
                        "achieved_algorithmic_tflops": round(alg_tf, 1), "issued_tflops_16bit": round(terms * alg_tf, 1),
                        "mfma_frac": round(terms * alg_tf / MFMA_16BIT_PEAK_TFLOPS, 4), "timing": "hip-event brackets (event_inflated)"}
+    del model, x
+    torch.cuda.empty_cache()
+    return res
+
+
+def scheme_leg(scheme, torch, dev, seconds=1.0):
+    """BASELINE config 3 with the whole path on another product scheme (the headline beside the same step in
+    exacter arithmetic, same box, same batch): 'bf16x3' = VQVAE_FWD_CONV_BF16_SPLIT (three-term bf16 products, per-layer kernels),
+    'fp32' = VQVAE_FWD_CONV_EXACT_FP32 (exact-fp32 MFMA kernels: the reference's arithmetic up to summation order)."""
+    import statistics
+    from vqvae_amd import conv as conv_mod, functional as F_hip
+    from vqvae_amd.modules import VQVAE
+    desc, B, HW, K, D, _ = WORKLOADS["c3"]
+    flags = {"bf16x3": F_hip.FWD_CONV_BF16_SPLIT, "fp32": F_hip.FWD_CONV_EXACT_FP32}[scheme]
+    conv_mod.set_conv_backend("hip")
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+    x = torch.randn(B, 3, HW, HW, generator=torch.Generator().manual_seed(1000)).to(dev)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                model._forward_c(x, fwd_flags=flags)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2)
+    steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
+    times = [run(steps) for _ in range(5)]
+    el = statistics.median(times)
+    res = {"workload": desc + {"bf16x3": " -- every conv layer on three-term bf16 products (6 MFMAs per fp32 product, <= 3 * 2^-24 rel "
+                                         "per product, no operand scales), per-layer kernels",
+                               "fp32": " -- every conv layer on the exact-fp32 MFMA kernels (v_mfma_f32_32x32x2_f32)"}[scheme],
+           "flag": {"bf16x3": "VQVAE_FWD_CONV_BF16_SPLIT", "fp32": "VQVAE_FWD_CONV_EXACT_FP32"}[scheme],
+           "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps,
+           "index_flips_vs_reference": index_flips(model, x, torch, flags)}
     del model, x
     torch.cuda.empty_cache()
     return res
@@ -411,6 +490,9 @@ def main():
             el = float(t.item())
         return el, out
 
+    calib = None
+    if not dry:
+        calib = calibrate(torch, dev)                  # every rank: the GPUs enter the timed region equally warm
     for _ in range(args.warmup):
         step()
     first, out = timed_repeat()
@@ -481,18 +563,23 @@ def main():
                        "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 4),
                        "timed_seconds_total": round(sum(times), 3)},
         }
+        if calib:
+            line["calibration"] = calib
+            # the same build on the calibration's reference box: value x (reference / measured) -- a first-order correction (the
+            # step is matrix-bound: 93 % of it is conv kernels at 60-70 % of this stream's rate)
+            line["value_normalised"] = round(line["value"] * CALIB_REFERENCE_TFLOPS / max(calib["mfma_fp16_random_tflops"], 1.0), 1)
         if dry:
             line["dry_run"] = True
             line["data"] = "dry-run stub (no kernels ran; not a measurement)"
         else:
             rows = B * (H // 4) * (W // 4)
-            pmc, pmc_stale = pmc_traffic(args.workload, _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0))
+            pmc, pmc_stale = pmc_traffic(args.workload, _lib.vq_kernel_name(K, D, 0x1))
             if vq_n:
                 t_vq = vq_ms / vq_n * 1e-3                     # seconds per launch
                 alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
                 achieved = alg_bytes / t_vq / 1e9
                 line["roofline"] = {
-                    "kernel": _lib.vq_kernel_name(K, D, 0x1 if conv_backend == "hip" else 0x0) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
+                    "kernel": _lib.vq_kernel_name(K, D, 0x1) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
                               "fp32 refine of the surviving codes; bit-exact indices)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
@@ -566,6 +653,9 @@ def main():
             if n_gpus == 1 and args.workload == "c3" and not args.no_other_workloads and not args.batch:
                 del out
                 line["other_workloads"] = {w: other_workload(w, torch, dev) for w in ("c2", "c4", "c5")}
+                # the headline's step in the two exacter product schemes, same box and batch (the headline itself = "fp16x2")
+                line["other_workloads"]["c3_bf16x3"] = scheme_leg("bf16x3", torch, dev)
+                line["other_workloads"]["c3_fp32"] = scheme_leg("fp32", torch, dev)
                 try:                                   # a next-row figure: its failure must not take the headline line with it
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)

@@ -68,6 +68,14 @@ VQVAE_API const char *vqvae_strerror(int code);
 VQVAE_API int vqvae_profile_enable(int on);
 VQVAE_API int vqvae_profile_collect(int kernel_id, double *total_ms, int *launches);
 
+/* Box calibration (bench.py): one launch of a bare fp16 MFMA stream on random operands (512 workgroups x 4 waves, `iters` x 4
+ * v_mfma_f32_32x32x16_f16 per wave = vqvae_calibration_flops(iters) flop); the caller times it with events.  scratch (at least
+ * vqvae_calibration_scratch_bytes()): afterwards 512 pairs of uint64 {shader cycles, 100 MHz ticks} of each workgroup's loop
+ * -- cycles / (ticks * 10 ns) = the clock the chip held under this load -- followed by the kernel's (meaningless) sums.       */
+VQVAE_API size_t vqvae_calibration_scratch_bytes(void);
+VQVAE_API double vqvae_calibration_flops(int iters);
+VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratch_bytes, vqvae_stream_t stream);
+
 /* ---------------------------------------------------------------- quantizer */
 
 /* flags for vqvae_vq_forward_f32 */

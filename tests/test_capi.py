@@ -140,11 +140,13 @@ def test_host_side_plans_without_gpu():
     assert L.vqvae_conv_term_products(7, 8, 8, 128, 128, 0) == 0                  # unknown kind
     # packed weights: fp32 image + three-term bf16 image + header + two-term fp16 image (4x4 s2: both in two chunk orders)
     cells = 9 * 4 * 4                                                            # taps x Cin chunks x Cout tiles
-    assert L.vqvae_conv_packed_bytes(1, 128, 128) == cells * (4096 + 6144) + 256 + cells * 4096
+    # header (round 4): 64 ints + one float (2^-kw[c]) and one int (kw[c]) per output channel of the 32-channel tiles
+    hdr = lambda ntile: 256 + 256 * ntile
+    assert L.vqvae_conv_packed_bytes(1, 128, 128) == cells * (4096 + 6144) + hdr(4) + cells * 4096
     cells = 16 * 2 * 4
-    assert L.vqvae_conv_packed_bytes(0, 64, 128) == cells * (4096 + 2 * 6144) + 256 + 2 * cells * 4096
+    assert L.vqvae_conv_packed_bytes(0, 64, 128) == cells * (4096 + 2 * 6144) + hdr(4) + 2 * cells * 4096
     # [fp32][three-term bf16][header][two-term fp16][A-operand image of the fused decoder tail: 16 KiB]
-    assert L.vqvae_convt_out_packed_bytes(64, 3) == 2 * 2 * (4096 + 6144) + 256 + 2 * 2 * 4096 + 16384
+    assert L.vqvae_convt_out_packed_bytes(64, 3) == 2 * 2 * (4096 + 6144) + hdr(1) + 2 * 2 * 4096 + 16384
     # whole-path workspace covers two activation buffers, the latents and the two maxima regions
     dims = _lib.VqvaeDims(128, 32, 2, 512, 64, 3, 0.25)
     ws = L.vqvae_workspace_bytes(dims, 4096, 32, 32)

@@ -44,6 +44,9 @@ SIGNATURES = {
     "vqvae_strerror": (C.c_char_p, [_i32]),
     "vqvae_profile_enable": (_i32, [_i32]),
     "vqvae_profile_collect": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
+    "vqvae_calibration_scratch_bytes": (_sz, []),
+    "vqvae_calibration_flops": (C.c_double, [_i32]),
+    "vqvae_calibration_mfma_f16": (_i32, [_i32, _vp, _sz, _vp]),
     "vqvae_vq_kernel_name": (C.c_char_p, [_i32, _i32, _i32]),
     "vqvae_vq_screen_sweeps": (_i32, [_i32, _i32, _i32]),
     "vqvae_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),

@@ -14,6 +14,38 @@ struct ProfState {
 } g_prof;
 }  // namespace
 
+// one launch = kCalibBlocks x 4 waves (two per SIMD on 256 CUs), `iters` x four independent MFMAs per wave; operands from a
+// fixed pseudo-random sequence (the power draw, and with it the clock, depends on the operand bits: zeros run 40 % faster);
+// clk[2 b] = shader cycles, clk[2 b + 1] = 100 MHz ticks of block b's first wave around its loop
+constexpr int kCalibBlocks = 512;
+typedef _Float16 calib_f16x8 __attribute__((ext_vector_type(8)));
+typedef float calib_f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void calib_mfma_kernel(float *__restrict__ out, unsigned long long *__restrict__ clk, int iters) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    calib_f16x8 a0, a1, b0, b1;
+    unsigned s = 0x9E3779B9u * (unsigned)(lane + 1);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        auto next = [&]() { s = s * 1664525u + 1013904223u; return (_Float16)((float)(s >> 8) * (1.0f / 16777216.0f) - 0.5f); };
+        a0[q] = next(); a1[q] = next(); b0[q] = next(); b1[q] = next();
+    }
+    calib_f32x16 y[4];
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) y[j][r] = 0.0f;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+#pragma unroll 1
+    for (int i = 0; i < iters; ++i) {
+        y[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b0, y[0], 0, 0, 0);
+        y[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b0, y[1], 0, 0, 0);
+        y[2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a0, b1, y[2], 0, 0, 0);
+        y[3] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, y[3], 0, 0, 0);
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    float acc = 0.0f;
+    for (int j = 0; j < 4; ++j) for (int r = 0; r < 16; ++r) acc += y[j][r];
+    out[(size_t)blockIdx.x * 256 + tid] = acc;
+    if (tid == 0) { clk[2 * blockIdx.x] = c1 - c0; clk[2 * blockIdx.x + 1] = w1 - w0; }
+}
+
 void prof_begin(int id, hipStream_t st) {
     if (!g_prof.on || id < 0 || id >= VQVAE_PROF_NUM_IDS || g_prof.n[id] >= kMaxRec) return;
     const int i = g_prof.n[id];
@@ -61,6 +93,24 @@ int vqvae_profile_collect(int kernel_id, double *total_ms, int *launches) {
 }
 
 int vqvae_abi_version(void) { return VQVAE_HIP_ABI_VERSION; }
+
+// ---- box calibration (round 4): a bare stream of v_mfma_f32_32x32x16_f16 on RANDOM operands, two waves
+// per SIMD, what tools/ubench/mfma_power.hip measures: the chip's sustained matrix rate on this data is set by the clock it
+// holds at its power limit, and that differs from box to box (profiles/r03_notes.txt section 10).  bench.py runs it for a
+// fraction of a second before the timed region and prints TFLOP/s and the in-kernel shader clock next to the step time.
+int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratch_bytes, vqvae_stream_t stream) {
+    if (!scratch) return VQVAE_ERR_NULL;
+    if (iters < 1) return VQVAE_ERR_SHAPE;
+    if (scratch_bytes < vqvae_calibration_scratch_bytes()) return VQVAE_ERR_WORKSPACE;
+    char *p = static_cast<char *>(scratch);
+    hipLaunchKernelGGL(vqvae::calib_mfma_kernel, dim3(vqvae::kCalibBlocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       reinterpret_cast<float *>(p + 16 * vqvae::kCalibBlocks), reinterpret_cast<unsigned long long *>(p), iters);
+    return (int)hipGetLastError();
+}
+
+size_t vqvae_calibration_scratch_bytes(void) { return (size_t)vqvae::kCalibBlocks * (16 + 256 * sizeof(float)); }
+
+double vqvae_calibration_flops(int iters) { return (double)vqvae::kCalibBlocks * 4 * (double)iters * 4 * 2.0 * 32 * 32 * 16; }
 
 const char *vqvae_strerror(int code) {
     switch (code) {
