@@ -115,7 +115,15 @@ def test_encode_decode_indices_wire_format(golden_models):
         _, x_hat_ref, _ = m(xd)
     # decode_indices uses e_k itself, forward uses z + (e_k - z): equal to fp32 rounding of z_q
     np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_ref.cpu().numpy(), atol=1e-6, rtol=1e-5)
-    assert (idx.cpu().numpy().reshape(-1) == golden_models[f"{name}/idx"]).mean() > 0.999
+    # indices against the reference's: exact except provable near-ties (fp64 gap below 8 eps32 (|z|^2 + |e|^2))
+    got, want = idx.cpu().numpy().reshape(-1), golden_models[f"{name}/idx"].astype(np.int64).reshape(-1)
+    cb = m.vector_quantization.embedding.weight.detach().cpu().double().numpy()
+    zr = np.transpose(golden_models[f"{name}/z_e"], (0, 2, 3, 1)).reshape(-1, D).astype(np.float64)
+    for r in np.nonzero(got != want)[0]:
+        d = ((zr[r][None, :] - cb) ** 2).sum(1)
+        assert abs(d[got[r]] - d[want[r]]) <= 8 * 2.0 ** -24 * ((zr[r] ** 2).sum() + (cb[want[r]] ** 2).sum()), \
+            f"row {r}: index {got[r]} vs reference {want[r]} is not a near-tie"
+    assert (got != want).sum() <= max(1, int(1e-4 * got.size))
 
 
 def test_forward_only_and_no_cpu_fallback():
@@ -561,6 +569,34 @@ def test_baseline_configs_4_and_5_at_full_size_properties(name, B, S, K, D):
         np.testing.assert_allclose(ppl.item(), float(torch.exp(-(p * torch.log(p + 1e-10)).sum())), rtol=1e-5)
         x_dec = m.decode_indices(idx, B, S // 4, S // 4)
         np.testing.assert_allclose(x_dec.cpu().numpy(), x_hat.cpu().numpy(), atol=1e-6, rtol=1e-5)
+        #  sampled images of the FULL-batch run against the reference's algorithm, stage by stage: the grid-size
+        # dependent paths (sixteen slabs per resolve group, persistent last layer, halo tile counts beyond one wave round) meet
+        # the oracle here and not only themselves.  z_e of the sampled images comes from the same launch configuration
+        # (vqvae_encoder_f32 on the whole batch); indices must equal the C oracle's on those z_e bits; x_hat of an image
+        # without a flip against the reference's decoder on the reference's z_q.
+        from oracle import c_oracle, torch_port
+        from vqvae_amd import _lib
+        L = _lib.load()
+        cw, _keep = m._c_weights()
+        nws = L.vqvae_workspace_bytes(cw.dims, B, S, S)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+        z_e = torch.empty(B, S // 4, S // 4, D, device=dev())
+        _lib.check(L.vqvae_encoder_f32(cw, x.data_ptr(), B, S, S, z_e.data_ptr(), ws.data_ptr(), nws, torch.cuda.current_stream().cuda_stream))
+        del ws
+        sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+        rows = (S // 4) ** 2
+        for b in (0, B // 3, B - 1):                       # first, middle, last image (last slab / last workgroups)
+            xb = x[b:b + 1].cpu()
+            z_ref = torch_port.encode(sd, xb.clone(), 2)
+            zb = z_e[b].permute(2, 0, 1).unsqueeze(0).cpu().contiguous()
+            np.testing.assert_allclose(zb.numpy(), z_ref.numpy(), atol=2e-6, rtol=0, err_msg=f"z_e of image {b}")
+            own = c_oracle.vq_forward(zb.numpy(), sd["vector_quantization.embedding.weight"].numpy(), 0.25)["idx"].reshape(-1)
+            got_b = idx.view(B, rows)[b].cpu().numpy()
+            assert np.array_equal(got_b, own), f"image {b}: {int((got_b != own).sum())} indices differ from the C oracle on the device's z_e bits"
+            _, zq_ref, _, _, idx_ref = torch_port.quantize(z_ref, sd["vector_quantization.embedding.weight"], 0.25)
+            if np.array_equal(got_b, idx_ref.numpy().reshape(-1)):
+                xh_ref = torch_port.decode(sd, zq_ref.clone(), 2)
+                np.testing.assert_allclose(x_hat[b:b + 1].cpu().numpy(), xh_ref.numpy(), atol=1e-5, rtol=1e-4, err_msg=f"x_hat of image {b}")
 
 
 @pytest.mark.parametrize("B,parts", [(4096, 4), (4096, 3), (1000, 4), (2112, 2), (4097, 4), (200, 8)])
