@@ -126,7 +126,8 @@ def test_host_side_plans_without_gpu():
     assert _lib.vq_kernel_name(1024, 64) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"
-    assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_filter_kernel_d64"          # NCHW rows
+    assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_track_kernel_d64"           # NCHW rows (maps of 64 k pixels; round 4)
+    assert _lib.vq_kernel_name(1024, 64, 0x0) == "vq_filter_kernel_d64"         # NCHW, codebook beyond the LDS-resident image
     assert _lib.vq_kernel_name(512, 256) == "vq_exact_kernel"
     assert _lib.vq_sweeps(512, 64) == 1 and _lib.vq_sweeps(512, 64, 0x1 | 0x8) == 2 and _lib.vq_sweeps(512, 256) == 0
     # the streamed kernels' scratch does not grow with the row count (slabs of 2^18 rows)

@@ -19,14 +19,14 @@ def _dev():
 
 
 def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, top3_keys=False,
-         sixteen_waves=False):
+         sixteen_waves=False, inline_exact=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
                                             exact_sweep=exact, bf16_filter=bf16_filter, top3_keys=top3_keys,
-                                            sixteen_waves=sixteen_waves)
+                                            sixteen_waves=sixteen_waves, inline_exact=inline_exact)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -34,7 +34,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "top3_keys", "sixteen_waves", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "inline_exact", "top3_keys", "sixteen_waves", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -43,7 +43,7 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
     loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter",
-                                    top3_keys=kernel == "top3_keys", sixteen_waves=kernel == "sixteen_waves")
+                                    top3_keys=kernel == "top3_keys", sixteen_waves=kernel == "sixteen_waves", inline_exact=kernel == "inline_exact")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -71,6 +71,11 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     (512, 32, 7, 9, 5, 1.0),
     (300, 256, 2, 6, 6, 1.0),
     (1, 64, 2, 4, 4, 1.0),           # single code
+    # round 4: the stream-tracker kernel on NCHW input (maps whose pixel count is a multiple of 64: a unit = 64 positions of
+    # one image) -- several units per image, a 3136-pixel map (49 units), K % 32 != 0
+    (512, 64, 3, 16, 16, 0.066),
+    (500, 64, 40, 8, 16, 1.0),
+    (256, 64, 2, 56, 56, 0.066),
 ])
 def test_vq_matches_oracle_fresh(K, D, B, H, W, scale):
     from oracle import c_oracle
@@ -113,6 +118,10 @@ def test_vq_filter_adversarial_near_ties():
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
+    for rowmajor in (False, True):                                               # round 3's inline exact part, both layouts
+        loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor, inline_exact=True)
+        np.testing.assert_array_equal(idx, ref["idx"])
+        assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
     loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, sixteen_waves=True)       # 32-row units: rescan / hard-row paths of that form
     np.testing.assert_array_equal(idx, ref["idx"])
     assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
@@ -181,7 +190,7 @@ def _oracle_vq_chunked(z, cb, beta, n_chunks=64, workers=32):
     return np.concatenate([o["idx"] for o in outs]), np.concatenate([o["z_q"] for o in outs])
 
 
-@pytest.mark.parametrize("B,H,W", [(4096, 8, 8), (2100, 7, 9)], ids=["config3_262144rows", "ragged_132300rows"])
+@pytest.mark.parametrize("B,H,W", [(4096, 8, 8), (2100, 7, 9), (16384, 8, 8)], ids=["config3_262144rows", "ragged_132300rows", "1048576rows_queue_flushes_inside_the_loop"])
 def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     """BASELINE config-3 size against the ORACLE (not against the kernels themselves): 262 144 rows of the benchmark
     distribution, and a ragged row count above 131 072 (rows % 64 != 0, several pairs per wave) -- indices and z_q
@@ -191,7 +200,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
     z = torch.randn(B, D, H, W, generator=g) * 0.066
     ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
-    for kw in ({}, {"top3_keys": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
+    for kw in ({}, {"inline_exact": True}, {"top3_keys": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
         loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
         np.testing.assert_array_equal(idx, ref_idx)
         assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))

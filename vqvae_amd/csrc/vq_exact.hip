@@ -467,11 +467,15 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
     if constexpr (D == 64) {
-        if (rowmajor && vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
+        // NCHW maps whose pixel count is a multiple of 64 (a unit = 64 positions of one image): the stream-tracker kernel reads
+        // and writes the reference's own layout (round 4); other NCHW maps stay on the two-sweep kernel below
+        const bool track_nchw = !rowmajor && vq_track_nchw_ok(K, D, HW) &&
+                                !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES));
+        if (track_nchw || (rowmajor && vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
-            const int rc = (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)))
-                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid)
+            const int rc = (track_nchw || (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))))
+                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw, (flags & VQVAE_VQ_INLINE_EXACT) != 0)
                                : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, (flags & VQVAE_VQ_SIXTEEN_WAVES) != 0);
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
@@ -551,6 +555,10 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_sweep_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER))
             return (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))) ? "vq_track_kernel_d64" : "vq_sweep_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
+        // NCHW (the module boundary): the stream-tracker kernel on maps whose pixel count is a multiple of 64 (8x8, 56x56, 64x64
+        // ...: what this function answers for); other NCHW maps run vq_filter_kernel_d64
+        if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)) && vq_track_ok(K, D))
+            return "vq_track_kernel_d64";
         if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
     }
     if (D == 128 && (flags & VQVAE_VQ_ROWMAJOR) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)) && vq_chunk_ok(K, D))
