@@ -99,9 +99,6 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
                                         chip at 262 144 rows, no faster inside the forward, and its 92 spilled registers cost 1.6x the
                                         algorithmic traffic: not the default */
 
-#define VQVAE_VQ_INLINE_EXACT   0x80 /* vq_track_kernel_d64 only: resolve every unit's open rows inside the unit (round 3's four-tasks-per-pass
-                                       * chains) instead of queueing them for a pass of one lane per task (round 4's default).  Same
-                                       * bits; A/B timing and tests of the inline path (which hard / non-finite rows always take) */
 #define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
                                         kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 512, D = 64: z_e is
                                         then never written); identical outputs, A/B timing and tests */

@@ -149,3 +149,17 @@ def test_onehot_and_decode_indices():
     zq = c_oracle.decode_indices(out["idx"], cb.numpy(), B, H, W)
     ref = (torch.from_numpy(oh) @ cb).view(B, H, W, D).permute(0, 3, 1, 2).numpy()
     np.testing.assert_array_equal(zq, ref)
+
+
+def test_hetero_unit_fixture_is_the_oracle():
+    """tests/golden/vq_hetero_unit.npz (round 4's regression unit for the quantizer kernels): its stored indices and z_q are
+    what the C oracle AND the reference's ATen ops (oracle/torch_port.py) compute for its rows and codebook."""
+    import os
+    import torch
+    from oracle import c_oracle, torch_port
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "vq_hetero_unit.npz"))
+    z = np.ascontiguousarray(d["z_rows"].reshape(1, 8, 8, 64).transpose(0, 3, 1, 2))
+    out = c_oracle.vq_forward(z, d["codebook"], 0.25)
+    assert np.array_equal(out["idx"].reshape(-1), d["idx"]) and np.array_equal(out["z_q"].view(np.uint32), d["z_q"].view(np.uint32))
+    t = torch_port.quantize(torch.from_numpy(z), torch.from_numpy(d["codebook"]), 0.25)
+    assert np.array_equal(t[4].numpy().reshape(-1), d["idx"]) and np.array_equal(t[1].numpy().view(np.uint32), d["z_q"].view(np.uint32))

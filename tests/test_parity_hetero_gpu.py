@@ -139,8 +139,18 @@ def test_whole_path_on_heterogeneous_channel_scales(weights, images, scheme, cap
         own_t = torch_port.quantize(torch.from_numpy(ze).contiguous(), cbk, 0.25)[4].numpy().reshape(-1)
     host_disagree = int((own != own_t).sum())
     got = idx.cpu().numpy().reshape(-1)
-    assert np.array_equal(got, own), \
-        f"{int((got != own).sum())} indices differ from the C oracle on the device's own z_e bits (torch on this host differs from the C oracle on {host_disagree} rows)"
+    if not np.array_equal(got, own):
+        rows = np.nonzero(got != own)[0]
+        zrows = np.transpose(ze, (0, 2, 3, 1)).reshape(-1, D)
+        diag = []
+        for r in rows[:4]:
+            one = c_oracle.vq_forward(np.ascontiguousarray(zrows[r].reshape(1, D, 1, 1)), cbk.numpy(), 0.25, want_dist=True)
+            dd = one["dist"][0]
+            diag.append(f"row {r} (image {r // 64}): device {got[r]} oracle {own[r]} fp32 d[device]={dd[got[r]]!r} d[oracle]={dd[own[r]]!r} "
+                        f"min={dd.min()!r} argmin={int(dd.argmin())} ties_at_min={int((dd == dd.min()).sum())} |z|^2={float((zrows[r].astype(np.float64) ** 2).sum()):.6g} "
+                        f"finite={bool(np.isfinite(zrows[r]).all())} max|z|={float(np.abs(zrows[r]).max()):.4g}")
+        raise AssertionError(f"{len(rows)} indices differ from the C oracle on the device's own z_e bits (torch on this host differs from the "
+                             f"C oracle on {host_disagree} rows): " + " ;; ".join(diag))
     # ... and every flip against the reference's indices explained by the z_e tolerance
     want = ref["idx"].numpy().reshape(-1)
     flips = np.nonzero(got != want)[0]

@@ -3,6 +3,11 @@
 8 bytes whose soffset is an SGPR, followed within two instructions by a vector instruction that writes one of its data
 registers.  LLVM's hazard recognizer exempts the SGPR-soffset form (GCNHazardRecognizer::createsVALUHazard); on MI355X the
 overwrite corrupts the last dword of the last lanes of each row (found with vq_track_kernel_d64's z_q stores, round 3).
+Round 4 added a second pattern, a MISCOMPILE rather than a hazard: four __builtin_amdgcn_fdot2 calls on the components of one
+loaded 16-byte vector came out as four `v_dot2c_f32_f16 vD, vS, vS` reading the SAME register vS (the first component), so a
+row norm was 4 (x0^2 + x1^2) instead of the sum over eight values; the sources now use inline assembly (common.h, sqsum8_f16).
+Two or more dot2c instructions with identical destination AND identical sources inside a window of four instructions, with no
+write to that source in between, are reported.
 usage: hazard_scan.py file.s [...]   exit code 1 if a site is found."""
 import re
 import sys
@@ -35,6 +40,21 @@ def scan(path):
             if regs(dst) & data:
                 print(f"{path}:{i + 1}: {l}\n{path}:{i2 + 1}:     {l2}   <- overwrites store data after {j} wait state(s)")
                 found += 1
+    # ---- repeated v_dot2c on one source register (the fdot2 miscompile)
+    for n, (i, l) in enumerate(ins):
+        m = re.match(r'v_dot2c_f32_f16(?:_e32)?\s+(v\d+),\s*(v\d+),\s*(v\d+)\s*$', l)
+        if not m or m.group(2) != m.group(3):
+            continue
+        for i2, l2 in ins[n + 1:n + 4]:
+            op = l2.split()[0]
+            if l2 == l:
+                print(f"{path}:{i + 1}: {l}\n{path}:{i2 + 1}:     {l2}   <- the same dot product twice: the fdot2 miscompile (common.h, sqsum8_f16)")
+                found += 1
+                break
+            if op.startswith(('v_', 'ds_read', 'buffer_load', 'global_load')) and len(l2.split(None, 1)) > 1:
+                dst = l2.split(None, 1)[1].split(',')[0].strip()
+                if regs(dst) & regs(m.group(2)):
+                    break                                       # the source was legitimately rewritten in between
     return found
 
 

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
 """Round-4 A/B of vq_track_kernel_d64 on the MODEL'S OWN z_e distribution (K=512, D=64) at 65 536 / 262 144 / 2 097 152 rows:
-    rows / queue      row-major rows, open rows queued for a lane-per-task pass (the default)
-    rows / inline     row-major rows, round 3's inline four-tasks-per-pass exact part (VQVAE_VQ_INLINE_EXACT)
-    nchw / queue      the reference's NCHW boundary layout read and written directly (round 4)
+    rows     row-major rows (the whole path's internal layout)
+    nchw     the reference's NCHW boundary layout read and written directly (round 4: 16-byte accesses + an fp32 LDS transposition)
 Kernel time = HIP events around the launch (vqvae_profile_*), best and median of `iters` launches; indices and z_q of the
 three forms are compared bit for bit at every size."""
 import json
@@ -52,12 +51,12 @@ def main():
         zr = zn.permute(0, 2, 3, 1).contiguous()
         N = zr.shape[0] * 64
         res = {}
-        for name, z, rm, kw in (("rows/queue", zr, True, {}), ("rows/inline", zr, True, {"inline_exact": True}), ("nchw/queue", zn, False, {})):
+        for name, z, rm, kw in (("rows", zr, True, {}), ("nchw", zn, False, {})):
             (loss, zq, ppl, idx, hist), best, med = time_form(z, cb, iters, rm, **kw)
             if not rm:
                 zq = zq.permute(0, 2, 3, 1).contiguous()
             res[name] = (idx, zq, loss, best, med)
-        ref = res["rows/inline"]
+        ref = res["rows"]
         line = {"rows": N}
         for name, r in res.items():
             line[name] = {"best_us": round(r[3], 2), "median_us": round(r[4], 2), "frac_of_8TBps": round(N * 520 / r[3] / 8e6, 4),

@@ -13,6 +13,19 @@ namespace vqvae {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+// |v|^2 of the eight fp16 values in a 16-byte vector (four packed pairs), added to s.  Inline assembly on purpose: hipcc (ROCm 7.2,
+// clang 22) lowers four consecutive __builtin_amdgcn_fdot2 calls on the components .x .y .z .w of one loaded vector to four
+// v_dot2c_f32_f16 that ALL read the FIRST component's register -- the sum came out as 4 (x0^2 + x1^2), right in expectation on
+// i.i.d. channels and silently far too small on rows whose energy sits in other channels.  Round 3's screen bound took its row
+// norm |z^| from that sum (vq_track.hip, vq_sweep.hip, the fused quantizer in conv.hip): found in round 4 by the
+// heterogeneous-channel parity test (tests/golden/vq_hetero_unit.npz is the row that came back with the wrong index).
+// tools/hazard_scan.py now also rejects the miscompiled pattern in every source's assembly.
+__device__ __forceinline__ float sqsum8_f16(unsigned vx, unsigned vy, unsigned vz, unsigned vw, float s) {
+    asm("v_dot2c_f32_f16 %0, %1, %1\n\tv_dot2c_f32_f16 %0, %2, %2\n\tv_dot2c_f32_f16 %0, %3, %3\n\tv_dot2c_f32_f16 %0, %4, %4"
+        : "+v"(s) : "v"(vx), "v"(vy), "v"(vz), "v"(vw));
+    return s;
+}
+
 constexpr int kWave = 64;            // CDNA wavefront
 constexpr int kLdsBytes = 160 * 1024;  // per CU on gfx950
 
@@ -102,7 +115,7 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 bool vq_track_ok(int K, int D);
 bool vq_track_nchw_ok(int K, int D, int HW);       // NCHW input: maps whose pixel count is a multiple of 64
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false, bool inline_exact = false);
+                        char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false);
 void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);
 // vq_chunk.hip: the same screen with the codebook image streamed through LDS (D = 64 / 128, any K <= 16384)
 // zq_amax: NULL, or an array of N / hw ints (images of hw consecutive rows) that receives max |z_q| per image (atomicMax on the

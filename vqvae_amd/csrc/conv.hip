@@ -3027,10 +3027,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                         v.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{Q[0], Q[1]}), f16x2));
                         v.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2v{Q[2], Q[3]}), f16x2));
                         zb[mt][2 * n3 + t] = v;
-                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), sq, false);
-                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), sq, false);
-                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), sq, false);
-                        sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), sq, false);
+                        sq = sqsum8_f16(v.x, v.y, v.z, v.w, sq);       // (not four fdot2 builtins: miscompiled, common.h)
                     }
                 const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
                 zn2[mt] = sq + __uint_as_float(h ? sw[0] : sw[1]);

@@ -475,7 +475,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
             const int rc = (track_nchw || (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))))
-                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw, (flags & VQVAE_VQ_INLINE_EXACT) != 0)
+                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw)
                                : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, (flags & VQVAE_VQ_SIXTEEN_WAVES) != 0);
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;

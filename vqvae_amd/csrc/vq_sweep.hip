@@ -270,10 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_sweep_kernel_d64(
             for (int q = 0; q < 4; ++q) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + l31 * 128 + ((((2 * q + h) ^ (l31 >> 1)) & 7) << 4));
                 zb[t][q] = __builtin_bit_cast(f16x8, v);
-                s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), s, false);
-                s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), s, false);
-                s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), s, false);
-                s = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), s, false);
+                s = sqsum8_f16(v.x, v.y, v.z, v.w, s);       // (not four fdot2 builtins: miscompiled, common.h)
             }
             __builtin_amdgcn_wave_barrier();
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(s), __float_as_uint(s), false, false);

@@ -40,16 +40,18 @@ using vqu::lds_order_wave;
 // every codebook operand and seed read from LDS; its first unit is static, later units come from an LDS ticket.  Rows stay
 // in registers in the coalesced load layout (16 lanes x 16 bytes per row) from load to store: HBM traffic is the
 // algorithmic 520 B per row.
-// NCHW (round 4): z / z_q are (B, 64, HW) with HW % 64 == 0 -- the reference's module boundary (models/quantizer.py:45-46, :74
-// are its two permutes).  A unit is 64 consecutive positions of ONE image, and the MFMA B operand wants exactly what that layout
-// offers: lane = row (position), registers = channels -- 64 dword loads per lane (every instruction two contiguous 128-byte runs),
-// no trip through LDS, the rows' codes and flags already in the right lane at the epilogue.
+// NCHW (round 4): z / z_q are (B, 64, HW) with HW % 64 == 0 -- the reference's own module boundary (models/quantizer.py:45-46
+// and :74 are its two permute + copy passes).  A unit is 64 consecutive positions of ONE image.  Per row tile the wave reads 8
+// channels x 32 positions per instruction (16 bytes per lane = four positions of one channel, whole 128-byte lines), turns the
+// 32 x 64 fp32 block around in its 8 KiB LDS tile (conflict-free both ways: 16-byte chunk c >> 2 of row r sits at slot
+// (c >> 2) ^ (r >> 2)) and continues in the row-major register layout; z_q takes the same way back.  Everything between is the
+// row-major kernel, bit for bit.
 template <int NW, bool NCHW = false>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
     long long N, int K, int K32, long long nunits, float *__restrict__ zq, long long *__restrict__ idx,
-    int *__restrict__ hist, double *__restrict__ partials, int HW, int defer_on) {
+    int *__restrict__ hist, double *__restrict__ partials, int HW) {
     constexpr int D = 64, T = 2, RU = 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ntile = K32 >> 5;
@@ -62,11 +64,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int TILEB = 4096 * T, TABB = 1552 + vqu::kDqBytes;
+    constexpr int TILEB = 4096 * T, TABB = 1552;
     unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);                // the unit's fp16 rows; later 16 fp32 row slots
     unsigned char *tab_s = tile_s + TILEB;
-    const vqu::Deferred dq = vqu::deferred(tab_s + 1552);                               // this wave's queue of open rows (vq_unit.h)
-    int qn = 0, qrows = 0;                                                              // queued tasks / rows (wave-uniform)
 
 #ifdef VQ_SWEEP_TIMING
     // debug build (tools/build_variant.py NAME -DVQ_SWEEP_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
@@ -90,26 +90,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     // ---- row I/O: F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the unit (1 KiB contiguous per instruction) ----
     // a buffer descriptor over the unit's 16 KiB clipped at the end of z: rows past the end read zeros (their results are
     // never stored), one 32-bit lane offset serves all 16 loads
-    // NCHW: F[t][2 q + (j >> 2)][j & 3] = channel 16 q + 8 h + j of row 32 t + l31 (the B operands' own layout); the descriptor
-    // starts at the unit's first position of channel 0 and ends with its image
-    auto unit_base = [&](long long p, const float *base) {          // first element (channel 0) of unit p
-        if constexpr (!NCHW) return base + (size_t)p * RU * D;
-        const long long b = (p * RU) / HW, hw0 = p * RU - b * HW;
-        return base + (size_t)b * D * HW + hw0;
+    auto unit_base = [&](long long p, const float *base) -> const float * {      // first element (channel 0) of unit p
+        if constexpr (NCHW) {
+            const long long b = (p * RU) / HW;
+            return base + (size_t)b * D * HW + (p * RU - b * HW);
+        } else {
+            return base + (size_t)p * RU * D;
+        }
     };
     auto load_unit = [&](long long p, f32x4(&F)[T][8], int lane) {
         if constexpr (NCHW) {
+            // F[t][i] = positions 32 t + 4 j8 .. +3 of channel 8 i + cl (lane = cl * 8 + j8); convert() turns the block around
             const long long hw0 = (p * RU) % HW;
             const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(unit_base(p, z)), 0,
                                                               (unsigned)(((long long)D * HW - hw0) * 4), 0x00020000);
-            const unsigned vo = (unsigned)((8 * (lane >> 5)) * HW + (lane & 31)) * 4u;
+            const unsigned vo = (unsigned)((lane >> 3) * HW + 4 * (lane & 7)) * 4u;
 #pragma unroll
             for (int t = 0; t < T; ++t)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-#pragma unroll
-                    for (int j = 0; j < 8; ++j)
-                        F[t][2 * q + (j >> 2)][j & 3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (unsigned)((16 * q + j) * HW + 32 * t) * 4u, 0));
+                for (int i = 0; i < 8; ++i)
+                    F[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, vo, (unsigned)(8 * i * HW + 32 * t) * 4u, 0));
             return;
         }
         const long long left = (N - p * RU) * (D * 4);
@@ -152,33 +152,28 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     f16x8 zb[T][4];
     float zn2[T];
     auto convert = [&]() {
-        if constexpr (NCHW) {
-            const int h = (tid & 63) >> 5;
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                float sq = 0.0f;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    u32x4 v;
-                    const f32x4 a = F[t][2 * q], b = F[t][2 * q + 1];
-                    v.x = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a.x, a.y}), f16x2));
-                    v.y = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{a.z, a.w}), f16x2));
-                    v.z = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{b.x, b.y}), f16x2));
-                    v.w = __builtin_bit_cast(unsigned, __builtin_convertvector((f32x2{b.z, b.w}), f16x2));
-                    zb[t][q] = __builtin_bit_cast(f16x8, v);
-                    sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), sq, false);
-                    sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), sq, false);
-                    sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), sq, false);
-                    sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), sq, false);
-                }
-                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
-                zn2[t] = sq + __uint_as_float(h ? sw[0] : sw[1]);
-            }
-            return;
-        }
         int lane_c = tid & 63;
         asm volatile("" : "+v"(lane_c));
         const int l31 = lane_c & 31, h = lane_c >> 5, j16 = lane_c & 15, g4 = lane_c >> 4;
+        if constexpr (NCHW) {
+            // (32 positions x 64 channels) fp32 through the tile, one row tile at a time: in as [channel][4 positions] per lane,
+            // out as F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 -- the row-major layout everything below works on
+            float *tf = reinterpret_cast<float *>(tile_s);
+            const int cl = lane_c >> 3, j8 = lane_c & 7;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                lds_order_wave();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        tf[(4 * j8 + e) * 64 + ((((2 * i + (cl >> 2)) ^ j8) & 15) << 2) + (cl & 3)] = F[t][i][e];
+                lds_order_wave();
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    F[t][i] = *reinterpret_cast<const f32x4 *>(tf + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2));
+            }
+        }
         const unsigned wbase = (unsigned)g4 * 128u + ((((unsigned)j16 >> 1) ^ ((unsigned)g4 >> 1)) << 4) + (((unsigned)j16 & 1u) << 3);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -200,10 +195,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             for (int q = 0; q < 4; ++q) {
                 const u32x4 v = *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + (rbase ^ ((unsigned)(2 * q) << 4)));
                 zb[t][q] = __builtin_bit_cast(f16x8, v);
-                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.x), __builtin_bit_cast(f16x2, v.x), sq, false);
-                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.y), __builtin_bit_cast(f16x2, v.y), sq, false);
-                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.z), __builtin_bit_cast(f16x2, v.z), sq, false);
-                sq = __builtin_amdgcn_fdot2(__builtin_bit_cast(f16x2, v.w), __builtin_bit_cast(f16x2, v.w), sq, false);
+                sq = sqsum8_f16(v.x, v.y, v.z, v.w, sq);       // (not four fdot2 builtins: miscompiled, common.h)
             }
             const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
             zn2[t] = sq + __uint_as_float(h ? sw[0] : sw[1]);
@@ -292,12 +284,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         //   hard rows: the row tile's screen is run again with the row's now-known threshold and every code at or above
         //       it becomes a task (same accumulators as in the sweep)
         //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
-        int nopen = 0;
-        const bool can_defer = defer_on && vqu::defer_fits(R, lane, qn, qrows, nopen);       // (defer_on == 0: VQVAE_VQ_INLINE_EXACT, A/B and tests)
-        if (can_defer) {
-            // the common case: the unit's open rows wait in the wave's queue for a pass of one lane per task (vqu::flush)
-            if (R.ncls > 0) vqu::defer_unit(R, tb, dq, qn, qrows, r0, lane);
-        } else {
+        {
             vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
             int ntasks = FL.ndirect;
             if (FL.hmask && FL.ndirect <= 64) {
@@ -309,10 +296,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                         const unsigned rb = (unsigned)l31 * 128u + ((((unsigned)h ^ ((unsigned)l31 >> 1)) & 7u) << 4);
                         f16x8 zbr[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            if constexpr (NCHW) zbr[q] = zb[t][q];        // (still in registers: the layout of F is the B operands')
-                            else zbr[q] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + (rb ^ ((unsigned)(2 * q) << 4))));
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            zbr[q] = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4 *>(tile_s + t * 4096 + (rb ^ ((unsigned)(2 * q) << 4))));
                         u32x4 ra[4];
                         f32x16 rs;
                         auto rfetch = [&](int ct) {
@@ -341,7 +326,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 ntasks = FL.ndirect + tb.cnt_s[0];
             }
             if constexpr (NCHW) {
-                const float *zu = unit_base(p, z);
+                const float *zu = unit_base(p, z);                 // (strided dword reads: ~3 % of the rows, L2-resident)
                 vqu::exact_end(R, FL, ntasks, lane, tb, cb, ee_g, K,
                                [&](int rr, int jc) { const float *q = zu + (size_t)(4 * jc) * HW + rr; return f32x4{q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]}; },
                                [&](int rr, int c) { return zu[(size_t)c * HW + rr]; });
@@ -361,36 +346,26 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
             float sacc;
             if constexpr (NCHW)
-                sacc = vqu::epilogue_nchw(R, lane, cb, K, F, zq ? const_cast<float *>(unit_base(p, zq)) : nullptr,
-                                          (unsigned)(((long long)D * HW - (p * RU) % HW) * 4), HW, idx + r0, hist_s);
-            else
                 sacc = vqu::epilogue<true>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
-                                           zq ? zq + (size_t)p * RU * D : nullptr, nleft, idx + r0, hist_s);
+                                           zq ? const_cast<float *>(unit_base(p, zq)) : nullptr, nleft, idx + r0, hist_s,
+                                           reinterpret_cast<float *>(tile_s), HW, (unsigned)(((long long)D * HW - (p * RU) % HW) * 4));
+            else
+                sacc = vqu::epilogue(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                                     zq ? zq + (size_t)p * RU * D : nullptr, nleft, idx + r0, hist_s);
             dacc += (double)sacc;
         }
+#ifdef VQ_DEBUG_VERDICT
+        // debug build (tools/build_variant.py dbg -DVQ_DEBUG_VERDICT): the classification of every row next to its index --
+        // bits 20..23 = open / hard / bad / valid, high word = the row's threshold (float bits)
+        if (h == 0) {
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+                if (R.valid[t])
+                    idx[r0 + 32 * t + l31] = (long long)R.kbest[t] | ((long long)(R.openf[t] ? 1 : 0) << 20) | ((long long)(R.hardf[t] ? 1 : 0) << 21) |
+                                             ((long long)(R.bad[t] ? 1 : 0) << 22) | ((long long)__float_as_uint(VQ_DEBUG_VERDICT == 2 ? zn2[t] : R.thr[t]) << 32);
+        }
+#endif
         VQ_STAMP(5);                                           // epilogue
-        // the queue is resolved when the next unit's tasks might not fit any more (and once more behind the loop)
-        auto flush_queue = [&]() {
-            if constexpr (NCHW)
-                dacc += vqu::flush(dq, qn, qrows, lane, cb, ee_g, K, idx, hist_s,
-                                   [&](long long grow, int c4) {
-                                       const long long b = grow / HW;
-                                       const float *q = z + (size_t)b * D * HW + (grow - b * HW) + (size_t)(4 * c4) * HW;
-                                       return f32x4{q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]};
-                                   },
-                                   [&](long long grow, int c4, f32x4 v) {
-                                       if (!zq) return;
-                                       const long long b = grow / HW;
-                                       float *q = zq + (size_t)b * D * HW + (grow - b * HW) + (size_t)(4 * c4) * HW;
-                                       q[0] = v.x; q[HW] = v.y; q[2 * (size_t)HW] = v.z; q[3 * (size_t)HW] = v.w;
-                                   });
-            else
-                dacc += vqu::flush(dq, qn, qrows, lane, cb, ee_g, K, idx, hist_s,
-                                   [&](long long grow, int c4) { return *reinterpret_cast<const f32x4 *>(z + (size_t)grow * D + 4 * c4); },
-                                   [&](long long grow, int c4, f32x4 v) { if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)grow * D + 4 * c4) = v; });
-        };
-        if (qn >= 40) flush_queue();
-        VQ_STAMP(4);                                           // (queue passes count as exact part)
         {
             int q = 0;
             if (lane == 0) q = atomicAdd(ticket_s, 1);
@@ -404,26 +379,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         VQ_STAMP(1);                                           // next rows landed, fp16 conversion
     }
 
-    if (qn > 0) {
-        const int lane = tid & 63;
-        if constexpr (NCHW)
-            dacc += vqu::flush(dq, qn, qrows, lane, cb, ee_g, K, idx, hist_s,
-                               [&](long long grow, int c4) {
-                                   const long long b = grow / HW;
-                                   const float *q = z + (size_t)b * D * HW + (grow - b * HW) + (size_t)(4 * c4) * HW;
-                                   return f32x4{q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]};
-                               },
-                               [&](long long grow, int c4, f32x4 v) {
-                                   if (!zq) return;
-                                   const long long b = grow / HW;
-                                   float *q = zq + (size_t)b * D * HW + (grow - b * HW) + (size_t)(4 * c4) * HW;
-                                   q[0] = v.x; q[HW] = v.y; q[2 * (size_t)HW] = v.z; q[3 * (size_t)HW] = v.w;
-                               });
-        else
-            dacc += vqu::flush(dq, qn, qrows, lane, cb, ee_g, K, idx, hist_s,
-                               [&](long long grow, int c4) { return *reinterpret_cast<const f32x4 *>(z + (size_t)grow * D + 4 * c4); },
-                               [&](long long grow, int c4, f32x4 v) { if (zq) *reinterpret_cast<f32x4 *>(zq + (size_t)grow * D + 4 * c4) = v; });
-    }
 #ifdef VQ_SWEEP_TIMING
     VQ_STAMP(6);
     if ((tid & 63) == 0) atomicMax(&tsum[7], (unsigned)(wall_clock64() - tstart));     // slowest wave of the workgroup
@@ -449,18 +404,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
 size_t vq_track_lds_bytes(int K) {
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + 8 * 8 + 16 + 8 * (size_t)(8192 + 1552 + vqu::kDqBytes);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + 8 * 8 + 16 + 8 * (size_t)(8192 + 1552);
 }
 
 bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K) <= (size_t)kLdsBytes; }
 bool vq_track_nchw_ok(int K, int D, int HW) { return vq_track_ok(K, D) && HW >= 64 && HW % 64 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll; }
 
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw, bool inline_exact) {
+                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw) {
     const VqPlan p = vq_plan(K, 64);
     const int cus = num_cus();
     constexpr int NW = 8;
-    if (nchw && (HW < 64 || HW % 64)) return VQVAE_ERR_UNSUPPORTED;          // a unit = 64 positions of ONE image
+    if (nchw && !vq_track_nchw_ok(K, 64, HW)) return VQVAE_ERR_UNSUPPORTED;          // a unit = 64 positions of ONE image
     const long long nunits = (N + 63) / 64;
     long long grid = (nunits + NW - 1) / NW;
     if (grid > cus) grid = cus;
@@ -473,7 +428,7 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
         hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K), st, z, cb,                          \
                            reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds), \
                            reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K, \
-                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW, inline_exact ? 0 : 1); \
+                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW);                  \
     } while (0)
     if (nchw) VQT_LAUNCH(true); else VQT_LAUNCH(false);
 #undef VQT_LAUNCH

@@ -251,26 +251,27 @@ __device__ __forceinline__ void exact_end(Rows &R, Flagged &F, int ntasks, int l
 // ---- epilogue: gather, z + (e_k - z), squared error, z_q stores, index, histogram -> the unit's squared error (this lane) ---
 // frow(t, i) -> floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the unit (the coalesced load layout); zq_unit: z_q of the
 // unit's first row (or NULL); nleft: rows of the unit that exist; idx_unit: index of its first row
-template <bool DEFER = false, class FRow>
+// NCHW (vq_track_kernel_d64<., true>): zq_unit = the unit's first position of channel 0 in a (B, 64, HW) tensor, zq_bytes = bytes from
+// there to the end of its image; the values leave through the wave's 8 KiB LDS tile `tile_f` (one row tile at a time, the layout
+// of the kernel's input transposition) as 16-byte stores of four positions of one channel.
+template <bool NCHW = false, class FRow>
 __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
                                           float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
-                                          int *__restrict__ hist_s) {
+                                          int *__restrict__ hist_s, float *tile_f = nullptr, int HW = 0, unsigned zq_bytes = 0u) {
     constexpr int D = 64, T = 2, RU = 64;
     const int l31 = lane & 31, h = lane >> 5, j16 = lane & 15, g4 = lane >> 4;
     const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
     f32x4 ev[T][8];
-    int krow[T][8];                                        // (DEFER only: the row's code again at the store)
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int kr = __builtin_amdgcn_ds_bpermute((4 * i + g4) << 2, R.kbest[t]);
-            krow[t][i] = kr;
             ev[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr * (D * 4) + (unsigned)j16 * 16u, 0, 0));
         }
     // the descriptor covers exactly the unit's existing rows: stores of rows past the end are dropped by the hardware
     const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq_unit ? zq_unit : const_cast<float *>(cb), 0,
-                                                         zq_unit ? (unsigned)nleft * (D * 4) : 0u, 0x00020000);
+                                                         zq_unit ? (NCHW ? zq_bytes : (unsigned)nleft * (D * 4)) : 0u, 0x00020000);
     // Store offsets: four lane bases 4 KiB apart + an immediate, NO scalar offset register.  hipcc (ROCm 7.2) does not
     // guard a 16-byte buffer store whose soffset is an SGPR against the next vector instruction overwriting its data
     // registers (LLVM exempts that form from the store-data hazard); on gfx950 the overwrite corrupted the last dword
@@ -291,209 +292,37 @@ __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *
             const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
             f32x4 o;
             o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
-            float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-            unsigned so = vo[(t * 8 + i) >> 2];
-            if (DEFER) {
-                // a DEFERRED row (kbest < 0: its exact part runs later, vqu::flush writes it): no store (the sign bit pushes the
-                // offset past every descriptor), no squared error; its gather above read zeros (offset past the codebook)
-                so |= (unsigned)krow[t][i] & 0x80000000u;
-                sq = krow[t][i] < 0 ? 0.0f : sq;
-            }
+            const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
             if (nleft == RU) sacc += sq;                   // fp32 over the unit's 16 groups, one fp64 add per unit
             else sacc += 32 * t + 4 * i + g4 < nleft ? sq : 0.0f;
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, so + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
+            if constexpr (!NCHW) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
+            } else {
+                // row tile t: rows in, [channel][four positions] out (conflict-free both ways, see the kernel's convert())
+                if (i == 0) lds_order_wave();              // the previous row tile's reads are behind us
+                *reinterpret_cast<f32x4 *>(tile_f + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2)) = o;
+                if (i == 7) {
+                    lds_order_wave();
+                    const int cl = lane >> 3, j8 = lane & 7;
+                    unsigned so = (unsigned)(cl * HW + 4 * j8 + 32 * t) * 4u;           // (offsets in the VECTOR operand: the hazard note above)
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        f32x4 w;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) w[e] = tile_f[(4 * j8 + e) * 64 + ((((2 * c8 + (cl >> 2)) ^ j8) & 15) << 2) + (cl & 3)];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, w), zq_rs, so, 0, 0);
+                        so += (unsigned)(8 * HW) * 4u;
+                    }
+                }
+            }
         }
 #pragma unroll
     for (int t = 0; t < T; ++t)
-        if (R.valid[t] && h == 0 && (!DEFER || R.kbest[t] >= 0)) {
+        if (R.valid[t] && h == 0) {
             idx_unit[32 * t + l31] = R.kbest[t];
             atomicAdd(&hist_s[R.kbest[t]], 1);
         }
     return sacc;
-}
-
-// ---- the same epilogue for NCHW units (vq_track_kernel_d64<., true>): lane (l31, h) holds channels 16 q + 8 h + j of row
-// 32 t + l31 in F[t][2 q + (j >> 2)][j & 3] and the row's code in R.kbest[t]; zq_unit = first position (channel 0) of the unit in
-// z_q, zq_bytes = bytes from there to the end of its image.  Rows with kbest < 0 (deferred) are skipped.
-__device__ __forceinline__ float epilogue_nchw(const Rows &R, int lane, const float *__restrict__ cb, int K, const f32x4 (&F)[2][8],
-                                               float *__restrict__ zq_unit, unsigned zq_bytes, int HW, long long *__restrict__ idx_unit,
-                                               int *__restrict__ hist_s) {
-    constexpr int D = 64, T = 2;
-    const int l31 = lane & 31, h = lane >> 5;
-    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
-    const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq_unit ? zq_unit : const_cast<float *>(cb), 0, zq_unit ? zq_bytes : 0u, 0x00020000);
-    float sacc = 0.0f;
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const int k = R.kbest[t];
-        const bool live = R.valid[t] && k >= 0;
-        // (a deferred row's gather reads zeros: offset past the codebook; its stores go past the descriptor)
-        const unsigned eo = (unsigned)k * (D * 4) + (unsigned)(8 * h) * 4u;
-        const unsigned so = ((unsigned)((8 * h) * HW + 32 * t + l31) * 4u) | (live ? 0u : 0x80000000u);
-        f32x4 ev[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            ev[2 * q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, eo + (unsigned)(16 * q) * 4u, 0, 0));
-            ev[2 * q + 1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, eo + (unsigned)(16 * q + 4) * 4u, 0, 0));
-        }
-        float st = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 zv = F[t][i], e = ev[i];
-            const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
-            const float o[4] = {zv.x + d0, zv.y + d1, zv.z + d2, zv.w + d3};
-            st += ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-            const int c0 = 16 * (i >> 1) + 4 * (i & 1);               // + 8 h: in the lane offset
-#pragma unroll
-            for (int e4 = 0; e4 < 4; ++e4)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o[e4]), zq_rs, so, (unsigned)((c0 + e4) * HW) * 4u, 0);
-        }
-        sacc += live ? st : 0.0f;
-        if (live && h == 0) {
-            idx_unit[32 * t + l31] = k;
-            atomicAdd(&hist_s[k], 1);
-        }
-    }
-    return sacc;
-}
-
-// ---- DEFERRED exact part (round 4) -------------------------------------------------------------------------------------------
-// The chains of exact_end run FOUR tasks per pass (16 lanes per task, DPP-serial fmaf chain): an open row costs ~430 vector
-// instructions and every unit with an open row (88 % of them) pays a ~3 us latency chain before its epilogue may start.  The
-// chain is 64 dependent FMAs whichever way it is laid out -- so one LANE per task runs 64 tasks in the time of four, if there
-// are 64 tasks.  A wave therefore QUEUES the open rows of its units (global row, the two candidate codes of each task) in LDS,
-// lets the unit's epilogue skip them, and resolves the queue when it is nearly full and at the end: one pass of one lane per
-// task (||z||^2 in ATen's order, two c-ordered fmaf chains, (d, k) folded per row by a 64-bit LDS minimum), then one lane per
-// row (index, histogram, z + (e_k - z), squared error).  Hard / non-finite rows and units whose tasks do not fit take the
-// inline path above, unchanged.  Same arithmetic, same bits.
-constexpr int kDqCap = 64;                               // tasks and rows per wave
-constexpr int kDqBytes = kDqCap * (4 + 8 + 8);           // [64] task: slot | a << 6 | b << 19;  [64] global row;  [64] (distance, index) minimum
-struct Deferred {
-    unsigned *task;
-    unsigned long long *grow, *best;
-};
-__device__ __forceinline__ Deferred deferred(unsigned char *p) {
-    return Deferred{reinterpret_cast<unsigned *>(p + 16 * kDqCap), reinterpret_cast<unsigned long long *>(p),
-                    reinterpret_cast<unsigned long long *>(p + 8 * kDqCap)};
-}
-
-// may this unit's open rows be queued?  (wave-uniform; nopen: its open rows)
-__device__ __forceinline__ bool defer_fits(const Rows &R, int lane, int qn, int qrows, int &nopen) {
-    const int h = lane >> 5;
-    const bool o_open = h ? R.openf[1] : R.openf[0];
-    const bool o_other = h ? (R.hardf[1] || R.bad[1]) : (R.hardf[0] || R.bad[0]);
-    nopen = __builtin_popcountll(__builtin_amdgcn_ballot_w64(o_open));
-    return __builtin_amdgcn_ballot_w64(o_other) == 0ull && qn + R.ncls <= kDqCap && qrows + nopen <= kDqCap;
-}
-
-// queue the unit's open rows (the classification's tasks are in tb.task_s[0 .. R.ncls)); their kbest becomes -1
-__device__ __forceinline__ void defer_unit(Rows &R, const Tables &tb, const Deferred &dq, int &qn, int &qrows, long long r0, int lane) {
-    const int h = lane >> 5;
-    const bool o_open = h ? R.openf[1] : R.openf[0];             // lane L speaks for row L of the unit
-    const unsigned long long om = __builtin_amdgcn_ballot_w64(o_open);
-    int *slot_of = reinterpret_cast<int *>(tb.zz_s);             // (the inline path's ||z||^2 table: unused by a deferred unit)
-    __builtin_amdgcn_wave_barrier();
-    if (o_open) {
-        const int slot = qrows + __builtin_popcountll(om & ((1ull << lane) - 1ull));
-        dq.grow[slot] = (unsigned long long)(r0 + lane);
-        dq.best[slot] = ~0ull;
-        slot_of[lane] = slot;
-    }
-    lds_order_wave();
-    if (lane < R.ncls) {
-        const unsigned t = tb.task_s[lane];
-        dq.task[qn + lane] = (t & ~63u) | (unsigned)slot_of[t & 63u];
-    }
-    lds_order_wave();
-    qn += R.ncls;
-    qrows += __builtin_popcountll(om);
-    if (R.openf[0]) R.kbest[0] = -1;
-    if (R.openf[1]) R.kbest[1] = -1;
-}
-
-// resolve the queue.  zload(grow, c4) -> floats 4 c4 .. +3 of global row grow; zstore(grow, c4, v) stores them into z_q (or
-// does nothing); returns this lane's squared error (fp64) of the rows it finished
-template <class ZLoad, class ZStore>
-__device__ __forceinline__ double flush(const Deferred &dq, int &qn, int &qrows, int lane, const float *__restrict__ cb,
-                                        const float *__restrict__ ee_g, int K, long long *__restrict__ idx, int *__restrict__ hist_s,
-                                        ZLoad &&zload, ZStore &&zstore) {
-    constexpr int D = 64;
-    double out = 0.0;
-    if (qn == 0) return out;
-    lds_order_wave();
-    if (lane < qn) {
-        const unsigned task = dq.task[lane];
-        const int slot = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb = (int)(task >> 19);
-        const long long grow = (long long)dq.grow[slot];
-        const f32x4 *ea = reinterpret_cast<const f32x4 *>(cb + (size_t)ka * D), *eb = reinterpret_cast<const f32x4 *>(cb + (size_t)kb * D);
-        // ||z||^2 in ATen's order: squares s[c] (rounded products), eight 8-lane vectors v_j, P_q = v_q + v_{q+4},
-        // A = ((P_0 + P_1) + P_2) + P_3 lanewise, then A_0 .. A_7 in order;  m = the c-ordered fmaf chain
-        float sq[32], ma = 0.0f, mb = 0.0f;
-#pragma unroll
-        for (int c4 = 0; c4 < 16; ++c4) {
-            const f32x4 zv = zload(grow, c4), va = ea[c4], vb = eb[c4];
-            const float s4[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                if (c4 < 8) sq[4 * c4 + e] = s4[e];
-                else sq[4 * (c4 - 8) + e] = sq[4 * (c4 - 8) + e] + s4[e];       // P_q[l]: element 8 q + l  +  element 8 (q + 4) + l
-            }
-            ma = __builtin_fmaf(zv.w, va.w, __builtin_fmaf(zv.z, va.z, __builtin_fmaf(zv.y, va.y, __builtin_fmaf(zv.x, va.x, ma))));
-            mb = __builtin_fmaf(zv.w, vb.w, __builtin_fmaf(zv.z, vb.z, __builtin_fmaf(zv.y, vb.y, __builtin_fmaf(zv.x, vb.x, mb))));
-        }
-        float zz = 0.0f;
-#pragma unroll
-        for (int l = 0; l < 8; ++l) zz = zz + (((sq[l] + sq[8 + l]) + sq[16 + l]) + sq[24 + l]);
-        const float da = (zz + ee_g[ka]) - 2.0f * ma, db = (zz + ee_g[kb]) - 2.0f * mb;
-        atomicMin(&dq.best[slot], trk::dist_key(da, ka));
-        atomicMin(&dq.best[slot], trk::dist_key(db, kb));
-    }
-    lds_order_wave();
-    if (lane < qrows) {
-        const long long grow = (long long)dq.grow[lane];
-        int k = (int)(unsigned)dq.best[lane];
-        if (dq.best[lane] == ~0ull || k < 0 || k >= K) {
-            // no task came back for the row (cannot happen: every queued row has one): torch.argmin over the whole codebook
-            float sq[32];
-#pragma unroll
-            for (int c4 = 0; c4 < 16; ++c4) {
-                const f32x4 zv = zload(grow, c4);
-                const float s4[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (c4 < 8) sq[4 * c4 + e] = s4[e];
-                    else sq[4 * (c4 - 8) + e] = sq[4 * (c4 - 8) + e] + s4[e];
-                }
-            }
-            float zz = 0.0f, bd = 0.0f;
-#pragma unroll
-            for (int l = 0; l < 8; ++l) zz = zz + (((sq[l] + sq[8 + l]) + sq[16 + l]) + sq[24 + l]);
-            k = 0;
-            for (int kk = 0; kk < K; ++kk) {
-                float m = 0.0f;
-                for (int c4 = 0; c4 < 16; ++c4) {
-                    const f32x4 zv = zload(grow, c4), e = *reinterpret_cast<const f32x4 *>(cb + (size_t)kk * D + 4 * c4);
-                    m = __builtin_fmaf(zv.w, e.w, __builtin_fmaf(zv.z, e.z, __builtin_fmaf(zv.y, e.y, __builtin_fmaf(zv.x, e.x, m))));
-                }
-                const float d = (zz + ee_g[kk]) - 2.0f * m;
-                if (kk == 0 || d < bd) { k = kk; bd = d; }
-            }
-        }
-        idx[grow] = k;
-        atomicAdd(&hist_s[k], 1);
-        const f32x4 *ek = reinterpret_cast<const f32x4 *>(cb + (size_t)k * D);
-#pragma unroll
-        for (int c4 = 0; c4 < 16; ++c4) {
-            const f32x4 zv = zload(grow, c4), e = ek[c4];
-            const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
-            zstore(grow, c4, f32x4{zv.x + d0, zv.y + d1, zv.z + d2, zv.w + d3});
-            out += (double)(((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3);
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    qn = 0;
-    qrows = 0;
-    return out;
 }
 
 }  // namespace vqu

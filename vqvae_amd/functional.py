@@ -16,7 +16,6 @@ VQ_BF16_FILTER = 0x8
 VQ_TOP3_KEYS = 0x10
 VQ_SIXTEEN_WAVES = 0x20
 VQ_UNFUSED = 0x40
-VQ_INLINE_EXACT = 0x80
 # whole-path product scheme (vqvae_forward_f32 / vqvae_encoder_ex_f32 / vqvae_decoder_ex_f32)
 FWD_CONV_BF16_SPLIT = 0x1000
 FWD_CONV_EXACT_FP32 = 0x2000
@@ -44,7 +43,7 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
                exact_sweep: bool = False, bf16_filter: bool = False, top3_keys: bool = False,
-               sixteen_waves: bool = False, inline_exact: bool = False):
+               sixteen_waves: bool = False):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
     z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
@@ -80,7 +79,7 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
             (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0) | \
-            (VQ_TOP3_KEYS if top3_keys else 0) | (VQ_SIXTEEN_WAVES if sixteen_waves else 0) | (VQ_INLINE_EXACT if inline_exact else 0)
+            (VQ_TOP3_KEYS if top3_keys else 0) | (VQ_SIXTEEN_WAVES if sixteen_waves else 0)
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
