@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 5   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+#define VQVAE_HIP_ABI_VERSION 6   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
                                     4: forward in parts (begin / part / end), residual layer with hidden output, larger
                                        weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions) */
 
@@ -90,21 +90,15 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
 #define VQVAE_VQ_BF16_FILTER    0x8  /* use round 1's two-sweep bf16 filter kernel where the default would be the
                                         single-sweep fp16 kernel (identical outputs; A/B timing and tests) */
 
-#define VQVAE_VQ_TOP3_KEYS      0x10 /* use round 2's tracker (the three largest screen values of a lane as index-carrying keys,
-                                        vq_sweep_kernel_d64) where the default is round 3's stream tracker (vq_track_kernel_d64;
-                                        identical outputs; A/B timing and tests) */
-
-#define VQVAE_VQ_SIXTEEN_WAVES 0x20 /* run round 2's kernel (implies VQVAE_VQ_TOP3_KEYS) with 32-row units on sixteen waves per CU (K <= 512, at most two
-                                        units per wave) instead of 64-row pairs on eight (identical outputs).  8 us faster on an idle
-                                        chip at 262 144 rows, no faster inside the forward, and its 92 spilled registers cost 1.6x the
-                                        algorithmic traffic: not the default */
+#define VQVAE_VQ_REMOVED_FLAGS  0x30 /* 0x10 / 0x20 selected round 2's tracker kernel (vq_sweep_kernel_d64: index-carrying top-3 keys; 32-row units
+                                        on sixteen waves) for A/B runs.  Round 4 removed that kernel: VQVAE_ERR_UNSUPPORTED */
 
 #define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
                                         kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 512, D = 64: z_e is
                                         then never written); identical outputs, A/B timing and tests */
 
-/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" / "vq_sweep_kernel_d64" (codebook image
- * resident in LDS: D = 64, K <= ~600), "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
+/* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" (codebook image resident in LDS: D = 64,
+ * K <= ~600; row-major rows, or NCHW maps whose pixel count is a multiple of 64), "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
  * "vq_filter_kernel_d64", "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix
  * cores per row (0 for the exact-fp32 kernel).  For reporting (bench.py). */
 VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);
@@ -404,7 +398,7 @@ VQVAE_API int vqvae_decoder_ex_f32(const VqvaeWeights *w, const float *z_q, int6
 
 /* VQVAE.forward: x -> (embedding_loss, x_hat, perplexity) (models/vqvae.py:44); idx (B*H/4*W/4 int64) is optional.
  * vq_flags: VQVAE_VQ_CODEBOOK_PREPARED (only meaningful with a persistent vq_workspace of vqvae_vq_workspace_bytes),
- * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER / _TOP3_KEYS / _SIXTEEN_WAVES, VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32.  vq_workspace may
+ * VQVAE_VQ_EXACT_SWEEP / _BF16_FILTER, VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32.  vq_workspace may
  * be NULL (then the codebook images are rebuilt inside `workspace` on every call).                                                                       */
 VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags,
                                 float *x_hat, float *loss, float *perplexity, int64_t *idx, void *workspace,

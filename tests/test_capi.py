@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(lib):
     lib.vqvae_strerror.restype = ctypes.c_char_p
     lib.vqvae_vq_workspace_bytes.restype = ctypes.c_size_t
     lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
-    assert lib.vqvae_abi_version() == 5
+    assert lib.vqvae_abi_version() == 6
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
     assert b"NULL" in lib.vqvae_strerror(-1)
@@ -122,7 +122,7 @@ def test_host_side_plans_without_gpu():
     L = _lib.load()
     # quantizer dispatch (row-major flag 0x1): resident-image sweep for small codebooks, streamed image beyond, exact on request
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
-    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "vq_sweep_kernel_d64"      # VQVAE_VQ_TOP3_KEYS: round 2's tracker
+    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "unsupported"              # round 2's tracker (flags 0x10 / 0x20): removed in round 4
     assert _lib.vq_kernel_name(1024, 64) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"

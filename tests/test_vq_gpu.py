@@ -18,15 +18,13 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, top3_keys=False,
-         sixteen_waves=False):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact, bf16_filter=bf16_filter, top3_keys=top3_keys,
-                                            sixteen_waves=sixteen_waves)
+                                            exact_sweep=exact, bf16_filter=bf16_filter)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -34,7 +32,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "top3_keys", "sixteen_waves", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -42,8 +40,7 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     two-sweep bf16 filter (default for NCHW D=64 rows) and the exhaustive fp32-MFMA sweep -- must reproduce
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
-    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter",
-                                    top3_keys=kernel == "top3_keys", sixteen_waves=kernel == "sixteen_waves")
+    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter")
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -118,9 +115,6 @@ def test_vq_filter_adversarial_near_ties():
         np.testing.assert_array_equal(idx, ref["idx"])
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
         np.testing.assert_allclose(loss, ref["loss"], rtol=1e-6)
-    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, sixteen_waves=True)       # 32-row units: rescan / hard-row paths of that form
-    np.testing.assert_array_equal(idx, ref["idx"])
-    assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
 @pytest.mark.parametrize("p", [8, 11], ids=["bf16mid", "fp16mid"])
@@ -138,8 +132,6 @@ def test_vq_aligned_rounding_adversarial(p, seed):
     z = torch.from_numpy(np.ascontiguousarray(zr.reshape(n // 64, 8, 8, d).transpose(0, 3, 1, 2)))
     cbt = torch.from_numpy(cb)
     ref = c_oracle.vq_forward(z.numpy(), cb, 0.25)
-    loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, True, sixteen_waves=True)
-    np.testing.assert_array_equal(idx, ref["idx"])
     for rowmajor, exact, bf in ((True, False, False), (True, False, True), (False, False, False), (True, True, False)):
         loss, zq, ppl, idx, hist = _run(z, cbt, 0.25, rowmajor, exact=exact, bf16_filter=bf)
         np.testing.assert_array_equal(idx, ref["idx"])
@@ -175,8 +167,7 @@ def test_vq_near_ties_within_one_lane_half(shrink):
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
-ALL_FORMS = (("track rows", dict(rowmajor=True)), ("track nchw", dict(rowmajor=False)), ("top3", dict(rowmajor=True, top3_keys=True)),
-             ("sixteen waves", dict(rowmajor=True, sixteen_waves=True)), ("bf16 filter", dict(rowmajor=True, bf16_filter=True)),
+ALL_FORMS = (("track rows", dict(rowmajor=True)), ("track nchw", dict(rowmajor=False)), ("bf16 filter", dict(rowmajor=True, bf16_filter=True)), ("bf16 filter nchw", dict(rowmajor=False, bf16_filter=True)),
              ("exact", dict(rowmajor=True, exact=True)))
 
 
@@ -240,7 +231,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
     z = torch.randn(B, D, H, W, generator=g) * 0.066
     ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
-    for kw in ({}, {"top3_keys": True}, {"sixteen_waves": True}, {"bf16_filter": True}):
+    for kw in ({}, {"bf16_filter": True}):
         loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
         np.testing.assert_array_equal(idx, ref_idx)
         assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
@@ -253,7 +244,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
 def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
-    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "vq_sweep_kernel_d64"      # VQVAE_VQ_TOP3_KEYS: round 2's tracker
+    assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "unsupported"              # round 2's tracker kernel and its flags: removed in round 4
     for K, D in ((640, 64), (1024, 64), (16384, 64), (64, 128), (8192, 128)):
         assert _lib.vq_kernel_name(K, D) == "vq_stream_sweep_kernel", (K, D)
         assert _lib.vq_sweeps(K, D) == 1

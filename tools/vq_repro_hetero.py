@@ -27,7 +27,7 @@ for kind, seed, img in (("coupled", 2, "mixed"), ("coupled", 1, "normal"), ("cou
     zd, cbd = ze.to(dev), cb.to(dev)
     zr = zd.permute(0, 2, 3, 1).contiguous()
     for name, z, kw in (("track rows", zr, dict(rowmajor=True)), ("track nchw", zd, dict(rowmajor=False)),
-                        ("top3", zr, dict(rowmajor=True, top3_keys=True)), ("filter", zr, dict(rowmajor=True, bf16_filter=True)),
+                        ("filter", zr, dict(rowmajor=True, bf16_filter=True)),
                         ("exact", zr, dict(rowmajor=True, exact_sweep=True))):
         idx = F.vq_forward(z, cbd, 0.25, **kw)[3].cpu().numpy().reshape(-1)
         bad = np.nonzero(idx != ref)[0]

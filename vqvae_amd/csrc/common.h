@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // clang 22) lowers four consecutive __builtin_amdgcn_fdot2 calls on the components .x .y .z .w of one loaded vector to four
 // v_dot2c_f32_f16 that ALL read the FIRST component's register -- the sum came out as 4 (x0^2 + x1^2), right in expectation on
 // i.i.d. channels and silently far too small on rows whose energy sits in other channels.  Round 3's screen bound took its row
-// norm |z^| from that sum (vq_track.hip, vq_sweep.hip, the fused quantizer in conv.hip): found in round 4 by the
+// norm |z^| from that sum (vq_track.hip, round 2's vq_sweep.hip, the fused quantizer in conv.hip): found in round 4 by the
 // heterogeneous-channel parity test (tests/golden/vq_hetero_unit.npz is the row that came back with the wrong index).
 // tools/hazard_scan.py now also rejects the miscompiled pattern in every source's assembly.
 __device__ __forceinline__ float sqsum8_f16(unsigned vx, unsigned vy, unsigned vz, unsigned vw, float s) {
@@ -67,7 +67,7 @@ constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many 
 constexpr int kVqSlabRows = 1 << 18; // rows per pass of the streamed-codebook kernels (vq_chunk.hip): bounds their scratch
 constexpr int kVqGroupSlabs = 16;    // slabs whose open / hard rows are resolved by ONE launch (their records' scratch: 44.1 B per row of a group)
 
-bool vq_sweep_ok(int K, int D);
+bool vq_track_ok(int K, int D);          // vq_track.hip: the codebook's fp16 image fits LDS next to eight waves' tiles (D = 64, K <= ~600)
 bool vq_chunk_ok(int K, int D);
 size_t vq_chunk_scratch_bytes(int D);
 
@@ -98,7 +98,7 @@ inline VqPlan vq_plan(int K, int D) {
     p.off_imgf = align_up(p.off_seeds + (size_t)p.K32 * 4 + 4096, 256);
     p.off_chunk = align_up(p.off_imgf + (size_t)(p.K32 + 512) * D * 2, 256);
     // row scratch of the streamed-codebook kernels: only where they are the default path
-    p.total = p.off_chunk + ((vq_chunk_ok(K, D) && !vq_sweep_ok(K, D)) ? vq_chunk_scratch_bytes(D) : 0);
+    p.total = p.off_chunk + ((vq_chunk_ok(K, D) && !vq_track_ok(K, D)) ? vq_chunk_scratch_bytes(D) : 0);
     // LDS of the filter kernel: bf16 image + (-||e||^2/2) + histogram + per-wave candidate lists + scratch
     p.filter_lds_bytes = (size_t)p.K32 * D * 2 + (size_t)p.K32 * 4 + (size_t)K * 4 +
                          kVqTilesPerWave * (8 * 32 * 2 * kVqCandCap * 2 + 8 * 96 * 4) + 256 + 8;
@@ -110,9 +110,7 @@ inline VqPlan vq_plan(int K, int D) {
 int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, int K, bool rowmajor,
                          float *zq, long long *idx, int *hist, char *ws, hipStream_t st, int *grid_out);
 
-// vq_sweep.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel (D = 64, row-major rows)
-// vq_track.hip: the same screen with round 3's stream tracker (the default where it fits)
-bool vq_track_ok(int K, int D);
+// vq_track.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel with the stream tracker (D = 64; row-major rows or NCHW)
 bool vq_track_nchw_ok(int K, int D, int HW);       // NCHW input: maps whose pixel count is a multiple of 64
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false);
@@ -122,8 +120,6 @@ void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st
 // bits of a non-negative float: the caller has filled it with -1)
 int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D, float *zq, long long *idx, int *hist,
                       char *ws, hipStream_t st, int *grid_out, int *zq_amax = nullptr, int hw = 1);
-int launch_vq_sweep_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, bool sixteen);
 
 // conv.hip: the per-layer entry points with the per-image activation maxima of the two-term fp16 product path
 // (arrays of B ints, -1 = not provided; NULL = none): written by a producing layer, read by the consuming one.

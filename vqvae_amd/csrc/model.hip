@@ -442,7 +442,7 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                               (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
-                                           VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)) | VQVAE_VQ_ROWMAJOR,
+                                           VQVAE_VQ_REMOVED_FLAGS)) | VQVAE_VQ_ROWMAJOR,
                               z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
                               zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
     return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf);    // :36

@@ -1,5 +1,5 @@
 // Fused VectorQuantizer forward for LARGE codebooks and D = 64 / 128 (row-major rows) -- the single-sweep fp16 screen of
-// vq_sweep.hip with the codebook image STREAMED through LDS instead of resident in it.
+// The single-sweep fp16 screen (vq_prepare16.hip has the bound) with the codebook image STREAMED through LDS instead of resident in it.
 //
 // Same contract and the same bits out as vq_exact.hip (indices and z_q bit-identical to the reference,
 // models/quantizer.py:45-74).  vq_sweep.hip needs the whole fp16 image (K x D x 2 B), the ||e||^2 table, a histogram and
@@ -23,7 +23,7 @@
 //                       (NaN is minimal, first index wins)
 //   vq_stream_gather_kernel   z_q = z + (e_k - z), squared error, histogram (once per call, over all rows)
 //
-// The bound is the one derived in vq_sweep.hip with g' = (D + 1) 2^-23 and g = D 2^-24 * 1.01.  Extra HBM traffic against
+// The bound is the one derived in vq_prepare16.hip with g' = (D + 1) 2^-23 and g = D 2^-24 * 1.01.  Extra HBM traffic against
 // the fused kernel (fp16 image written and read once, rows read a second time by the gather): 3 D bytes per row -- 0.4 ms
 // of config 5's step, against the ~70 ms the fp32 sweep costs.
 #include "common.h"

@@ -444,7 +444,7 @@ static int launch_vq_prepare(const float *cb, int K, char *ws, hipStream_t st) {
     hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((kmax + 63) / 64), dim3(64), 0, st, cb, K, p.KC, p.K_pad,
                        reinterpret_cast<float *>(ws + p.off_ee), reinterpret_cast<float *>(ws + p.off_img), wflags, p.K32,
                        reinterpret_cast<unsigned short *>(ws + p.off_img16), reinterpret_cast<float *>(ws + p.off_neh));
-    if (vq_sweep_ok(K, D) || vq_chunk_ok(K, D)) launch_vq_prepare16(cb, K, D, ws, st);
+    if (vq_track_ok(K, D) || vq_chunk_ok(K, D)) launch_vq_prepare16(cb, K, D, ws, st);
     return (int)hipGetLastError();
 }
 
@@ -469,14 +469,11 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     if constexpr (D == 64) {
         // NCHW maps whose pixel count is a multiple of 64 (a unit = 64 positions of one image): the stream-tracker kernel reads
         // and writes the reference's own layout (round 4); other NCHW maps stay on the two-sweep kernel below
-        const bool track_nchw = !rowmajor && vq_track_nchw_ok(K, D, HW) &&
-                                !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES));
-        if (track_nchw || (rowmajor && vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
+        const bool track_nchw = !rowmajor && vq_track_nchw_ok(K, D, HW) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER));
+        if (track_nchw || (rowmajor && vq_track_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
-            const int rc = (track_nchw || (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))))
-                               ? launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw)
-                               : launch_vq_sweep_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, (flags & VQVAE_VQ_SIXTEEN_WAVES) != 0);
+            const int rc = launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw);
             prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
             hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
@@ -486,7 +483,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     }
     if constexpr (D == 64 || D == 128) {
         // larger codebooks / D = 128: the same fp16 screen with the codebook image streamed through LDS (vq_chunk.hip)
-        if (rowmajor && vq_chunk_ok(K, D) && !vq_sweep_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
+        if (rowmajor && vq_chunk_ok(K, D) && !vq_track_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER))) {
             int fgrid = 0;
             prof_begin(VQVAE_PROF_VQ_MAIN, st);
             const int rc = launch_vq_chunked(z, cb, N, K, D, zq, idx, hist, ws, st, &fgrid, zq_amax, HW);
@@ -550,14 +547,13 @@ using namespace vqvae;
 extern "C" {
 
 const char *vqvae_vq_kernel_name(int K, int D, int flags) {
-    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return "unsupported";
+    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256) || (flags & VQVAE_VQ_REMOVED_FLAGS)) return "unsupported";
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
-        if ((flags & VQVAE_VQ_ROWMAJOR) && vq_sweep_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER))
-            return (vq_track_ok(K, D) && !(flags & (VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES))) ? "vq_track_kernel_d64" : "vq_sweep_kernel_d64";
+        if ((flags & VQVAE_VQ_ROWMAJOR) && vq_track_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_track_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
         // NCHW (the module boundary): the stream-tracker kernel on maps whose pixel count is a multiple of 64 (8x8, 56x56, 64x64
         // ...: what this function answers for); other NCHW maps run vq_filter_kernel_d64
-        if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES)) && vq_track_ok(K, D))
+        if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER)) && vq_track_ok(K, D))
             return "vq_track_kernel_d64";
         if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
     }
@@ -591,7 +587,7 @@ bool vqvae::vq_fuse_ok(int K, int D, int64_t B, int flags) {
     const VqPlan p = vq_plan(K > 0 ? K : 1, 64);
     (void)B;
     return D == 64 && K >= 1 && K <= 512 && p.K32 % 128 == 0 && vq_track_ok(K, D) &&
-           !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_TOP3_KEYS | VQVAE_VQ_SIXTEEN_WAVES | VQVAE_VQ_UNFUSED));
+           !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_UNFUSED));
 }
 
 int vqvae::vq_prepare_impl(const float *codebook, int K, int D, int flags, void *workspace, size_t workspace_bytes, hipStream_t st) {
@@ -637,6 +633,7 @@ int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, i
     if ((int64_t)H * W > (int64_t)1 << 30) return VQVAE_ERR_OVERFLOW;
     const int64_t N = B * (int64_t)H * W;
     if (N / ((int64_t)H * W) != B || N > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
+    if (flags & VQVAE_VQ_REMOVED_FLAGS) return VQVAE_ERR_UNSUPPORTED;     // round 2's tracker kernel and its A/B flags are gone (round 4)
     const size_t need = vqvae_vq_workspace_bytes(N, K, D);
     if (!workspace || workspace_bytes < need) return VQVAE_ERR_WORKSPACE;
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -1,0 +1,97 @@
+// Second stage of the codebook preparation for the fp16-screened VectorQuantizer kernels (vq_track.hip: image resident in LDS;
+// vq_chunk.hip: image streamed through LDS; conv.hip: the quantizer inside the encoder's last kernel) -- and the derivation of
+// the screen's bound they share.  (Round 2's own single-sweep kernel with index-carrying top-3 keys, vq_sweep_kernel_d64, lived
+// here; round 4 removed it together with its flags VQVAE_VQ_TOP3_KEYS / VQVAE_VQ_SIXTEEN_WAVES: it was reachable only through
+// those A/B flags, and the heterogeneous-channel tests of round 4 found a row it got wrong.)
+//
+// The screen: acc_k = z^ . e^_k - A ee_k / 2 on v_mfma_f32_32x32x16_f16, with z^ = fp16(z) and e^ = fp16(A e), A = 2^a_e the power
+// of two that puts the codebook's largest element at 2^13..2^14 (exact).  models/quantizer.py:49-54 picks argmin_k d_k;
+// maximising S_k := A (z . e_k - ee_k / 2) is the same thing.
+//
+// Bound (all quantities in "accumulator units"; u = 2^-11; g' = 65 * 2^-23 covers fp32 accumulation of <= 65 terms even if the
+// matrix core truncates; g = 64 * 2^-24 * 1.01 is the reference's fmaf chain):
+//   errz := |z - z^| <= u |z| + 2^-22 (vq_track.hip; vq_chunk.hip measures it per row);   |z| <= zn := |z^| + errz
+//   |acc_k - S_k| <= eps := errz Ehat + (zn + errz) dE + g' (zn Ehat + EEh),   Ehat = max |e^_k|, dE = max |e'_k - e^_k|, e' = A e,
+//                                                                              EEh = A max ee_k / 2
+//   reference: d_k = fl(fl(zz + ee_k) - 2 m_k) = zz + ee_k - 2 z.e_k + xi_k,  A |xi_k| / 2 <= xi := g zn Emax' + 2^-23 (A zz + EEa),
+//                                                                              Emax' = max |e'_k|, EEa = A max ee_k
+//   => the reference's argmin k* satisfies  acc_k* >= max_k acc_k - (2 eps + 2 xi)  (+ a truncation term where index bits ride in
+//      the tracked values).  The code evaluates DELTA with every factor rounded up (> 1 % slack on the constants).
+// |z^| itself must be the true norm of the fp16 row: csrc/common.h, sqsum8_f16 (round 3 had it from a miscompiled builtin chain).
+// tests/adversarial.py builds inputs whose 64 channel roundings all align; tests/test_vq_gpu.py checks them bit for bit.
+#include "common.h"
+#include "vq_device.h"
+
+namespace vqvae {
+
+constexpr float kPadSeed = -3.0e38f;          // padded codes: finite (a key must stay an ordered float), below any score
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Prepare, second stage (after vq_prepare_kernel wrote ee[] and the max |e| / max ee statistics): fp16 A-operand image
+// [tile][q][half][32 codes] x 16 B of the scaled codebook, seeds -A ee_k / 2 in accumulator-register order
+// [tile][half][16], and the statistics of the bound.  One thread per (padded) code.
+template <int D>
+__global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restrict__ cb, const float *__restrict__ ee,
+                                                          int K, int K32, int *__restrict__ flags,
+                                                          unsigned short *__restrict__ img, float *__restrict__ seeds,
+                                                          unsigned short *__restrict__ imgf) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= K32) return;
+    const float emax = __int_as_float(flags[2]);
+    int a_e = 0;
+    if (emax > 0.0f && emax < 3.0e38f) {
+        int x;
+        (void)__builtin_frexpf(emax, &x);                 // emax = m 2^x, 0.5 <= m < 1
+        a_e = 14 - x;
+        a_e = a_e > 100 ? 100 : (a_e < -100 ? -100 : a_e);
+    }
+    const float A = __builtin_ldexpf(1.0f, a_e);
+    if (k == 0) flags[5] = a_e;
+    const int ct = k >> 5, i = k & 31;
+    float eh2 = 0.0f, de2 = 0.0f;
+    for (int c8 = 0; c8 < D / 8; ++c8) {                   // chunk c8 = (q, half): channels 8 c8 .. 8 c8 + 7
+        unsigned short v[8];
+        for (int j = 0; j < 8; ++j) {
+            const float es = k < K ? cb[(size_t)k * D + 8 * c8 + j] * A : 0.0f;
+            const _Float16 hv = (_Float16)es;                // round to nearest even
+            const float hf = (float)hv;
+            const float d = es - hf;                       // exact
+            eh2 = __builtin_fmaf(hf, hf, eh2);
+            de2 = __builtin_fmaf(d, d, de2);
+            v[j] = __builtin_bit_cast(unsigned short, hv);
+        }
+        unsigned short *dst = img + ((size_t)(ct * (D / 8) + c8) * 32 + i) * 8;
+        for (int j = 0; j < 8; ++j) dst[j] = v[j];
+        if (imgf) {
+            // the fused conv kernels' channel order (conv.hip, acc_to_ksteps): k-step 2 n3 + t, half h holds channels
+            // 32 n3 + 16 h + 8 t + [0, 8) -- chunk c8 = 4 n3 + 2 h + t moves to position 4 n3 + 2 t + h
+            const int c8f = (c8 & ~3) | ((c8 & 1) << 1) | ((c8 >> 1) & 1);
+            unsigned short *dstf = imgf + ((size_t)(ct * (D / 8) + c8f) * 32 + i) * 8;
+            for (int j = 0; j < 8; ++j) dstf[j] = v[j];
+        }
+    }
+    float seed = kPadSeed;
+    if (k < K) {
+        const float e2 = ee[k];
+        seed = -0.5f * e2 * A;
+        if (!(e2 * A * A < 1.0e36f) || !(eh2 < 1.0e36f)) atomicOr(flags, 1);     // screen units would overflow
+        atomicMax(flags + 3, __float_as_int(eh2 * 1.0001f));
+        atomicMax(flags + 4, __float_as_int(de2 * 1.0001f));
+    }
+    const int h = (i >> 2) & 1, r = (i & 3) + 4 * (i >> 3);                       // code i = (r&3) + 8 (r>>2) + 4 h
+    seeds[ct * 32 + h * 16 + r] = seed;
+}
+
+void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st) {
+    const VqPlan p = vq_plan(K, D);
+    const float *ee = reinterpret_cast<const float *>(ws + p.off_ee);
+    int *fl = reinterpret_cast<int *>(ws + p.off_flags);
+    unsigned short *img = reinterpret_cast<unsigned short *>(ws + p.off_imgh);
+    float *seeds = reinterpret_cast<float *>(ws + p.off_seeds);
+    unsigned short *imgf = reinterpret_cast<unsigned short *>(ws + p.off_imgf);
+    if (D == 64) hipLaunchKernelGGL(vq_prepare16_kernel<64>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds, imgf);
+    else hipLaunchKernelGGL(vq_prepare16_kernel<128>, dim3((p.K32 + 63) / 64), dim3(64), 0, st, cb, ee, K, p.K32, fl, img, seeds,
+                            static_cast<unsigned short *>(nullptr));
+}
+
+}  // namespace vqvae

@@ -1,7 +1,7 @@
 // Fused VectorQuantizer forward for gfx950, round 3: single-sweep fp16 screen with a STREAM TRACKER, exact refine
 // (D = 64, row-major rows, K <= 512 so that the codebook image stays resident in LDS next to eight waves' tiles).
 //
-// Same contract and the same bits out as vq_exact.hip / vq_sweep.hip (indices and z_q bit-identical to the reference,
+// Same contract and the same bits out as vq_exact.hip (indices and z_q bit-identical to the reference,
 // models/quantizer.py:45-74).  What changes against round 2's vq_sweep_kernel_d64 -- which was bound by vector-instruction
 // issue (17 M vector instructions per 262 144 rows against 0.5 M MFMAs, profiles/r02_pmc_sq.txt):
 //   * the sweep tracks per-lane maxima over two partitions of the accumulator values (8 "streams" by position in the code
@@ -19,7 +19,7 @@
 // Bound (accumulator units; A = 2^a_e the codebook scale, e' = A e, e^ = fp16(e'), z^ = fp16(z), u = 2^-11):
 //   errz := |z - z^| <= u |z| + 2^-22 (the second term covers fp16-subnormal channels, 64 x 2^-25 each at most);
 //           |z| <= zn := |z^| + errz
-//   eps, xi as in vq_sweep.hip:24-35;  DELTA = 2 eps + 2 xi.  A cell key differs from its cell's maximum by less than
+//   eps, xi as in vq_prepare16.hip (header);  DELTA = 2 eps + 2 xi.  A cell key differs from its cell's maximum by less than
 //   2^6 ulp <= 2^-17 (zn Ehat + EEh) =: tB < DELTA / 2, and keys are compared against thr - tB.
 #include "common.h"
 #include "vq_device.h"

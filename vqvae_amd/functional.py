@@ -13,8 +13,6 @@ VQ_ROWMAJOR = 0x1
 VQ_CODEBOOK_PREPARED = 0x2
 VQ_EXACT_SWEEP = 0x4
 VQ_BF16_FILTER = 0x8
-VQ_TOP3_KEYS = 0x10
-VQ_SIXTEEN_WAVES = 0x20
 VQ_UNFUSED = 0x40
 # whole-path product scheme (vqvae_forward_f32 / vqvae_encoder_ex_f32 / vqvae_decoder_ex_f32)
 FWD_CONV_BF16_SPLIT = 0x1000
@@ -42,16 +40,14 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
-               exact_sweep: bool = False, bf16_filter: bool = False, top3_keys: bool = False,
-               sixteen_waves: bool = False):
+               exact_sweep: bool = False, bf16_filter: bool = False):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
     z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
     Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
     exact_sweep=True forces the exhaustive fp32-MFMA kernel, bf16_filter=True round 1's two-sweep bf16 filter
-    kernel, instead of the default (single-sweep fp16 screen for row-major D=64 rows); all three produce
-    identical bits, the flags exist for testing and A/B timing (so do top3_keys and sixteen_waves: round 2's tracker
-    in its two forms, where the default is round 3's stream tracker).
+    kernel, instead of the default (single-sweep fp16 screen with the stream tracker: D=64 rows, row-major or NCHW maps of
+    64 k pixels); all three produce identical bits, the flags exist for testing and A/B timing.
     """
     _check_dev("z_e", z_e)
     _check_dev("codebook", codebook)
@@ -78,8 +74,7 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         hist = torch.empty((K,), dtype=torch.int32, device=dev)
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
-            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0) | \
-            (VQ_TOP3_KEYS if top3_keys else 0) | (VQ_SIXTEEN_WAVES if sixteen_waves else 0)
+            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0)
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
