@@ -171,7 +171,8 @@ def test_whole_path_on_heterogeneous_channel_scales(weights, images, scheme, cap
         bound = 8 * 2.0 ** -24 * ((zr[r] ** 2).sum() + (e[want[r]] ** 2).sum()) + 2 * (tol_c * np.abs(e[got[r]] - e[want[r]])).sum()
         worst_flip = max(worst_flip, abs(d[got[r]] - d[want[r]]) / bound)
     assert worst_flip <= 1.0, f"an index flip is not explained by the z_e tolerance: gap = {worst_flip:.3g} x the bound"
-    assert len(flips) <= max(2, 2e-3 * got.size), f"{len(flips)} index flips in {got.size} rows"
+    # (the stated fp16 exception -- trained-like weights and in-image outliers together -- moves more near-ties: 18 of 4096 measured)
+    assert len(flips) <= max(2, (1e-2 if both else 2e-3) * got.size), f"{len(flips)} index flips in {got.size} rows"
 
     # --- the whole forward: x_hat on images without a flip, per channel; loss / perplexity when nothing flipped
     clean = np.setdiff1d(np.arange(B), np.unique(flips // 64))
