@@ -227,8 +227,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #pragma unroll
         for (int t = 0; t < T; ++t) trk::init(L[t], ninf);
         {
-            // operands of tile ct+1 are requested right behind the MFMAs of tile ct and land under its vector work; two
-            // operand sets ping-pong through a loop unrolled by two, so nothing is copied
             auto fetch = [&](int ct, u32x4(&a)[4], f32x16 &seed) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
@@ -238,32 +236,60 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                     seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
                 }
             };
-            auto cell = [&](int ct, const u32x4(&a)[4], const f32x16 &seed, u32x4(&an)[4], f32x16 &seedn) {
-                f32x16 acc[T];
+            // Round 4: the sweep as a software pipeline over code tiles.  The eight MFMAs of tile ct are issued INTERLEAVED with the
+            // 48 vector instructions that track tile ct - 1's accumulators (two accumulator sets, one operand set: the same 96
+            // registers as the operand ping-pong before), six vector instructions behind every MFMA: a wave issues in order, so
+            // vector work placed behind a block of MFMAs waits for the block, and the matrix pipe idles while a block of
+            // vector work runs -- a 32-cycle MFMA slot has room for about six vector issues (MI355X_MICROARCH.md, "5 fillers
+            // per gap"), which is exactly the tracker's budget (24 per 16 values = 6 per MFMA).
+            auto mma = [&](f32x16(&acc)[T], const u32x4(&a)[4], const f32x16 &seed) {
 #pragma unroll
-                for (int t = 0; t < T; ++t) {
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[t][0], seed, 0, 0, 0);
+                for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[t][0], seed, 0, 0, 0);
 #pragma unroll
-                    for (int q = 1; q < 4; ++q)
+                for (int q = 1; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < T; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[t][q], acc[t], 0, 0, 0);
-                }
-                fetch(ct + 1 < ntile ? ct + 1 : ct, an, seedn);
+            };
+            auto track = [&](int ct, const f32x16(&acc)[T]) {
                 unsigned cell0 = (unsigned)(2 * ct), cell1 = cell0 + 1u;        // scalars (opaque: else or3(x & mask, cell0, 1))
                 asm volatile("" : "+s"(cell0), "+s"(cell1));
 #pragma unroll
                 for (int t = 0; t < T; ++t) trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
-                // the prefetched operands are first "used" here: their loads cannot sink below, their wait cannot rise above
-                asm volatile("" : "+v"(an[0]), "+v"(an[1]), "+v"(an[2]), "+v"(an[3]));
             };
-            u32x4 aA[4], aB[4];
-            f32x16 sA, sB;
-            fetch(0, aA, sA);
-            int ct = 0;
-            for (; ct + 1 < ntile; ct += 2) {
-                cell(ct, aA, sA, aB, sB);
-                cell(ct + 1, aB, sB, aA, sA);
+            // one pipeline step: operands of tile ct, its MFMAs into `accn`, the tracker of tile ct - 1 on `accp` between them
+            auto step = [&](int ct, f32x16(&accn)[T], const f32x16(&accp)[T]) {
+                u32x4 a[4];
+                f32x16 seed;
+                fetch(ct, a, seed);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(accn, a, seed);
+                track(ct - 1, accp);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);          // six vector instructions
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            f32x16 accA[T], accB[T];
+            {
+                u32x4 a[4];
+                f32x16 seed;
+                fetch(0, a, seed);
+                mma(accA, a, seed);
             }
-            if (ct < ntile) cell(ct, aA, sA, aB, sB);
+            int ct = 1;
+            for (; ct + 1 < ntile; ct += 2) {
+                step(ct, accB, accA);
+                step(ct + 1, accA, accB);
+            }
+            if (ct < ntile) {                              // an even number of tiles: one more step, the last tile is in accB
+                step(ct, accB, accA);
+                track(ct, accB);
+            } else {
+                track(ct - 1, accA);
+            }
         }
 
         VQ_STAMP(2);                                           // sweep
