@@ -417,7 +417,12 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
  * different parts on different streams can fill those ends -- measured between -7 % and +9 % per step depending on the box
  * (profiles/r03_notes.txt section 11), which is why the Python host layer does not do it by default.
  * The library creates no streams or events: ordering between the streams is the caller's (hipStreamWaitEvent / torch
- * wait_stream). */
+ * wait_stream).
+ * PRECONDITIONS the library does not (and, allocating nothing, cannot cheaply) verify -- violating them gives wrong loss /
+ * perplexity or races, not an error code: begin / every part / end get the SAME B, H, W, flags and workspaces; the parts cover
+ * [0, B) exactly once (no overlap, no gap: a part leaves one loss partial per four images and adds to the histogram
+ * atomically); with vq_workspace == NULL the codebook images live inside `workspace`, prepared by begin -- parts never
+ * prepare them; every buffer stays alive, and untouched by other work, until the stream of `end` has passed it. */
 VQVAE_API int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int vq_flags, void *workspace,
                                       size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
                                       vqvae_stream_t stream);

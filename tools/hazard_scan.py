@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Scans gfx950 assembly (hipcc -S) for a store-data hazard hipcc (ROCm 7.2) does not guard: a buffer store of more than
-8 bytes whose soffset is an SGPR, followed within two instructions by a vector instruction that writes one of its data
-registers.  LLVM's hazard recognizer exempts the SGPR-soffset form (GCNHazardRecognizer::createsVALUHazard); on MI355X the
+8 bytes whose soffset is an SGPR (or a global store with an saddr pair), followed within two wait states by an instruction
+that writes one of its data registers (vector ALU results; `s_nop N` counts N + 1 wait states).  LLVM's hazard recognizer exempts the SGPR-soffset form (GCNHazardRecognizer::createsVALUHazard); on MI355X the
 overwrite corrupts the last dword of the last lanes of each row (found with vq_track_kernel_d64's z_q stores, round 3).
 Round 4 added a second pattern, a MISCOMPILE rather than a hazard: four __builtin_amdgcn_fdot2 calls on the components of one
 loaded 16-byte vector came out as four `v_dot2c_f32_f16 vD, vS, vS` reading the SAME register vS (the first component), so a
@@ -26,20 +26,32 @@ def scan(path):
     ins = [(i, l) for i, l in enumerate(lines) if l and not l.startswith((';', '.', '/')) and not l.endswith(':')]
     found = 0
     for n, (i, l) in enumerate(ins):
-        m = re.match(r'buffer_store_dwordx[34]\s+(v\[\d+:\d+\]),\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0)\b', l)
+        # 16- / 12-byte stores whose address carries an SGPR offset: the buffer form with an soffset register (the one that
+        # bit us) and, as a precaution, the global form with an saddr pair
+        m = re.match(r'buffer_store_dwordx[34]\s+(v\[\d+:\d+\]),\s*\S+,\s*s\[\d+:\d+\],\s*(s\d+|m0)\b', l) or \
+            re.match(r'global_store_dwordx[34]\s+v\d+,\s*(v\[\d+:\d+\]),\s*s\[\d+:\d+\]', l)
         if not m:
             continue
         data = regs(m.group(1))
-        for j, (i2, l2) in enumerate(ins[n + 1:n + 3]):
+        waits = 0                                               # wait states between the store and the candidate writer
+        for i2, l2 in ins[n + 1:n + 4]:
+            if waits >= 2:
+                break
             op = l2.split()[0]
-            if not op.startswith('v_') or op.startswith('v_cmp'):
-                if op.startswith(('s_nop',)):
-                    break
+            if op == 's_nop':
+                waits += int(l2.split()[1], 0) + 1                # s_nop N = N + 1 wait states
                 continue
-            dst = l2.split(None, 1)[1].split(',')[0].strip()
-            if regs(dst) & data:
-                print(f"{path}:{i + 1}: {l}\n{path}:{i2 + 1}:     {l2}   <- overwrites store data after {j} wait state(s)")
-                found += 1
+            # (vector ALU results only.  Loads landing in the data registers were tried as "writers" too -- hundreds of sites,
+            # e.g. every tile_epilogue store followed by the next ds_read_b128 into the same registers, all verified bit-exact on
+            # hardware: a load returns tens of cycles after the store has read its data, the hazard window is two wait states)
+            writer = op.startswith('v_') and not op.startswith('v_cmp')
+            if writer and len(l2.split(None, 1)) > 1:
+                dst = l2.split(None, 1)[1].split(',')[0].strip()
+                if regs(dst) & data:
+                    print(f"{path}:{i + 1}: {l}\n{path}:{i2 + 1}:     {l2}   <- overwrites store data after {waits} wait state(s)")
+                    found += 1
+                    break
+            waits += 1
     # ---- repeated v_dot2c on one source register (the fdot2 miscompile)
     for n, (i, l) in enumerate(ins):
         m = re.match(r'v_dot2c_f32_f16(?:_e32)?\s+(v\d+),\s*(v\d+),\s*(v\d+)\s*$', l)

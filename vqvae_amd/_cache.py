@@ -24,3 +24,43 @@ def drop(mod, *keys) -> None:
         d.clear()
     for k in keys:
         d.pop(k, None)
+
+
+# ---- packed images are produced asynchronously on the stream that first misses the cache; a forward on ANOTHER stream that
+# hits the cache right afterwards must not read them before the pack kernels finished: every cache entry carries
+# the event recorded behind its pack launches, and a hit from a different stream waits on it.
+def mark_ready(device):
+    """-> (event, stream id) recorded on the current stream of `device` (None on the CPU)."""
+    import torch
+    if device.type != "cuda":
+        return None
+    ev = torch.cuda.Event()
+    st = torch.cuda.current_stream(device)
+    ev.record(st)
+    return (ev, st.cuda_stream)
+
+
+def wait_ready(mark, device):
+    import torch
+    if mark is None:
+        return
+    ev, sid = mark
+    cur = torch.cuda.current_stream(device)
+    if cur.cuda_stream != sid:
+        cur.wait_event(ev)
+
+
+def lru_put(table: dict, key, value, cap: int):
+    """Insert at the most-recent end; evict only the least recently used entries beyond `cap` (never the whole table: the hot
+    entry of a model that alternates two batch sizes must survive)."""
+    table.pop(key, None)
+    table[key] = value
+    while len(table) > cap:
+        table.pop(next(iter(table)))
+
+
+def lru_get(table: dict, key):
+    v = table.pop(key, None)
+    if v is not None:
+        table[key] = v
+    return v

@@ -32,13 +32,14 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
     cache = _cache.side(mod).setdefault("packed", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == key:
+        _cache.wait_ready(hit[2], w.device)
         return hit[1]
     n = nbytes_fn()
     if n == 0:
         raise _lib.VqvaeHipError(f"layer shape {tuple(w.shape)} not supported by the gfx950 conv kernels")
     buf = torch.empty(n // 4, dtype=torch.float32, device=w.device)
     _lib.check(pack_fn(w.contiguous(), buf))
-    cache[kind] = (key, buf)
+    cache[kind] = (key, buf, _cache.mark_ready(w.device))
     return buf
 
 

@@ -70,11 +70,10 @@ class VectorQuantizer(nn.Module):
         key = (w.data_ptr(), w._version, w.device)
         table = _cache.side(self).setdefault("ws", {})
         skey = (str(w.device), torch.cuda.current_stream(w.device).cuda_stream if w.is_cuda else 0)
-        slot = table.get(skey)
+        slot = _cache.lru_get(table, skey)
         if slot is None:
-            if len(table) >= 8:                                  # streams come and go: keep the table small
-                table.clear()
-            slot = table[skey] = [F_hip.vq_workspace(self.n_e, self.e_dim, w.device), None]
+            slot = [F_hip.vq_workspace(self.n_e, self.e_dim, w.device), None]
+            _cache.lru_put(table, skey, slot, 8)                 # streams come and go: the least recently used slot leaves
         return slot[0], slot[1] == key, key, slot
 
     def quantize(self, z, *, rowmajor=False, want_zq=True):
@@ -242,6 +241,7 @@ class VQVAE(nn.Module):
         key = tuple((t.data_ptr(), t._version) for t in tensors.values()) + (str(tensors["enc0_w"].device),)
         hit = _cache.side(self).get("c_weights")
         if hit is not None and hit[0] == key:
+            _cache.wait_ready(hit[3], tensors["enc0_w"].device)          # packed on another stream a moment ago?
             return hit[1], hit[2]
         L = _lib.load()
         w0 = tensors["enc0_w"]
@@ -258,7 +258,8 @@ class VQVAE(nn.Module):
         with torch.cuda.device(w0.device):
             _lib.check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, cw,
                                                 torch.cuda.current_stream(w0.device).cuda_stream))
-        _cache.side(self)["c_weights"] = (key, cw, (keep, packed))
+            ready = _cache.mark_ready(w0.device)
+        _cache.side(self)["c_weights"] = (key, cw, (keep, packed), ready)
         return cw, (keep, packed)
 
     # The step can run as n parts on n side streams (vqvae_forward_begin / part / end; _forward_c(x, parts=n)): the kernels of
@@ -287,18 +288,22 @@ class VQVAE(nn.Module):
         per = -(-per // 64) * 64                        # whole 64-image blocks per part
         b0 = 0
         used = []
-        for s in streams[:n]:
-            if b0 >= B:
-                break
-            bc = min(per, B - b0)
-            s.wait_stream(cur)
-            _lib.check(L.vqvae_forward_part_f32(cw, x.data_ptr(), B, b0, bc, H, W, flags, x_hat.data_ptr(),
-                                                idx.data_ptr() if idx is not None else None, ws.data_ptr(), nws, vws.data_ptr(),
-                                                vws.numel(), s.cuda_stream))
-            used.append(s)
-            b0 += bc
-        for s in used:
-            cur.wait_stream(s)
+        try:
+            for s in streams[:n]:
+                if b0 >= B:
+                    break
+                bc = min(per, B - b0)
+                s.wait_stream(cur)
+                used.append(s)                                  # (before the launch: a failing part may have enqueued kernels already)
+                _lib.check(L.vqvae_forward_part_f32(cw, x.data_ptr(), B, b0, bc, H, W, flags, x_hat.data_ptr(),
+                                                    idx.data_ptr() if idx is not None else None, ws.data_ptr(), nws, vws.data_ptr(),
+                                                    vws.numel(), s.cuda_stream))
+                b0 += bc
+        finally:
+            # ALWAYS: the caller's stream must not free or reuse x_hat / ws / idx while a side stream still writes them, also
+            # when a part raised
+            for s in used:
+                cur.wait_stream(s)
         _lib.check(L.vqvae_forward_end_f32(cw, B, H, W, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), nws, stream))
         return True
 
@@ -322,13 +327,15 @@ class VQVAE(nn.Module):
                 raise VqvaeHipError(f"shape {tuple(x.shape)} not supported by the gfx950 whole-path entry points")
             # one activation workspace per (shape, device, stream), reused: forwards on different streams never share one
             stream = torch.cuda.current_stream(dev).cuda_stream
-            wkey = (nws, str(dev), stream)
+            # (keyed on (device, stream) only: ONE buffer per stream, grown to the largest batch seen -- a model that alternates
+            # a training and an evaluation batch size keeps one workspace, not one per size)
+            wkey = (str(dev), stream)
             table = _cache.side(self).setdefault("c_ws", {})
-            ws = table.get(wkey)
-            if ws is None:
-                if len(table) >= 4:
-                    table.clear()
-                ws = table[wkey] = torch.empty(nws, dtype=torch.uint8, device=dev)
+            ws = _cache.lru_get(table, wkey)
+            if ws is None or ws.numel() < nws:
+                ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+                _cache.lru_put(table, wkey, ws, 4)
+            nws = ws.numel()
             vq = self.vector_quantization
             vws, prepared, key, slot = vq._workspace()
             if not prepared:
