@@ -359,6 +359,40 @@ def other_workload(name, torch, dev, seconds=1.0):
     return res
 
 
+def wide_leg(torch, dev, seconds=1.0):
+    """main.py's other hyper-parameters: --n_hiddens 256 --n_residual_hiddens 64 on 32x32 images, K = 512, D = 64.
+    Widths outside the fused kernels: per-layer conv kernels, the residual layers as conv -> conv -> combine."""
+    import statistics
+    from vqvae_amd import conv as conv_mod
+    from vqvae_amd.modules import VQVAE
+    B = 1024
+    conv_mod.set_conv_backend("hip")
+    torch.manual_seed(0)
+    model = VQVAE(256, 64, 2, 512, 64, 0.25).eval().to(dev)
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1000)).to(dev)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                model(x)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2)
+    steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
+    times = [run(steps) for _ in range(5)]
+    el = statistics.median(times)
+    res = {"workload": "main.py --n_hiddens 256 --n_residual_hiddens 64 (h_dim 256, res_h 64, 2 residual layers), 32x32x3, K=512, D=64: "
+                       "per-layer kernels, residual layers outside the fused widths as conv -> conv -> combine",
+           "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps}
+    del model, x
+    torch.cuda.empty_cache()
+    return res
+
+
 def scheme_leg(scheme, torch, dev, seconds=1.0):
     """BASELINE config 3 with the whole path on another product scheme (the headline beside the same step in
     exacter arithmetic, same box, same batch): 'bf16x3' = VQVAE_FWD_CONV_BF16_SPLIT (three-term bf16 products, per-layer kernels),
@@ -656,6 +690,7 @@ def main():
                 # the headline's step in the two exacter product schemes, same box and batch (the headline itself = "fp16x2")
                 line["other_workloads"]["c3_bf16x3"] = scheme_leg("bf16x3", torch, dev)
                 line["other_workloads"]["c3_fp32"] = scheme_leg("fp32", torch, dev)
+                line["other_workloads"]["wide_h256_rh64"] = wide_leg(torch, dev)
                 try:                                   # a next-row figure: its failure must not take the headline line with it
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)

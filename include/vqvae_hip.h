@@ -205,11 +205,18 @@ VQVAE_API int vqvae_conv_forward_f32(int kind, const float *x, const float *pack
  *   followed by ReLU if VQVAE_CONV_RELU_OUT (the stack's final F.relu, residual.py:50, or the
  *   next layer's in-place ReLU hoisted into this one).
  * packed_w1 = pack(VQVAE_CONV_3x3_S1, res_block[1].weight (Rh,C,3,3)), packed_w2 =
- * pack(VQVAE_CONV_1x1, res_block[3].weight (C,Rh,1,1)).  C in {32,64,128}, Rh <= 32, x != y.     */
+ * pack(VQVAE_CONV_1x1, res_block[3].weight (C,Rh,1,1)).  C in {32,64,128}, Rh <= 32, x != y (other widths:
+ * vqvae_res_layer_forward_ws_f32 below; here VQVAE_ERR_UNSUPPORTED).                                */
 VQVAE_API int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1,
                                           const float *packed_w2, int64_t B, int H, int W, int C,
                                           int Rh, int flags, float *y, vqvae_stream_t stream);
 
+/* The same for ANY width with C % 4 == 0 and Rh % 4 == 0 (round 4: main.py's --n_hiddens / --n_residual_hiddens are free):
+ * widths outside the fused kernels (C not in {32,64,128} or Rh > 32) run as 3x3 conv -> 1x1 conv -> skip + ReLU through the conv
+ * kernels, the hidden map in `scratch` (at least B*H*W*Rh floats; unused and may be NULL for the fused widths).              */
+VQVAE_API int vqvae_res_layer_forward_ws_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H,
+                                             int W, int C, int Rh, int flags, float *y, float *scratch, size_t scratch_bytes,
+                                             vqvae_stream_t stream);
 /* The same layer for a training step (main.py:74-78 through models/residual.py:27-29): also writes the hidden
  * activation relu(W1 (*) r(x)) as hidden (B,H,W,Rh) row-major, which the backward pass needs for the ReLU mask and the
  * 1x1 weight gradient -- instead of recomputing the 3x3 conv there.  Only where a wave owns whole images:

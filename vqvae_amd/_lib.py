@@ -59,6 +59,7 @@ SIGNATURES = {
     "vqvae_conv_pack_f32": (_i32, [_i32, _vp, _i32, _i32, _vp, _vp]),
     "vqvae_conv_forward_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vqvae_res_layer_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_res_layer_forward_ws_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_res_layer_forward_hidden_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vqvae_conv_in_packed_bytes": (_sz, [_i32, _i32]),
     "vqvae_conv_in_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),

@@ -80,14 +80,17 @@ def res_layer(x, layer, flags, want_hidden=False):
     c1, c2 = layer.res_block[1], layer.res_block[3]
     B, H, W, C = x.shape
     Rh = c1.weight.shape[0]
-    if Rh > 32 or C not in (32, 64, 128):
-        # unfused: conv3x3 -> conv1x1, skip added by torch-free kernels is not available for this
-        # shape; be explicit rather than silently slow
-        raise _lib.VqvaeHipError(f"residual layer C={C}, res_h={Rh} not supported by the fused gfx950 kernel "
-                                 "(C in {32,64,128}, res_h <= 32)")
+    if C % 4 or Rh % 4:
+        raise _lib.VqvaeHipError(f"residual layer C={C}, res_h={Rh}: the gfx950 kernels need multiples of 4 channels")
     p1 = _pack_conv(c1, CONV_3x3_S1, c1.weight, C, Rh)
     p2 = _pack_conv(c2, CONV_1x1, c2.weight, Rh, C)
     y = torch.empty_like(x)
+    if Rh > 32 or C not in (32, 64, 128):
+        # widths outside the fused kernel (round 4): 3x3 conv -> 1x1 conv -> skip + ReLU through the conv kernels
+        scratch = torch.empty((B, H, W, Rh), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.load().vqvae_res_layer_forward_ws_f32(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, H, W, C, Rh, flags,
+                                                              y.data_ptr(), scratch.data_ptr(), scratch.numel() * 4, _sp(x)))
+        return (y, None) if want_hidden else y
     if want_hidden and H == 8 and W == 8 and Rh == 32:
         hid = torch.empty((B, H, W, Rh), dtype=torch.float32, device=x.device)
         _lib.check(_lib.load().vqvae_res_layer_forward_hidden_f32(x.data_ptr(), p1.data_ptr(), p2.data_ptr(), B, H, W, C, Rh,

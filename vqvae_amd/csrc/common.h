@@ -127,7 +127,9 @@ int conv_forward_impl(int kind, const float *x, const float *packed, const float
                       int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
 int res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                            int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
-                           float *hidden = nullptr);      // hidden: relu(W1 (*) r(x)) as (B,8,8,32), kept for backward (8x8 maps, Rh = 32)
+                           float *hidden = nullptr, float *hid_scratch = nullptr);
+// widths the fused residual kernels cover (else: 3x3 conv -> 1x1 conv -> combine through hid_scratch, B*H*W*Rh floats)
+bool res_layer_fused_ok(int C, int Rh);      // hidden: relu(W1 (*) r(x)) as (B,8,8,32), kept for backward (8x8 maps, Rh = 32)
 bool res_pair_supported(int H, int W, int C, int Rh, int flags);
 // a 1x1 conv (+ bias) fused behind a residual pair: packed = vqvae_conv_pack_f32(VQVAE_CONV_1x1, ...), out (B,8,8,Cout) row-major
 // zero / zero_n (conv_res_pair_forward_impl only): ints the kernel clears for the next kernel of the stream

@@ -4619,6 +4619,22 @@ __global__ __launch_bounds__(256) void convt_out_pack_bf3_kernel(const float *__
 }
 
 // ---------------------------------------------------------------------------
+// The skip connection of a residual layer whose width the fused kernels do not cover (round 4: C not in {32, 64, 128} or
+// more than 32 hidden channels -- main.py's --n_hiddens / --n_residual_hiddens are free parameters): y = r(x) + t, r = ReLU if
+// relu_in (the in-place nn.ReLU(True) of residual.py:19 also rewrites the skip), then ReLU if relu_out.  t may alias y.
+__global__ __launch_bounds__(256) void res_combine_kernel(const float *__restrict__ x, const float *t, float *y, long long n4,
+                                                          int relu_in, int relu_out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 a = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 b = reinterpret_cast<const f32x4 *>(t)[i];
+        if (relu_in) a = relu4(a);
+        f32x4 o = a + b;
+        if (relu_out) o = relu4(o);
+        reinterpret_cast<f32x4 *>(y)[i] = o;
+    }
+}
+
+// ---------------------------------------------------------------------------
 // Batched 2-D transpose in[b][R][Cc] -> out[b][Cc][R] (NCHW <-> row-major at module boundaries).
 __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict__ in, float *__restrict__ out,
                                                         int R, int Cc) {
@@ -4911,6 +4927,13 @@ int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const fl
     return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
+int vqvae_res_layer_forward_ws_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
+                                   int Rh, int flags, float *y, float *scratch, size_t scratch_bytes, vqvae_stream_t stream) {
+    if (!vqvae::res_layer_fused_ok(C, Rh) && (!scratch || scratch_bytes < (size_t)B * H * W * Rh * sizeof(float))) return VQVAE_ERR_WORKSPACE;
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                                         nullptr, scratch);
+}
+
 int vqvae_res_layer_forward_hidden_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B,
                                        int H, int W, int C, int Rh, int flags, float *y, float *hidden,
                                        vqvae_stream_t stream) {
@@ -4919,15 +4942,33 @@ int vqvae_res_layer_forward_hidden_f32(const float *x, const float *packed_w1, c
 }
 }  // extern "C"
 
+bool vqvae::res_layer_fused_ok(int C, int Rh) { return Rh >= 1 && Rh <= 32 && (C == 32 || C == 64 || C == 128); }
+
 int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
                                   int C, int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
-                                  float *hidden) {
+                                  float *hidden, float *hid_scratch) {
     if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
     // the hidden activation is written by the kernels that own whole 8x8 images only (full 32-wide hidden tile)
     if (hidden && (H != 8 || W != 8 || Rh != 32 || (flags & VQVAE_CONV_EXACT_FP32) || (reinterpret_cast<uintptr_t>(hidden) & 15)))
         return VQVAE_ERR_UNSUPPORTED;
     if (B < 1 || H < 1 || W < 1 || C < 1 || Rh < 1) return VQVAE_ERR_SHAPE;
-    if (Rh > 32 || C % 4 || !(C == 32 || C == 64 || C == 128)) return VQVAE_ERR_UNSUPPORTED;
+    if (!res_layer_fused_ok(C, Rh)) {
+        // widths outside the fused kernels: 3x3 conv -> 1x1 conv through the conv kernels + one combine pass; the hidden map
+        // goes through the caller's scratch (vqvae_res_layer_forward_ws_f32 / the whole-path workspace)
+        if (C % 4 || Rh % 4 || !hid_scratch || hidden) return VQVAE_ERR_UNSUPPORTED;
+        if (x == y) return VQVAE_ERR_UNSUPPORTED;
+        const int cf = flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32);
+        int rc = conv_forward_impl(VQVAE_CONV_3x3_S1, x, packed_w1, nullptr, B, H, W, C, Rh,
+                                   (flags & VQVAE_CONV_RELU_IN) | VQVAE_CONV_RELU_OUT | cf, hid_scratch, stream, nullptr, nullptr);
+        if (rc != 0) return rc;
+        if ((rc = conv_forward_impl(VQVAE_CONV_1x1, hid_scratch, packed_w2, nullptr, B, H, W, Rh, C, cf, y, stream, nullptr, nullptr)) != 0) return rc;
+        const long long n4 = (long long)B * H * W * C / 4;
+        long long grid = (n4 + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(res_combine_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, y, y, n4,
+                           (flags & VQVAE_CONV_RELU_IN) ? 1 : 0, (flags & VQVAE_CONV_RELU_OUT) ? 1 : 0);
+        return (int)hipGetLastError();
+    }
     if (x == y) return VQVAE_ERR_UNSUPPORTED;           // 3x3 halo: not in place
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte accesses
     hipStream_t st = static_cast<hipStream_t>(stream);

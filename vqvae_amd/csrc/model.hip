@@ -38,7 +38,7 @@ size_t act_elems(const VqvaeDims *d, int64_t B, int H, int W) {
 // amax: NULL, or (n_layers + 1) arrays of B ints (-1 = not provided): [0] belongs to x, [i + 1] to layer i's output
 int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H, int W, int C, int Rh, int n_layers,
               bool first_relu_in, bool final_relu, float *y, float *tmp, hipStream_t st, const float **out, int *amax = nullptr,
-              const ResPairPost *post = nullptr, bool *post_done = nullptr, int conv_flags = 0) {
+              const ResPairPost *post = nullptr, bool *post_done = nullptr, int conv_flags = 0, float *hid_scratch = nullptr) {
     // every layer's output feeds the next layer's in-place ReLU (residual.py:19) or the stack's final F.relu (:50), so
     // the producer applies it.  Layers run in PAIRS where the fused two-layer kernel applies (8x8 maps, two-term fp16
     // products; the intermediate map stays on chip), a trailing odd layer alone; buffers alternate so that the result of
@@ -46,7 +46,10 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
     // never has to.
     const float *cur = x;
     *out = x;
-    const bool pairs = n_layers >= 2 && res_pair_supported(H, W, C, Rh, conv_flags);
+    const bool generic = !res_layer_fused_ok(C, Rh);      // widths outside the fused kernels: conv + conv + combine, no maxima
+    if (generic && !hid_scratch) return VQVAE_ERR_UNSUPPORTED;
+    if (generic) amax = nullptr;
+    const bool pairs = !generic && n_layers >= 2 && res_pair_supported(H, W, C, Rh, conv_flags);
     const int nsteps = pairs ? n_layers / 2 + (n_layers & 1) : n_layers;
     int i = 0;
     for (int j = 0; j < nsteps; ++j) {
@@ -64,7 +67,7 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
         const bool with_post = pair && post && j == nsteps - 1 && res_pair_post_supported(C, post->Cout);
 #endif
         const int rc = pair ? res_pair_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout, with_post ? post : nullptr)
-                            : res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout);
+                            : res_layer_forward_impl(cur, w1, w2, B, H, W, C, Rh, flags, dst, st, ain, aout, nullptr, hid_scratch);
         if (with_post && post_done) *post_done = true;
         if (rc != 0) return rc;
         cur = dst;
@@ -72,6 +75,12 @@ int res_stack(const float *w1, const float *w2, const float *x, int64_t B, int H
     }
     *out = cur;
     return 0;
+}
+
+// hidden map of a residual layer outside the fused kernels' widths (generic path), else nothing
+size_t res_hidden_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
+    if (d->n_res_layers < 1 || res_layer_fused_ok(d->h_dim, d->res_h_dim)) return 0;
+    return align_up((size_t)B * (H / 4) * (W / 4) * d->res_h_dim * sizeof(float), 256);
 }
 
 // per-image activation maxima handed from layer to layer (two-term fp16 product path): one array of B ints per
@@ -162,7 +171,7 @@ size_t vqvae_workspace_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
     const size_t lat = align_up((size_t)B * (H / 4) * (W / 4) * d->embedding_dim * sizeof(float), 256);
     const size_t rows = (size_t)B * (H / 4) * (W / 4);
     return 2 * act + 2 * amax_bytes(d, B) + 2 * lat + align_up(rows * sizeof(int64_t), 256) +
-           align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) + align_up(vq, 256) + 256;
+           align_up((size_t)d->n_embeddings * sizeof(int32_t), 256) + align_up(vq, 256) + 256 + res_hidden_bytes(d, B, H, W);
 }
 
 int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const float *x, int64_t B, int H, int W, int C,
@@ -181,7 +190,8 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
 // vq: quantize inside the last kernel (fused 32x32 path only; z_e is then NOT written and zero_buf is cleared by the FIRST kernel)
 static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, int *zero_buf = nullptr, int zero_n = 0,
-                       bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr, int cf = 0) {
+                       bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr, int cf = 0,
+                       float *hid_given = nullptr) {
     // cf: 0 = the default product scheme (two-term fp16 where the kernels have it), VQVAE_CONV_BF16_SPLIT / VQVAE_CONV_EXACT_FP32 =
     // every layer through the per-layer kernels of that scheme (no fused kernels: they exist for the fp16 products only)
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
@@ -198,6 +208,12 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
         am = static_cast<int *>(c.raw(amax_bytes(d, B)));
         // (no fill where every array that is read has a one-wave-per-image producer with plain stores: fused_c3_path)
         if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    }
+    // residual widths outside the fused kernels: the hidden map's scratch (given by the forward entry, else carved here)
+    float *hid = hid_given;
+    if (!hid && res_hidden_bytes(d, B, H, W)) {
+        hid = static_cast<float *>(c.raw(res_hidden_bytes(d, B, H, W)));
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;
     }
     int *am0 = am, *am1 = am ? am + B : nullptr, *am2 = am ? am + 2 * B : nullptr;     // conv_in, enc2, enc4 (+ residual layers)
     const int h = d->h_dim;
@@ -236,10 +252,11 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
         const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e};
         bool post_done = false;
         if ((rc = res_stack(w->enc_res_w1, w->enc_res_w2, a, B, H / 4, W / 4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am2,
-                            &post, &post_done, cf)) != 0)
+                            &post, &post_done, cf, hid)) != 0)
             return rc;
         if (post_done) return 0;
         if (am2) amt = am2 + (size_t)d->n_res_layers * B;
+        if (!res_layer_fused_ok(h, d->res_h_dim)) amt = nullptr;          // the generic residual path publishes no maxima
     }
     // n_res_layers == 0: F.relu of an already ReLU'd tensor is the identity
     return conv_forward_impl(VQVAE_CONV_1x1, t, w->pre, w->pre_b, B, H / 4, W / 4, h, d->embedding_dim, cf, z_e, st, amt, nullptr);   // vqvae.py:33
@@ -291,7 +308,7 @@ static bool zq_amax_wanted(const VqvaeDims *d, int h4, int w4) {
 // zq_amax_given: the quantizer has already published z_q's maxima into the region's slot
 static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false, bool zq_amax_given = false,
-                       int cf = 0) {
+                       int cf = 0, float *hid_given = nullptr) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -303,6 +320,11 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     if (!am) {
         am = static_cast<int *>(c.raw(amax_bytes(d, B)));
         if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
+    }
+    float *hid = hid_given;
+    if (!hid && res_hidden_bytes(d, B, 4 * h4, 4 * w4)) {
+        hid = static_cast<float *>(c.raw(res_hidden_bytes(d, B, 4 * h4, 4 * w4)));
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;
     }
     const int h = d->h_dim;
     int rc;
@@ -331,8 +353,9 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     if (!front && d->n_res_layers > 0) {
         float *y = (d->n_res_layers & 1) ? b : a, *tmp = (d->n_res_layers & 1) ? a : b;
         if ((rc = res_stack(w->dec_res_w1, w->dec_res_w2, a, B, h4, w4, h, d->res_h_dim, d->n_res_layers, false, true, y, tmp, st, &t, am,
-                            nullptr, nullptr, cf)) != 0) return rc;
+                            nullptr, nullptr, cf, hid)) != 0) return rc;
         if (am) amt = am + (size_t)d->n_res_layers * B;
+        if (!res_layer_fused_ok(h, d->res_h_dim)) amt = nullptr;
     }
 #ifndef VQVAE_NO_DEC_TAIL_FUSION    // A/B builds (tools/build_variant.py)
     // decoder.py:31-35 in ONE launch on 8x8 latent maps: the 16x16 x h/2 map between the two stride-2 transposed convs is never written
@@ -364,6 +387,7 @@ namespace {
 // The whole-batch workspace of the forward entry points (vqvae_workspace_bytes), carved the same way by all of them
 struct FwdWs {
     void *acts; size_t act, rows; int *am2; float *z_e, *z_q; int64_t *idx_ws; int32_t *hist; void *vqws; size_t vqws_bytes;
+    float *hid;          // hidden map of the generic residual path (NULL where the fused kernels cover the widths)
 };
 // with_vq = false: the caller does not touch the quantizer's workspace (vqvae_forward_end_f32); everything in front of it
 // lies where the other entry points put it
@@ -389,6 +413,7 @@ int carve_forward(const VqvaeDims *d, int64_t B, int H, int W, void *workspace, 
         f.vqws_bytes = vqb;
         vq_flags &= ~VQVAE_VQ_CODEBOOK_PREPARED;
     }
+    f.hid = res_hidden_bytes(d, B, H, W) ? static_cast<float *>(c.raw(res_hidden_bytes(d, B, H, W))) : nullptr;
     return c.ok ? VQVAE_OK : VQVAE_ERR_WORKSPACE;
 }
 }  // namespace
@@ -438,14 +463,14 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     }
     bool zq_amax_done = false;
     if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, fused ? hist : nullptr, d->n_embeddings, &hist_zeroed, false,
-                          nullptr, cf)) != 0)
+                          nullptr, cf, f.hid)) != 0)
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                               (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
                                            VQVAE_VQ_REMOVED_FLAGS)) | VQVAE_VQ_ROWMAJOR,
                               z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
                               zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
-    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf);    // :36
+    return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf, f.hid);    // :36
 }
 
 
