@@ -18,13 +18,13 @@ def _dev():
     return torch.device("cuda:0")
 
 
-def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False):
+def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=False, form=0):
     from vqvae_amd import functional as F
     zd = z.to(_dev())
     if rowmajor:
         zd = zd.permute(0, 2, 3, 1).contiguous()
     loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), beta, rowmajor=rowmajor, want_zq=want_zq,
-                                            exact_sweep=exact, bf16_filter=bf16_filter)
+                                            exact_sweep=exact, bf16_filter=bf16_filter, form=form)
     torch.cuda.synchronize()
     if zq is not None and rowmajor:
         zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -32,7 +32,7 @@ def _run(z, cb, beta, rowmajor=False, want_zq=True, exact=False, bf16_filter=Fal
         idx.cpu().numpy(), hist.cpu().numpy()
 
 
-@pytest.mark.parametrize("kernel", ["default", "bf16_filter", "exact"])
+@pytest.mark.parametrize("kernel", ["default", "units64_8waves", "units32_16waves", "bf16_filter", "exact"])
 @pytest.mark.parametrize("rowmajor", [False, True])
 @pytest.mark.parametrize("name", list(cases.VQ_CASES))
 def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
@@ -40,7 +40,7 @@ def test_vq_matches_reference_golden(name, rowmajor, kernel, golden_vq):
     two-sweep bf16 filter (default for NCHW D=64 rows) and the exhaustive fp32-MFMA sweep -- must reproduce
     the reference bit for bit."""
     z, cb, beta = cases.vq_inputs(name)
-    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter")
+    loss, zq, ppl, idx, hist = _run(z, cb, beta, rowmajor, exact=kernel == "exact", bf16_filter=kernel == "bf16_filter", form={"units64_8waves": 8, "units32_16waves": 16}.get(kernel, 0))
     assert idx.shape == (z.shape[0] * z.shape[2] * z.shape[3], 1) and idx.dtype == np.int64
     np.testing.assert_array_equal(idx.reshape(-1), golden_vq[f"{name}/idx"].astype(np.int64))
     sha = golden_vq[f"{name}/sha"]
@@ -167,7 +167,8 @@ def test_vq_near_ties_within_one_lane_half(shrink):
         assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
 
 
-ALL_FORMS = (("track rows", dict(rowmajor=True)), ("track nchw", dict(rowmajor=False)), ("bf16 filter", dict(rowmajor=True, bf16_filter=True)), ("bf16 filter nchw", dict(rowmajor=False, bf16_filter=True)),
+ALL_FORMS = (("track rows", dict(rowmajor=True)), ("track rows 8 waves", dict(rowmajor=True, form=8)), ("track rows 16 waves", dict(rowmajor=True, form=16)),
+             ("track nchw", dict(rowmajor=False)), ("bf16 filter", dict(rowmajor=True, bf16_filter=True)), ("bf16 filter nchw", dict(rowmajor=False, bf16_filter=True)),
              ("exact", dict(rowmajor=True, exact=True)))
 
 
@@ -231,7 +232,7 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
     z = torch.randn(B, D, H, W, generator=g) * 0.066
     ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
-    for kw in ({}, {"bf16_filter": True}):
+    for kw in ({}, {"form": 8}, {"form": 16}, {"bf16_filter": True}):
         loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True, **kw)
         np.testing.assert_array_equal(idx, ref_idx)
         assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))

@@ -51,7 +51,7 @@ def main():
         zr = zn.permute(0, 2, 3, 1).contiguous()
         N = zr.shape[0] * 64
         res = {}
-        for name, z, rm, kw in (("rows", zr, True, {}), ("nchw", zn, False, {})):
+        for name, z, rm, kw in (("rows", zr, True, {"form": 8}), ("rows16", zr, True, {"form": 16}), ("nchw", zn, False, {})):
             (loss, zq, ppl, idx, hist), best, med = time_form(z, cb, iters, rm, **kw)
             if not rm:
                 zq = zq.permute(0, 2, 3, 1).contiguous()

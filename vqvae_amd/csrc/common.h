@@ -113,7 +113,7 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 // vq_track.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel with the stream tracker (D = 64; row-major rows or NCHW)
 bool vq_track_nchw_ok(int K, int D, int HW);       // NCHW input: maps whose pixel count is a multiple of 64
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false);
+                        char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false, int form = 0);
 void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);
 // vq_chunk.hip: the same screen with the codebook image streamed through LDS (D = 64 / 128, any K <= 16384)
 // zq_amax: NULL, or an array of N / hw ints (images of hw consecutive rows) that receives max |z_q| per image (atomicMax on the

@@ -46,13 +46,17 @@ using vqu::lds_order_wave;
 // 32 x 64 fp32 block around in its 8 KiB LDS tile (conflict-free both ways: 16-byte chunk c >> 2 of row r sits at slot
 // (c >> 2) ^ (r >> 2)) and continues in the row-major register layout; z_q takes the same way back.  Everything between is the
 // row-major kernel, bit for bit.
-template <int NW, bool NCHW = false>
+// T (round 4): 32-row tiles per unit.  2 = 64-row units on eight waves per CU (the two tiles share every codebook operand read);
+// 1 = 32-row units on SIXTEEN waves per CU (<= 128 registers per lane): four waves per SIMD interleave their latency-bound phases
+// (classification, exact part, epilogue, row loads) with each other's sweeps -- what pays when a wave has only one or two units.
+template <int NW, bool NCHW = false, int T = 2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
     long long N, int K, int K32, long long nunits, float *__restrict__ zq, long long *__restrict__ idx,
     int *__restrict__ hist, double *__restrict__ partials, int HW) {
-    constexpr int D = 64, T = 2, RU = 64;
+    constexpr int D = 64, RU = 32 * T;
+    static_assert(!NCHW || T == 2, "the NCHW form turns a 32 x 64 fp32 block around in an 8 KiB tile: 64-row units only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ntile = K32 >> 5;
     uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                                  // [ntile][4][2][32] x 16 B
@@ -266,7 +270,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 mma(accn, a, seed);
                 track(ct - 1, accp);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
+                for (int i = 0; i < 4 * T; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
                     __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);          // six vector instructions
                 }
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         vqu::Rows R;
 #pragma unroll
         for (int t = 0; t < T; ++t) R.valid[t] = r0 + 32 * t + l31 < N;
-        vqu::classify(L, zn2, bound, K, lane, ninf, tb.task_s, R);
+        vqu::classify<T>(L, zn2, bound, K, lane, ninf, tb.task_s, R);
 
         VQ_STAMP(3);                                           // threshold + verdict
         // ================= exact part (rows the screen left open) =========================================================
@@ -372,11 +376,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
             float sacc;
             if constexpr (NCHW)
-                sacc = vqu::epilogue<true>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                sacc = vqu::epilogue<true, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                            zq ? const_cast<float *>(unit_base(p, zq)) : nullptr, nleft, idx + r0, hist_s,
                                            reinterpret_cast<float *>(tile_s), HW, (unsigned)(((long long)D * HW - (p * RU) % HW) * 4));
             else
-                sacc = vqu::epilogue(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                sacc = vqu::epilogue<false, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                      zq ? zq + (size_t)p * RU * D : nullptr, nleft, idx + r0, hist_s);
             dacc += (double)sacc;
         }
@@ -428,36 +432,42 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     }
 }
 
-size_t vq_track_lds_bytes(int K) {
+size_t vq_track_lds_bytes(int K, int nw = 8) {        // nw = 16: one 32-row tile per unit and wave, nw = 8: two
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + 8 * 8 + 16 + 8 * (size_t)(8192 + 1552);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nw > 8 ? 4096 : 8192) + 1552);
 }
 
-bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K) <= (size_t)kLdsBytes; }
+bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K, 8) <= (size_t)kLdsBytes; }
 bool vq_track_nchw_ok(int K, int D, int HW) { return vq_track_ok(K, D) && HW >= 64 && HW % 64 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll; }
 
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw) {
+                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw, int form) {
     const VqPlan p = vq_plan(K, 64);
     const int cus = num_cus();
-    constexpr int NW = 8;
     if (nchw && !vq_track_nchw_ok(K, 64, HW)) return VQVAE_ERR_UNSUPPORTED;          // a unit = 64 positions of ONE image
-    const long long nunits = (N + 63) / 64;
+    // Sixteen waves per CU with 32-row units where a wave gets at most two of them (N <= 2 x 16 x CUs x 32 rows: BASELINE
+    // configs 2 and 3) and the codebook image leaves room for sixteen 4 KiB tiles: the kernel is a chain of latency-bound
+    // phases per unit, and four waves per SIMD overlap them four-fold.  With more units per wave the sweep's issue slots
+    // dominate and the 64-row form (two tiles share every operand read, half the LDS traffic) wins.  form: 0 = this rule,
+    // 8 / 16 = forced (A/B: tools/vq_ab4.py)
+    const bool fits16 = !nchw && vq_track_lds_bytes(K, 16) <= (size_t)kLdsBytes;
+    const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
+    const int NW = wide ? 16 : 8, RU = wide ? 32 : 64;
+    const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
     if (grid > cus) grid = cus;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
     *grid_out = (int)grid;
-#define VQT_LAUNCH(NCHW_)                                                                                                       \
-    do {                                                                                                                        \
-        auto kfn = vq_track_kernel_d64<NW, NCHW_>;                                                                              \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);  \
-        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K), st, z, cb,                          \
-                           reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds), \
-                           reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K, \
-                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW);                  \
-    } while (0)
-    if (nchw) VQT_LAUNCH(true); else VQT_LAUNCH(false);
-#undef VQT_LAUNCH
+    auto launch = [&](auto kfn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, z, cb,
+                           reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
+                           reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K,
+                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW);
+    };
+    if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
+    else if (wide) launch(vq_track_kernel_d64<16, false, 1>);
+    else launch(vq_track_kernel_d64<8, false, 2>);
     return (int)hipGetLastError();
 }
 

@@ -14,6 +14,10 @@
 #include "common.h"
 #include "vq_track.h"
 
+#ifndef VQ_ZQ_STORE_AUX
+#define VQ_ZQ_STORE_AUX 0          // cache policy of the z_q stores (gfx950 aux bits: 1 = sc0, 2 = nt, 16 = sc1); see vq_track.hip
+#endif
+
 namespace vqvae {
 namespace vqu {
 
@@ -61,13 +65,17 @@ struct Rows {                        // per lane, per row tile t: row 32 t + (la
 
 // ---- threshold, merge of the two lane halves of every row, verdict --------------------------------------------------
 // zn2[t]: |z^|^2 of the lane's row (both halves hold the full sum); R.valid[] set by the caller
-__device__ __forceinline__ void classify(const trk::Lane (&L)[2], const float (&zn2)[2], const Bound &B, int K, int lane,
+// T: 32-row tiles per unit (2: the 64-row units of eight-wave workgroups and of the fused conv kernel; 1: the 32-row units of
+// vq_track_kernel_d64's sixteen-wave form, round 4)
+template <int T = 2>
+__device__ __forceinline__ void classify(const trk::Lane (&L)[T], const float (&zn2)[T], const Bound &B, int K, int lane,
                                          float ninf, unsigned *task_s, Rows &R) {
     const int l31 = lane & 31, h = lane >> 5;
     R.ncls = 0;
+    if (T == 1) { R.openf[1] = false; R.hardf[1] = false; R.bad[1] = false; R.valid[1] = false; R.kbest[1] = 0; R.thr[1] = 0.0f; }
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < T; ++t) {
         const float vA = trk::lane_max(L[t], ninf);
         const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(vA), __float_as_uint(vA), false, false);
         const float v1 = trk::max3(vA, __uint_as_float(h ? sv[0] : sv[1]), ninf);
@@ -162,7 +170,7 @@ __device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int 
 // ---- exact part, second half: chains, decision, scalar path; R.kbest[] final afterwards ------------------------------------
 // ntasks: ndirect + what the caller's rescan appended.  zrow(rr, j16) -> floats 4 j16 .. +3 of row rr of the unit;
 // zscalar(rr, c) -> one float of it (non-finite rows only)
-template <class ZRow, class ZScalar>
+template <class ZRow, class ZScalar>   // (T = 1 units: rows 32..63 do not exist; their flags are false and R.kbest[1] is never read)
 __device__ __forceinline__ void exact_end(Rows &R, Flagged &F, int ntasks, int lane, const Tables &tb, const float *__restrict__ cb,
                                           const float *__restrict__ ee_g, int K, ZRow &&zrow, ZScalar &&zscalar) {
     constexpr int D = 64;
@@ -254,11 +262,11 @@ __device__ __forceinline__ void exact_end(Rows &R, Flagged &F, int ntasks, int l
 // NCHW (vq_track_kernel_d64<., true>): zq_unit = the unit's first position of channel 0 in a (B, 64, HW) tensor, zq_bytes = bytes from
 // there to the end of its image; the values leave through the wave's 8 KiB LDS tile `tile_f` (one row tile at a time, the layout
 // of the kernel's input transposition) as 16-byte stores of four positions of one channel.
-template <bool NCHW = false, class FRow>
+template <bool NCHW = false, int T = 2, class FRow>
 __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
                                           float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
                                           int *__restrict__ hist_s, float *tile_f = nullptr, int HW = 0, unsigned zq_bytes = 0u) {
-    constexpr int D = 64, T = 2, RU = 64;
+    constexpr int D = 64, RU = 32 * T;
     const int l31 = lane & 31, h = lane >> 5, j16 = lane & 15, g4 = lane >> 4;
     const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
     f32x4 ev[T][8];
@@ -296,7 +304,7 @@ __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *
             if (nleft == RU) sacc += sq;                   // fp32 over the unit's 16 groups, one fp64 add per unit
             else sacc += 32 * t + 4 * i + g4 < nleft ? sq : 0.0f;
             if constexpr (!NCHW) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, VQ_ZQ_STORE_AUX);
             } else {
                 // row tile t: rows in, [channel][four positions] out (conflict-free both ways, see the kernel's convert())
                 if (i == 0) lds_order_wave();              // the previous row tile's reads are behind us
@@ -310,7 +318,7 @@ __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *
                         f32x4 w;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) w[e] = tile_f[(4 * j8 + e) * 64 + ((((2 * c8 + (cl >> 2)) ^ j8) & 15) << 2) + (cl & 3)];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, w), zq_rs, so, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, w), zq_rs, so, 0, VQ_ZQ_STORE_AUX);
                         so += (unsigned)(8 * HW) * 4u;
                     }
                 }

@@ -14,6 +14,8 @@ VQ_CODEBOOK_PREPARED = 0x2
 VQ_EXACT_SWEEP = 0x4
 VQ_BF16_FILTER = 0x8
 VQ_UNFUSED = 0x40
+VQ_UNITS64_8WAVES = 0x100
+VQ_UNITS32_16WAVES = 0x200
 # whole-path product scheme (vqvae_forward_f32 / vqvae_encoder_ex_f32 / vqvae_decoder_ex_f32)
 FWD_CONV_BF16_SPLIT = 0x1000
 FWD_CONV_EXACT_FP32 = 0x2000
@@ -40,14 +42,15 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
 
 def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmajor: bool = False,
                workspace: torch.Tensor | None = None, prepared: bool = False, want_zq: bool = True,
-               exact_sweep: bool = False, bf16_filter: bool = False):
+               exact_sweep: bool = False, bf16_filter: bool = False, form: int = 0):
     """Fused VectorQuantizer forward (models/quantizer.py:29-76).
 
     z_e: (B,D,H,W) contiguous, or (B,H,W,D) contiguous when rowmajor.
     Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
     exact_sweep=True forces the exhaustive fp32-MFMA kernel, bf16_filter=True round 1's two-sweep bf16 filter
     kernel, instead of the default (single-sweep fp16 screen with the stream tracker: D=64 rows, row-major or NCHW maps of
-    64 k pixels); all three produce identical bits, the flags exist for testing and A/B timing.
+    64 k pixels); all three produce identical bits, the flags exist for testing and A/B timing.  form: 8 / 16 forces the
+    stream-tracker kernel's launch form (64-row units on eight waves / 32-row units on sixteen waves per CU; 0 = by row count).
     """
     _check_dev("z_e", z_e)
     _check_dev("codebook", codebook)
@@ -74,7 +77,8 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
         hist = torch.empty((K,), dtype=torch.int32, device=dev)
         scal = torch.empty((2,), dtype=torch.float32, device=dev)
         flags = (VQ_ROWMAJOR if rowmajor else 0) | (VQ_CODEBOOK_PREPARED if prepared else 0) | \
-            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0)
+            (VQ_EXACT_SWEEP if exact_sweep else 0) | (VQ_BF16_FILTER if bf16_filter else 0) | \
+            (VQ_UNITS32_16WAVES if form == 16 else (VQ_UNITS64_8WAVES if form == 8 else 0))
         rc = _lib.load().vqvae_vq_forward_f32(
             z_e.data_ptr(), codebook.data_ptr(), B, D, H, W, K, float(beta), flags,
             z_q.data_ptr() if want_zq else None, idx.data_ptr(), hist.data_ptr(),
