@@ -359,16 +359,29 @@ def other_workload(name, torch, dev, seconds=1.0):
     return res
 
 
-def wide_leg(torch, dev, seconds=1.0):
-    """main.py's other hyper-parameters: --n_hiddens 256 --n_residual_hiddens 64 on 32x32 images, K = 512, D = 64.
-    Widths outside the fused kernels: per-layer conv kernels, the residual layers as conv -> conv -> combine."""
+HPARAM_LEGS = {
+    # main.py:16-25's other hyper-parameters on 32x32 images: (h_dim, res_h, n_res, K, D, batch, what runs)
+    "wide_h256_rh64": (256, 64, 2, 512, 64, 1024,
+                       "main.py --n_hiddens 256 --n_residual_hiddens 64 (h_dim 256, res_h 64, 2 residual layers), 32x32x3, K=512, D=64: "
+                       "per-layer kernels, residual layers outside the fused widths as conv -> conv -> combine"),
+    "k256": (128, 32, 2, 256, 64, 4096,
+             "main.py --n_embeddings 256, 32x32x3, D=64: the four fused conv kernels, quantizer inside the encoder's last kernel "
+             "(32 KiB codebook image)"),
+    "k1024": (128, 32, 2, 1024, 64, 4096,
+              "main.py --n_embeddings 1024, 32x32x3, D=64: the four fused conv kernels; the codebook image (128 KiB) does not fit beside "
+              "the conv stages in LDS, so z_e is written and the quantizer runs as its own kernel"),
+}
+
+
+def hparam_leg(name, torch, dev, seconds=1.0):
+    """One of HPARAM_LEGS through the module mirror's forward (one vqvae_forward_f32 call per step)."""
     import statistics
-    from vqvae_amd import conv as conv_mod
+    from vqvae_amd import _lib, conv as conv_mod
     from vqvae_amd.modules import VQVAE
-    B = 1024
+    h, rh, nres, K, D, B, desc = HPARAM_LEGS[name]
     conv_mod.set_conv_backend("hip")
     torch.manual_seed(0)
-    model = VQVAE(256, 64, 2, 512, 64, 0.25).eval().to(dev)
+    model = VQVAE(h, rh, nres, K, D, 0.25).eval().to(dev)
     x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1000)).to(dev)
 
     def run(n):
@@ -384,8 +397,7 @@ def wide_leg(torch, dev, seconds=1.0):
     steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
     times = [run(steps) for _ in range(5)]
     el = statistics.median(times)
-    res = {"workload": "main.py --n_hiddens 256 --n_residual_hiddens 64 (h_dim 256, res_h 64, 2 residual layers), 32x32x3, K=512, D=64: "
-                       "per-layer kernels, residual layers outside the fused widths as conv -> conv -> combine",
+    res = {"workload": desc, "standalone_vq_kernel_for_K": _lib.vq_kernel_name(K, D, 0x1),
            "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
            "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps}
     del model, x
@@ -629,7 +641,9 @@ def main():
                     "screen_tflops_16bit": round(2.0 * rows * K * D * _lib.vq_sweeps(K, D) / t_vq / 1e12, 1),
                     "hbm_achievable_frac": round(achieved / HBM_ACHIEVABLE_GBPS, 4),
                     "note": "algorithmic bytes = rows x (8D+8): read z_e, write z_q, write int64 idx; avg_kernel_us is "
-                            "the live HIP-event average over the instrumented steps; an exhaustive exact-fp32 sweep "
+                            "the live HIP-event average over the instrumented launches, the events being the dispatch's own start / "
+                            "stop (hipExtLaunchKernelGGL) on the launch stream -- the interval rocprofv3's kernel trace reports; "
+                            "two marker events around the launch read 2-3 us more; an exhaustive exact-fp32 sweep "
                             "(VQVAE_VQ_EXACT_SWEEP) is capped at 15.6% of HBM peak by arithmetic at K=512, D=64",
                 }
             if conv_backend == "hip" and "conv_igemm" in extra and "res_layer" in extra:
@@ -690,7 +704,8 @@ def main():
                 # the headline's step in the two exacter product schemes, same box and batch (the headline itself = "fp16x2")
                 line["other_workloads"]["c3_bf16x3"] = scheme_leg("bf16x3", torch, dev)
                 line["other_workloads"]["c3_fp32"] = scheme_leg("fp32", torch, dev)
-                line["other_workloads"]["wide_h256_rh64"] = wide_leg(torch, dev)
+                for name in HPARAM_LEGS:
+                    line["other_workloads"][name] = hparam_leg(name, torch, dev, seconds=0.6)
                 try:                                   # a next-row figure: its failure must not take the headline line with it
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)

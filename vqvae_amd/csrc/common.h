@@ -46,6 +46,7 @@ inline int num_cus() {
 // profiling hooks (capi.hip); no-ops unless vqvae_profile_enable(1)
 void prof_begin(int id, hipStream_t st);
 void prof_end(int id, hipStream_t st);
+bool prof_dispatch(int id, hipEvent_t *start, hipEvent_t *stop);    // events for hipExtLaunchKernelGGL (null when profiling is off)
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 

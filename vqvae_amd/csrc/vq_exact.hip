@@ -472,10 +472,8 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
         const bool track_nchw = !rowmajor && vq_track_nchw_ok(K, D, HW) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER));
         if (track_nchw || (rowmajor && vq_track_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
             int fgrid = 0;
-            prof_begin(VQVAE_PROF_VQ_MAIN, st);
             const int rc = launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw,
                                                (flags & VQVAE_VQ_UNITS32_16WAVES) ? 16 : ((flags & VQVAE_VQ_UNITS64_8WAVES) ? 8 : 0));
-            prof_end(VQVAE_PROF_VQ_MAIN, st);
             if (rc != 0) return rc;
             hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
                                beta, loss, ppl);

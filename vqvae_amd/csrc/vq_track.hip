@@ -25,6 +25,7 @@
 #include "vq_device.h"
 #include "vq_track.h"
 #include "vq_unit.h"
+#include <hip/hip_ext.h>          // hipExtLaunchKernelGGL: start / stop events on the dispatch itself (prof_dispatch)
 
 namespace vqvae {
 
@@ -460,7 +461,9 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     *grid_out = (int)grid;
     auto launch = [&](auto kfn) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
-        hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, z, cb,
+        hipEvent_t e0, e1;
+        prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1);
+        hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, e0, e1, 0, z, cb,
                            reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
                            reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K,
                            p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW);
