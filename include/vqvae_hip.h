@@ -30,9 +30,11 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 6   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+#define VQVAE_HIP_ABI_VERSION 7   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
                                     4: forward in parts (begin / part / end), residual layer with hidden output, larger
-                                       weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions) */
+                                       weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions);
+                                    5-6: round 4's headers in front of the two-term images, whole-path product flags, removed
+                                       quantizer flags; 7: data-gradient epilogues (vqvae_conv_forward_ep_f32) */
 
 #define VQVAE_OK               0
 #define VQVAE_ERR_NULL        -1   /* a required pointer is NULL                       */
@@ -314,6 +316,21 @@ VQVAE_API int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C,
 /* grad_in = grad_out * (y > 0): backward of y = relu(.)                                                      */
 VQVAE_API int vqvae_relu_backward_f32(const float *grad_out, const float *y, int64_t n, float *grad_in,
                                       vqvae_stream_t stream);
+
+/* Data-gradient launches with the element-wise tail of the backward chain in the conv's epilogue (round 4):
+ *     y = (mask > 0) ? conv(x) + addend : 0
+ *   addend (or NULL): the gradient arriving over a residual layer's skip (models/residual.py:28: d(x + block(x)));
+ *   mask   (or NULL): the activation whose ReLU sits below this layer in the forward order -- the conv's own INPUT in the
+ *                     forward pass is relu(.) of the layer below, so its data gradient times (input > 0) is that ReLU's
+ *                     backward (what vqvae_relu_backward_f32 did in a pass of its own);
+ *   both row-major with y's shape, 16-byte aligned, distinct from y.  Split-product kernels only: VQVAE_ERR_UNSUPPORTED with
+ *   VQVAE_CONV_EXACT_FP32, and for the first-layer kernel outside its row-band form (the caller then uses the separate passes). */
+VQVAE_API int vqvae_conv_forward_ep_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H,
+                                        int W, int Cin, int Cout, int flags, const float *addend, const float *mask,
+                                        float *y, vqvae_stream_t stream);
+VQVAE_API int vqvae_conv_in_forward_ep_f32(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H,
+                                           int W, int Cin, int Cout, int flags, const float *mask, float *y,
+                                           vqvae_stream_t stream);
 
 /* ------------------------------------------------------- GatedPixelCNN prior
  * pixelcnn/models.py: the masked convolutions run as im2col over their causal tap list followed by the 1x1 conv

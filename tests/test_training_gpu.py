@@ -341,3 +341,98 @@ def test_last_layer_backward_vs_torch_autograd(C, Cout, B, H, W):
     _close_grad(td.grad.permute(0, 3, 1, 2), tr.grad, "grad_t")
     _close_grad(md.weight.grad, m.weight.grad, "grad_w")
     _close_grad(md.bias.grad, m.bias.grad, "grad_b")
+
+
+# ---- round 4: ReLU masks and skip sums in the data-gradient kernels' epilogues (vqvae_conv_forward_ep_f32) ----------------------
+EP_CASES = [  # kind, B, H, W, Cin, Cout
+    (1, 5, 8, 8, 128, 128),      # 3x3 on 8x8 maps, four output tiles (conv_tile8_bf3_kernel<4, false, 8>)
+    (3, 3, 8, 8, 32, 128),       # conv-transpose 3x3: a residual layer's skip + block gradient
+    (4, 3, 8, 8, 128, 64),       # conv-transpose 4x4 s2, four phases (conv_tile8_bf3_kernel<2, false, 4>)
+    (0, 3, 16, 16, 64, 128),     # 4x4 s2 over 2x2 input blocks (space-to-depth form)
+    (5, 4, 8, 8, 128, 32),       # transposed 1x1, one output tile (conv_igemm_bf3_kernel<1>)
+    (2, 2, 5, 7, 64, 64),        # 1x1 on an odd map (generic kernel)
+    (1, 2, 12, 12, 32, 64),      # 3x3 on a map that is not 8x8 (generic kernel)
+]
+
+
+@pytest.mark.parametrize("case", EP_CASES, ids=lambda c: f"kind{c[0]}-{c[4]}to{c[5]}-{c[2]}x{c[3]}")
+@pytest.mark.parametrize("which", ["mask", "addend", "both"])
+def test_conv_epilogue_addend_and_mask_bitwise_vs_separate_passes(case, which):
+    """y = (mask > 0) ? conv + addend : 0 from the kernel's epilogue is bit for bit conv -> torch add -> vqvae_relu_backward_f32."""
+    import torch.nn as nn
+    from vqvae_amd import _lib, conv_hip
+    kind, B, H, W, Cin, Cout = case
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(kind * 100 + Cin)
+    k = {0: 4, 1: 3, 2: 1, 3: 3, 4: 4, 5: 1}[kind]
+    transposed = kind in (3, 4, 5)
+    w = (torch.randn((Cin, Cout, k, k) if transposed else (Cout, Cin, k, k), generator=g) * 0.05).to(dev)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    hold = nn.Module()
+    y0 = conv_hip.conv(kind, x, hold, w, None, Cin, Cout, 0)
+    add = torch.randn(y0.shape, generator=g).to(dev) if which in ("addend", "both") else None
+    mask = torch.relu(torch.randn(y0.shape, generator=g)).to(dev) if which in ("mask", "both") else None
+    want = y0 if add is None else y0 + add
+    if mask is not None:
+        want = want * (mask > 0)
+    L = _lib.load()
+    packed = conv_hip._pack_conv(hold, kind, w, Cin, Cout)
+    got = torch.full_like(y0, float("nan"))
+    sp = torch.cuda.current_stream(dev).cuda_stream
+    rc = L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), None, B, H, W, Cin, Cout, 0,
+                                     add.data_ptr() if add is not None else None, mask.data_ptr() if mask is not None else None,
+                                     got.data_ptr(), sp)
+    assert rc == 0, rc                       # every split-product kernel of the per-layer entry has the epilogue
+    assert torch.equal(got, want)
+    assert torch.equal(conv_hip.conv(kind, x, hold, w, None, Cin, Cout, 0, addend=add, mask=mask), want)
+    # refusals: in place, misaligned, the fp32-MFMA form
+    t = add if add is not None else mask
+    assert L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), None, B, H, W, Cin, Cout, 0, got.data_ptr(), None,
+                                       got.data_ptr(), sp) == -3
+    assert L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), None, B, H, W, Cin, Cout, 0, t.data_ptr() + 4, None,
+                                       got.data_ptr(), sp) == -3
+    assert L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), None, B, H, W, Cin, Cout, 4, t.data_ptr(), None,
+                                       got.data_ptr(), sp) == -3
+
+
+@pytest.mark.parametrize("C,Cout,B,H,W", [(64, 3, 5, 16, 16), (32, 1, 2, 8, 12), (128, 4, 2, 5, 7)])
+def test_last_layer_data_gradient_mask_bitwise(C, Cout, B, H, W):
+    """The last layer's data gradient (first-layer kernel on the NCHW gradient) with (t > 0) in its epilogue."""
+    import torch.nn as nn
+    from vqvae_amd import autograd_conv as A
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(C + Cout)
+    layer = nn.ConvTranspose2d(C, Cout, 4, 2, 1).to(dev)
+    t = torch.relu(torch.randn(B, H, W, C, generator=g)).to(dev)
+    gout = torch.randn(B, Cout, 2 * H, 2 * W, generator=g).to(dev)
+    grads = []
+    for fused in (False, True):
+        tt = t.clone().requires_grad_(True)
+        A.ConvTOutFn.apply(tt, layer.weight, layer.bias, layer, fused).backward(gout)
+        grads.append(tt.grad if fused else tt.grad * (t > 0))
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_fused_backward_epilogues_equal_separate_passes_bitwise():
+    """The whole training step's parameter gradients with the ReLU masks / skip sums in the data-gradient epilogues are bit for
+    bit those of the separate passes (a + b = b + a; a mask is a select), with and without residual layers."""
+    from vqvae_amd import autograd_conv as A, conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    dev = torch.device("cuda:0")
+    for n_res in (2, 0, 1):
+        torch.manual_seed(n_res)
+        m = VQVAE(128, 32, n_res, 512, 64, 0.25).train().to(dev)
+        x = torch.randn(16, 3, 32, 32, device=dev)
+        res = []
+        try:
+            for fused in (False, True):
+                A.FUSE_EPILOGUES = fused
+                m.zero_grad(set_to_none=True)
+                el, xh, _ = m(x)
+                (torch.mean((xh - x) ** 2) / 0.06 + el).backward()
+                res.append({k: p.grad.clone() for k, p in m.named_parameters()})
+        finally:
+            A.FUSE_EPILOGUES = True
+        for k in res[0]:
+            assert torch.equal(res[0][k], res[1][k]), (n_res, k)

@@ -64,6 +64,8 @@ SIGNATURES = {
     "vqvae_conv_in_packed_bytes": (_sz, [_i32, _i32]),
     "vqvae_conv_in_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "vqvae_conv_in_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vqvae_conv_forward_ep_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "vqvae_conv_in_forward_ep_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vqvae_convt_out_packed_bytes": (_sz, [_i32, _i32]),
     "vqvae_convt_out_pack_f32": (_i32, [_vp, _i32, _i32, _vp, _vp]),
     "vqvae_convt_out_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -117,10 +119,13 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
-    if lib.vqvae_abi_version() != 6:
+    if lib.vqvae_abi_version() != 7:
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+ERR_UNSUPPORTED = -3      # VQVAE_ERR_UNSUPPORTED (include/vqvae_hip.h)
 
 
 def check(code: int):

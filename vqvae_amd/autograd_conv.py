@@ -6,6 +6,11 @@ conv-transpose and residual layer on libvqvae_hip.so, forward AND backward.
   weight gradients  vqvae_conv_wgrad_f32 (exact fp32 MFMA, fixed-order reduction, bit-reproducible)
   bias gradients    vqvae_bias_grad_f32;   ReLU masks  vqvae_relu_backward_f32
 
+ReLU masks and skip sums ride in the data-gradient kernels' epilogues (round 4, vqvae_conv_forward_ep_f32): a layer whose INPUT
+is the ReLU'd output of the layer below (`x_is_relu`) returns its input gradient already multiplied by (x > 0) -- that IS the
+ReLU backward of the layer below, which is told `consumer_masks` and skips its own pass; a residual layer's skip gradient is
+the epilogue's addend.  FUSE_EPILOGUES = False restores the separate passes (tests compare the two).
+
 Activations are row-major (B,H,W,C) between layers, as in the forward-only path.  ResidualLayer keeps its
 fused forward kernel, which also writes the hidden activation for backward on 8x8 maps (other shapes: recomputed in
 backward).  No CPU path, no fallback.
@@ -26,6 +31,9 @@ _GEOM = {
     CONVT_3x3_S1: (3, 1, 1, True, CONV_3x3_S1),
     CONVT_4x4_S2: (4, 2, 1, True, CONV_4x4_S2),
 }
+
+
+FUSE_EPILOGUES = True
 
 
 class _Holder:
@@ -82,13 +90,14 @@ class ConvFn(torch.autograd.Function):
     """One nn.Conv2d / nn.ConvTranspose2d (+ optional fused output ReLU) on row-major activations."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, mod, kind, relu_out):
+    def forward(ctx, x, weight, bias, mod, kind, relu_out, x_is_relu=False, consumer_masks=False):
         k, s, p, transposed, _ = _GEOM[kind]
         Cin, Cout = (weight.shape[0], weight.shape[1]) if transposed else (weight.shape[1], weight.shape[0])
         y = conv_hip.conv(kind, x.detach().contiguous(), mod, weight.detach(), bias.detach() if bias is not None else None,
                           Cin, Cout, RELU_OUT if relu_out else 0)
-        ctx.save_for_backward(x.detach(), weight.detach(), y if relu_out else None)
-        ctx.mod, ctx.kind, ctx.relu_out, ctx.has_bias = mod, kind, relu_out, bias is not None
+        own_mask = relu_out and not consumer_masks           # the ReLU backward of this layer's output runs here
+        ctx.save_for_backward(x.detach().contiguous(), weight.detach(), y if own_mask else None)
+        ctx.mod, ctx.kind, ctx.own_mask, ctx.has_bias, ctx.x_is_relu = mod, kind, own_mask, bias is not None, x_is_relu
         return y
 
     @staticmethod
@@ -96,23 +105,24 @@ class ConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         k, s, p, transposed, dkind = _GEOM[ctx.kind]
         Cin, Cout = (w.shape[0], w.shape[1]) if transposed else (w.shape[1], w.shape[0])
-        gy = relu_backward(gy, y) if ctx.relu_out else gy.contiguous()
+        gy = relu_backward(gy, y) if ctx.own_mask else gy.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            # data gradient: the mirrored conv, same weight tensor, channels swapped
-            gx = conv_hip.conv(dkind, gy, _holder(ctx.mod, ("dgrad", ctx.kind)), w, None, Cout, Cin, 0)
+            # data gradient: the mirrored conv, same weight tensor, channels swapped (+ the ReLU mask of the layer below)
+            gx = conv_hip.conv(dkind, gy, _holder(ctx.mod, ("dgrad", ctx.kind)), w, None, Cout, Cin, 0,
+                               mask=x if ctx.x_is_relu else None)
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(x, gy, k, s, p) if transposed else conv_wgrad(gy, x, k, s, p)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = bias_grad(gy)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class ConvInFn(torch.autograd.Function):
     """First layer: nn.Conv2d(Cin<=4, C0, 4, 2, 1) + ReLU on the NCHW image (models/encoder.py:29-31)."""
 
     @staticmethod
-    def forward(ctx, x_nchw, weight, bias, mod):
+    def forward(ctx, x_nchw, weight, bias, mod, consumer_masks=False):
         L = _lib.load()
         x = x_nchw.detach().contiguous()
         B, Cin, H, W = x.shape
@@ -122,23 +132,23 @@ class ConvInFn(torch.autograd.Function):
         y = torch.empty((B, H // 2, W // 2, C0), dtype=torch.float32, device=x.device)
         _lib.check(L.vqvae_conv_in_forward_f32(x.data_ptr(), p0.data_ptr(), bias.detach().data_ptr(), B, H, W, Cin, C0,
                                                RELU_OUT, y.data_ptr(), _sp(x)))
-        ctx.save_for_backward(x, y)
+        ctx.save_for_backward(x, None if consumer_masks else y)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y = ctx.saved_tensors
-        gy = relu_backward(gy, y)
+        gy = relu_backward(gy, y) if y is not None else gy.contiguous()
         gw = conv_wgrad(gy, x, 4, 2, 1, bt_nchw=True) if ctx.needs_input_grad[1] else None
         gb = bias_grad(gy) if ctx.needs_input_grad[2] else None
-        return None, gw, gb, None
+        return None, gw, gb, None, None
 
 
 class ConvTOutFn(torch.autograd.Function):
     """Last layer: nn.ConvTranspose2d(C, Cout<=4, 4, 2, 1), row-major in, NCHW image out (decoder.py:34-35)."""
 
     @staticmethod
-    def forward(ctx, t, weight, bias, mod):
+    def forward(ctx, t, weight, bias, mod, x_is_relu=False):
         L = _lib.load()
         t = t.detach().contiguous()
         B, H, W, C = t.shape
@@ -149,7 +159,7 @@ class ConvTOutFn(torch.autograd.Function):
         _lib.check(L.vqvae_convt_out_forward_f32(t.data_ptr(), p4.data_ptr(), bias.detach().data_ptr(), B, H, W, C, Cout, 0,
                                                  x_hat.data_ptr(), _sp(t)))
         ctx.save_for_backward(t, weight.detach())
-        ctx.mod = mod
+        ctx.mod, ctx.x_is_relu = mod, x_is_relu
         return x_hat
 
     @staticmethod
@@ -167,13 +177,22 @@ class ConvTOutFn(torch.autograd.Function):
             pk = conv_hip._packed(hold, ("conv_in",), w, lambda: L.vqvae_conv_in_packed_bytes(Cout, C),
                                   lambda wt, buf: L.vqvae_conv_in_pack_f32(wt.data_ptr(), Cout, C, buf.data_ptr(), _sp(wt)))
             gt = torch.empty_like(t)
-            _lib.check(L.vqvae_conv_in_forward_f32(g.data_ptr(), pk.data_ptr(), None, B, 2 * H, 2 * W, Cout, C, 0,
-                                                   gt.data_ptr(), _sp(g)))
+            rc = _lib.ERR_UNSUPPORTED
+            if ctx.x_is_relu:                             # (t > 0) in the kernel's epilogue: the ReLU backward of the layer below
+                rc = L.vqvae_conv_in_forward_ep_f32(g.data_ptr(), pk.data_ptr(), None, B, 2 * H, 2 * W, Cout, C, 0, t.data_ptr(),
+                                                    gt.data_ptr(), _sp(g))
+                if rc not in (0, _lib.ERR_UNSUPPORTED):
+                    _lib.check(rc)
+            if rc != 0:
+                _lib.check(L.vqvae_conv_in_forward_f32(g.data_ptr(), pk.data_ptr(), None, B, 2 * H, 2 * W, Cout, C, 0,
+                                                       gt.data_ptr(), _sp(g)))
+                if ctx.x_is_relu:
+                    gt = relu_backward(gt, t)
         if ctx.needs_input_grad[1]:
             gw = conv_wgrad(t, g, 4, 2, 1, bt_nchw=True)
         if ctx.needs_input_grad[2]:
             gb = bias_grad(g, nchw=True)
-        return gt, gw, gb, None
+        return gt, gw, gb, None, None
 
 
 class ResLayerFn(torch.autograd.Function):
@@ -181,11 +200,12 @@ class ResLayerFn(torch.autograd.Function):
     backward on 8x8 maps (recomputed in backward elsewhere).  y = [relu](r + W2 * relu(W1 * r)),  r = relu(x) if relu_in else x."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, layer, relu_in, relu_out):
+    def forward(ctx, x, w1, w2, layer, relu_in, relu_out, x_is_relu=False, consumer_masks=False):
         flags = (RELU_IN if relu_in else 0) | (RELU_OUT if relu_out else 0)
         y, hid = conv_hip.res_layer(x.detach().contiguous(), layer, flags, want_hidden=True)
-        ctx.save_for_backward(x.detach(), w1.detach(), w2.detach(), y if relu_out else None, hid)
-        ctx.layer, ctx.relu_in, ctx.relu_out = layer, relu_in, relu_out
+        own_mask = relu_out and not consumer_masks
+        ctx.save_for_backward(x.detach().contiguous(), w1.detach(), w2.detach(), y if own_mask else None, hid)
+        ctx.layer, ctx.relu_in, ctx.own_mask, ctx.x_is_relu = layer, relu_in, own_mask, x_is_relu
         return y
 
     @staticmethod
@@ -193,31 +213,36 @@ class ResLayerFn(torch.autograd.Function):
         x, w1, w2, y, h = ctx.saved_tensors
         c1, c2 = ctx.layer.res_block[1], ctx.layer.res_block[3]
         C, Rh = w1.shape[1], w1.shape[0]
-        g = relu_backward(gy, y) if ctx.relu_out else gy.contiguous()
+        g = relu_backward(gy, y) if ctx.own_mask else gy.contiguous()
         if h is None:
             # h = relu(W1 * r) again with the plain conv kernel (shapes whose fused forward kernel does not write it)
             h = conv_hip.conv(CONV_3x3_S1, x, _holder(ctx.layer, "w1_fwd"), w1, None, C, Rh,
                               (RELU_IN if ctx.relu_in else 0) | RELU_OUT)
-        gh = conv_hip.conv(CONVT_1x1, g, _holder(ctx.layer, "w2_dgrad"), w2, None, C, Rh, 0)   # (B,H,W,Rh)
-        gh = relu_backward(gh, h)
+        # (B,H,W,Rh), times (h > 0): the hidden ReLU's backward in the 1x1 data gradient's epilogue
+        gh = conv_hip.conv(CONVT_1x1, g, _holder(ctx.layer, "w2_dgrad"), w2, None, C, Rh, 0, mask=h)
         gx = gw1 = gw2 = None
         if ctx.needs_input_grad[0]:
-            gr = g + conv_hip.conv(CONVT_3x3_S1, gh, _holder(ctx.layer, "w1_dgrad"), w1, None, Rh, C, 0)
-            gx = relu_backward(gr, x) if ctx.relu_in else gr
+            # skip + block: g + W1^T gh, times (x > 0) for the layer's own in-place ReLU and / or the ReLU of the layer below
+            gx = conv_hip.conv(CONVT_3x3_S1, gh, _holder(ctx.layer, "w1_dgrad"), w1, None, Rh, C, 0, addend=g,
+                               mask=x if (ctx.relu_in or ctx.x_is_relu) else None)
         r = torch.relu(x) if ctx.relu_in else x
         if ctx.needs_input_grad[1]:
             gw1 = conv_wgrad(gh, r, 3, 1, 1)                      # (Rh, C, 3, 3)
         if ctx.needs_input_grad[2]:
             gw2 = conv_wgrad(g, h, 1, 1, 0)                       # (C, Rh, 1, 1)
-        return gx, gw1, gw2, None, None, None
+        return gx, gw1, gw2, None, None, None, None, None
 
 
-def _res_stack_train(t, layers, first_relu_in, final_relu):
+def _res_stack_train(t, layers, first_relu_in, final_relu, x_is_relu=False, consumer_masks=False):
+    """x_is_relu: t is the ReLU'd output of a layer that was told consumer_masks; consumer_masks: the consumer of the
+    stack's (ReLU'd) output applies that ReLU's backward."""
     n = len(layers)
     for i, layer in enumerate(layers):
         relu_in = i == 0 and first_relu_in
         relu_out = i < n - 1 or final_relu
-        t = ResLayerFn.apply(t, layer.res_block[1].weight, layer.res_block[3].weight, layer, relu_in, relu_out)
+        # inside the stack every layer's output feeds exactly the next layer, which masks with its own input
+        t = ResLayerFn.apply(t, layer.res_block[1].weight, layer.res_block[3].weight, layer, relu_in, relu_out,
+                             (x_is_relu if i == 0 else FUSE_EPILOGUES), (consumer_masks if i == n - 1 else FUSE_EPILOGUES))
     if n == 0 and final_relu:
         t = torch.relu(t)
     return t
@@ -227,18 +252,24 @@ def encoder_forward_train(enc, x, pre_quant):
     """models/encoder.py:28-43 (+ models/vqvae.py:33) under autograd; returns row-major z_e."""
     cs = enc.conv_stack
     c0, c2, c4, stack = cs[0], cs[2], cs[4], cs[5]
-    a0 = ConvInFn.apply(x, c0.weight, c0.bias, c0)
-    a1 = ConvFn.apply(a0, c2.weight, c2.bias, c2, CONV_4x4_S2, True)
-    a2 = ConvFn.apply(a1, c4.weight, c4.bias, c4, CONV_3x3_S1, True)      # + the stack's first in-place ReLU
-    t = _res_stack_train(a2, list(stack.stack), False, True)
-    return ConvFn.apply(t, pre_quant.weight, pre_quant.bias, pre_quant, CONV_1x1, False)
+    f = FUSE_EPILOGUES
+    layers = list(stack.stack)
+    fs = f and len(layers) > 0          # (no residual layers: torch.relu sits between the 3x3 conv and the 1x1 conv)
+    a0 = ConvInFn.apply(x, c0.weight, c0.bias, c0, f)
+    a1 = ConvFn.apply(a0, c2.weight, c2.bias, c2, CONV_4x4_S2, True, f, f)
+    a2 = ConvFn.apply(a1, c4.weight, c4.bias, c4, CONV_3x3_S1, True, f, fs)      # + the stack's first in-place ReLU
+    t = _res_stack_train(a2, layers, False, True, fs, fs)
+    return ConvFn.apply(t, pre_quant.weight, pre_quant.bias, pre_quant, CONV_1x1, False, fs, False)
 
 
 def decoder_forward_train(dec, z_q_rows):
     """models/decoder.py:27-39 under autograd; z_q row-major (B,h,w,D) -> x_hat NCHW."""
     ds = dec.inverse_conv_stack
     d0, stack, d2, d4 = ds[0], ds[1], ds[2], ds[4]
-    a0 = ConvFn.apply(z_q_rows, d0.weight, d0.bias, d0, CONVT_3x3_S1, True)
-    a1 = _res_stack_train(a0, list(stack.stack), False, True)
-    a2 = ConvFn.apply(a1, d2.weight, d2.bias, d2, CONVT_4x4_S2, True)
-    return ConvTOutFn.apply(a2, d4.weight, d4.bias, d4)
+    f = FUSE_EPILOGUES
+    layers = list(stack.stack)
+    fs = f and len(layers) > 0
+    a0 = ConvFn.apply(z_q_rows, d0.weight, d0.bias, d0, CONVT_3x3_S1, True, False, fs)
+    a1 = _res_stack_train(a0, layers, False, True, fs, fs)
+    a2 = ConvFn.apply(a1, d2.weight, d2.bias, d2, CONVT_4x4_S2, True, fs, f)
+    return ConvTOutFn.apply(a2, d4.weight, d4.bias, d4, f)

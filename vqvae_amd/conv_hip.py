@@ -55,8 +55,10 @@ def _pack_conv(mod, kind, weight, Cin, Cout):
                    lambda w, buf: L.vqvae_conv_pack_f32(kind, w.data_ptr(), Cin, Cout, buf.data_ptr(), _sp(w)))
 
 
-def conv(kind, x, mod, weight, bias, Cin, Cout, flags):
-    """One nn.Conv2d / nn.ConvTranspose2d on row-major activations."""
+def conv(kind, x, mod, weight, bias, Cin, Cout, flags, addend=None, mask=None):
+    """One nn.Conv2d / nn.ConvTranspose2d on row-major activations.  addend / mask (training's data-gradient launches):
+    y = (mask > 0) ? conv + addend : 0 in the kernel's epilogue; where the kernel has no such epilogue the two passes run
+    separately (torch add, vqvae_relu_backward_f32)."""
     B, H, W, C = x.shape
     assert C == Cin
     packed = _pack_conv(mod, kind, weight, Cin, Cout)
@@ -68,9 +70,26 @@ def conv(kind, x, mod, weight, bias, Cin, Cout, flags):
         Ho, Wo = H, W
     y = torch.empty((B, Ho, Wo, Cout), dtype=torch.float32, device=x.device)
     b = bias.detach() if bias is not None else None
-    _lib.check(_lib.load().vqvae_conv_forward_f32(kind, x.data_ptr(), packed.data_ptr(),
-                                                  b.data_ptr() if b is not None else None,
-                                                  B, H, W, Cin, Cout, flags, y.data_ptr(), _sp(x)))
+    L = _lib.load()
+    if addend is not None or mask is not None:
+        for t in (addend, mask):
+            if t is not None and (t.shape != y.shape or not t.is_contiguous()):
+                raise ValueError("addend / mask must be contiguous with the output's shape")
+        rc = L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), b.data_ptr() if b is not None else None,
+                                         B, H, W, Cin, Cout, flags, addend.data_ptr() if addend is not None else None,
+                                         mask.data_ptr() if mask is not None else None, y.data_ptr(), _sp(x))
+        if rc == 0:
+            return y
+        if rc != _lib.ERR_UNSUPPORTED:
+            _lib.check(rc)
+    _lib.check(L.vqvae_conv_forward_f32(kind, x.data_ptr(), packed.data_ptr(), b.data_ptr() if b is not None else None,
+                                        B, H, W, Cin, Cout, flags, y.data_ptr(), _sp(x)))
+    if addend is not None:
+        y = y + addend
+    if mask is not None:
+        out = torch.empty_like(y)
+        _lib.check(L.vqvae_relu_backward_f32(y.data_ptr(), mask.data_ptr(), y.numel(), out.data_ptr(), _sp(y)))
+        y = out
     return y
 
 

@@ -125,7 +125,8 @@ int launch_vq_chunked(const float *z, const float *cb, long long N, int K, int D
 // conv.hip: the per-layer entry points with the per-image activation maxima of the two-term fp16 product path
 // (arrays of B ints, -1 = not provided; NULL = none): written by a producing layer, read by the consuming one.
 int conv_forward_impl(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
-                      int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax);
+                      int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
+                      const float *ep_add = nullptr, const float *ep_mask = nullptr);   // vqvae_conv_forward_ep_f32
 int res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                            int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
                            float *hidden = nullptr, float *hid_scratch = nullptr);
@@ -173,6 +174,6 @@ bool dec_tail_supported(int h4, int w4, int C, int C1, int Cout);
 int dec_tail_forward_impl(const float *x, const float *packed2, const float *bias2, const float *packed4, const float *bias4,
                           int64_t B, int h4, int w4, int C, int C1, int Cout, float *y_nchw, hipStream_t st, const int *in_amax);
 int conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
-                         int Cout, int flags, float *y, hipStream_t stream, int *out_amax);
+                         int Cout, int flags, float *y, hipStream_t stream, int *out_amax, const float *ep_mask = nullptr);
 
 }  // namespace vqvae

@@ -52,7 +52,25 @@ struct ConvGeom {
     int kk;                     // kh*kw
     int transposed;             // weight is (Cin,Cout,kh,kw)
     int s2d;                    // pack only: space-to-depth chunk order of the 4x4 s2 conv (conv_tile8_bf3_kernel<., true>)
+    // epilogue of the data-gradient launches (vqvae_conv_forward_ep_f32; both NULL otherwise), output layout, row-major:
+    //   out = (ep_mask > 0) ? conv + ep_add : 0      -- the skip gradient of a residual layer and the ReLU mask of the layer below
+    const float *ep_add, *ep_mask;
 };
+
+// (a 16-byte group of the output, `off` floats into it)
+__device__ __forceinline__ f32x4 ep_apply4(const ConvGeom &g, long long off, f32x4 a) {
+    if (g.ep_add) a += *reinterpret_cast<const f32x4 *>(g.ep_add + off);
+    if (g.ep_mask) {
+        const f32x4 m = *reinterpret_cast<const f32x4 *>(g.ep_mask + off);
+        a.x = m.x > 0.0f ? a.x : 0.0f; a.y = m.y > 0.0f ? a.y : 0.0f; a.z = m.z > 0.0f ? a.z : 0.0f; a.w = m.w > 0.0f ? a.w : 0.0f;
+    }
+    return a;
+}
+__device__ __forceinline__ float ep_apply1(const ConvGeom &g, long long off, float v) {
+    if (g.ep_add) v += g.ep_add[off];
+    if (g.ep_mask) v = g.ep_mask[off] > 0.0f ? v : 0.0f;
+    return v;
+}
 
 constexpr int kFlagReluIn = 1, kFlagReluOut = 2;
 
@@ -818,6 +836,23 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
     const long long img0 = __shfl(myimg, 0);
     const bool one_img = out_amax && __builtin_amdgcn_ballot_w64(myimg != img0) == 0 && img0 >= 0;
     float omax = 0.0f;
+    // data-gradient epilogue (ep_add / ep_mask): every value this lane will need is requested up front -- one memory round trip
+    // for the whole tile instead of one per store
+    const bool ep = g.ep_add || g.ep_mask;
+    float ea[16][NT], em[16][NT];
+    if (ep) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long off = __shfl(myoff, (r & 3) + 8 * (r >> 2) + 4 * h);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int n = (nb * NT + nt) * 32 + l31;
+                const bool ok = off >= 0 && n < g.Cout;
+                ea[r][nt] = (g.ep_add && ok) ? g.ep_add[off + n] : 0.0f;
+                em[r][nt] = (g.ep_mask && ok) ? g.ep_mask[off + n] : 1.0f;
+            }
+        }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -832,6 +867,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
                     float v = (H2 ? acc[nt][r] * drow * wd[nt] : acc[nt][r]) + bv[nt];
                     if (relu_out) v = fmaxf(v, 0.0f);
                     rmax = fmaxf(rmax, __builtin_fabsf(v));
+                    if (ep) v = em[r][nt] > 0.0f ? v + ea[r][nt] : 0.0f;
                     out[off + n] = v;
                 }
             }
@@ -1122,10 +1158,36 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
     if (img_ok && (g.Cout & 7) == 0) {
         // the operand tile is free now (wave-private): stage the outputs through it, 16-byte stores
         float *tile = reinterpret_cast<float *>(As);
+        // pass k of tile (mt, nt): pixel 32 mt + (lane >> 3) + 8 k, channels n0 .. n0 + 3
+        auto out_off = [&](int mt, int k) {
+            const int px = 32 * mt + (lane >> 3) + 8 * k;
+            const int gy = px >> 3, gx = px & 7;
+            return ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride + g.opx[phase]) * (long long)g.Cout;
+        };
+        // data-gradient epilogue (ep_add / ep_mask): the NEXT tile's sixteen-byte groups are requested while this tile goes
+        // through the LDS tile, so that the stores do not wait a memory round trip each
+        // (the two-tile kernels request the tile's own groups in front of its staging instead: one set of registers fewer keeps
+        // them at three waves per SIMD)
+        const bool ep = g.ep_add || g.ep_mask;
+        constexpr int AHEAD = NT >= 4 ? 1 : 0;
+        f32x4 pa[1 + AHEAD][4], pm[1 + AHEAD][4];
+        auto ep_fetch = [&](int tix, int slot) {
+            const int mt = tix / NT, nt = tix % NT, n0 = (nb * NT + nt) * 32 + 4 * (lane & 7);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const long long o = out_off(mt, k) + n0;
+                pa[slot][k] = (g.ep_add && n0 < g.Cout) ? *reinterpret_cast<const f32x4 *>(g.ep_add + o) : f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                pm[slot][k] = (g.ep_mask && n0 < g.Cout) ? *reinterpret_cast<const f32x4 *>(g.ep_mask + o) : f32x4{1.0f, 1.0f, 1.0f, 1.0f};
+            }
+        };
+        if (ep && AHEAD) ep_fetch(0, 0);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
+                const int tix = mt * NT + nt;
+                if (ep && AHEAD && tix + 1 < MT * NT) ep_fetch(tix + 1, (tix + 1) & 1);
+                if (ep && !AHEAD) ep_fetch(tix, 0);
                 float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -1133,11 +1195,14 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                     if (relu_out) v[r] = fmaxf(v[r], 0.0f);
                     omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
-                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int) {
-                    const int px = 32 * mt + p;
-                    const int gy = px >> 3, gx = px & 7;
-                    const long long off = ((img * g.Hout + gy * g.ostride + g.opy[phase]) * g.Wout + gx * g.ostride +
-                                           g.opx[phase]) * (long long)g.Cout;
+                tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int k) {
+                    (void)p;
+                    const long long off = out_off(mt, k);
+                    if (ep) {
+                        const f32x4 m = pm[tix & AHEAD][k];
+                        a += pa[tix & AHEAD][k];
+                        a.x = m.x > 0.0f ? a.x : 0.0f; a.y = m.y > 0.0f ? a.y : 0.0f; a.z = m.z > 0.0f ? a.z : 0.0f; a.w = m.w > 0.0f ? a.w : 0.0f;
+                    }
                     if (n < g.Cout)                            // Cout % 8 == 0: a 4-channel group is all in or all out
                         *reinterpret_cast<f32x4 *>(out + off + n) = a;
                 });
@@ -1158,7 +1223,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                         float v = (H2 ? acc[mt][nt][r] * wd[nt] : acc[mt][nt][r]) + bv[nt];
                         if (relu_out) v = fmaxf(v, 0.0f);
                         omax = fmaxf(omax, __builtin_fabsf(v));
-                        out[off + n] = v;
+                        out[off + n] = ep_apply1(g, off + n, v);
                     }
                 }
             }
@@ -4095,7 +4160,10 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                                                            const float *__restrict__ wimg,
                                                            const float *__restrict__ bias,
                                                            float *__restrict__ out, int B, int H, int W,
-                                                           int Cout, int flags, int *__restrict__ out_amax, int tw_log2) {
+                                                           int Cout, int flags, int *__restrict__ out_amax, int tw_log2,
+                                                           const float *__restrict__ ep_mask) {
+    // ep_mask (row-major like out, or NULL): out = ep_mask > 0 ? conv : 0 -- the last layer's data gradient with the ReLU mask
+    // of the layer below (vqvae_conv_in_forward_ep_f32)
     constexpr int MT = 2, S = CIN * 8, JG = (S + 3) / 4;
     constexpr int WF = BF3 ? NT * CIN * 768 : NT * JG * 256;     // floats of the weight image
     extern __shared__ __attribute__((aligned(16))) float smem_ci[];
@@ -4194,6 +4262,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
         // the image's base is scalar, this lane's eight output pixels (two pixel tiles x four row groups of the staged tile)
         // are byte offsets inside the image: no address arithmetic per store
         float *obase = out + (size_t)b * Hg * Wg * Cout;
+        const float *mbase = ep_mask ? ep_mask + (size_t)b * Hg * Wg * Cout : nullptr;
         unsigned ooff[MT][4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -4210,6 +4279,12 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                 for (int nt = 0; nt < NT; ++nt) {
                     const bool nok = nt * 32 + 4 * (lane & 7) < Cout, cok = nt * 32 + l31 < Cout;
                     const f32x2v b2 = {bv[nt], bv[nt]};
+                    f32x4 mk[4];                           // (ep_mask) requested before the staging: in flight under it
+                    if (mbase && nok) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+                            mk[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(mbase + nt * 32) + ooff[mt][k]);
+                    }
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const f32x2v y = f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]} + b2;
@@ -4222,7 +4297,11 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                     lds_order_wave();
 #pragma unroll
                     for (int k = 0; k < 4; ++k) {
-                        const f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+                        f32x4 q = *reinterpret_cast<const f32x4 *>(tile + k * 256 + lane * 4);
+                        if (mbase && nok) {
+                            const f32x4 m = mk[k];
+                            q.x = m.x > 0.0f ? q.x : 0.0f; q.y = m.y > 0.0f ? q.y : 0.0f; q.z = m.z > 0.0f ? q.z : 0.0f; q.w = m.w > 0.0f ? q.w : 0.0f;
+                        }
                         if (nok) *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(obase + nt * 32) + ooff[mt][k]) = q;
                     }
                     __builtin_amdgcn_wave_barrier();
@@ -4245,6 +4324,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                     float v = acc[mt][nt][r] + bv[nt];
                     if (relu_out) v = fmaxf(v, 0.0f);
                     omax = fmaxf(omax, __builtin_fabsf(v));
+                    if (ep_mask) v = ep_mask[prow * Cout + n] > 0.0f ? v : 0.0f;
                     out[prow * Cout + n] = v;
                 }
             }
@@ -4801,13 +4881,26 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
                            int H, int W, int Cin, int Cout, int flags, float *y, vqvae_stream_t stream) {
     return vqvae::conv_forward_impl(kind, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
+
+int vqvae_conv_forward_ep_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
+                              int Cout, int flags, const float *addend, const float *mask, float *y, vqvae_stream_t stream) {
+    if ((addend && addend == y) || (mask && mask == y)) return VQVAE_ERR_UNSUPPORTED;     // no in-place form: other waves still read them
+    return vqvae::conv_forward_impl(kind, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                                    addend, mask);
+}
 }  // extern "C"
 
 // in_amax / out_amax: per-image activation maxima handed from layer to layer inside the whole-path entry points
 // (model.hip); NULL from the per-layer C entry points, where the consuming kernel measures its image itself.
 int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
-                             int Cin, int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax) {
+                             int Cin, int Cout, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
+                             const float *ep_add, const float *ep_mask) {
     if (!x || !packed || !y) return VQVAE_ERR_NULL;
+    if (ep_add || ep_mask) {
+        // the data-gradient epilogue lives in the split-product kernels of the per-layer entry (no maxima hand-over, no fp32-MFMA form)
+        if (in_amax || out_amax || (flags & VQVAE_CONV_EXACT_FP32)) return VQVAE_ERR_UNSUPPORTED;
+        if ((reinterpret_cast<uintptr_t>(ep_add) | reinterpret_cast<uintptr_t>(ep_mask)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    }
     if (B < 1 || H < 1 || W < 1 || Cin < 1 || Cout < 1) return VQVAE_ERR_SHAPE;
     if (Cin % 4) return VQVAE_ERR_UNSUPPORTED;          // float4 activation loads
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte accesses
@@ -4815,6 +4908,8 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
     ConvGeom g;
     int rc = make_geom(kind, B, H, W, Cin, Cout, flags, g);
     if (rc != VQVAE_OK) return rc;
+    g.ep_add = ep_add;
+    g.ep_mask = ep_mask;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long M = (long long)B * g.Hg * g.Wg;
     prof_begin(VQVAE_PROF_CONV_IGEMM, st);
@@ -5202,6 +5297,11 @@ int vqvae_conv_in_forward_f32(const float *x_nchw, const float *packed, const fl
                               int W, int Cin, int Cout, int flags, float *y, vqvae_stream_t stream) {
     return vqvae::conv_in_forward_impl(x_nchw, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr);
 }
+
+int vqvae_conv_in_forward_ep_f32(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
+                                 int flags, const float *mask, float *y, vqvae_stream_t stream) {
+    return vqvae::conv_in_forward_impl(x_nchw, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, mask);
+}
 }  // extern "C"
 
 // The encoder's first two layers in one launch (enc_front8_h2_kernel): 32x32 images, 3 input channels, 64 -> 128 channels.
@@ -5235,15 +5335,15 @@ void vqvae::act_absmax_impl(const float *x, int64_t B, long long elems_per_image
 }
 
 int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const float *bias, int64_t B, int H, int W,
-                                int Cin, int Cout, int flags, float *y, hipStream_t stream, int *out_amax) {
+                                int Cin, int Cout, int flags, float *y, hipStream_t stream, int *out_amax, const float *ep_mask) {
     if (!x_nchw || !packed || !y) return VQVAE_ERR_NULL;
+    if (ep_mask && (ep_mask == y || (reinterpret_cast<uintptr_t>(ep_mask) & 15) || out_amax)) return VQVAE_ERR_UNSUPPORTED;
     if (B < 1 || H < 2 || W < 2) return VQVAE_ERR_SHAPE;
     if (H % 2 || W % 2 || vqvae_conv_in_packed_bytes(Cin, Cout) == 0) return VQVAE_ERR_UNSUPPORTED;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const long long M = B * (long long)(H / 2) * (W / 2);
     const unsigned gx = (unsigned)((M + 255) / 256);
     const int ntile = (Cout + 31) / 32;
-    prof_begin(VQVAE_PROF_CONV_IN, st);
     // whole output rows per workgroup -> LDS-staged input band (conv_in_rows_kernel)
     const int Hg = H / 2, Wg = W / 2;
     // tile: the widest power of two TW <= 256 that divides Wg with 256 / TW rows dividing Hg
@@ -5262,10 +5362,10 @@ int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const 
     do {                                                                                                           \
         if (rows && rows_lds <= 64 * 1024 && bf3)                                                                  \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, true>), dim3(gx), dim3(256), rows_lds, st, x_nchw,  \
-                               packed3, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2);                    \
+                               packed3, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2, ep_mask);           \
         else if (rows && rows_lds <= 64 * 1024)                                                                    \
             hipLaunchKernelGGL((conv_in_rows_kernel<CIN_, NT_, false>), dim3(gx), dim3(256), rows_lds, st, x_nchw, \
-                               packed, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2);                     \
+                               packed, bias, y, (int)B, H, W, Cout, flags, out_amax, tw_log2, ep_mask);            \
         else                                                                                                       \
         {                                                                                                          \
             hipLaunchKernelGGL((conv_in_kernel<CIN_, NT_>), dim3(gx), dim3(256), 0, st, x_nchw, packed, bias, y,    \
@@ -5280,6 +5380,8 @@ int vqvae::conv_in_forward_impl(const float *x_nchw, const float *packed, const 
         case 3: CI_LAUNCH(CIN_, 3); break;                                \
         default: CI_LAUNCH(CIN_, 4); break;                               \
     }
+    if (ep_mask && !(rows && rows_lds <= 64 * 1024)) return VQVAE_ERR_UNSUPPORTED;     // the mask lives in the row-band kernel only
+    prof_begin(VQVAE_PROF_CONV_IN, st);
     switch (Cin) {
         case 1: CI_NT(1); break;
         case 3: CI_NT(3); break;
