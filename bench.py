@@ -444,6 +444,45 @@ def scheme_leg(scheme, torch, dev, seconds=1.0):
     return res
 
 
+def pixelcnn_leg(torch, dev, seconds=0.6):
+    """one GatedPixelCNN forward (pixelcnn/models.py:118-127; 15 gated layers, dim 64, 512 codes) over the
+    8x8 latent index maps of 1024 images, and the ancestral sampler (:129-146, 64 forwards) for 64 samples replayed from a hipGraph."""
+    import statistics
+    from vqvae_amd.pixelcnn import GatedPixelCNN
+    torch.manual_seed(0)
+    m = GatedPixelCNN(512, 64, 15, 10).to(dev).eval()
+    B = 1024
+    x = torch.randint(0, 512, (B, 8, 8), device=dev)
+    label = torch.randint(0, 10, (B,), device=dev)
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                m(x, label)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2)
+    steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
+    el = statistics.median([run(steps) for _ in range(5)])
+    lab64 = torch.arange(10, device=dev).repeat(7)[:64]
+    with torch.no_grad():
+        m.generate(lab64, (8, 8), 64, use_graph=True)          # capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m.generate(lab64, (8, 8), 64, use_graph=True)
+        torch.cuda.synchronize()
+        gen = time.perf_counter() - t0
+    res = {"workload": "GatedPixelCNN(512 codes, dim 64, 15 layers, 10 classes) forward over 8x8 index maps",
+           "per_gpu_batch": B, "ms_per_forward": round(el / steps * 1e3, 3), "maps_per_s": round(B * steps / el, 1),
+           "generate_64_samples_8x8_ms": round(gen * 1e3, 1), "steps_per_repeat": steps}
+    del m, x
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -710,6 +749,10 @@ def main():
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)
                     line["training_step"] = {"error": f"{type(e).__name__}: {e}"}
+                try:
+                    line["pixelcnn"] = pixelcnn_leg(torch, dev)
+                except Exception as e:                 # noqa: BLE001
+                    line["pixelcnn"] = {"error": f"{type(e).__name__}: {e}"}
                 conv_mod.set_conv_backend(conv_backend)
         print(json.dumps(line), flush=True)
     if dist:
