@@ -309,6 +309,15 @@ VQVAE_API int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, i
                                    int HB, int WB, int CB, int k, int stride, int pad, int bt_nchw,
                                    float *grad_w, void *workspace, size_t workspace_bytes,
                                    vqvae_stream_t stream);
+/* The same with a product-scheme flag (round 4).  flags = 0: on the map-resident shapes (8x8 a maps, 32-channel multiples) with
+ * k >= 3 the products are formed from two fp16 terms per operand on the fp16 matrix cores (conv_wgrad_map8_h2_kernel: <= 2^-21 relative per
+ * product, one power-of-two scale per image and operand tile measured inside the kernel, accumulators rescaled exactly between
+ * images, still a fixed summation order) -- about three times the fp32 pipe's rate; every other shape runs the fp32 kernels
+ * either way.  flags = VQVAE_CONV_EXACT_FP32: vqvae_conv_wgrad_f32 (which is this call with that flag).  Same workspace. */
+VQVAE_API int vqvae_conv_wgrad_ex_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA,
+                                      int HB, int WB, int CB, int k, int stride, int pad, int bt_nchw, int flags,
+                                      float *grad_w, void *workspace, size_t workspace_bytes,
+                                      vqvae_stream_t stream);
 /* grad_b[c] = sum over pixels of grad_y[.., c]; grad_y (B*HW, C) row-major, or (B,C,HW) when nchw != 0.  C <= 256. */
 VQVAE_API size_t vqvae_bias_grad_workspace_bytes(int C);
 VQVAE_API int vqvae_bias_grad_f32(const float *grad_y, int64_t B, int HW, int C, int nchw, float *grad_b,

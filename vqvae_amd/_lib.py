@@ -79,6 +79,8 @@ SIGNATURES = {
     "vqvae_conv_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "vqvae_conv_wgrad_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                     _vp, _vp, _sz, _vp]),
+    "vqvae_conv_wgrad_ex_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                       _vp, _vp, _sz, _vp]),
     "vqvae_bias_grad_workspace_bytes": (_sz, [_i32]),
     "vqvae_bias_grad_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),

@@ -3,7 +3,8 @@ conv-transpose and residual layer on libvqvae_hip.so, forward AND backward.
 
   data gradients    the forward kernels with the mirrored `kind` and the SAME weight tensor
                     (d/dx Conv2d = ConvTranspose2d and vice versa; last layer: the first-layer kernel)
-  weight gradients  vqvae_conv_wgrad_f32 (exact fp32 MFMA, fixed-order reduction, bit-reproducible)
+  weight gradients  vqvae_conv_wgrad_ex_f32 (two-term fp16 products on the 8x8-map layers, exact fp32 MFMA elsewhere or with
+                    WGRAD_EXACT_FP32; fixed-order reduction, bit-reproducible)
   bias gradients    vqvae_bias_grad_f32;   ReLU masks  vqvae_relu_backward_f32
 
 ReLU masks and skip sums ride in the data-gradient kernels' epilogues (round 4, vqvae_conv_forward_ep_f32): a layer whose INPUT
@@ -34,6 +35,8 @@ _GEOM = {
 
 
 FUSE_EPILOGUES = True
+WGRAD_EXACT_FP32 = False        # True: every weight gradient on the exact-fp32 MFMA kernels (round 3's arithmetic); default: two-term
+                                # fp16 products on the map-resident shapes (vqvae_conv_wgrad_ex_f32)
 
 
 class _Holder:
@@ -81,8 +84,9 @@ def conv_wgrad(a_rows, bt, k, stride, pad, bt_nchw=False):
     n = L.vqvae_conv_wgrad_workspace_bytes(CA, CB, k)
     ws = torch.empty(n, dtype=torch.uint8, device=a_rows.device)
     gw = torch.empty((CA, CB, k, k), dtype=torch.float32, device=a_rows.device)
-    _lib.check(L.vqvae_conv_wgrad_f32(a_rows.data_ptr(), bt.data_ptr(), B, HA, WA, CA, HB, WB, CB, k, stride, pad,
-                                      1 if bt_nchw else 0, gw.data_ptr(), ws.data_ptr(), n, _sp(a_rows)))
+    _lib.check(L.vqvae_conv_wgrad_ex_f32(a_rows.data_ptr(), bt.data_ptr(), B, HA, WA, CA, HB, WB, CB, k, stride, pad,
+                                         1 if bt_nchw else 0, conv_hip.EXACT_FP32 if WGRAD_EXACT_FP32 else 0, gw.data_ptr(),
+                                         ws.data_ptr(), n, _sp(a_rows)))
     return gw
 
 

@@ -12,6 +12,7 @@ from . import _cache, _lib
 
 CONV_4x4_S2, CONV_3x3_S1, CONV_1x1, CONVT_3x3_S1, CONVT_4x4_S2 = range(5)
 RELU_IN, RELU_OUT = 1, 2
+EXACT_FP32 = 4                 # VQVAE_CONV_EXACT_FP32
 
 
 def _sp(t):

@@ -274,6 +274,198 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_map8_kernel(const float *__
     }
 }
 
+// The map-resident weight gradient on two-term fp16 products (round 4): the same decomposition as conv_wgrad_map8_kernel -- a
+// workgroup owns (WA x 32) x (WB x 32) channels of (ca, cb) and a range of images, a wave a 32 x 32 tile for NTW taps -- with
+// v_mfma_f32_32x32x16_f16 instead of v_mfma_f32_32x32x2_f32: three term products per 16 pixels instead of eight fp32 steps,
+// about three times the fp32 pipe's rate at the clock the chip holds under this load.
+//   * The reduction index of an MFMA is the pixel, so each lane needs EIGHT CONSECUTIVE PIXELS of one channel, while the
+//     activations are [pixel][channel].  The LDS images stay [pixel][32 channels] (64-byte rows of fp16, written with 8-byte
+//     stores straight from the converted float4s), and ds_read_b64_tr_b16 turns 4 pixels x 16 channels around on the way to the
+//     registers: lane (c = lane & 31, h = lane >> 5) receives pixels 8 h + 4 rd .. + 3 of channel c from the address
+//     row(8 h + 4 rd + ((lane & 15) >> 2)) * 64 + (16 ((lane >> 4) & 1) + 4 (lane & 3)) * 2 (tools/ubench/tr_probe.hip checks
+//     exactly this on the device).  A tap is a different ROW offset into the zero-framed Bt image -- a compile-time immediate,
+//     no alignment case -- and for the stride-2 layer the image keeps even and odd columns in separate planes so that the four
+//     pixels of a read stay consecutive.  Rows of 64 bytes: the four rows of a 32-lane half cover all 64 banks once.
+//   * Scales: x = (h1 + h2) 2^-k with ONE power of two per image and operand tile, measured by the workgroup while the image
+//     sits in its registers (no pass over the tensors, no maxima handed in).  Images of one range carry different scales, so the
+//     fp32 accumulators live on the CURRENT image's scale 2^(ka + kb) and are multiplied by the exact power of two between two
+//     images; the partial sums leave through v_ldexp.  Relative error per product <= 2^-21 as in the forward kernels
+//     (representation 2^-23 per operand + the dropped h2 h2 term); elements 2^17 below their image tile's maximum keep fewer bits
+//     -- absolute error <= 2^-39 of the tile maxima's product -- which is the forward scheme's statement for activations.
+//   * Fixed summation order as before (image order inside a range, ranges by conv_wgrad_reduce_kernel): bit-reproducible.
+typedef short s16x4v __attribute__((__vector_size__(8)));
+typedef short s16x8v __attribute__((__vector_size__(16)));
+typedef _Float16 wg_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 wg_f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned wg_u32x2 __attribute__((ext_vector_type(2)));
+
+// two fp32 values times sc -> packed fp16 leading terms (p1) and packed fp16 remainders (p2)
+__device__ __forceinline__ void wg_split2(float a, float b, float sc, unsigned &p1, unsigned &p2) {
+    unsigned hh;
+    float ra, rb;
+    asm("v_fma_mixlo_f16 %0, %1, %2, 0" : "=v"(hh) : "v"(a), "v"(sc));
+    asm("v_fma_mixhi_f16 %0, %1, %2, 0" : "+v"(hh) : "v"(b), "v"(sc));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(ra) : "v"(a), "v"(sc), "v"(hh));
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(rb) : "v"(b), "v"(sc), "v"(hh));
+    const wg_f16x2 r = {(_Float16)ra, (_Float16)rb};
+    p1 = hh;
+    p2 = __builtin_bit_cast(unsigned, r);
+}
+
+template <int K, int S, int WA, int WB>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_map8_h2_kernel(const float *__restrict__ A, const float *__restrict__ Bt,
+                                                                    float *__restrict__ partial, WgradGeom g, int imgs_per_split) {
+    constexpr int TG = 4 / (WA * WB), NTW = K * K / TG, PH = 7 * S + K, HB = 8 * S, PAD = K == 1 ? 0 : 1;
+    static_assert(WA * WB * TG == 4 && NTW * TG == K * K && NTW % K == 0, "wave layout");
+    static_assert(S == 1 || (S == 2 && PH % 2 == 0), "column planes of the stride-2 image");
+    constexpr int NPIXB = PH * PH;                                             // pixels of the framed Bt image (both column planes)
+    constexpr int APL = WA * 64 * 64, BPL = WB * NPIXB * 64;                   // bytes of one term's A / Bt planes
+    constexpr int NPA = WA * 8, NPB = WB * HB * S, NPIECE = NPA + NPB, PPW = (NPIECE + 3) / 4;   // 8-pixel x 32-channel pieces
+    static_assert(2 * (APL + BPL) + 64 <= 64 * 1024, "static LDS");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (APL + BPL)];
+    __shared__ float red[8];
+    unsigned char *As = smem, *Bs = smem + 2 * APL;                            // [term][tile][pixel][32 ch] fp16 each
+    const int tid = threadIdx.x, lane = tid & 63, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qa = wave_u % WA, qb = (wave_u / WA) % WB, tg = wave_u / (WA * WB);
+    const int tiles_b = g.CB / (32 * WB);
+    const int tb = blockIdx.x % tiles_b, ta = blockIdx.x / tiles_b;
+    const int ca0 = ta * 32 * WA, cb0 = tb * 32 * WB;
+    const int split = blockIdx.y;
+    const long long b_lo = (long long)split * imgs_per_split;
+    long long b_hi = b_lo + imgs_per_split;
+    if (b_hi > g.B) b_hi = g.B;
+
+    for (int i = tid; i < 2 * BPL / 16; i += 256) reinterpret_cast<f32x4 *>(Bs)[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};   // the frame stays zero
+    f32x16 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+
+    // piece p = wave + 4 j of an image: lane -> pixel lane / 8 of the piece, channels 4 (lane % 8) .. + 3
+    f32x4 raw[PPW];
+    auto load_image = [&](long long b) {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave_u + 4 * j;
+            if (p < NPA) {
+                const int ct = p >> 3, px = (p & 7) * 8 + (lane >> 3);
+                raw[j] = *reinterpret_cast<const f32x4 *>(A + (size_t)(b * 64 + px) * g.CA + ca0 + 32 * ct + 4 * (lane & 7));
+            } else if (p < NPIECE) {
+                const int r = p - NPA, ct = r / (HB * S), rr = r - ct * (HB * S), y = rr / S, u = rr - y * S;
+                raw[j] = *reinterpret_cast<const f32x4 *>(Bt + (size_t)((b * HB + y) * HB + 8 * u + (lane >> 3)) * g.CB + cb0 + 32 * ct + 4 * (lane & 7));
+            } else raw[j] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        }
+    };
+    // operand addresses of this lane (see the header): A pixel 8 h + r, Bt frame row h * S / column r * S of the wave's first tap row
+    const int r4 = (lane & 15) >> 2, chb = (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    typedef __attribute__((address_space(3))) s16x4v *lds_tr_t;
+    const unsigned char *aop = As + ((qa * 64 + 8 * h + r4) * 64 + chb);
+    const int trow = tg * (NTW / K);                                            // first kernel row of this wave's taps
+    const unsigned char *bop = Bs + ((qb * NPIXB + (S == 1 ? (h + trow) * PH + r4 : ((h * 2 + trow) * 2) * (PH / 2) + r4)) * 64 + chb);
+    auto tr8 = [&](const unsigned char *base, int off) {                       // eight pixels of this lane's channel: two transposing reads
+        const s16x4v lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + off));
+        const s16x4v hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_tr_t)(base + off + 4 * 64));
+        return __builtin_bit_cast(wg_f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+
+    int e_acc = 0;                                                              // the accumulators hold sum * 2^e_acc
+    bool first = true;
+    if (b_lo < b_hi) load_image(b_lo);
+    for (long long b = b_lo; b < b_hi; ++b) {
+        // ---- this image's two scales: maxima of the A tile and of the Bt tile over the workgroup ----
+        float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const float m = fmaxf(fmaxf(__builtin_fabsf(raw[j].x), __builtin_fabsf(raw[j].y)), fmaxf(__builtin_fabsf(raw[j].z), __builtin_fabsf(raw[j].w)));
+            if (wave_u + 4 * j < NPA) ma = fmaxf(ma, m); else mb = fmaxf(mb, m);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { ma = fmaxf(ma, __shfl_xor(ma, o)); mb = fmaxf(mb, __shfl_xor(mb, o)); }
+        if (lane == 0) { red[2 * wave_u] = ma; red[2 * wave_u + 1] = mb; }
+        __syncthreads();                                    // + every wave is done with the previous image's operands
+        ma = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
+        mb = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+        auto scale_exp = [](float m) {                      // -> the power of two that puts m into [2^14, 2^15); 0 for 0 / non-finite
+            int e = 15;
+            if (m > 0.0f && m < 3.0e38f) (void)__builtin_frexpf(m, &e);
+            e = 15 - e;
+            return e > 100 ? 100 : (e < -100 ? -100 : e);
+        };
+        const int ka = scale_exp(ma);
+        int kb = scale_exp(mb);
+        // an image far SMALLER than what has been summed so far would push the accumulators towards overflow when they follow
+        // its scale: such an image keeps a coarser scale instead (its whole contribution is below 2^-60 of the sum)
+        if (!first && ka + kb > e_acc + 60) kb = e_acc + 60 - ka;
+        const int e_img = __builtin_amdgcn_readfirstlane(ka + kb);
+        const float sa = __builtin_ldexpf(1.0f, ka), sb = __builtin_ldexpf(1.0f, kb);
+        // ---- convert and park: [term][tile][pixel][32 ch], 8 bytes per lane and term ----
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) {
+            const int p = wave_u + 4 * j;
+            unsigned p1a, p2a, p1b, p2b;
+            unsigned char *dst;
+            if (p < NPA) {
+                const int ct = p >> 3, px = (p & 7) * 8 + (lane >> 3);
+                wg_split2(raw[j].x, raw[j].y, sa, p1a, p2a);
+                wg_split2(raw[j].z, raw[j].w, sa, p1b, p2b);
+                dst = As + ((ct * 64 + px) * 64 + (lane & 7) * 8);
+                *reinterpret_cast<wg_u32x2 *>(dst) = wg_u32x2{p1a, p1b};
+                *reinterpret_cast<wg_u32x2 *>(dst + APL) = wg_u32x2{p2a, p2b};
+            } else if (p < NPIECE) {
+                const int r = p - NPA, ct = r / (HB * S), rr = r - ct * (HB * S), y = rr / S, u = rr - y * S;
+                const int Y = y + PAD, X = 8 * u + (lane >> 3) + PAD;
+                const int idx = S == 1 ? Y * PH + X : (Y * 2 + (X & 1)) * (PH / 2) + (X >> 1);
+                wg_split2(raw[j].x, raw[j].y, sb, p1a, p2a);
+                wg_split2(raw[j].z, raw[j].w, sb, p1b, p2b);
+                dst = Bs + ((ct * NPIXB + idx) * 64 + (lane & 7) * 8);
+                *reinterpret_cast<wg_u32x2 *>(dst) = wg_u32x2{p1a, p1b};
+                *reinterpret_cast<wg_u32x2 *>(dst + BPL) = wg_u32x2{p2a, p2b};
+            }
+        }
+        __syncthreads();
+        if (b + 1 < b_hi) load_image(b + 1);                // in flight under this image's matrix work
+        // ---- the accumulators follow the image's scale ----
+        if (first) { e_acc = e_img; first = false; }
+        else if (e_img != e_acc) {
+            const int d = e_img - e_acc;
+            const float f = d < -120 ? 0.0f : __builtin_ldexpf(1.0f, d);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] *= f;
+            e_acc = e_img;
+        }
+        // ---- 64 pixels = four 16-pixel steps (A rows 2 s, 2 s + 1), every tap of this wave per step ----
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const wg_f16x8 a1 = tr8(aop, (16 * s4) * 64), a2 = tr8(aop, (16 * s4) * 64 + APL);
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) {
+                const int ky = t / K, kx = t % K;
+                const int off = S == 1 ? ((2 * s4 + ky) * PH + kx) * 64
+                                       : ((((2 * s4) * 2 + ky) * 2 + (kx & 1)) * (PH / 2) + (kx >> 1)) * 64;
+                const wg_f16x8 b1 = tr8(bop, off), b2 = tr8(bop, off + BPL);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a2, b1, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b2, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a1, b1, acc[t], 0, 0, 0);
+            }
+        }
+    }
+    const int l31 = lane & 31;
+    float *dst = partial + (size_t)split * K * K * g.CA * g.CB;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int tap = tg * NTW + t;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int a = ca0 + qa * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            dst[((size_t)tap * g.CA + a) * g.CB + cb0 + qb * 32 + l31] = __builtin_ldexpf(acc[t][r], -e_acc);
+        }
+    }
+}
+
 // Weight gradient when Bt is a small NCHW image tensor (first / last layer: CB <= 4 image channels): the k*k taps
 // are folded into the MFMA N dimension (column n = tap*CB + cb, k*k*CB <= 64), so one pass over the pixels serves
 // every tap instead of k*k passes that each fill 3 of 64 columns.  One wave owns one image at a time: the image's
@@ -548,7 +740,18 @@ size_t vqvae_conv_wgrad_workspace_bytes(int CA, int CB, int k) {
 int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA, int HB, int WB, int CB,
                          int k, int stride, int pad, int bt_nchw, float *grad_w, void *workspace,
                          size_t workspace_bytes, vqvae_stream_t stream) {
+    return vqvae_conv_wgrad_ex_f32(a, bt, B, HA, WA, CA, HB, WB, CB, k, stride, pad, bt_nchw, VQVAE_CONV_EXACT_FP32, grad_w, workspace,
+                                   workspace_bytes, stream);
+}
+
+int vqvae_conv_wgrad_ex_f32(const float *a, const float *bt, int64_t B, int HA, int WA, int CA, int HB, int WB, int CB,
+                            int k, int stride, int pad, int bt_nchw, int flags, float *grad_w, void *workspace,
+                            size_t workspace_bytes, vqvae_stream_t stream) {
     if (!a || !bt || !grad_w) return VQVAE_ERR_NULL;
+    if (flags & ~VQVAE_CONV_EXACT_FP32) return VQVAE_ERR_UNSUPPORTED;
+    // two-term fp16 products where the map-resident kernel applies and multiplies enough to pay for its conversion pass (the
+    // 1x1 layers are operand-bound: their fp32 form is the faster one, 38 against 53 us at B = 4096)
+    const bool h2 = !(flags & VQVAE_CONV_EXACT_FP32) && k >= 3;
     if (B < 1 || HA < 1 || WA < 1 || CA < 1 || HB < 1 || WB < 1 || CB < 1 || stride < 1 || pad < 0) return VQVAE_ERR_SHAPE;
     if (k < 1 || k > 4) return VQVAE_ERR_UNSUPPORTED;
     if (B * (int64_t)HA * WA > INT32_MAX || B * (int64_t)HB * WB * CB > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
@@ -594,13 +797,19 @@ int vqvae_conv_wgrad_f32(const float *a, const float *bt, int64_t B, int HA, int
             const int ips = (int)((B + ns - 1) / ns);
             ns = (B + ips - 1) / ips;
             const dim3 grid((unsigned)tiles, (unsigned)ns);
-            if (k == 4) hipLaunchKernelGGL((conv_wgrad_map8_kernel<4, 2, 2, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else if (k == 3 && wa == 2) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 2, 2>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else if (k == 3 && wa == 1) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 1, 4>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else if (k == 3) hipLaunchKernelGGL((conv_wgrad_map8_kernel<3, 1, 4, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else if (wa == 2) hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 2, 2>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else if (wa == 1) hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 1, 4>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
-            else hipLaunchKernelGGL((conv_wgrad_map8_kernel<1, 1, 4, 1>), grid, dim3(256), 0, st, a, bt, partial, g, ips);
+#define MAP8_LAUNCH(K_, S_, WA_, WB_)                                                                                         \
+    do {                                                                                                                      \
+        if (h2) hipLaunchKernelGGL((conv_wgrad_map8_h2_kernel<K_, S_, WA_, WB_>), grid, dim3(256), 0, st, a, bt, partial, g, ips); \
+        else hipLaunchKernelGGL((conv_wgrad_map8_kernel<K_, S_, WA_, WB_>), grid, dim3(256), 0, st, a, bt, partial, g, ips);  \
+    } while (0)
+            if (k == 4) MAP8_LAUNCH(4, 2, 2, 1);
+            else if (k == 3 && wa == 2) MAP8_LAUNCH(3, 1, 2, 2);
+            else if (k == 3 && wa == 1) MAP8_LAUNCH(3, 1, 1, 4);
+            else if (k == 3) MAP8_LAUNCH(3, 1, 4, 1);
+            else if (wa == 2) MAP8_LAUNCH(1, 1, 2, 2);
+            else if (wa == 1) MAP8_LAUNCH(1, 1, 1, 4);
+            else MAP8_LAUNCH(1, 1, 4, 1);
+#undef MAP8_LAUNCH
             hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((unsigned)rgrid), dim3(256), 0, st, partial, (int)ns, k * k, CA, CB, grad_w);
             return (int)hipGetLastError();
         }
