@@ -33,7 +33,11 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
     cache = _cache.side(mod).setdefault("packed", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == key:
-        _cache.wait_ready(hit[2], w.device)
+        if hit[2] is not None:                       # packed on some stream a moment ago: wait for it from another stream, and
+            if hit[2][0].query():                    # forget the event once it has completed (no per-call cost from then on)
+                cache[kind] = (hit[0], hit[1], None)
+            else:
+                _cache.wait_ready(hit[2], w.device)
         return hit[1]
     n = nbytes_fn()
     if n == 0:
