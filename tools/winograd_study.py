@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Winograd F(2x2, 3x3) for the encoder's 3x3 128 -> 128 layer under the two-term fp16 product scheme: what it would do to the
-error budget and to the operand traffic (a keep / kill decision with numbers, not a half-landed kernel).
+error budget and to the work around the MFMAs (a keep / kill decision with numbers, not a half-landed kernel).
 CPU only; the products are emulated exactly in fp64 from the fp16 terms (as tests/test_fp16_scheme_cpu.py does), so what is
 measured is the scheme's representation error through the transforms, not an accumulation order.
 
