@@ -178,6 +178,7 @@ VQVAE_API int vqvae_vq_decode_indices_f32(const int64_t *idx, const float *codeb
 #define VQVAE_CONV_1x1      2   /* nn.Conv2d(k=1),         weight (Cout,Cin,1,1)   vqvae.py:16, residual.py:23 */
 #define VQVAE_CONVT_3x3_S1  3   /* nn.ConvTranspose2d(k=3,s=1,p=1), weight (Cin,Cout,3,3)  decoder.py:28 */
 #define VQVAE_CONVT_4x4_S2  4   /* nn.ConvTranspose2d(k=4,s=2,p=1), weight (Cin,Cout,4,4)  decoder.py:31 */
+#define VQVAE_CONV_TAPS     6   /* stride-1 conv over an explicit tap list: only through the vqvae_conv_taps_* entry points below */
 #define VQVAE_CONVT_1x1     5   /* nn.ConvTranspose2d(k=1), weight (Cin,Cout,1,1): the data gradient of a 1x1 nn.Conv2d */
 
 #define VQVAE_CONV_RELU_IN  0x1 /* apply ReLU to the input as it is read (the in-place nn.ReLU(True)
@@ -355,6 +356,18 @@ VQVAE_API int vqvae_gather_rows_f32(const int64_t *idx, const float *table, int6
                                     float *out, vqvae_stream_t stream);
 VQVAE_API int vqvae_im2col_rows_f32(const float *x, int64_t B, int H, int W, int C, int ntaps,
                                     const int8_t *dy, const int8_t *dx, float *out, vqvae_stream_t stream);
+/* A masked convolution WITHOUT the im2col pass (round 4): a stride-1 conv over an explicit list of ntaps <= 16 taps, tap t reading
+ * the input at (y + dy[t], x + dx[t]) (zero outside the map; |dy|, |dx| <= 7).  w is (Cout, Cin, ntaps) contiguous -- a masked
+ * conv's own (Cout, Cin, kh, kw) tensor when the list enumerates (ky, kx) in row-major order (GatedMaskedConv2d's vertical
+ * (k//2+1) x k and horizontal 1 x (k//2+1) stacks, pixelcnn/models.py:45-58).  dy / dx are HOST arrays.  Same kernels, packed
+ * image and flags as vqvae_conv_forward_f32 (on 8x8 maps with 32-channel multiples: the tile-resident kernel, every tap from
+ * one parked image).                                                                                                   */
+VQVAE_API size_t vqvae_conv_taps_packed_bytes(int ntaps, int Cin, int Cout);
+VQVAE_API int vqvae_conv_taps_pack_f32(const float *w, int ntaps, const int8_t *dy, const int8_t *dx, int Cin, int Cout,
+                                       float *packed, vqvae_stream_t stream);
+VQVAE_API int vqvae_conv_taps_forward_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
+                                          int Cin, int Cout, int ntaps, const int8_t *dy, const int8_t *dx, int flags,
+                                          float *y, vqvae_stream_t stream);
 VQVAE_API int vqvae_gated_activation_f32(const float *t1, const float *t2, const float *cond, int64_t B,
                                          int HW, int dim, float *out, vqvae_stream_t stream);
 VQVAE_API int vqvae_add_f32(const float *a, const float *b, int64_t n, float *out, vqvae_stream_t stream);

@@ -116,3 +116,39 @@ def test_hip_layer_boundary_and_generate():
     with torch.no_grad():
         ref = pixelcnn_port.forward(sd, s.cpu(), label.cpu(), nl)
     np.testing.assert_allclose(l1.cpu().numpy(), ref.numpy(), atol=2e-4, rtol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,Cout,taps", [
+    (5, 8, 8, 64, 128, [(ky - 1, kx - 1) for ky in range(2) for kx in range(3)]),      # vertical stack, k = 3: tile-resident kernel
+    (5, 8, 8, 64, 128, [(0, kx - 1) for kx in range(2)]),                               # horizontal stack, k = 3
+    (3, 8, 8, 32, 64, [(0, kx - 3) for kx in range(4)]),                                # horizontal stack, k = 7
+    (2, 6, 6, 32, 64, [(ky - 1, kx - 1) for ky in range(2) for kx in range(3)]),       # a map the generic kernel takes
+    (2, 5, 7, 16, 24, [(-2, 3), (0, 0), (1, -1)]),                                      # an arbitrary list, odd shapes
+])
+def test_tap_list_conv_vs_shifted_sum(B, H, W, Cin, Cout, taps):
+    """vqvae_conv_taps_forward_f32 against the defining sum y[b,y,x,:] = b + sum_t W[:, :, t] x[b, y + dy_t, x + dx_t, :] (zero outside
+    the map), fp64 on the CPU; fp32-grade products: atol 1e-5 * max|y| + rtol 1e-4."""
+    import torch.nn as nn
+    from vqvae_amd import conv_hip
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(len(taps) * 100 + Cin)
+    n = len(taps)
+    w = torch.randn(Cout, Cin, 1, n, generator=g) * 0.1
+    bias = torch.randn(Cout, generator=g)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    ref = bias.double().expand(B, H, W, Cout).clone()
+    xd = x.double()
+    for t, (dy, dx) in enumerate(taps):
+        sh = torch.zeros_like(xd)
+        ys, ye = max(0, -dy), min(H, H - dy)
+        xs, xe = max(0, -dx), min(W, W - dx)
+        if ys < ye and xs < xe:
+            sh[:, ys:ye, xs:xe] = xd[:, ys + dy:ye + dy, xs + dx:xe + dx]
+        ref += sh @ w[:, :, 0, t].double().T
+    hold = nn.Module()
+    got = conv_hip.conv_taps(x.to(dev), hold, w.to(dev), bias.to(dev), taps).cpu().double()
+    lim = 1e-5 * float(ref.abs().max()) + 1e-4 * ref.abs()
+    assert bool(((got - ref).abs() <= lim).all()), float(((got - ref).abs() / lim).max())
+    L = __import__("vqvae_amd._lib", fromlist=["load"]).load()
+    assert L.vqvae_conv_taps_packed_bytes(17, Cin, Cout) == 0 and L.vqvae_conv_taps_packed_bytes(0, Cin, Cout) == 0

@@ -98,6 +98,29 @@ def conv(kind, x, mod, weight, bias, Cin, Cout, flags, addend=None, mask=None):
     return y
 
 
+def conv_taps(x, mod, weight, bias, taps, flags=0):
+    """A stride-1 convolution over an explicit tap list [(dy, dx), ...] (<= 16 taps) on row-major activations: weight
+    (Cout, Cin, kh, kw) with kh * kw == len(taps), the list in the weight's (ky, kx) order -- a masked convolution without an
+    im2col pass (vqvae_conv_taps_forward_f32)."""
+    import ctypes as C
+    B, H, W, Cin = x.shape
+    Cout, n = weight.shape[0], len(taps)
+    if weight.shape[1] != Cin or weight.shape[2] * weight.shape[3] != n:
+        raise ValueError("weight must be (Cout, Cin, kh, kw) with kh * kw taps")
+    dy = (C.c_int8 * n)(*[t[0] for t in taps])
+    dx = (C.c_int8 * n)(*[t[1] for t in taps])
+    L = _lib.load()
+    packed = _packed(mod, ("taps", tuple(taps)), weight,
+                     lambda: L.vqvae_conv_taps_packed_bytes(n, Cin, Cout),
+                     lambda w, buf: L.vqvae_conv_taps_pack_f32(w.data_ptr(), n, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), Cin, Cout,
+                                                               buf.data_ptr(), _sp(w)))
+    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+    b = bias.detach() if bias is not None else None
+    _lib.check(L.vqvae_conv_taps_forward_f32(x.data_ptr(), packed.data_ptr(), b.data_ptr() if b is not None else None, B, H, W,
+                                             Cin, Cout, n, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), flags, y.data_ptr(), _sp(x)))
+    return y
+
+
 def res_layer(x, layer, flags, want_hidden=False):
     """One ResidualLayer on row-major activations (fused kernel).  want_hidden: also return relu(W1 * r(x)) as
     (B,H,W,Rh) where the kernel can write it (8x8 maps, res_h = 32), else None -- a training step keeps it for backward."""

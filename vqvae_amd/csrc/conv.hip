@@ -4738,6 +4738,19 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float *__restrict_
 }
 
 // ---------------------------------------------------------------------------
+// kind VQVAE_CONV_TAPS: a stride-1 convolution over an explicit tap list (the masked convolutions of the GatedPixelCNN prior,
+// pixelcnn/models.py:45-58, without an im2col pass): the list is handed to make_geom by the vqvae_conv_taps_* entry points
+// through this thread-local slot for the duration of the call.
+struct TapSpec {
+    int n;
+    signed char dy[16], dx[16];
+};
+static thread_local const TapSpec *t_taps = nullptr;
+struct TapScope {
+    explicit TapScope(const TapSpec *t) { t_taps = t; }
+    ~TapScope() { t_taps = nullptr; }
+};
+
 static int make_geom(int kind, long long B, int H, int W, int Cin, int Cout, int flags, ConvGeom &g) {
     memset(&g, 0, sizeof(g));
     g.B = (int)B; g.Hin = H; g.Win = W; g.Cin = Cin; g.Cout = Cout; g.flags = flags;
@@ -4760,6 +4773,13 @@ static int make_geom(int kind, long long B, int H, int W, int Cin, int Cout, int
             conv_taps(3, 1); g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
         case VQVAE_CONV_1x1:
             conv_taps(1, 0); g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
+        case VQVAE_CONV_TAPS:                     // weight (Cout, Cin, n taps): tap t reads the input at (y + dy[t], x + dx[t])
+            if (!t_taps || t_taps->n < 1 || t_taps->n > 16) return VQVAE_ERR_UNSUPPORTED;
+            g.ntaps = g.kk = t_taps->n;
+            for (int t = 0; t < t_taps->n; ++t) {
+                g.dy[0][t] = t_taps->dy[t]; g.dx[0][t] = t_taps->dx[t]; g.kyx[0][t] = (signed char)t;
+            }
+            g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
         case VQVAE_CONVT_1x1:                     // = the data gradient of a 1x1 nn.Conv2d (weight read transposed)
             conv_taps(1, 0); g.transposed = 1; g.Hg = g.Hout = H; g.Wg = g.Wout = W; break;
         case VQVAE_CONVT_3x3_S1:
@@ -4882,6 +4902,45 @@ int vqvae_conv_forward_f32(int kind, const float *x, const float *packed, const 
     return vqvae::conv_forward_impl(kind, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
 }
 
+static int fill_taps(vqvae::TapSpec &t, int ntaps, const int8_t *dy, const int8_t *dx) {
+    if (!dy || !dx) return VQVAE_ERR_NULL;
+    if (ntaps < 1 || ntaps > 16) return VQVAE_ERR_UNSUPPORTED;
+    t.n = ntaps;
+    for (int i = 0; i < ntaps; ++i) {
+        if (dy[i] < -7 || dy[i] > 7 || dx[i] < -7 || dx[i] > 7) return VQVAE_ERR_UNSUPPORTED;     // four bits per tap in the kernels' masks
+        t.dy[i] = dy[i]; t.dx[i] = dx[i];
+    }
+    return VQVAE_OK;
+}
+
+size_t vqvae_conv_taps_packed_bytes(int ntaps, int Cin, int Cout) {
+    vqvae::TapSpec t;
+    t.n = ntaps;
+    for (int i = 0; i < 16; ++i) t.dy[i] = t.dx[i] = 0;
+    if (ntaps < 1 || ntaps > 16) return 0;
+    vqvae::TapScope scope(&t);
+    return vqvae_conv_packed_bytes(VQVAE_CONV_TAPS, Cin, Cout);
+}
+
+int vqvae_conv_taps_pack_f32(const float *w, int ntaps, const int8_t *dy, const int8_t *dx, int Cin, int Cout, float *packed,
+                             vqvae_stream_t stream) {
+    vqvae::TapSpec t;
+    const int rc = fill_taps(t, ntaps, dy, dx);
+    if (rc != VQVAE_OK) return rc;
+    vqvae::TapScope scope(&t);
+    return vqvae_conv_pack_f32(VQVAE_CONV_TAPS, w, Cin, Cout, packed, stream);
+}
+
+int vqvae_conv_taps_forward_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
+                                int ntaps, const int8_t *dy, const int8_t *dx, int flags, float *y, vqvae_stream_t stream) {
+    vqvae::TapSpec t;
+    const int rc = fill_taps(t, ntaps, dy, dx);
+    if (rc != VQVAE_OK) return rc;
+    vqvae::TapScope scope(&t);
+    return vqvae::conv_forward_impl(VQVAE_CONV_TAPS, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr,
+                                    nullptr);
+}
+
 int vqvae_conv_forward_ep_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
                               int Cout, int flags, const float *addend, const float *mask, float *y, vqvae_stream_t stream) {
     if ((addend && addend == y) || (mask && mask == y)) return VQVAE_ERR_UNSUPPORTED;     // no in-place form: other waves still read them
@@ -4925,7 +4984,11 @@ int vqvae::conv_forward_impl(int kind, const float *x, const float *packed, cons
             // whole 8x8 input images per wave: operands split once per chunk and kept in LDS for all taps.  With four
             // output tiles per wave (all 128 channels: the image is read and split once) the workgroup has eight
             // waves, so that its weight chunks (2 x 24 KiB) and eight operand tiles still fit one CU's LDS.
-            const bool wide = g.ntile % 4 == 0;
+            // ... unless that leaves most of the chip without a workgroup (round 4: the prior's sampler runs these layers at
+            // B = 64): below one eight-wave workgroup per CU the four-wave form, two channel halves per image, spreads the same
+            // images over four times the workgroups
+            const long long wg_wide = ((B + 7) / 8) * (S2D_ ? 1 : g.nphase) * (g.ntile / 4);
+            const bool wide = g.ntile % 4 == 0 && wg_wide >= num_cus();
             const int ny = (S2D_ ? 1 : g.nphase) * (g.ntile / (wide ? 4 : 2));
             const unsigned gxt = (unsigned)((B + (wide ? 7 : 3)) / (wide ? 8 : 4)) * ny;
             const bool h2 = !(flags & VQVAE_CONV_BF16_SPLIT);

@@ -7,8 +7,9 @@ initialisation as the reference, so a PixelCNN checkpoint written by `pixelcnn/g
         .forward(x (B,H,W) int64, label (B,) int64) -> logits (B, input_dim, H, W)          (models.py:118-127)
         .generate(label, shape=(8, 8), batch_size=64) -> (B, *shape) int64                   (models.py:129-142)
 
-Forward-only.  Activations are row-major (B,H,W,C); each masked convolution runs as im2col over its causal tap
-list (vqvae_im2col_rows_f32) followed by the split-bf16 1x1 GEMM kernel of the conv path; embeddings, the gated
+Forward-only.  Activations are row-major (B,H,W,C); a masked convolution is a stride-1 convolution over its causal tap list
+(round 4: vqvae_conv_taps_forward_f32 -- the conv path's kernels with an explicit tap list, no im2col pass; lists of more than
+16 taps, i.e. the first layer's 4 x 7 vertical stack, keep round 2's im2col + 1x1 GEMM); embeddings, the gated
 activation (+ class-conditional term) and the residual add are small HIP kernels (csrc/pixelcnn.hip).  The
 categorical sampling of `generate` uses torch's softmax + multinomial on the device, as the reference does.
 No CPU path, no fallback.
@@ -118,19 +119,23 @@ class GatedMaskedConv2d(nn.Module):
         cache[tag] = (key, w2, holder)
         return w2, holder
 
+    def _masked(self, x_rows, conv, taps, tag):
+        """One masked conv (bias included): the conv kernels over the tap list, or im2col + 1x1 GEMM for long lists."""
+        if len(taps) <= 16:          # (mask 'A' zeroes weights in place on every call: the version bump re-packs, conv_hip._packed)
+            return conv_hip.conv_taps(x_rows, conv, conv.weight, conv.bias, taps)
+        w2, holder = self._gemm_weight(conv, tag)
+        cols = _im2col(x_rows, taps)
+        return conv_hip.conv(CONV_1x1, cols, holder, w2, conv.bias, cols.shape[3], conv.weight.shape[0], 0)
+
     def forward_rows(self, x_v, x_h, label):
         """x_v, x_h row-major (B,H,W,dim); label (B,) int64 -> (out_v, out_h) row-major."""
         if self.mask_type == 'A':
             self.make_causal()
         dim = self.dim
         cond = _gather_rows(label, self.class_cond_embedding.weight)                       # :68
-        wv, hv = self._gemm_weight(self.vert_stack, "vert")
-        wh, hh = self._gemm_weight(self.horiz_stack, "horiz")
-        cv = _im2col(x_v, self._vtaps)
-        h_vert = conv_hip.conv(CONV_1x1, cv, hv, wv, self.vert_stack.bias, cv.shape[3], 2 * dim, 0)     # :69-70
+        h_vert = self._masked(x_v, self.vert_stack, self._vtaps, "vert")                   # :69-70
         out_v = _gate(h_vert, None, cond, dim)                                              # :71
-        ch = _im2col(x_h, self._htaps)
-        h_horiz = conv_hip.conv(CONV_1x1, ch, hh, wh, self.horiz_stack.bias, ch.shape[3], 2 * dim, 0)   # :73-74
+        h_horiz = self._masked(x_h, self.horiz_stack, self._htaps, "horiz")                # :73-74
         v2h = conv_hip.conv(CONV_1x1, h_vert, self.vert_to_horiz, self.vert_to_horiz.weight, self.vert_to_horiz.bias,
                             2 * dim, 2 * dim, 0)                                            # :75
         out = _gate(v2h, h_horiz, cond, dim)                                                # :77
