@@ -136,13 +136,13 @@ class GatedMaskedConv2d(nn.Module):
         h_vert = self._masked(x_v, self.vert_stack, self._vtaps, "vert")                   # :69-70
         out_v = _gate(h_vert, None, cond, dim)                                              # :71
         h_horiz = self._masked(x_h, self.horiz_stack, self._htaps, "horiz")                # :73-74
+        # :75, :77  v2h + h_horiz in the 1x1 conv's epilogue (same sum, same order: (v2h + h_horiz) + cond in the gate)
         v2h = conv_hip.conv(CONV_1x1, h_vert, self.vert_to_horiz, self.vert_to_horiz.weight, self.vert_to_horiz.bias,
-                            2 * dim, 2 * dim, 0)                                            # :75
-        out = _gate(v2h, h_horiz, cond, dim)                                                # :77
+                            2 * dim, 2 * dim, 0, addend=h_horiz)
+        out = _gate(v2h, None, cond, dim)
+        # :78-79  the horizontal residual in the 1x1 conv's epilogue
         out_h = conv_hip.conv(CONV_1x1, out, self.horiz_resid, self.horiz_resid.weight, self.horiz_resid.bias, dim,
-                              dim, 0)
-        if self.residual:
-            out_h = _add(out_h, x_h)                                                        # :79
+                              dim, 0, addend=x_h.contiguous() if self.residual else None)
         return out_v, out_h
 
     def forward(self, x_v, x_h, h):
