@@ -1,6 +1,6 @@
 // Weight / bias gradients and ReLU masks for the conv layers of the path, gfx950.
 // The DATA gradients need no kernels of their own: the gradient of a conv w.r.t. its input is the transposed
-// conv with the same weight tensor and vice versa, i.e. the forward kernels of conv.hip with the other `kind`
+// conv with the same weight tensor and vice versa, i.e. the forward kernels of conv.hip / conv_ends.hip with the other `kind`
 // (vqvae_amd/autograd_conv.py does that mapping).
 //
 //   vqvae_conv_wgrad_f32   dW[ca][cb][ky][kx] = sum over pixels of  A[pixel][ca] * Bt[pixel*s + (ky,kx) - p][cb]

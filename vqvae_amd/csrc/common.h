@@ -17,7 +17,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 // clang 22) lowers four consecutive __builtin_amdgcn_fdot2 calls on the components .x .y .z .w of one loaded vector to four
 // v_dot2c_f32_f16 that ALL read the FIRST component's register -- the sum came out as 4 (x0^2 + x1^2), right in expectation on
 // i.i.d. channels and silently far too small on rows whose energy sits in other channels.  Round 3's screen bound took its row
-// norm |z^| from that sum (vq_track.hip, round 2's vq_sweep.hip, the fused quantizer in conv.hip): found in round 4 by the
+// norm |z^| from that sum (vq_track.hip, round 2's vq_sweep.hip, the fused quantizer in conv_fused.hip): found in round 4 by the
 // heterogeneous-channel parity test (tests/golden/vq_hetero_unit.npz is the row that came back with the wrong index).
 // tools/hazard_scan.py now also rejects the miscompiled pattern in every source's assembly.
 __device__ __forceinline__ float sqsum8_f16(unsigned vx, unsigned vy, unsigned vz, unsigned vw, float s) {

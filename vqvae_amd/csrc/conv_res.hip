@@ -1,0 +1,1412 @@
+// Residual layers (models/residual.py:18-29, 47-51) for gfx950: per-layer kernels on the three product schemes, tile-resident
+// and halo forms, fused pairs of layers; split out of conv.hip in round 4 (shared device code: conv_device.h).
+#include "conv_host.h"
+
+namespace vqvae {
+// ---------------------------------------------------------------------------
+// Fused residual layer on the split-bf16 product path (same math and layout as res_layer_kernel below;
+// see conv_igemm_bf3_kernel for the split).  GEMM1 (3x3, C -> 32 hidden) is barrier-free: each wave
+// reads its 6-KiB weight chunk (three bf16 terms) straight from L1/L2 next to its A operands.
+// GEMM2 (1x1, 32 -> C) takes the three-term W2 image from LDS.
+// H2: two-term fp16 products; every pixel row carries its image's scale in the 3x3 GEMM (in_amax holds the maxima) and
+// its OWN scale (largest of its 32 hidden values) in the 1x1 GEMM, whose rows are independent.
+template <int NT2, bool H2 = false>
+__global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__restrict__ in,
+                                                            const u32x4 *__restrict__ w1img,
+                                                            const u32x4 *__restrict__ w2img,
+                                                            float *__restrict__ out, int B, int H, int W,
+                                                            int C, int flags, const int *__restrict__ hdr1,
+                                                            const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                            int *__restrict__ out_amax) {
+    constexpr int MT = 2, TERMS = H2 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1536 + 4 * MT * 32 * 33];
+    u32x4 *W2s = reinterpret_cast<u32x4 *>(smem_res);                       // [NT2][384]
+    float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1536);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const long long M = (long long)B * H * W;
+    const int cpt = (C + 31) / 32;
+    const int nchunk = 9 * cpt;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+
+    for (int i = tid; i < NT2 * 128 * TERMS; i += 256) W2s[i] = w2img[i];
+
+    const long long wbase = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT);
+    const long long img_px = (long long)H * W;
+    const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
+    unsigned pbase[MT], tapmask[MT];
+    long long myimg[MT];
+    float xsc[MT], d1[MT];                              // H2: image scale 2^kx and its inverse of this lane's pixel rows
+    const float w1d = H2 ? h2_dw(hdr1)[l31] : 1.0f;     // H2: 2^-kw1[n] of this lane's hidden channel
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long p = wbase + mt * 32 + l31;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / W, gx = rem - gy * W;
+        pbase[mt] = (unsigned)((((b - b_first) * H + gy) * W + gx) * C * 4 + 64 * h);
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = gy + t / 3 - 1, ix = gx + t % 3 - 1;
+            if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) m |= 1u << t;
+        }
+        tapmask[mt] = m;
+        myimg[mt] = valid ? b : -1;
+        xsc[mt] = 1.0f; d1[mt] = 1.0f;
+        if (H2 && valid) {
+            const float mx = __int_as_float(in_amax[b]);
+            int e = 15;
+            if (mx > 0.0f && mx < 3.0e38f) (void)__builtin_frexpf(mx, &e);
+            int kx = 15 - e;
+            kx = kx > 100 ? 100 : (kx < -100 ? -100 : kx);
+            xsc[mt] = __builtin_ldexpf(1.0f, kx);
+            d1[mt] = __builtin_ldexpf(1.0f, -kx);
+        }
+    }
+
+    constexpr int KC = 2;
+    f32x4 a[KC][MT][4];
+    u32x4 bq[KC][6];                                   // [term*2 + step] for this lane's half
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    const u32x4 *w1v = w1img + h * 32 + l31;          // + chunk*384 + (term*2 + step)*64
+    auto load_ab = [&](int c, f32x4(&dst)[MT][4], u32x4(&bd)[6]) {
+        const int tap = c / cpt, cc = c - tap * cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int tapbytes = (dy * W + dx) * C * 4;
+        const unsigned soff = (unsigned)cc * 128u;
+#pragma unroll
+        for (int q = 0; q < 2 * TERMS; ++q) bd[q] = w1v[(size_t)c * (128 * TERMS) + q * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+        }
+    };
+
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < nchunk) load_ab(k, a[k], bq[k]);
+    for (int c0 = 0; c0 < nchunk; c0 += KC) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (c0 + k < nchunk) {
+                u32x4 S1[MT][2], S2[MT][2], S3[MT][2], bw[6];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (relu_in) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) a[k][mt][j] = relu4(a[k][mt][j]);
+                    }
+                    if constexpr (H2) {
+                        split8_h(a[k][mt][0], a[k][mt][1], xsc[mt], S1[mt][0], S2[mt][0]);
+                        split8_h(a[k][mt][2], a[k][mt][3], xsc[mt], S1[mt][1], S2[mt][1]);
+                    } else {
+                        split8(a[k][mt][0], a[k][mt][1], S1[mt][0], S2[mt][0], S3[mt][0]);
+                        split8(a[k][mt][2], a[k][mt][3], S1[mt][1], S2[mt][1], S3[mt][1]);
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 2 * TERMS; ++q) bw[q] = bq[k][q];
+                if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {         // the two pixel tiles share the weights, separate accumulators
+                    if constexpr (H2)
+                        prod3x2(S1[0][t], S2[0][t], S1[1][t], S2[1][t], bw[t], bw[2 + t], acc1[0], acc1[1]);
+                    else
+                        prod6x2(S1[0][t], S2[0][t], S3[0][t], S1[1][t], S2[1][t], S3[1][t], bw[t], bw[2 + t], bw[4 + t],
+                                acc1[0], acc1[1]);
+                }
+            }
+        }
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+
+    // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33: conflict-free)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float dr = H2 ? __shfl(d1[mt], prow) * w1d : 1.0f;  // the row's 3x3 accumulator scale 2^-(kx + kw1[n])
+            Hs[wave][mt][prow * 33 + l31] = fmaxf(H2 ? acc1[mt][r] * dr : acc1[mt][r], 0.0f);
+        }
+    lds_order_wave();
+    u32x4 H1[MT][2], Hb[MT][2], H3[MT][2];
+    float d2[MT];                                       // H2: 1x1 accumulator scale of this lane's pixel rows
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[wave][mt][l31 * 33 + 16 * h + q];
+        d2[mt] = 1.0f;
+        if constexpr (H2) {
+            float m = 0.0f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) m = fmaxf(m, a2[q]);
+            m = fmaxf(m, __shfl_xor(m, 32));             // the pixel's other sixteen hidden values
+            int e = 15;
+            if (m > 0.0f && m < 3.0e38f) (void)__builtin_frexpf(m, &e);
+            int kh = 15 - e;
+            kh = kh > 100 ? 100 : (kh < -100 ? -100 : kh);
+            const float hsc = __builtin_ldexpf(1.0f, kh);
+            d2[mt] = __builtin_ldexpf(1.0f, -kh);
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hsc, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hsc, H1[mt][1], Hb[mt][1]);
+        } else {
+            split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], Hb[mt][0], H3[mt][0]);
+            split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], Hb[mt][1],
+                   H3[mt][1]);
+        }
+    }
+    // maxima for the next layer: one image per wave in the common case, per pixel row otherwise
+    const long long img0 = __shfl(myimg[0], 0);
+    const bool one_img = out_amax && img0 >= 0 && __builtin_amdgcn_ballot_w64(myimg[0] != img0 || myimg[1] != img0) == 0;
+    float omax = 0.0f;
+
+    // second GEMM, one n-tile at a time (two pixel tiles = two interleaved accumulators)
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        f32x16 acc2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * (128 * TERMS) + (t * 2 + h) * 32 + l31;
+            if constexpr (H2) {
+                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+            } else {
+                const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+                prod6x2(H1[0][t], Hb[0][t], H3[0][t], H1[1][t], Hb[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            }
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int src = (r & 3) + 8 * (r >> 2) + 4 * h;
+                const long long prow = wbase + mt * 32 + src;
+                const int n = nt * 32 + l31;
+                const float dr = H2 ? __shfl(d2[mt], src) * h2_dw(hdr2)[n] : 1.0f;     // 2^-(kh + kw2[n])
+                float rmax = 0.0f;
+                if (prow < M && n < C) {
+                    float u = in[prow * C + n];
+                    if (relu_in) u = fmaxf(u, 0.0f);
+                    float v = u + (H2 ? acc2[mt][r] * dr : acc2[mt][r]);
+                    if (relu_out) v = fmaxf(v, 0.0f);
+                    rmax = __builtin_fabsf(v);
+                    out[prow * C + n] = v;
+                }
+                if (out_amax && !one_img) {
+                    const long long rimg = __shfl(myimg[mt], src);
+#pragma unroll
+                    for (int o = 16; o > 0; o >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, o));
+                    if (l31 == 0 && rimg >= 0) atomicMax(out_amax + rimg, __float_as_int(rmax));
+                } else {
+                    omax = fmaxf(omax, rmax);
+                }
+            }
+    }
+    if (one_img) publish_amax(out_amax, img0, omax, lane);
+}
+
+// ---------------------------------------------------------------------------
+// Fused residual layer for 8x8 feature maps (the reference's 32x32 images: both residual stacks run at 8x8).
+// One wave owns one whole image, so every 3x3 tap of every pixel lives inside the wave's own tile:
+//   for each 16-channel slice of the input (one MFMA k-step of the packed weight image; slice outer, tap inner):
+//       load the slice of the image once, apply the in-place ReLU, split it ONCE into its three bf16
+//       terms and park them in a wave-private LDS tile (64 pixels + one all-zero "padding" pixel);
+//       the nine taps then read their A operands from that tile with ds_read_b128 at shifted pixel indices.
+// Compared with res_layer_bf3_kernel (A re-loaded from L2 and re-split for each of the 9 taps) this cuts
+// the L1/TA traffic and the split VALU work of the 3x3 GEMM 9x; no workgroup barrier in the reduction.
+// The hidden tile and the 1x1 GEMM / skip / ReLU epilogue are the same as in res_layer_bf3_kernel.
+// H2: two-term fp16 products (split8_h): per-image scale for x, a second one for the hidden tile, per-layer weight scales
+// in the headers hdr1 / hdr2 of the two weight images.
+template <int NT2, bool H2 = false>
+__global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const float *__restrict__ in,
+                                                               const u32x4 *__restrict__ w1img,
+                                                               const u32x4 *__restrict__ w2img,
+                                                               float *__restrict__ out, int B, int C, int flags,
+                                                               const int *__restrict__ hdr1, const int *__restrict__ hdr2,
+                                                               const int *__restrict__ in_amax, int *__restrict__ out_amax,
+                                                               float *__restrict__ hid_out) {
+    constexpr int TERMS = H2 ? 2 : 3;
+    // u32x4 per wave tile: [term][half][pixel + zero], at least the 32 x 33 floats of the hidden tile that aliases it.
+    // H2: 4.1 KiB per wave + 16 KiB of W2 = 33 KiB per workgroup -> four workgroups (16 waves) per CU, and the 1024
+    // workgroups of a B = 4096 layer are all resident at once (no second, part-filled round)
+    constexpr int MT = 2, PX = 64, TILE4 = H2 ? 264 : 3 * (PX + 1) * 2;
+    constexpr int HP = PX + 1;                                     // (consecutive lanes = consecutive 16 B: no bank conflicts)
+    static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
+    __shared__ u32x4 W2s[NT2 * 128 * TERMS];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 128 * TERMS; i += 256) W2s[i] = w2img[i];
+    if (lane < 2 * TERMS) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
+
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+    const float *src = in + (size_t)(img_ok ? img : 0) * PX * C + (size_t)lane * C;   // this lane's pixel row
+
+    // operand pixel index per (tap, m-tile): the shifted pixel, or the zero pixel outside the image
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        }
+        tapok[mt] = m;
+    }
+
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    // slice sl = k-step (sl & 1) of 32-channel chunk (sl >> 1) of the packed weight image: channels
+    // 32*chunk + 8*step + [0,8) for the h = 0 operand half and 32*chunk + 16 + 8*step + [0,8) for h = 1
+    auto load_raw = [&](int sl, f32x4(&r)[4]) {
+        const float *q = src + 32 * (sl >> 1) + 8 * (sl & 1);
+        r[0] = *reinterpret_cast<const f32x4 *>(q);
+        r[1] = *reinterpret_cast<const f32x4 *>(q + 4);
+        r[2] = *reinterpret_cast<const f32x4 *>(q + 16);
+        r[3] = *reinterpret_cast<const f32x4 *>(q + 20);
+    };
+    // weights of (tap, slice): 16 k x 32 hidden x 3 terms, this lane's 8 k of each term.  The image is the
+    // conv_pack_bf3 layout: chunk = tap*cpt + slice/2, k-step = slice & 1
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[3]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * (128 * TERMS) + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+        if constexpr (!H2) bw[2] = p[256];
+    };
+
+    f32x4 raw[4];
+    u32x4 bw[2][3];
+    float xscale = 1.0f, d1 = 1.0f;                  // H2: image scale 2^kx, GEMM1 accumulator scale 2^-(kx + kw1)
+    if constexpr (H2) {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;        // the producer's maximum of this image, if any
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl, raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = raw[j];
+                if (relu_in) v = relu4(v);
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+            }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -kx) * h2_dw(hdr1)[l31];          // this lane's hidden channel: 2^-(kx + kw1[n])
+    }
+    load_raw(0, raw);
+    load_w(0, 0, bw[0]);
+    // one 16-channel slice; PAR = slice parity (nine taps per slice flip which weight register set is "current")
+    auto slice = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+        // ---- stage this slice: ReLU, split once, park the three terms (the tile is wave-private) ----
+        {
+            if (relu_in) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
+            }
+            u32x4 t1a, t2a, t3a, t1b, t2b, t3b;
+            if constexpr (H2) {
+                split8_h(raw[0], raw[1], xscale, t1a, t2a);
+                split8_h(raw[2], raw[3], xscale, t1b, t2b);
+            } else {
+                split8(raw[0], raw[1], t1a, t2a, t3a);
+                split8(raw[2], raw[3], t1b, t2b, t3b);
+            }
+            if (sl + 1 < nslice) load_raw(sl + 1, raw);
+            __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+            u32x4 *dst = As + lane;
+            dst[0] = t1a; dst[HP] = t1b;
+            dst[HP * 2] = t2a; dst[HP * 3] = t2b;
+            if constexpr (!H2) { dst[HP * 4] = t3a; dst[HP * 5] = t3b; }
+            lds_order_wave();
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+            u32x4 S[MT][3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + h * HP + p;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+                if constexpr (!H2) S[mt][2] = ap[HP * 4];
+            }
+            if constexpr (H2)
+                prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+            else
+                prod6x2(S[0][0], S[0][1], S[0][2], S[1][0], S[1][1], S[1][2], bw[cur][0], bw[cur][1], bw[cur][2], acc1[0],
+                        acc1[1]);
+        }
+    };
+    for (int sl = 0; sl < nslice; sl += 2) {                  // C % 32 == 0: an even number of slices
+        slice(sl, std::integral_constant<int, 0>{});
+        slice(sl + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete; operand tile no longer read
+
+    // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33), one m-tile at a time in the
+    // (now free) operand tile
+    float *Hs = reinterpret_cast<float *>(As);
+    u32x4 H1[MT][2], Hb[MT][2], H3[MT][2];
+    float hscale = 1.0f, d2 = 1.0f;                  // H2: hidden-tile scale 2^kh, GEMM2 accumulator scale 2^-(kh + kw2)
+    if constexpr (H2) {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
+        const int kh = wave_scale_exp(m);
+        hscale = __builtin_ldexpf(1.0f, kh);
+        d2 = __builtin_ldexpf(1.0f, -kh);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+        }
+        lds_order_wave();
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+        if (hid_out && img_ok) {                            // training: the hidden activation (B, 8, 8, 32) for backward
+            f32x4 *hp = reinterpret_cast<f32x4 *>(hid_out + ((size_t)img * PX + mt * 32 + l31) * 32 + 16 * h);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hp[q] = f32x4{a2[4 * q], a2[4 * q + 1], a2[4 * q + 2], a2[4 * q + 3]};
+        }
+        if constexpr (H2) {
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+        } else {
+            split8(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, H1[mt][0], Hb[mt][0], H3[mt][0]);
+            split8(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, H1[mt][1], Hb[mt][1],
+                   H3[mt][1]);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    const long long wbase = img * PX;
+    float omax = 0.0f;
+#pragma unroll
+    for (int nt = 0; nt < NT2; ++nt) {
+        f32x16 acc2[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * (128 * TERMS) + (t * 2 + h) * 32 + l31;
+            if constexpr (H2) {
+                prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+            } else {
+                const u32x4 w1 = bp[0], w2 = bp[128], w3 = bp[256];
+                prod6x2(H1[0][t], Hb[0][t], H3[0][t], H1[1][t], Hb[1][t], H3[1][t], w1, w2, w3, acc2[0], acc2[1]);
+            }
+        }
+        if (img_ok) {
+            // skip connection, activation and store in the staged layout: 16-byte loads and stores
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float v[16];
+                const float d2n = H2 ? d2 * h2_dw(hdr2)[nt * 32 + l31] : 1.0f;       // 2^-(kh + kw2[n]) of this lane's channel
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = H2 ? acc2[mt][r] * d2n : acc2[mt][r];
+                // the four skip values of this lane are requested before the tile goes through LDS
+                f32x4 u[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    u[k] = *reinterpret_cast<const f32x4 *>(in + (wbase + mt * 32 + (lane >> 3) + 8 * k) * C + nt * 32 +
+                                                            4 * (lane & 7));
+                tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int k) {
+                    f32x4 u0 = u[k];
+                    if (relu_in) u0 = relu4(u0);
+                    f32x4 y0 = u0 + a4;
+                    if (relu_out) y0 = relu4(y0);
+                    omax = fmaxf(omax, fmaxf(fmaxf(__builtin_fabsf(y0.x), __builtin_fabsf(y0.y)), fmaxf(__builtin_fabsf(y0.z), __builtin_fabsf(y0.w))));
+                    *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = y0;
+                });
+            }
+        }
+    }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+}
+
+// ---------------------------------------------------------------------------
+// res_tile8_bf3_kernel<., true> on maps LARGER than 8x8 (round 3; BASELINE configs 4 / 5): one wave owns one 8x8 tile of
+// one image's map plus a one-pixel halo (a 10x10 patch).  Per 16-channel slice the patch is loaded once (pixels outside the
+// image read as zero through the buffer descriptor), ReLU'd, split once into its two fp16 terms and parked in the wave's
+// LDS tile; the nine taps read their operands at shifted patch indices, no masks.  Hidden tile, 1x1 GEMM, skip, ReLU and
+// the staged stores are res_tile8_bf3_kernel's (the skip re-reads the tile's 64 centre pixels).  Two-term fp16 products;
+// the scale of x is the image's maximum from the producing layer (in_amax), or the patch's own where none is given.
+template <int NT2>
+__global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w1img,
+                                                             const u32x4 *__restrict__ w2img, float *__restrict__ out, int B,
+                                                             int H, int W, int C, int flags, const int *__restrict__ hdr1,
+                                                             const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                             int *__restrict__ out_amax) {
+    constexpr int MT = 2, PW = 10, PP = PW * PW, HP = PP + 1, TILE4 = 4 * HP;      // [term 2][half 2][patch pixel]
+    static_assert(TILE4 * 16 >= 32 * 33 * 4, "the hidden tile aliases the operand tile");
+    __shared__ u32x4 W2s[NT2 * 256];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    u32x4 *As = As_all + wave * TILE4;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+
+    const int tx_n = W >> 3, ty_n = H >> 3;
+    // (wave-uniform: a lane-derived tile index costs a waterfall loop around every buffer load)
+    const long long tile_id = (long long)blockIdx.x * 4 + wave_u, ntile_all = (long long)B * ty_n * tx_n;
+    const bool img_ok = tile_id < ntile_all;
+    const long long tq = img_ok ? tile_id : 0;
+    const long long img = tq / (ty_n * tx_n);
+    const int trem = (int)(tq - img * (ty_n * tx_n));
+    const int y0 = (trem / tx_n) * 8, x0 = (trem % tx_n) * 8;
+    const float *img_base = in + (size_t)img * H * W * C;
+    const auto rs = act_rsrc(img_base, img_ok ? (unsigned long long)H * W * C * 4ull : 0ull);
+    unsigned poff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int q = 64 * k + lane;
+        const int iy = y0 - 1 + q / PW, ix = x0 - 1 + q % PW;
+        poff[k] = (q < PP && iy >= 0 && iy < H && ix >= 0 && ix < W) ? (unsigned)((iy * W + ix) * C) * 4u : kOobOffset;
+    }
+    int spx[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int p = 32 * mt + l31;
+        spx[mt] = ((p >> 3) + 1) * PW + (p & 7) + 1;
+    }
+
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    // slice sl = k-step (sl & 1) of 32-channel chunk (sl >> 1): channels 32 chunk + 8 step + [0, 8) (h = 0), + 16 (h = 1)
+    f32x4 raw[2][4];
+    auto load_raw = [&](int sl) {
+        const unsigned co = (unsigned)(32 * (sl >> 1) + 8 * (sl & 1)) * 4u;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {                      // (the slice's offset rides in the scalar offset: no vector instruction)
+            raw[k][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k], co, 0));
+            raw[k][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 16u, co, 0));
+            raw[k][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 64u, co, 0));
+            raw[k][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, poff[k] + 80u, co, 0));
+        }
+    };
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[2]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+    };
+    u32x4 bw[3][2];                                    // three taps' weights: two in flight behind the one in use
+    float xscale, d1;
+    {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl);
+#pragma unroll
+            for (int k = 0; k < 2; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = raw[k][j];
+                    if (relu_in) v = relu4(v);
+                    m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+                }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -kx) * h2_dw(hdr1)[l31];          // this lane's hidden channel: 2^-(kx + kw1[n])
+    }
+    load_raw(0);
+    load_w(0, 0, bw[0]);
+    load_w(1, 0, bw[1]);
+    auto slice = [&](int sl) {
+        {
+            u32x4 t1a[2], t2a[2], t1b[2], t2b[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (relu_in) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) raw[k][j] = relu4(raw[k][j]);
+                }
+                split8_h(raw[k][0], raw[k][1], xscale, t1a[k], t2a[k]);
+                split8_h(raw[k][2], raw[k][3], xscale, t1b[k], t2b[k]);
+            }
+            if (sl + 1 < nslice) load_raw(sl + 1);
+            __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                if (k == 1 && lane >= PP - 64) break;
+                u32x4 *dst = As + 64 * k + lane;
+                dst[0] = t1a[k]; dst[HP] = t1b[k];
+                dst[HP * 2] = t2a[k]; dst[HP * 3] = t2b[k];
+            }
+            lds_order_wave();
+        }
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {            // (nine taps: the ring position of tap 0 is the same for every slice)
+            const int cur = tap % 3, nxt = (tap + 2) % 3;
+            if (tap + 2 < 9) load_w(tap + 2, sl, bw[nxt]);
+            else if (sl + 1 < nslice) load_w(tap + 2 - 9, sl + 1, bw[nxt]);
+            const int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
+            u32x4 S[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const u32x4 *ap = As + h * HP + spx[mt] + shift;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+            }
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+        }
+    };
+#pragma unroll 1
+    for (int sl = 0; sl < nslice; ++sl) slice(sl);
+    __syncthreads();          // W2 image (copied at kernel start) is complete; operand tile no longer read
+
+    float *Hs = reinterpret_cast<float *>(As);
+    u32x4 H1[MT][2], Hb[MT][2];
+    float hscale, d2;
+    {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                acc1[mt][r] = vmax(acc1[mt][r] * d1, 0.0f);
+                m = vmax(m, acc1[mt][r]);
+            }
+        const int kh = wave_scale_exp(m);
+        hscale = __builtin_ldexpf(1.0f, kh);
+        d2 = __builtin_ldexpf(1.0f, -kh);
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[prow * 33 + l31] = acc1[mt][r];
+        }
+        lds_order_wave();
+        float a2[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+        split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+        split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    float omax = 0.0f;
+    if (img_ok) {
+        // Per 32-channel tile: the 1x1 GEMM, then per pixel tile the skip and the output rows -- a scalar row base + this
+        // lane's constant offset, packed multiplies, single-instruction max: whatever a wave issues here waits behind the
+        // other waves' MFMAs.  The skip values of the NEXT (channel tile, pixel tile) step are requested a step ahead.  One
+        // straight-line copy per ReLU flag pair (branches inside would cut it into blocks with a full wait at every join).
+        const unsigned olane = (unsigned)((lane >> 3) * C + 4 * (lane & 7)) * 4u;
+        auto urow0 = [&](int step) { return ((size_t)(y0 + 4 * (step & 1)) * W + x0) * C + (step >> 1) * 32; };     // wave-uniform
+        auto skip_load = [&](int step, f32x4(&u)[4]) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                u[k] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(img_base + urow0(step) + (size_t)k * W * C) + olane);
+        };
+        auto finish = [&](auto RI, auto RO) {
+            constexpr bool ri = decltype(RI)::value, ro = decltype(RO)::value;
+            f32x4 u[2][4];
+            skip_load(0, u[0]);
+#pragma unroll 1
+            for (int nt = 0; nt < NT2; ++nt) {
+                f32x16 acc2[MT];
+#pragma unroll
+                for (int m2 = 0; m2 < MT; ++m2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[m2][r] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+                    prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int step = 2 * nt + mt;
+                    if (step + 1 < 2 * NT2) skip_load(step + 1, u[mt ^ 1]);
+                    const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];                // 2^-(kh + kw2[n]) of this lane's channel
+                    const f32x2v dd = {d2n, d2n};
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2v v = f32x2v{acc2[mt][r], acc2[mt][r + 1]} * dd;
+                        Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v.x;
+                        Hs[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v.y;
+                    }
+                    lds_order_wave();
+                    float *orow0 = out + (size_t)img * H * W * C + urow0(step);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f32x4 q = *reinterpret_cast<const f32x4 *>(Hs + k * 256 + lane * 4);
+                        f32x4 uu = u[mt][k];
+                        if (ri) uu = relu4(uu);
+                        f32x4 yv = uu + q;
+                        if (ro) yv = relu4(yv);
+                        vmax3_abs(omax, yv.x, yv.y);
+                        vmax3_abs(omax, yv.z, yv.w);
+                        *reinterpret_cast<f32x4 *>(reinterpret_cast<char *>(orow0 + (size_t)k * W * C) + olane) = yv;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        };
+        if (relu_in && relu_out) finish(std::true_type{}, std::true_type{});
+        else if (relu_in) finish(std::true_type{}, std::false_type{});
+        else if (relu_out) finish(std::false_type{}, std::true_type{});
+        else finish(std::false_type{}, std::false_type{});
+    }
+    if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+}
+
+// ---------------------------------------------------------------------------
+// TWO residual layers of a stack in one kernel (models/residual.py:47-51: the layers of a stack share their weights), 8x8
+// maps, two-term fp16 products.  One wave owns one image; the first layer's output never leaves the chip:
+//   layer 1:  as res_tile8_bf3_kernel<., true>, but the skip relu(x) is added in the ACCUMULATOR layout (dword loads, 128
+//             contiguous bytes per pixel row) and y1' = relu(relu(x) + W2 h1) -- the ReLU is the second layer's in-place
+//             one -- stays in 128 registers per lane, Y[m-tile][n-tile][16];
+//   layer 2:  per 32-channel chunk Y goes accumulator layout -> [pixel][channel] through the wave's LDS tile (the hidden
+//             tile's path), is split with the image's scale (maximum taken from the registers) and parked as the 3x3 GEMM's
+//             operands; the skip of the second 1x1 GEMM comes straight from Y.
+// HBM-side traffic per pair of layers: x read twice (reduction + skip), y2 written once -- 3 maps instead of 6.
+// NT3 > 0: a 1x1 conv (C -> 32 NT3 channels, + bias; the encoder's pre-quantisation conv, models/vqvae.py:33) consumes the
+// pair's output straight from the registers: y2 is not stored at all, out3 receives the conv's result.
+template <int NT2, int NT3 = 0>
+__global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__restrict__ in, const u32x4 *__restrict__ w1img,
+                                                              const u32x4 *__restrict__ w2img, float *__restrict__ out,
+                                                              int B, int C, int flags, const int *__restrict__ hdr1,
+                                                              const int *__restrict__ hdr2, const int *__restrict__ in_amax,
+                                                              int *__restrict__ out_amax, const u32x4 *__restrict__ w3img,
+                                                              const int *__restrict__ hdr3, const float *__restrict__ bias3,
+                                                              float *__restrict__ out3) {
+    constexpr int MT = 2, PX = 64, TILE4 = 264, HP = PX + 1;
+    __shared__ u32x4 W2s[NT2 * 256];
+    __shared__ u32x4 As_all[4 * TILE4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    u32x4 *As = As_all + wave * TILE4;
+    float *Hs = reinterpret_cast<float *>(As);
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+    const int cpt = C >> 5, nslice = C >> 4;
+
+    for (int i = tid; i < NT2 * 256; i += 256) W2s[i] = w2img[i];
+    if (lane < 4) As[(lane >> 1) * (HP * 2) + (lane & 1) * HP + PX] = u32x4{0, 0, 0, 0};        // padding pixel
+
+    const long long img = (long long)blockIdx.x * 4 + wave;
+    const bool img_ok = img < B;
+    const float *src = in + (size_t)(img_ok ? img : 0) * PX * C + (size_t)lane * C;   // this lane's pixel row
+    const float w1d = h2_dw(hdr1)[l31];                  // 2^-kw1[n] of this lane's hidden channel
+
+    int spx[MT];
+    unsigned tapok[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        spx[mt] = 32 * mt + l31;
+        const int y = spx[mt] >> 3, x = spx[mt] & 7;
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < 8 && xx >= 0 && xx < 8) m |= 1u << t;
+        }
+        tapok[mt] = m;
+    }
+    const u32x4 *w1v = w1img + h * 32 + l31;
+    auto load_w = [&](int tap, int sl, u32x4(&bw)[2]) {
+        const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
+        bw[0] = p[0]; bw[1] = p[128];
+    };
+    // nine taps of one parked 16-channel slice into acc1; PAR = which weight register set is current at tap 0
+    u32x4 bw[2][2];
+    f32x16 acc1[MT];
+    auto taps = [&](int sl, auto PAR) {
+        constexpr int par = decltype(PAR)::value;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int cur = (tap + par) & 1;
+            if (tap + 1 < 9) load_w(tap + 1, sl, bw[cur ^ 1]);
+            else if (sl + 1 < nslice) load_w(0, sl + 1, bw[cur ^ 1]);
+            const int shift = (tap / 3 - 1) * 8 + (tap % 3 - 1);
+            u32x4 S[MT][2];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int p = ((tapok[mt] >> tap) & 1u) ? spx[mt] + shift : PX;
+                const u32x4 *ap = As + h * HP + p;
+                S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
+            }
+            prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
+        }
+    };
+    // hidden tile: relu, scale, accumulator layout -> A operands of the 1x1 GEMM; returns that GEMM's accumulator scale
+    u32x4 H1[MT][2], Hb[MT][2];
+    auto hidden = [&](float d1) -> float {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) SCALE_BIAS_RELU2(acc1[mt][r], acc1[mt][r + 1], d1, 0.0f, 0.0f, m);
+        const int kh = wave_scale_exp(m);
+        const float hscale = __builtin_ldexpf(1.0f, kh);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = acc1[mt][r];
+            lds_order_wave();
+            float a2[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) a2[q] = Hs[l31 * 33 + 16 * h + q];
+            split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, hscale, H1[mt][0], Hb[mt][0]);
+            split8_h(f32x4{a2[8], a2[9], a2[10], a2[11]}, f32x4{a2[12], a2[13], a2[14], a2[15]}, hscale, H1[mt][1], Hb[mt][1]);
+            __builtin_amdgcn_wave_barrier();
+        }
+        return __builtin_ldexpf(1.0f, -kh);               // (x the 1x1 rows' 2^-kw2[n] at the use)
+    };
+    auto gemm2 = [&](int nt, f32x16(&acc2)[MT]) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[mt][r] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4 *bp = W2s + nt * 256 + (t * 2 + h) * 32 + l31;
+            prod3x2(H1[0][t], Hb[0][t], H1[1][t], Hb[1][t], bp[0], bp[128], acc2[0], acc2[1]);
+        }
+    };
+
+    // =========================================== layer 1 ===========================================
+    auto load_raw = [&](int sl, f32x4(&r)[4]) {
+        const float *q = src + 32 * (sl >> 1) + 8 * (sl & 1);
+        r[0] = *reinterpret_cast<const f32x4 *>(q);
+        r[1] = *reinterpret_cast<const f32x4 *>(q + 4);
+        r[2] = *reinterpret_cast<const f32x4 *>(q + 16);
+        r[3] = *reinterpret_cast<const f32x4 *>(q + 20);
+    };
+    f32x4 raw[4];
+    float xscale, d1;
+    {
+        float m = 0.0f;
+        const int given = (in_amax && img_ok) ? in_amax[img] : -1;
+        if (given >= 0) m = __int_as_float(given);
+        else for (int sl = 0; sl < nslice; ++sl) {
+            load_raw(sl, raw);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = raw[j];
+                if (relu_in) v = relu4(v);
+                m = fmaxf(m, fmaxf(fmaxf(__builtin_fabsf(v.x), __builtin_fabsf(v.y)), fmaxf(__builtin_fabsf(v.z), __builtin_fabsf(v.w))));
+            }
+        }
+        const int kx = wave_scale_exp(img_ok ? m : 0.0f);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -kx) * w1d;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+    load_raw(0, raw);
+    load_w(0, 0, bw[0]);
+    auto slice1 = [&](int sl, auto PAR) {
+        if (relu_in) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) raw[j] = relu4(raw[j]);
+        }
+        u32x4 t1a, t2a, t1b, t2b;
+        split8_h(raw[0], raw[1], xscale, t1a, t2a);
+        split8_h(raw[2], raw[3], xscale, t1b, t2b);
+        if (sl + 1 < nslice) load_raw(sl + 1, raw);
+        __builtin_amdgcn_wave_barrier();                  // all taps of the previous slice have been read
+        u32x4 *dst = As + lane;
+        dst[0] = t1a; dst[HP] = t1b;
+        dst[HP * 2] = t2a; dst[HP * 3] = t2b;
+        lds_order_wave();
+        taps(sl, PAR);
+    };
+    for (int sl = 0; sl < nslice; sl += 2) {
+        slice1(sl, std::integral_constant<int, 0>{});
+        slice1(sl + 1, std::integral_constant<int, 1>{});
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+    float Y[MT][NT2][16];
+    {
+        const float d2 = hidden(d1);
+        const float *xb = in + (size_t)(img_ok ? img : 0) * PX * C;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16 acc2[MT];
+            // the skip values in accumulator layout: element r of m-tile mt = pixel 32 mt + (r&3) + 8 (r>>2) + 4 h, channel
+            // 32 nt + l31 (the first m-tile's are requested before the GEMM, the second's behind it: 16 live registers)
+            float u[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) u[r] = xb[(size_t)((r & 3) + 8 * (r >> 2) + 4 * h) * C + nt * 32 + l31];
+            gemm2(nt, acc2);
+            const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];            // 2^-(kh + kw2[n]) of this lane's channel
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float u0 = relu_in ? fmaxf(u[r], 0.0f) : u[r];
+                    Y[mt][nt][r] = fmaxf(u0 + acc2[mt][r] * d2n, 0.0f);      // + the second layer's in-place ReLU
+                }
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) u[r] = xb[(size_t)(32 * (mt + 1) + (r & 3) + 8 * (r >> 2) + 4 * h) * C + nt * 32 + l31];
+                }
+            }
+        }
+    }
+
+    // =========================================== layer 2 ===========================================
+    {
+        float m = 0.0f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, Y[mt][nt][r]);
+        const int kx = wave_scale_exp(m);
+        xscale = __builtin_ldexpf(1.0f, kx);
+        d1 = __builtin_ldexpf(1.0f, -kx) * w1d;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+    load_w(0, 0, bw[0]);
+#pragma unroll
+    for (int c = 0; c < NT2; ++c) {
+        // chunk c of Y: accumulator layout -> lane (pixel l31 of tile mt, half h) holds channels 32 c + 16 h + [0, 16); the
+        // transposition runs once per 16-channel slice (eight of the sixteen values each time: LDS traffic is cheaper
+        // than sixteen more live registers next to Y)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            u32x4 t1[MT], t2[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                __builtin_amdgcn_wave_barrier();          // the previous slice's taps / the previous tile's reads are behind us
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                lds_order_wave();
+                float a2[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xscale, t1[mt], t2[mt]);
+            }
+            __builtin_amdgcn_wave_barrier();              // scratch reads are done
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                As[(0 * 2 + h) * HP + 32 * mt + l31] = t1[mt];
+                As[(1 * 2 + h) * HP + 32 * mt + l31] = t2[mt];
+            }
+            if (lane < 4) As[lane * HP + PX] = u32x4{0, 0, 0, 0};      // the padding pixel was under the transposition scratch
+            lds_order_wave();
+            if (s2 == 0) taps(2 * c, std::integral_constant<int, 0>{});
+            else taps(2 * c + 1, std::integral_constant<int, 1>{});
+        }
+    }
+    {
+        const float d2 = hidden(d1);
+        const long long wbase = img * PX;
+        float omax = 0.0f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            f32x16 acc2[MT];
+            gemm2(nt, acc2);
+            const float d2n = d2 * h2_dw(hdr2)[nt * 32 + l31];
+            if (img_ok) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        v[r] = Y[mt][nt][r] + acc2[mt][r] * d2n;
+                        if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                        omax = fmaxf(omax, __builtin_fabsf(v[r]));
+                    }
+                    if constexpr (NT3 > 0) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Y[mt][nt][r] = v[r];       // stays on chip for the 1x1 conv below
+                    } else {
+                        tile_epilogue(Hs, v, lane, nt * 32, [&](int p, int n, f32x4 a4, int) {
+                            *reinterpret_cast<f32x4 *>(out + (wbase + mt * 32 + p) * C + n) = a4;
+                        });
+                    }
+                }
+            }
+        }
+        if (out_amax && img_ok) publish_amax(out_amax, img, omax, lane);
+
+        if constexpr (NT3 > 0) {
+            // ================================ 1x1 conv on y2 (same operand order as conv_tile8_bf3_kernel) ================
+            const int kx3 = wave_scale_exp(img_ok ? omax : 0.0f);
+            const float xs3 = __builtin_ldexpf(1.0f, kx3), d3 = __builtin_ldexpf(1.0f, -kx3);
+            f32x16 acc3[MT][NT3];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int n3 = 0; n3 < NT3; ++n3)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc3[mt][n3][r] = 0.0f;
+            const u32x4 *w3v = w3img + h * 32 + l31;
+#pragma unroll
+            for (int c = 0; c < NT2; ++c) {
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 t1[MT], t2[MT];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) Hs[((r & 3) + 8 * (r >> 2) + 4 * h) * 33 + l31] = Y[mt][c][r];
+                        lds_order_wave();
+                        float a2[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) a2[q] = Hs[l31 * 33 + 16 * h + 8 * s2 + q];
+                        split8_h(f32x4{a2[0], a2[1], a2[2], a2[3]}, f32x4{a2[4], a2[5], a2[6], a2[7]}, xs3, t1[mt], t2[mt]);
+                    }
+                    // lane (pixel l31 of tile mt, half h) holds the A operands of ITS pixel row: exactly the MFMA A layout
+#pragma unroll
+                    for (int n3 = 0; n3 < NT3; ++n3) {
+                        const u32x4 *bp = w3v + (size_t)(c * NT3 + n3) * 256 + s2 * 64;
+                        prod3x2(t1[0], t2[0], t1[1], t2[1], bp[0], bp[128], acc3[0][n3], acc3[1][n3]);
+                    }
+                }
+            }
+            if (img_ok) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int n3 = 0; n3 < NT3; ++n3) {
+                        const float bv = bias3 ? bias3[n3 * 32 + l31] : 0.0f, d3n = d3 * h2_dw(hdr3)[n3 * 32 + l31];
+                        float v[16];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = acc3[mt][n3][r] * d3n + bv;
+                        __builtin_amdgcn_wave_barrier();
+                        tile_epilogue(Hs, v, lane, n3 * 32, [&](int p, int n, f32x4 a4, int) {
+                            *reinterpret_cast<f32x4 *>(out3 + (wbase + mt * 32 + p) * (32 * NT3) + n) = a4;
+                        });
+                    }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Fused residual layer (models/residual.py:18-29):
+//     y = [relu](u) + W2 (*) relu(W1 (*) [relu](u)),  then optional relu(y)
+// W1: 3x3 pad 1, C -> Rh (<= 32), no bias;  W2: 1x1, Rh -> C = 32*NT2, no bias.
+// The hidden 32-channel tile goes accumulator -> LDS -> A operand inside the wave.
+template <int NT2>
+__global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restrict__ in,
+                                                        const float *__restrict__ w1img,
+                                                        const float *__restrict__ w2img,
+                                                        float *__restrict__ out, int B, int H, int W,
+                                                        int C, int flags) {
+    constexpr int MT = 2;
+    // LDS: W2 image (shared, read-only after the first barrier) | per-wave hidden tiles
+    __shared__ __attribute__((aligned(16))) float smem_res[NT2 * 1024 + 4 * MT * 32 * 33];
+    float *W2s = smem_res;
+    float(*Hs)[MT][32 * 33] = reinterpret_cast<float(*)[MT][32 * 33]>(smem_res + NT2 * 1024);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const long long M = (long long)B * H * W;
+    const int cpt = (C + 31) / 32;
+    const int nchunk = 9 * cpt;
+    const bool relu_in = flags & kFlagReluIn, relu_out = flags & kFlagReluOut;
+
+    {
+        const f32x4 *src = reinterpret_cast<const f32x4 *>(w2img);
+        f32x4 *dst = reinterpret_cast<f32x4 *>(W2s);
+#pragma unroll
+        for (int q = 0; q < NT2; ++q) dst[tid + 256 * q] = src[tid + 256 * q];
+    }
+
+    const long long wbase = (long long)blockIdx.x * (128 * MT) + wave * (32 * MT);
+    const long long img_px = (long long)H * W;
+    const long long b_first = ((long long)blockIdx.x * (128 * MT)) / img_px;
+    const auto in_rs = act_rsrc(in + (size_t)b_first * H * W * C, (unsigned long long)(B - b_first) * H * W * C * 4ull);
+    unsigned pbase[MT], tapmask[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const long long p = wbase + mt * 32 + l31;
+        const bool valid = p < M;
+        const long long pc = valid ? p : 0;
+        const long long b = pc / img_px;
+        const int rem = (int)(pc - b * img_px);
+        const int gy = rem / W, gx = rem - gy * W;
+        pbase[mt] = (unsigned)((((b - b_first) * H + gy) * W + gx) * C * 4 + 64 * h);
+        unsigned m = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int iy = gy + t / 3 - 1, ix = gx + t % 3 - 1;
+            if (valid && iy >= 0 && iy < H && ix >= 0 && ix < W) m |= 1u << t;
+        }
+        tapmask[mt] = m;
+    }
+
+    // GEMM1 (3x3, C -> 32 hidden): barrier-free.  With a single 32-wide n-tile the weight chunk a
+    // wave needs per step is only 4 KiB, so every wave reads its B operands straight from L1/L2
+    // (coalesced float4, same image layout) next to its A operands: no LDS staging, no workgroup
+    // barrier in the reduction loop, and the waves of a SIMD drift apart instead of stalling together.
+    constexpr int KC = 2;
+    f32x4 a[KC][MT][4], bq[KC][4];
+    f32x16 acc1[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc1[mt][r] = 0.0f;
+
+    const bool ragged_c = (C & 31) != 0;
+    const f32x4 *w1v = reinterpret_cast<const f32x4 *>(w1img) + h * 32 + l31;     // + (chunk*4 + j)*64
+    auto load_ab = [&](int c, f32x4(&dst)[MT][4], f32x4(&bd)[4]) {
+        const int tap = c / cpt, cc = c - tap * cpt;
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const int tapbytes = (dy * W + dx) * C * 4;                   // scalar
+        const unsigned soff = (unsigned)cc * 128u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bd[j] = w1v[(size_t)(c * 4 + j) * 64];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const unsigned vo = ((tapmask[mt] >> tap) & 1u) ? pbase[mt] + (unsigned)tapbytes : kOobOffset;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                dst[mt][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(in_rs, vo + 16 * j, soff, 0));
+        }
+    };
+    const bool needs_fix = relu_in || ragged_c;
+    auto fix_a = [&](int c, f32x4(&dst)[MT][4]) {
+        const int cc = c % cpt;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f32x4 v = dst[mt][j];
+                if (cc * 32 + 16 * h + 4 * j >= C) v = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+                dst[mt][j] = relu_in ? relu4(v) : v;
+            }
+    };
+
+#pragma unroll
+    for (int k = 0; k < KC; ++k)
+        if (k < nchunk) load_ab(k, a[k], bq[k]);
+    for (int c0 = 0; c0 < nchunk; c0 += KC) {
+#pragma unroll
+        for (int k = 0; k < KC; ++k) {
+            if (c0 + k < nchunk) {
+                if (needs_fix) fix_a(c0 + k, a[k]);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[k][mt][j][i], bq[k][j][i], acc1[mt], 0, 0, 0);
+                if (c0 + k + KC < nchunk) load_ab(c0 + k + KC, a[k], bq[k]);
+            }
+        }
+    }
+    __syncthreads();          // W2 image (copied at kernel start) is complete
+
+    // hidden tile: relu, accumulator layout -> [pixel][hidden] in LDS (stride 33: conflict-free)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
+            Hs[wave][mt][prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+        }
+    lds_order_wave();
+    float a2[MT][16];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int s = 0; s < 16; ++s) a2[mt][s] = Hs[wave][mt][l31 * 33 + 16 * h + s];
+
+    // second GEMM in groups of <= 2 n-tiles so the accumulators stay at 64 registers
+    constexpr int NG = NT2 < 2 ? NT2 : 2;
+    const f32x4 *ws = reinterpret_cast<const f32x4 *>(W2s);
+#pragma unroll
+    for (int n0 = 0; n0 < NT2; n0 += NG) {
+        f32x16 acc2[MT][NG];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NG; ++nt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc2[mt][nt][r] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f32x4 b4[NG];
+#pragma unroll
+            for (int nt = 0; nt < NG; ++nt) b4[nt] = ws[(((n0 + nt) * 4 + j) * 2 + h) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NG; ++nt)
+                        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[mt][4 * j + i], b4[nt][i],
+                                                                            acc2[mt][nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long prow = wbase + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (prow < M) {
+#pragma unroll
+                    for (int nt = 0; nt < NG; ++nt) {
+                        const int n = (n0 + nt) * 32 + l31;
+                        if (n < C) {
+                            float u = in[prow * C + n];
+                            if (relu_in) u = fmaxf(u, 0.0f);
+                            float v = u + acc2[mt][nt][r];
+                            if (relu_out) v = fmaxf(v, 0.0f);
+                            out[prow * C + n] = v;
+                        }
+                    }
+                }
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The skip connection of a residual layer whose width the fused kernels do not cover (round 4: C not in {32, 64, 128} or
+// more than 32 hidden channels -- main.py's --n_hiddens / --n_residual_hiddens are free parameters): y = r(x) + t, r = ReLU if
+// relu_in (the in-place nn.ReLU(True) of residual.py:19 also rewrites the skip), then ReLU if relu_out.  t may alias y.
+__global__ __launch_bounds__(256) void res_combine_kernel(const float *__restrict__ x, const float *t, float *y, long long n4,
+                                                          int relu_in, int relu_out) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 a = reinterpret_cast<const f32x4 *>(x)[i];
+        const f32x4 b = reinterpret_cast<const f32x4 *>(t)[i];
+        if (relu_in) a = relu4(a);
+        f32x4 o = a + b;
+        if (relu_out) o = relu4(o);
+        reinterpret_cast<f32x4 *>(y)[i] = o;
+    }
+}
+
+}  // namespace vqvae
+
+using namespace vqvae;
+
+extern "C" {
+
+int vqvae_res_layer_forward_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B,
+                                int H, int W, int C, int Rh, int flags, float *y, vqvae_stream_t stream) {
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr);
+}
+
+int vqvae_res_layer_forward_ws_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
+                                   int Rh, int flags, float *y, float *scratch, size_t scratch_bytes, vqvae_stream_t stream) {
+    if (!vqvae::res_layer_fused_ok(C, Rh) && (!scratch || scratch_bytes < (size_t)B * H * W * Rh * sizeof(float))) return VQVAE_ERR_WORKSPACE;
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr,
+                                         nullptr, scratch);
+}
+
+int vqvae_res_layer_forward_hidden_f32(const float *x, const float *packed_w1, const float *packed_w2, int64_t B,
+                                       int H, int W, int C, int Rh, int flags, float *y, float *hidden,
+                                       vqvae_stream_t stream) {
+    if (!hidden) return VQVAE_ERR_NULL;
+    return vqvae::res_layer_forward_impl(x, packed_w1, packed_w2, B, H, W, C, Rh, flags, y, static_cast<hipStream_t>(stream), nullptr, nullptr, hidden);
+}
+}  // extern "C"
+
+bool vqvae::res_layer_fused_ok(int C, int Rh) { return Rh >= 1 && Rh <= 32 && (C == 32 || C == 64 || C == 128); }
+
+int vqvae::res_layer_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
+                                  int C, int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,
+                                  float *hidden, float *hid_scratch) {
+    if (!x || !packed_w1 || !packed_w2 || !y) return VQVAE_ERR_NULL;
+    // the hidden activation is written by the kernels that own whole 8x8 images only (full 32-wide hidden tile)
+    if (hidden && (H != 8 || W != 8 || Rh != 32 || (flags & VQVAE_CONV_EXACT_FP32) || (reinterpret_cast<uintptr_t>(hidden) & 15)))
+        return VQVAE_ERR_UNSUPPORTED;
+    if (B < 1 || H < 1 || W < 1 || C < 1 || Rh < 1) return VQVAE_ERR_SHAPE;
+    if (!res_layer_fused_ok(C, Rh)) {
+        // widths outside the fused kernels: 3x3 conv -> 1x1 conv through the conv kernels + one combine pass; the hidden map
+        // goes through the caller's scratch (vqvae_res_layer_forward_ws_f32 / the whole-path workspace)
+        if (C % 4 || Rh % 4 || !hid_scratch || hidden) return VQVAE_ERR_UNSUPPORTED;
+        if (x == y) return VQVAE_ERR_UNSUPPORTED;
+        const int cf = flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32);
+        int rc = conv_forward_impl(VQVAE_CONV_3x3_S1, x, packed_w1, nullptr, B, H, W, C, Rh,
+                                   (flags & VQVAE_CONV_RELU_IN) | VQVAE_CONV_RELU_OUT | cf, hid_scratch, stream, nullptr, nullptr);
+        if (rc != 0) return rc;
+        if ((rc = conv_forward_impl(VQVAE_CONV_1x1, hid_scratch, packed_w2, nullptr, B, H, W, Rh, C, cf, y, stream, nullptr, nullptr)) != 0) return rc;
+        const long long n4 = (long long)B * H * W * C / 4;
+        long long grid = (n4 + 255) / 256;
+        if (grid > 8192) grid = 8192;
+        hipLaunchKernelGGL(res_combine_kernel, dim3((unsigned)grid), dim3(256), 0, stream, x, y, y, n4,
+                           (flags & VQVAE_CONV_RELU_IN) ? 1 : 0, (flags & VQVAE_CONV_RELU_OUT) ? 1 : 0);
+        return (int)hipGetLastError();
+    }
+    if (x == y) return VQVAE_ERR_UNSUPPORTED;           // 3x3 halo: not in place
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) return VQVAE_ERR_UNSUPPORTED;   // 16-byte accesses
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long long M = (long long)B * H * W;
+    const unsigned gx = (unsigned)((M + 255) / 256);
+    prof_begin(VQVAE_PROF_RES_LAYER, st);
+    if (!(flags & VQVAE_CONV_EXACT_FP32)) {
+        // split-bf16 images sit behind the fp32 ones in each packed buffer
+        const int cpt = (C + 31) / 32;
+        const u32x4 *w1b = reinterpret_cast<const u32x4 *>(packed_w1 + (size_t)9 * cpt * 1024);          // 3x3, C -> Rh
+        const u32x4 *w2b = reinterpret_cast<const u32x4 *>(packed_w2 + (size_t)((C + 31) / 32) * 1024);   // 1x1, Rh -> C
+        if (H == 8 && W == 8) {
+            // whole 8x8 images per wave: operands split once and kept in LDS for all nine taps
+            const unsigned gt = (unsigned)((B + 3) / 4);
+            if (!(flags & VQVAE_CONV_BF16_SPLIT)) {
+                // two-term fp16 images: [header {kw}][image] behind the bf16 ones (vqvae_conv_pack_f32)
+                const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+                const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+                const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes((C + 31) / 32));
+                const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+                switch (C / 32) {
+                    case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
+                    case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
+                    case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4, true>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, hidden); break;
+                }
+            } else switch (C / 32) {
+                case 1: hipLaunchKernelGGL((res_tile8_bf3_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
+                case 2: hipLaunchKernelGGL((res_tile8_bf3_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
+                case 4: hipLaunchKernelGGL((res_tile8_bf3_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1b, w2b, y, (int)B, C, flags, nullptr, nullptr, nullptr, out_amax, hidden); break;
+            }
+        } else if (in_amax && !(flags & VQVAE_CONV_BF16_SPLIT) && H % 8 == 0 && W % 8 == 0 && C % 32 == 0 &&
+                   (long long)H * W * C * 4 < 0x7FFFFFF0ll) {
+            // larger maps that are multiples of 8 both ways, inside the whole-path entry points: 8x8 tiles with a halo
+            const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2p + h2_header_bytes((C + 31) / 32));
+            const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
+            const long long tiles = (long long)B * (H / 8) * (W / 8);
+            const unsigned gt = (unsigned)((tiles + 3) / 4);
+            switch (C / 32) {
+                case 1: hipLaunchKernelGGL((res_halo8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
+                case 2: hipLaunchKernelGGL((res_halo8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
+                case 4: hipLaunchKernelGGL((res_halo8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, flags, hd1, hd2, in_amax, out_amax); break;
+            }
+        } else {
+            // generic maps: two-term fp16 products when the producing layer handed over the images' maxima
+            const bool h2 = in_amax && !(flags & VQVAE_CONV_BF16_SPLIT);
+            const char *h1p = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const char *h2p = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+            const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1p + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2p + h2_header_bytes((C + 31) / 32));
+            const int *hd1 = reinterpret_cast<const int *>(h1p), *hd2 = reinterpret_cast<const int *>(h2p);
+#define RES_GEN(NT_)                                                                                                             \
+    do {                                                                                                                         \
+        if (h2) hipLaunchKernelGGL((res_layer_bf3_kernel<NT_, true>), dim3(gx), dim3(256), 0, st, x, w1h, w2h, y, (int)B, H, W, C, \
+                                   flags, hd1, hd2, in_amax, out_amax);                                                          \
+        else hipLaunchKernelGGL((res_layer_bf3_kernel<NT_, false>), dim3(gx), dim3(256), 0, st, x, w1b, w2b, y, (int)B, H, W, C,  \
+                                flags, nullptr, nullptr, nullptr, out_amax);                                                     \
+    } while (0)
+            switch (C / 32) {
+            case 1: RES_GEN(1); break;
+            case 2: RES_GEN(2); break;
+            case 4: RES_GEN(4); break;
+            }
+#undef RES_GEN
+        }
+    } else {
+        switch (C / 32) {
+            case 1: hipLaunchKernelGGL((res_layer_kernel<1>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+            case 2: hipLaunchKernelGGL((res_layer_kernel<2>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+            case 4: hipLaunchKernelGGL((res_layer_kernel<4>), dim3(gx), dim3(256), 0, st, x, packed_w1, packed_w2, y, (int)B, H, W, C, flags); break;
+        }
+    }
+    prof_end(VQVAE_PROF_RES_LAYER, st);
+    return (int)hipGetLastError();
+}
+
+// Two layers of a residual stack (shared weights) in one launch: 8x8 maps on the two-term fp16 path only.  x == y is
+// allowed (every wave reads its image completely before it writes it).  Returns VQVAE_ERR_UNSUPPORTED when the caller
+// has to run the two layers separately.
+bool vqvae::res_pair_supported(int H, int W, int C, int Rh, int flags) {
+    return H == 8 && W == 8 && Rh >= 1 && Rh <= 32 && (C == 32 || C == 64 || C == 128) &&
+           !(flags & (VQVAE_CONV_BF16_SPLIT | VQVAE_CONV_EXACT_FP32));
+}
+
+// post (optional): a 1x1 conv (+ bias) applied to the pair's output inside the same kernel; y is then not written.
+bool vqvae::res_pair_post_supported(int C, int Cout) { return C == 128 && (Cout == 32 || Cout == 64 || Cout == 128); }
+
+int vqvae::res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W,
+                                 int C, int Rh, int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax,
+                                 const ResPairPost *post) {
+    if (!x || !packed_w1 || !packed_w2 || (!y && !post)) return VQVAE_ERR_NULL;
+    if (B < 1 || !res_pair_supported(H, W, C, Rh, flags)) return VQVAE_ERR_UNSUPPORTED;
+    if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(post ? post->out : nullptr)) & 15) return VQVAE_ERR_UNSUPPORTED;
+    const int cpt = (C + 31) / 32;
+    const char *h1 = reinterpret_cast<const char *>(packed_w1) + (size_t)9 * cpt * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const char *h2 = reinterpret_cast<const char *>(packed_w2) + (size_t)((C + 31) / 32) * (1024 * sizeof(float) + 3072 * sizeof(unsigned short));
+    const u32x4 *w1h = reinterpret_cast<const u32x4 *>(h1 + h2_header_bytes(1)), *w2h = reinterpret_cast<const u32x4 *>(h2 + h2_header_bytes((C + 31) / 32));
+    const int *hd1 = reinterpret_cast<const int *>(h1), *hd2 = reinterpret_cast<const int *>(h2);
+    const unsigned gt = (unsigned)((B + 3) / 4);
+    // the checks that can refuse come BEFORE prof_begin: an early return behind it would leave an unmatched begin event
+    ConvGeom g3;
+    if (post && (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout) ||
+                 make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK)) return VQVAE_ERR_UNSUPPORTED;
+    prof_begin(VQVAE_PROF_RES_LAYER, st);
+    if (post) {
+        const char *h3 = reinterpret_cast<const char *>(post->packed) + packed_h2_offset(g3, VQVAE_CONV_1x1);
+        const u32x4 *w3h = reinterpret_cast<const u32x4 *>(h3 + h2_header_bytes(g3.ntile));
+        const int *hd3 = reinterpret_cast<const int *>(h3);
+#define PAIR_POST(NT3_)                                                                                                         \
+    hipLaunchKernelGGL((res_pair8_h2_kernel<4, NT3_>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2,  \
+                       in_amax, out_amax, w3h, hd3, post->bias, post->out)
+        switch (post->Cout / 32) {
+            case 1: PAIR_POST(1); break;
+            case 2: PAIR_POST(2); break;
+            case 4: PAIR_POST(4); break;
+        }
+#undef PAIR_POST
+    } else switch (C / 32) {
+        case 1: hipLaunchKernelGGL((res_pair8_h2_kernel<1>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+        case 2: hipLaunchKernelGGL((res_pair8_h2_kernel<2>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+        case 4: hipLaunchKernelGGL((res_pair8_h2_kernel<4>), dim3(gt), dim3(256), 0, st, x, w1h, w2h, y, (int)B, C, flags, hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr); break;
+    }
+    prof_end(VQVAE_PROF_RES_LAYER, st);
+    return (int)hipGetLastError();
+}

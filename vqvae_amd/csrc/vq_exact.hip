@@ -581,7 +581,7 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
 }
 }  // extern "C"
 
-// ---- the quantizer inside the encoder's last kernel (conv.hip): what vqvae_forward_f32 does around that launch ---------
+// ---- the quantizer inside the encoder's last kernel (conv_fused.hip): what vqvae_forward_f32 does around that launch ---------
 bool vqvae::vq_fuse_ok(int K, int D, int64_t B, int flags) {
     const VqPlan p = vq_plan(K > 0 ? K : 1, 64);
     (void)B;

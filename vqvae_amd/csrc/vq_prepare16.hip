@@ -1,5 +1,5 @@
 // Second stage of the codebook preparation for the fp16-screened VectorQuantizer kernels (vq_track.hip: image resident in LDS;
-// vq_chunk.hip: image streamed through LDS; conv.hip: the quantizer inside the encoder's last kernel) -- and the derivation of
+// vq_chunk.hip: image streamed through LDS; conv_fused.hip: the quantizer inside the encoder's last kernel) -- and the derivation of
 // the screen's bound they share.  (Round 2's own single-sweep kernel with index-carrying top-3 keys, vq_sweep_kernel_d64, lived
 // here; round 4 removed it together with its flags VQVAE_VQ_TOP3_KEYS / VQVAE_VQ_SIXTEEN_WAVES: it was reachable only through
 // those A/B flags, and the heterogeneous-channel tests of round 4 found a row it got wrong.)
@@ -63,7 +63,7 @@ __global__ __launch_bounds__(64) void vq_prepare16_kernel(const float *__restric
         unsigned short *dst = img + ((size_t)(ct * (D / 8) + c8) * 32 + i) * 8;
         for (int j = 0; j < 8; ++j) dst[j] = v[j];
         if (imgf) {
-            // the fused conv kernels' channel order (conv.hip, acc_to_ksteps): k-step 2 n3 + t, half h holds channels
+            // the fused conv kernels' channel order (conv_device.h, acc_to_ksteps): k-step 2 n3 + t, half h holds channels
             // 32 n3 + 16 h + 8 t + [0, 8) -- chunk c8 = 4 n3 + 2 h + t moves to position 4 n3 + 2 t + h
             const int c8f = (c8 & ~3) | ((c8 & 1) << 1) | ((c8 >> 1) & 1);
             unsigned short *dstf = imgf + ((size_t)(ct * (D / 8) + c8f) * 32 + i) * 8;

@@ -1,6 +1,6 @@
 // What a wave does with ONE unit of the stream-tracker quantizer (64 rows = two 32-row tiles) once the sweep has filled its
 // trackers -- shared by the standalone kernel (vq_track.hip: codebook image resident in LDS, rows in registers in the load
-// layout) and by the encoder's last kernel (conv.hip, conv_res_pair8_h2_kernel<2, true>: z_e straight from the 1x1 conv's
+// layout) and by the encoder's last kernel (conv_fused.hip, conv_res_pair8_h2_kernel<2, true>: z_e straight from the 1x1 conv's
 // accumulators, codebook image streamed through the weight stages, rows parked in LDS).  The pieces:
 //     classify     threshold per row, merge of the two lane halves, verdict; open rows' exact tasks into the task table
 //     exact_begin  flagged rows (open / hard / non-finite), their table entries; hard rows are then screened again by the
