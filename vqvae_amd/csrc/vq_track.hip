@@ -462,11 +462,18 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     auto launch = [&](auto kfn) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         hipEvent_t e0, e1;
-        prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1);
-        hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, e0, e1, 0, z, cb,
-                           reinterpret_cast<const uint4 *>(ws + p.off_imgh), reinterpret_cast<const float *>(ws + p.off_seeds),
-                           reinterpret_cast<const float *>(ws + p.off_ee), reinterpret_cast<const int *>(ws + p.off_flags), N, K,
-                           p.K32, nunits, zq, idx, hist, reinterpret_cast<double *>(ws + p.off_partials), HW);
+        const uint4 *imgh = reinterpret_cast<const uint4 *>(ws + p.off_imgh);
+        const float *seeds = reinterpret_cast<const float *>(ws + p.off_seeds), *ee = reinterpret_cast<const float *>(ws + p.off_ee);
+        const int *wflags = reinterpret_cast<const int *>(ws + p.off_flags);
+        double *partials = reinterpret_cast<double *>(ws + p.off_partials);
+        // the extended launch only while profiling (it carries the dispatch's start / stop events); the plain one otherwise --
+        // that is the form a stream capture (vqvae_amd/graph.py) records
+        if (prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1))
+            hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, e0, e1, 0, z, cb, imgh, seeds, ee,
+                                  wflags, N, K, p.K32, nunits, zq, idx, hist, partials, HW);
+        else
+            hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, z, cb, imgh, seeds, ee, wflags, N, K,
+                               p.K32, nunits, zq, idx, hist, partials, HW);
     };
     if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
     else if (wide) launch(vq_track_kernel_d64<16, false, 1>);
