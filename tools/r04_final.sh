@@ -10,4 +10,4 @@ cat gpurun_out/r04_smoke.txt
 bash tools/r04_profile.sh
 cp gpurun_out/r04_pytest_full.txt gpurun_out/r04_smoke.txt gpurun_out/r04/
 VQ_ROWS_LIST="262144 2097152" bash tools/r03_vq_pmc.sh r04_vq_pmc > /dev/null 2>&1; cat gpurun_out/r04_vq_pmc/summary.txt | cut -c1-400
-bash tools/r04_run9.sh > /dev/null 2>&1; head -30 gpurun_out/r04t/train_kernel_stats.txt | cut -c1-150
+bash tools/r04_train_profile.sh > /dev/null 2>&1; head -30 gpurun_out/r04t/train_kernel_stats.txt | cut -c1-150

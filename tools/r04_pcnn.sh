@@ -9,7 +9,7 @@ from vqvae_amd.pixelcnn import GatedPixelCNN
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 m = GatedPixelCNN(512, 64, 15, 10).to(dev).eval()
-x = torch.randint(0, 512, (64, 8, 8), device=dev); label = torch.randint(0, 10, (64,), device=dev)
+x = torch.randint(0, 512, (1024, 8, 8), device=dev); label = torch.randint(0, 10, (1024,), device=dev)
 with torch.no_grad():
     for _ in range(8): m(x, label)
 torch.cuda.synchronize()
