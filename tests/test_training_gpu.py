@@ -488,3 +488,44 @@ def test_fused_backward_epilogues_equal_separate_passes_bitwise():
             A.FUSE_EPILOGUES = True
         for k in res[0]:
             assert torch.equal(res[0][k], res[1][k]), (n_res, k)
+
+
+@pytest.mark.parametrize("dims,HW,B", [((64, 16, 1, 64, 32), 16, 6),        # 4x4 latent maps, one residual layer, D = 32
+                                       ((32, 32, 3, 100, 64), 24, 3),       # 6x6 maps, three layers, K not a multiple of 32
+                                       ((256, 64, 2, 512, 64), 32, 4)])     # widths outside the fused residual kernel
+def test_full_model_backward_other_shapes(dims, HW, B):
+    """The autograd path away from main.py's defaults: maps that are not 8x8 (generic conv kernels, per-tap weight-gradient kernel,
+    data-gradient epilogues where the kernel has them and separate passes where it has not), other widths and codebooks --
+    parameter gradients against the reference's ops on the CPU, flip-free batches only."""
+    from oracle import torch_port
+    from vqvae_amd import conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    dev = torch.device("cuda:0")
+    h, rh, nres, K, D = dims
+    torch.manual_seed(11)
+    m = VQVAE(h, rh, nres, K, D, 0.25).train()
+    x = torch.randn(B, 3, HW, HW)
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    for i in range(1, nres):                                   # the stack's layers share storage upstream
+        for side in ("encoder.conv_stack.5.stack.", "decoder.inverse_conv_stack.1.stack."):
+            for k in list(sd):
+                if k.startswith(f"{side}{i}."):
+                    sd[k] = sd[f"{side}0." + k[len(f"{side}{i}."):]]
+    z_e = torch_port.encode(sd, x.clone(), nres)
+    loss_e, z_q, _, _, idx_ref = torch_port.quantize_train(z_e, sd["vector_quantization.embedding.weight"], 0.25)
+    x_hat = torch_port.decode(sd, z_q, nres)
+    loss_ref = torch.mean((x_hat - x) ** 2) / 0.06 + loss_e
+    loss_ref.backward()
+    md = m.to(dev)
+    embedding_loss, x_hat_d, _ = md(x.to(dev))
+    loss = torch.mean((x_hat_d - x.to(dev)) ** 2) / 0.06 + embedding_loss
+    loss.backward()
+    idx_d = md.encode(x.to(dev)).cpu().view(-1)
+    if not torch.equal(idx_d, idx_ref.view(-1)):
+        pytest.skip("an index flip on this batch: the decoder sides differ by construction")
+    np.testing.assert_allclose(loss.item(), loss_ref.item(), rtol=1e-5)
+    for name, p in md.named_parameters():
+        ref = sd[name].grad
+        assert ref is not None and p.grad is not None, name
+        _close_grad(p.grad, ref, name)
