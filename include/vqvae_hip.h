@@ -368,6 +368,11 @@ VQVAE_API int vqvae_conv_taps_pack_f32(const float *w, int ntaps, const int8_t *
 VQVAE_API int vqvae_conv_taps_forward_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
                                           int Cin, int Cout, int ntaps, const int8_t *dy, const int8_t *dx, int flags,
                                           float *y, vqvae_stream_t stream);
+/* the same with vqvae_conv_forward_ep_f32's epilogue, y = (mask > 0) ? conv + addend : 0: a tap list longer than 16 runs as a chain of
+ * launches over slices of it, each adding to the previous one's result (the first GatedMaskedConv2d's 4 x 7 vertical stack)      */
+VQVAE_API int vqvae_conv_taps_forward_ep_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W,
+                                             int Cin, int Cout, int ntaps, const int8_t *dy, const int8_t *dx, int flags,
+                                             const float *addend, const float *mask, float *y, vqvae_stream_t stream);
 VQVAE_API int vqvae_gated_activation_f32(const float *t1, const float *t2, const float *cond, int64_t B,
                                          int HW, int dim, float *out, vqvae_stream_t stream);
 VQVAE_API int vqvae_add_f32(const float *a, const float *b, int64_t n, float *out, vqvae_stream_t stream);

@@ -125,6 +125,8 @@ def test_hip_layer_boundary_and_generate():
     (3, 8, 8, 32, 64, [(0, kx - 3) for kx in range(4)]),                                # horizontal stack, k = 7
     (2, 6, 6, 32, 64, [(ky - 1, kx - 1) for ky in range(2) for kx in range(3)]),       # a map the generic kernel takes
     (2, 5, 7, 16, 24, [(-2, 3), (0, 0), (1, -1)]),                                      # an arbitrary list, odd shapes
+    (3, 8, 8, 64, 128, [(ky - 3, kx - 3) for ky in range(4) for kx in range(7)]),      # the first layer's 4 x 7 stack: two slices of 14
+    (2, 6, 6, 32, 64, [(ky - 3, kx - 3) for ky in range(4) for kx in range(7)]),
 ])
 def test_tap_list_conv_vs_shifted_sum(B, H, W, Cin, Cout, taps):
     """vqvae_conv_taps_forward_f32 against the defining sum y[b,y,x,:] = b + sum_t W[:, :, t] x[b, y + dy_t, x + dx_t, :] (zero outside
@@ -134,7 +136,7 @@ def test_tap_list_conv_vs_shifted_sum(B, H, W, Cin, Cout, taps):
     dev = torch.device("cuda:0")
     g = torch.Generator().manual_seed(len(taps) * 100 + Cin)
     n = len(taps)
-    w = torch.randn(Cout, Cin, 1, n, generator=g) * 0.1
+    w = torch.randn(Cout, Cin, 1, n, generator=g) * 0.1           # ((1, n): any (kh, kw) with kh * kw = n is the same memory)
     bias = torch.randn(Cout, generator=g)
     x = torch.randn(B, H, W, Cin, generator=g)
     ref = bias.double().expand(B, H, W, Cout).clone()
@@ -152,3 +154,23 @@ def test_tap_list_conv_vs_shifted_sum(B, H, W, Cin, Cout, taps):
     assert bool(((got - ref).abs() <= lim).all()), float(((got - ref).abs() / lim).max())
     L = __import__("vqvae_amd._lib", fromlist=["load"]).load()
     assert L.vqvae_conv_taps_packed_bytes(17, Cin, Cout) == 0 and L.vqvae_conv_taps_packed_bytes(0, Cin, Cout) == 0
+
+
+@pytest.mark.gpu
+def test_im2col_entry_agrees_with_the_tap_list_conv():
+    """vqvae_im2col_rows_f32 (round 2's path for the masked convs, still part of the C ABI) + the 1x1 GEMM against the tap-list
+    convolution that replaced it: the same sums in a different order."""
+    import torch.nn as nn
+    from vqvae_amd import conv_hip, pixelcnn
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    taps = [(ky - 1, kx - 1) for ky in range(2) for kx in range(3)]
+    B, H, W, Cin, Cout = 4, 8, 8, 64, 128
+    w = (torch.randn(Cout, Cin, 2, 3, generator=g) * 0.1).to(dev)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    cols = pixelcnn._im2col(x, taps)                                             # (B, H, W, 6 * Cin), tap-major
+    w2 = w.permute(0, 2, 3, 1).reshape(Cout, -1, 1, 1).contiguous()
+    a = conv_hip.conv(conv_hip.CONV_1x1, cols, nn.Module(), w2, None, cols.shape[3], Cout, 0)
+    b = conv_hip.conv_taps(x, nn.Module(), w, None, taps)
+    lim = 1e-5 * float(b.abs().max()) + 1e-4 * b.abs()
+    assert bool(((a - b).abs() <= lim).all())

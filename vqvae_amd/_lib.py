@@ -67,6 +67,7 @@ SIGNATURES = {
     "vqvae_conv_taps_packed_bytes": (_sz, [_i32, _i32, _i32]),
     "vqvae_conv_taps_pack_f32": (_i32, [_vp, _i32, _vp, _vp, _i32, _i32, _vp, _vp]),
     "vqvae_conv_taps_forward_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "vqvae_conv_taps_forward_ep_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "vqvae_conv_forward_ep_f32": (_i32, [_i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vqvae_conv_in_forward_ep_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vqvae_convt_out_packed_bytes": (_sz, [_i32, _i32]),

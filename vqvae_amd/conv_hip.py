@@ -99,25 +99,38 @@ def conv(kind, x, mod, weight, bias, Cin, Cout, flags, addend=None, mask=None):
 
 
 def conv_taps(x, mod, weight, bias, taps, flags=0):
-    """A stride-1 convolution over an explicit tap list [(dy, dx), ...] (<= 16 taps) on row-major activations: weight
-    (Cout, Cin, kh, kw) with kh * kw == len(taps), the list in the weight's (ky, kx) order -- a masked convolution without an
-    im2col pass (vqvae_conv_taps_forward_f32)."""
+    """A stride-1 convolution over an explicit tap list [(dy, dx), ...] on row-major activations: weight (Cout, Cin, kh, kw) with
+    kh * kw == len(taps), the list in the weight's (ky, kx) order -- a masked convolution without an im2col pass
+    (vqvae_conv_taps_forward_f32).  Lists of more than 16 taps run as a chain of launches over slices of at most 16, each adding to
+    the previous one's result in its epilogue (the sum over taps in slice order instead of one accumulator chain)."""
     import ctypes as C
     B, H, W, Cin = x.shape
     Cout, n = weight.shape[0], len(taps)
     if weight.shape[1] != Cin or weight.shape[2] * weight.shape[3] != n:
         raise ValueError("weight must be (Cout, Cin, kh, kw) with kh * kw taps")
-    dy = (C.c_int8 * n)(*[t[0] for t in taps])
-    dx = (C.c_int8 * n)(*[t[1] for t in taps])
     L = _lib.load()
-    packed = _packed(mod, ("taps", tuple(taps)), weight,
-                     lambda: L.vqvae_conv_taps_packed_bytes(n, Cin, Cout),
-                     lambda w, buf: L.vqvae_conv_taps_pack_f32(w.data_ptr(), n, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), Cin, Cout,
-                                                               buf.data_ptr(), _sp(w)))
-    y = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
     b = bias.detach() if bias is not None else None
-    _lib.check(L.vqvae_conv_taps_forward_f32(x.data_ptr(), packed.data_ptr(), b.data_ptr() if b is not None else None, B, H, W,
-                                             Cin, Cout, n, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), flags, y.data_ptr(), _sp(x)))
+    nsl = (n + 15) // 16
+    if nsl > 1 and (flags & RELU_OUT):
+        raise ValueError("an output ReLU cannot ride on a chain of tap slices")
+    per = (n + nsl - 1) // nsl
+    y = None
+    for s0 in range(0, n, per):
+        sl = taps[s0:s0 + per]
+        k = len(sl)
+        dy = (C.c_int8 * k)(*[t[0] for t in sl])
+        dx = (C.c_int8 * k)(*[t[1] for t in sl])
+        key = ("taps", tuple(sl), s0)
+        def pack(w, buf, dy=dy, dx=dx, k=k, s0=s0):
+            src = w if nsl == 1 else w.reshape(Cout, Cin, n)[:, :, s0:s0 + k].contiguous()
+            rc = L.vqvae_conv_taps_pack_f32(src.data_ptr(), k, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), Cin, Cout, buf.data_ptr(), _sp(w))
+            return rc                  # (a slice's temporary is freed in stream order behind the pack launch: same stream)
+        packed = _packed(mod, key, weight, lambda k=k: L.vqvae_conv_taps_packed_bytes(k, Cin, Cout), pack)
+        out = torch.empty((B, H, W, Cout), dtype=torch.float32, device=x.device)
+        _lib.check(L.vqvae_conv_taps_forward_ep_f32(x.data_ptr(), packed.data_ptr(), b.data_ptr() if (b is not None and y is None) else None,
+                                                    B, H, W, Cin, Cout, k, C.cast(dy, C.c_void_p), C.cast(dx, C.c_void_p), flags,
+                                                    y.data_ptr() if y is not None else None, None, out.data_ptr(), _sp(x)))
+        y = out
     return y
 
 

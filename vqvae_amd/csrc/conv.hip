@@ -1341,6 +1341,18 @@ int vqvae_conv_taps_forward_f32(const float *x, const float *packed, const float
                                     nullptr);
 }
 
+int vqvae_conv_taps_forward_ep_f32(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
+                                   int ntaps, const int8_t *dy, const int8_t *dx, int flags, const float *addend, const float *mask, float *y,
+                                   vqvae_stream_t stream) {
+    if ((addend && addend == y) || (mask && mask == y)) return VQVAE_ERR_UNSUPPORTED;
+    vqvae::TapSpec t;
+    const int rc = fill_taps(t, ntaps, dy, dx);
+    if (rc != VQVAE_OK) return rc;
+    vqvae::TapScope scope(&t);
+    return vqvae::conv_forward_impl(VQVAE_CONV_TAPS, x, packed, bias, B, H, W, Cin, Cout, flags, y, static_cast<hipStream_t>(stream), nullptr,
+                                    nullptr, addend, mask);
+}
+
 int vqvae_conv_forward_ep_f32(int kind, const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin,
                               int Cout, int flags, const float *addend, const float *mask, float *y, vqvae_stream_t stream) {
     if ((addend && addend == y) || (mask && mask == y)) return VQVAE_ERR_UNSUPPORTED;     // no in-place form: other waves still read them

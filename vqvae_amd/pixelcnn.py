@@ -9,7 +9,7 @@ initialisation as the reference, so a PixelCNN checkpoint written by `pixelcnn/g
 
 Forward-only.  Activations are row-major (B,H,W,C); a masked convolution is a stride-1 convolution over its causal tap list
 (round 4: vqvae_conv_taps_forward_f32 -- the conv path's kernels with an explicit tap list, no im2col pass; lists of more than
-16 taps, i.e. the first layer's 4 x 7 vertical stack, keep round 2's im2col + 1x1 GEMM); embeddings, the gated
+16 taps, i.e. the first layer's 4 x 7 vertical stack, run as a chain of launches over slices of the list); embeddings, the gated
 activation (+ class-conditional term) and the residual add are small HIP kernels (csrc/pixelcnn.hip).  The
 categorical sampling of `generate` uses torch's softmax + multinomial on the device, as the reference does.
 No CPU path, no fallback.
@@ -106,26 +106,11 @@ class GatedMaskedConv2d(nn.Module):
         self.vert_stack.weight.data[:, :, -1].zero_()
         self.horiz_stack.weight.data[:, :, :, -1].zero_()
 
-    def _gemm_weight(self, conv, tag):
-        """(Cout, Cin, kh, kw) -> (Cout, kh*kw*Cin, 1, 1) in im2col order, cached per parameter version."""
-        w = conv.weight
-        key = (w.data_ptr(), w._version, str(w.device))
-        cache = _cache.side(self).setdefault("gemm", {})
-        hit = cache.get(tag)
-        if hit is not None and hit[0] == key and self.mask_type != 'A':
-            return hit[1], hit[2]
-        w2 = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1, 1, 1).contiguous()
-        holder = _Holder()                                       # fresh packed-weight cache for the fresh tensor
-        cache[tag] = (key, w2, holder)
-        return w2, holder
-
     def _masked(self, x_rows, conv, taps, tag):
-        """One masked conv (bias included): the conv kernels over the tap list, or im2col + 1x1 GEMM for long lists."""
-        if len(taps) <= 16:          # (mask 'A' zeroes weights in place on every call: the version bump re-packs, conv_hip._packed)
-            return conv_hip.conv_taps(x_rows, conv, conv.weight, conv.bias, taps)
-        w2, holder = self._gemm_weight(conv, tag)
-        cols = _im2col(x_rows, taps)
-        return conv_hip.conv(CONV_1x1, cols, holder, w2, conv.bias, cols.shape[3], conv.weight.shape[0], 0)
+        """One masked conv (bias included): the conv kernels over the tap list."""
+        # (mask 'A' zeroes weights in place on every call: the version bump re-packs, conv_hip._packed; its 4 x 7 vertical stack is
+        # two slices of 14 taps, the second launch adding to the first)
+        return conv_hip.conv_taps(x_rows, conv, conv.weight, conv.bias, taps)
 
     def forward_rows(self, x_v, x_h, label):
         """x_v, x_h row-major (B,H,W,dim); label (B,) int64 -> (out_v, out_h) row-major."""
