@@ -250,6 +250,14 @@ def test_two_term_weight_gradient_across_image_scales(k, s, CA, CB):
     tile = ref.abs().amax(dim=(2, 3)).amax(dim=0 if False else 1, keepdim=True)
     assert bool(((err <= lim) | (err <= 2e-7 * tile)).all()), float((err / lim).max())
     assert torch.equal(got, A.conv_wgrad(a.to(dev), bt.to(dev), k, s, pad))
+    # a run of EVER SMALLER images (a factor of 10 per image and operand, 10^6 ... 10^-30): the accumulators must not climb after
+    # them binade by binade (the first version's rule, relative to the previous image, overflowed here: tests/test_wgrad_scheme_cpu.py)
+    a2 = torch.randn(B, 8, 8, CA, generator=g) * (10.0 ** (6 - torch.arange(B, dtype=torch.float32)))[:, None, None, None]
+    b2 = torch.randn(B, 8 * s, 8 * s, CB, generator=g) * (10.0 ** (6 - torch.arange(B, dtype=torch.float32)))[:, None, None, None]
+    ref2 = torch.nn.grad.conv2d_weight(b2.permute(0, 3, 1, 2).double(), (CA, CB, k, k), a2.permute(0, 3, 1, 2).double(), stride=s, padding=pad)
+    got2 = A.conv_wgrad(a2.to(dev), b2.to(dev), k, s, pad)
+    assert torch.isfinite(got2).all()
+    assert float((got2.cpu().double() - ref2).abs().max()) <= 2e-5 * float(ref2.abs().max())
 
 
 @pytest.mark.parametrize("C,flags", [(128, 2), (64, 3), (32, 0)])

@@ -289,8 +289,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_map8_kernel(const float *__
 //   * Scales: x = (h1 + h2) 2^-k with ONE power of two per image and operand tile, measured by the workgroup while the image
 //     sits in its registers (no pass over the tensors, no maxima handed in).  Images of one range carry different scales, so the
 //     fp32 accumulators live on the CURRENT image's scale 2^(ka + kb) and are multiplied by the exact power of two between two
-//     images; the partial sums leave through v_ldexp.  Relative error per product <= 2^-21 as in the forward kernels
-//     (representation 2^-23 per operand + the dropped h2 h2 term); elements 2^17 below their image tile's maximum keep fewer bits
+//     images; the partial sums leave through v_ldexp.  An image more than 2^60 below the LARGEST one of the range so far keeps a
+//     coarser scale, so that the accumulators cannot overflow however the magnitudes are ordered.  Relative error per product
+//     <= 2^-21 as in the forward kernels (representation 2^-23 per operand + the dropped h2 h2 term); elements 2^17 below their image tile's maximum keep fewer bits
 //     -- absolute error <= 2^-39 of the tile maxima's product -- which is the forward scheme's statement for activations.
 //   * Fixed summation order as before (image order inside a range, ranges by conv_wgrad_reduce_kernel): bit-reproducible.
 typedef short s16x4v __attribute__((__vector_size__(8)));
@@ -370,7 +371,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_map8_h2_kernel(const float 
         return __builtin_bit_cast(wg_f16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
     };
 
-    int e_acc = 0;                                                              // the accumulators hold sum * 2^e_acc
+    int e_acc = 0, e_min = 0;                                                   // the accumulators hold sum * 2^e_acc; e_min: the largest image's scale
     bool first = true;
     if (b_lo < b_hi) load_image(b_lo);
     for (long long b = b_lo; b < b_hi; ++b) {
@@ -395,9 +396,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_map8_h2_kernel(const float 
         };
         const int ka = scale_exp(ma);
         int kb = scale_exp(mb);
-        // an image far SMALLER than what has been summed so far would push the accumulators towards overflow when they follow
-        // its scale: such an image keeps a coarser scale instead (its whole contribution is below 2^-60 of the sum)
-        if (!first && ka + kb > e_acc + 60) kb = e_acc + 60 - ka;
+        // an image far SMALLER than the largest one summed so far would push the accumulators towards overflow when they follow
+        // its scale (sums at the largest image's own scale stay below 2^48: 2^30 per product, 64 pixels, <= 2^12 images): such
+        // an image keeps a coarser scale, at most 2^60 finer than the LARGEST image's -- not than the previous image's, or a run
+        // of ever smaller images would climb 60 binades at a time (tests/test_wgrad_scheme_cpu.py found that) -- and its whole
+        // contribution is below 2^-60 of that image's
+        e_min = first ? ka + kb : (ka + kb < e_min ? ka + kb : e_min);
+        if (ka + kb > e_min + 60) kb = e_min + 60 - ka;
         const int e_img = __builtin_amdgcn_readfirstlane(ka + kb);
         const float sa = __builtin_ldexpf(1.0f, ka), sb = __builtin_ldexpf(1.0f, kb);
         // ---- convert and park: [term][tile][pixel][32 ch], 8 bytes per lane and term ----
