@@ -412,6 +412,8 @@ EP_CASES = [  # kind, B, H, W, Cin, Cout
     (5, 4, 8, 8, 128, 32),       # transposed 1x1, one output tile (conv_igemm_bf3_kernel<1>)
     (2, 2, 5, 7, 64, 64),        # 1x1 on an odd map (generic kernel)
     (1, 2, 12, 12, 32, 64),      # 3x3 on a map that is not 8x8 (generic kernel)
+    (1, 3, 8, 8, 32, 60),        # output channels not a multiple of 8: the tile kernel's scalar store path
+    (1, 2, 8, 8, 32, 20),        # one ragged channel tile (generic kernel, scalar stores)
 ]
 
 
