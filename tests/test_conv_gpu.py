@@ -303,3 +303,33 @@ def test_fp16_two_term_product_bound_on_aligned_operands(kind, ctor, Cin, Cout, 
     assert worst["two-term fp16 (default)"] <= 2.0 ** -21 + 2.0 ** -22        # 8 units of 2^-24 + the fp32 accumulation's share
     if kind != "conv1x1":           # (the per-layer 1x1 entry on 8x8 maps comes out at fp32 level on these operands)
         assert worst["two-term fp16 (default)"] >= 2.0 ** -22
+
+
+@pytest.mark.parametrize("kind,ctor,Cin,Cout,H", [
+    (1, lambda ci, co: torch.nn.Conv2d(ci, co, 3, 1, 1), 128, 128, 8),
+    (3, lambda ci, co: torch.nn.ConvTranspose2d(ci, co, 3, 1, 1), 64, 128, 8),
+    (0, lambda ci, co: torch.nn.Conv2d(ci, co, 4, 2, 1), 64, 128, 16),
+    (2, lambda ci, co: torch.nn.Conv2d(ci, co, 1, 1, 0), 128, 128, 8),
+])
+@pytest.mark.parametrize("flags", [0, 8], ids=["fp16x2", "bf16x3"])
+def test_tile_kernel_both_launch_forms(kind, ctor, Cin, Cout, H, flags):
+    """conv_tile8_bf3_kernel runs its eight-wave form (one image per wave x all 128 output channels) only when that gives every CU
+    a workgroup (B >= 2048 on 256 CUs) and the four-wave form (two channel halves per image) below it (round 4).  The same images
+    through both -- one launch of 2304 images against nine launches of 256 -- must agree bit for bit (same operand order per
+    accumulator), and a sample of them with torch on the CPU."""
+    from vqvae_amd import conv_hip
+    dev = torch.device("cuda:0")
+    torch.manual_seed(kind * 10 + flags)
+    layer = ctor(Cin, Cout)
+    B = 2304
+    x = torch.randn(B, Cin, H, H)
+    xr = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    hold = torch.nn.Module()
+    big = conv_hip.conv(kind, xr, hold, layer.weight.detach().to(dev), layer.bias.detach().to(dev), Cin, Cout, flags)
+    parts = torch.cat([conv_hip.conv(kind, xr[i:i + 256].contiguous(), hold, layer.weight.detach().to(dev), layer.bias.detach().to(dev),
+                                     Cin, Cout, flags) for i in range(0, B, 256)])
+    assert torch.equal(big, parts)
+    with torch.no_grad():
+        ref = layer(x[::97]).permute(0, 2, 3, 1)
+    got = big[::97].cpu()
+    np.testing.assert_allclose(got.numpy(), ref.numpy(), atol=1e-5 * float(ref.abs().max()), rtol=1e-4)
