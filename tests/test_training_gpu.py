@@ -447,6 +447,12 @@ def test_conv_epilogue_addend_and_mask_bitwise_vs_separate_passes(case, which):
     assert rc == 0, rc                       # every split-product kernel of the per-layer entry has the epilogue
     assert torch.equal(got, want)
     assert torch.equal(conv_hip.conv(kind, x, hold, w, None, Cin, Cout, 0, addend=add, mask=mask), want)
+    # the fp32-MFMA form has no such epilogue: the front end runs the separate passes instead (same definition, that form's products)
+    y32 = conv_hip.conv(kind, x, hold, w, None, Cin, Cout, 4)
+    want32 = y32 if add is None else y32 + add
+    if mask is not None:
+        want32 = want32 * (mask > 0)
+    assert torch.equal(conv_hip.conv(kind, x, hold, w, None, Cin, Cout, 4, addend=add, mask=mask), want32)
     # refusals: in place, misaligned, the fp32-MFMA form
     t = add if add is not None else mask
     assert L.vqvae_conv_forward_ep_f32(kind, x.data_ptr(), packed.data_ptr(), None, B, H, W, Cin, Cout, 0, got.data_ptr(), None,
