@@ -289,6 +289,10 @@ BIG_SHAPES = {
     "rh64_halo_64x64": (128, 64, 2, 512, 64, 2, 64, 64),
     "k256_default_shapes": (128, 32, 2, 256, 64, 5, 32, 32),
     "k1024_default_shapes": (128, 32, 2, 1024, 64, 5, 32, 32),
+    # codebooks that do not fill their last 128-code group inside the fused encoder kernel (padding codes must never win)
+    "k100_default_shapes": (128, 32, 2, 100, 64, 5, 32, 32),
+    "k384_default_shapes": (128, 32, 2, 384, 64, 5, 32, 32),
+    "k37_default_shapes": (128, 32, 2, 37, 64, 3, 32, 32),
     "n_res_1": (128, 32, 1, 512, 64, 4, 32, 32),
     "n_res_4": (128, 32, 4, 512, 64, 4, 32, 32),
 }
