@@ -186,12 +186,13 @@ def test_whole_path_on_heterogeneous_channel_scales(weights, images, scheme, cap
               f"{t_ze:.2e}), x_hat {o_xh:.2e} ({t_xh:.2e});  {len(flips)} index flips / {got.size} rows; torch on this host vs the C oracle on the same z_e bits: {host_disagree} rows differ")
 
 
-@pytest.mark.parametrize("n_res", [1, 3])
+@pytest.mark.parametrize("n_res,HW", [(1, 32), (3, 32), (2, 64), (2, 96)])
 @pytest.mark.parametrize("kind", ["coupled", "independent"])
-def test_per_layer_two_term_kernels_on_heterogeneous_channel_scales(n_res, kind, capsys):
+def test_per_layer_two_term_kernels_on_heterogeneous_channel_scales(n_res, HW, kind, capsys):
     """The same question for the kernels BEHIND the four-kernel path: with one or three residual layers the default shapes run the
     per-layer / per-pair two-term fp16 kernels (conv_tile8_bf3<., H2>, res_tile8 / res_pair8: their own per-output-channel scale
-    tables and hand-over of image maxima).  Encoder and decoder per output channel against the reference, and against fp64."""
+    tables and hand-over of image maxima); 64x64 / 96x96 images put 16x16 / 24x24 latent maps on the halo-tile kernels of BASELINE
+    configs 4 / 5 (conv_halo8_h2, res_halo8_h2).  Encoder and decoder per output channel against the reference, and against fp64."""
     from oracle import torch_port
     from vqvae_amd import _lib, conv
     from vqvae_amd.modules import VQVAE
@@ -199,7 +200,8 @@ def test_per_layer_two_term_kernels_on_heterogeneous_channel_scales(n_res, kind,
     h, rh, K, D = DIMS[0], DIMS[1], DIMS[3], DIMS[4]
     sd0 = torch_port.init_state_dict(h, rh, K, D, seed=0, n_res_layers=n_res)
     sd = hetero.rescale_coupled(sd0, 1, 3.0, n_res) if kind == "coupled" else hetero.rescale_independent(sd0, 1, 3.0, n_res)
-    x = _images("normal")
+    Bn = B if HW == 32 else 6
+    x = torch.randn(Bn, 3, HW, HW, generator=torch.Generator().manual_seed(79))
     sd64 = {k: v.double() for k, v in sd.items()}
     with torch.no_grad():
         z_e = torch_port.encode(sd, x.clone(), n_res)
@@ -212,16 +214,17 @@ def test_per_layer_two_term_kernels_on_heterogeneous_channel_scales(n_res, kind,
     m = m.to(dev())
     L = _lib.load()
     cw, _keep = m._c_weights()
-    nws = L.vqvae_workspace_bytes(cw.dims, B, 32, 32)
+    nws = L.vqvae_workspace_bytes(cw.dims, Bn, HW, HW)
+    assert nws > 0
     ws = torch.empty(nws, dtype=torch.uint8, device=dev())
     st = torch.cuda.current_stream().cuda_stream
     xd = x.to(dev()).contiguous()
     with torch.no_grad():
-        ze_d = torch.empty(B, 8, 8, D, device=dev())
-        _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), B, 32, 32, ze_d.data_ptr(), ws.data_ptr(), nws, st))
+        ze_d = torch.empty(Bn, HW // 4, HW // 4, D, device=dev())
+        _lib.check(L.vqvae_encoder_f32(cw, xd.data_ptr(), Bn, HW, HW, ze_d.data_ptr(), ws.data_ptr(), nws, st))
         zq_rows = z_q.to(dev()).permute(0, 2, 3, 1).contiguous()
         xh_d = torch.empty_like(xd)
-        _lib.check(L.vqvae_decoder_f32(cw, zq_rows.data_ptr(), B, 8, 8, xh_d.data_ptr(), ws.data_ptr(), nws, st))
+        _lib.check(L.vqvae_decoder_f32(cw, zq_rows.data_ptr(), Bn, HW // 4, HW // 4, xh_d.data_ptr(), ws.data_ptr(), nws, st))
     torch.cuda.synchronize()
     ze = ze_d.permute(0, 3, 1, 2).cpu().numpy()
     w_ze = hetero.per_channel_check(ze, z_e.numpy(), "z_e", per_image=False)
@@ -231,5 +234,5 @@ def test_per_layer_two_term_kernels_on_heterogeneous_channel_scales(n_res, kind,
     w_xh = hetero.per_channel_check(xh_d.cpu().numpy(), x_hat.numpy(), "x_hat", per_image=False)
     o_xh, t_xh = _vs_fp64(xh_d.cpu().numpy(), x_hat.numpy(), x_hat64.numpy(), "x_hat", lim=4e-5)
     with capsys.disabled():
-        print(f"\n   [{kind}, {n_res} residual layer(s), per-layer kernels] worst error in units of the channel maximum: z_e {w_ze:.2e}, x_hat {w_xh:.2e};"
+        print(f"\n   [{kind}, {n_res} residual layer(s), {HW}x{HW} images, per-layer kernels] worst error in units of the channel maximum: z_e {w_ze:.2e}, x_hat {w_xh:.2e};"
               f"  vs fp64 per (image, channel): z_e {o_ze:.2e} (fp32 reference {t_ze:.2e}), x_hat {o_xh:.2e} ({t_xh:.2e})")
