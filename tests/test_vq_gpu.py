@@ -470,3 +470,25 @@ def test_module_interface_matches_reference_signature():
         vq(z.cpu())                          # no CPU fallback
     out = vq(z.clone().requires_grad_())     # under autograd: HIP forward + HIP backward (tests/test_training_gpu.py)
     assert out[0].requires_grad and out[1].requires_grad and torch.equal(out[1].detach(), z_q)
+
+
+@pytest.mark.parametrize("K,D,N", [(1024, 64, 4096), (2048, 128, 2048), (8192, 128, 1024), (600, 64, 4096), (512, 32, 4096), (100, 256, 1024)])
+@pytest.mark.parametrize("rowmajor", [True, False])
+def test_vq_heterogeneous_rows_on_every_kernel_family(K, D, N, rowmajor):
+    """Round 4's lesson (a row norm that was wrong only when a row's channels differ by decades) applied to the OTHER kernel
+    families: the streamed-codebook kernels (K > ~600 or D = 128: BASELINE configs 4 / 5), the bf16 two-sweep filter and the
+    exhaustive kernel's shapes -- rows whose channels carry independent 10^U(-3, 3) factors, a codebook of perturbed rows (every row
+    has a near neighbour, many have several), against the C oracle bit for bit."""
+    from oracle import c_oracle
+    g = torch.Generator().manual_seed(K + D)
+    f = 10.0 ** (torch.rand(D, generator=g) * 6 - 3)
+    zr = torch.randn(N, D, generator=g) * f
+    pick = torch.randint(0, N, (K,), generator=g)
+    cb = zr[pick] * (1 + 1e-3 * torch.randn(K, D, generator=g))
+    cb[::7] = zr[pick[::7]] + 1e-6 * f * torch.randn(len(pick[::7]), D, generator=g)      # some codes a hair away from a row
+    z = zr.view(N // 64, 8, 8, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, rowmajor)
+    np.testing.assert_array_equal(idx, ref["idx"])
+    assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
+    np.testing.assert_allclose(loss, ref["loss"], rtol=1e-5)
