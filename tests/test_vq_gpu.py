@@ -242,6 +242,46 @@ def test_vq_headline_size_bit_exact_vs_oracle(B, H, W):
     assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
 
 
+def test_vq_pooled_tail_units_and_counter_reset_vs_oracle():
+    """From four units per wave on (589 824 rows on 256 CUs: 8-wave form and the forced 16-wave form alike) the last quarter of the
+    units comes from per-group counters in the workspace (vq_track.hip, pool_pct) that the last workgroup of a group puts back to
+    zero: three launches on ONE workspace must each reproduce the oracle bit for bit, row-major and NCHW."""
+    from vqvae_amd import functional as F
+    dev = _dev()
+    g = torch.Generator().manual_seed(77)
+    K, D, B = 512, 64, 9216
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, 8, 8, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25)
+    cbd, zn = cb.to(dev), z.to(dev)
+    zr = zn.permute(0, 2, 3, 1).contiguous()
+    hist_ref = np.bincount(ref_idx.reshape(-1), minlength=K)
+    for kw, zin, rm in (({}, zr, True), ({"form": 16}, zr, True), ({}, zn, False)):
+        ws = F.vq_workspace(K, D, dev)
+        for rep in range(3):
+            loss, zq, ppl, idx, hist = F.vq_forward(zin, cbd, 0.25, rowmajor=rm, workspace=ws, prepared=rep > 0, **kw)
+            if rm:
+                zq = zq.permute(0, 3, 1, 2).contiguous()
+            np.testing.assert_array_equal(idx.cpu().numpy(), ref_idx, err_msg=f"{kw} nchw={not rm} launch {rep}")
+            assert np.array_equal(zq.cpu().numpy().view(np.uint32), ref_zq.view(np.uint32)), (kw, rm, rep)
+            np.testing.assert_array_equal(hist.cpu().numpy(), hist_ref)
+
+
+@pytest.mark.parametrize("B", [1, 37, 1024, 1025], ids=lambda b: f"{b * 64}rows")
+def test_vq_few_rows_take_the_eight_wave_32_row_form_bit_exact(B):
+    """Up to 8 x CUs x 32 rows (BASELINE config 2's 65 536 on 256 CUs) the default launch is 32-row units on eight waves per CU;
+    one image, a ragged count, the last size of the rule and the first one past it against the oracle."""
+    g = torch.Generator().manual_seed(300 + B)
+    K, D = 512, 64
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, 8, 8, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25, n_chunks=min(B, 64))
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, True)
+    np.testing.assert_array_equal(idx, ref_idx)
+    assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+    np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
+
+
 def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"

@@ -64,6 +64,7 @@ struct VqPlan {
 };
 constexpr int kVqCandCap = 8;   // per lane half (16 per row), unsigned short entries   // candidate list capacity per row in the filter kernel
 constexpr int kVqTilesPerWave = 2;   // 32-row tiles a wave of the filter kernel walks per iteration
+constexpr int kVqTicketBytes = 4096;  // unit counters behind the workspace's flags (see vq_plan)
 constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many workgroups
 constexpr int kVqSlabRows = 1 << 18; // rows per pass of the streamed-codebook kernels (vq_chunk.hip): bounds their scratch
 constexpr int kVqGroupSlabs = 16;    // slabs whose open / hard rows are resolved by ONE launch (their records' scratch: 44.1 B per row of a group)
@@ -86,7 +87,9 @@ inline VqPlan vq_plan(int K, int D) {
     p.K_pad = p.nchunks * p.KC;
     p.lds_bytes = (size_t)p.KC * D * 4 + (size_t)p.KC * 4 + (size_t)K * 4 + 256;
     p.off_flags = 0;
-    p.off_ee = 256;
+    // behind the flags: kVqTicketBytes of unit counters of the stream-tracker kernel (vq_track.hip: eight groups of workgroups, one
+    // 256-byte slot each for the group's next pooled unit and for the workgroups that have left; zero between launches)
+    p.off_ee = 256 + kVqTicketBytes;
     p.off_img = align_up(p.off_ee + (size_t)p.K_pad * 4, 256);
     p.off_partials = align_up(p.off_img + (size_t)p.K_pad * D * 4, 256);
     p.K32 = (K + 31) / 32 * 32;

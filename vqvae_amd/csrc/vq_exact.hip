@@ -439,7 +439,7 @@ static int launch_vq_prepare(const float *cb, int K, char *ws, hipStream_t st) {
     const VqPlan p = vq_plan(K, D);
     int *wflags = reinterpret_cast<int *>(ws + p.off_flags);
     hipError_t e;
-    if ((e = hipMemsetAsync(wflags, 0, 256, st)) != hipSuccess) return (int)e;
+    if ((e = hipMemsetAsync(wflags, 0, 256 + kVqTicketBytes, st)) != hipSuccess) return (int)e;
     const int kmax = p.K_pad > p.K32 ? p.K_pad : p.K32;
     hipLaunchKernelGGL(vq_prepare_kernel<D>, dim3((kmax + 63) / 64), dim3(64), 0, st, cb, K, p.KC, p.K_pad,
                        reinterpret_cast<float *>(ws + p.off_ee), reinterpret_cast<float *>(ws + p.off_img), wflags, p.K32,

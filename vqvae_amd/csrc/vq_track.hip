@@ -37,6 +37,18 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 using vqu::lds_order_wave;
 
+// Debug builds (tools/build_variant.py NAME -DVQ_TRACE, tools/ubench/vq_ab.cpp): absolute 100 MHz stamps of every wave --
+// [0] wave start, [1] past the prologue's barrier, [2..5] end of its first four units, [6] loop exit, [7] last instruction
+#ifdef VQ_TRACE2                 // slots 2..5 = end of the sweep / classification / exact part / epilogue of the wave's FIRST unit
+#define VQ_TRACE 1
+#endif
+#ifdef VQ_TRACE
+__device__ unsigned long long g_vq_trace[4096 * 8];
+#define VQ_TR(slot) do { if ((tid & 63) == 0) g_vq_trace[((size_t)blockIdx.x * NW + wave_u) * 8 + (slot)] = wall_clock64(); } while (0)
+#else
+#define VQ_TR(slot) do {} while (0)
+#endif
+
 // Eight waves per workgroup, one workgroup per CU.  A wave owns UNITS of two 32-row tiles (64 consecutive rows) that share
 // every codebook operand and seed read from LDS; its first unit is static, later units come from an LDS ticket.  Rows stay
 // in registers in the coalesced load layout (16 lanes x 16 bytes per row) from load to store: HBM traffic is the
@@ -55,7 +67,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
     long long N, int K, int K32, long long nunits, float *__restrict__ zq, long long *__restrict__ idx,
-    int *__restrict__ hist, double *__restrict__ partials, int HW) {
+    int *__restrict__ hist, double *__restrict__ partials, int HW, int pool_pct) {
     constexpr int D = 64, RU = 32 * T;
     static_assert(!NCHW || T == 2, "the NCHW form turns a 32 x 64 fp32 block around in an 8 KiB tile: 64-row units only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -72,6 +84,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     constexpr int TILEB = 4096 * T, TABB = 1552;
     unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);                // the unit's fp16 rows; later 16 fp32 row slots
     unsigned char *tab_s = tile_s + TILEB;
+#ifdef VQ_TRACE
+    if ((tid & 63) == 0) for (int i = 0; i < 8; ++i) g_vq_trace[((size_t)blockIdx.x * NW + wave_u) * 8 + i] = 0ull;
+    int trace_u = 0;
+#endif
+    VQ_TR(0);
 
 #ifdef VQ_SWEEP_TIMING
     // debug build (tools/build_variant.py NAME -DVQ_SWEEP_TIMING, tools/vq_phase.py): per-phase wall-clock sums (100 MHz
@@ -130,11 +147,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const long long pstride = (long long)gridDim.x * NW;
     long long p = (long long)blockIdx.x * NW + wave_u;
     f32x4 F[T][8];
-    if (p < nunits) load_unit(p, F, tid & 63);
 
-    // codebook image -> LDS by LDS-DMA (1 KiB pieces, no staging registers), issued behind the first unit's row requests:
-    // the rows' HBM round trip, the image's L2 round trip and the first unit's fp16 conversion overlap; the workgroup meets once,
-    // in front of its first sweep.  (Inline assembly: for the builtin hipcc waits vmcnt(0) before every later LDS read.)
+    // ---- prologue (round 4, second session; profiles/r04b_vq_timeline.txt has the per-wave stamps this order comes from) ----
+    // The workgroup meets on the codebook image ALONE.  Image and seeds go to LDS by LDS-DMA (1 KiB pieces, no staging registers;
+    // inline assembly: for the builtin hipcc waits vmcnt(0) before every later LDS read) and are requested FIRST; the barrier waits
+    // for everything but a wave's own row requests (vmcnt counts in issue order).  Only the first-dispatched wave of every SIMD
+    // (waves 0..3) asks for its rows in front of the barrier, the others behind it (the last two a little later still): all waves'
+    // first units together are half of z at BASELINE config 3 and arrive interleaved, so with every request in flight at once no
+    // wave's unit was complete before nearly every wave's was (barrier at 6.0 us after the first wave's start; 2.6 us this way) --
+    // and a SIMD serves its oldest wave first anyway.
+    const bool early = (wave_u >> 2) == 0;
     {
         const u32x4 *src16 = reinterpret_cast<const u32x4 *>(img_g);
         u32x4 *dst16 = reinterpret_cast<u32x4 *>(Eimg);
@@ -146,8 +168,17 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)(dst16 + sp * 64));
             asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src16 + sp * 64 + lane0), "s"(lds) : "memory");
         }
+        // the seeds in whole 1 KiB pieces the same way (a register copy would make hipcc wait for EVERY request of the wave before
+        // its LDS write); a seed table that is not whole pieces (K % 256 != 0) copies the rest through registers
+        const int nsp = (ntile * 32) / 256;
+        for (int pc = wave_u; pc < nsp; pc += NW) {
+            const unsigned lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(__attribute__((address_space(3))) char *)(char *)(seeds + pc * 256));
+            asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(reinterpret_cast<const u32x4 *>(seeds_g) + pc * 64 + lane0), "s"(lds) : "memory");
+        }
+        if ((ntile * 32) % 256)
+            for (int i = nsp * 256 + tid; i < ntile * 32; i += NW * 64) seeds[i] = seeds_g[i];
     }
-    for (int i = tid; i < ntile * 32; i += NW * 64) seeds[i] = seeds_g[i];
+    if (p < nunits && early) load_unit(p, F, tid & 63);
     for (int k = tid; k < K; k += NW * 64) hist_s[k] = 0;
     if (tid == 0) ticket_s[0] = NW;                          // units 0 .. NW-1 of the workgroup are taken statically
 
@@ -206,9 +237,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             zn2[t] = sq + __uint_as_float(h ? sw[0] : sw[1]);
         }
     };
-    if (p < nunits) convert();                               // the first unit, while the codebook image is still landing
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // this wave's pieces of the image
-    __syncthreads();
+    if (p < nunits && early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * T) : "memory");    // all but the 8 T row requests
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // histogram, ticket (and a ragged seed table's tail)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    VQ_TR(1);
+    if ((wave_u >> 2) == 2) __builtin_amdgcn_s_sleep(20);     // (64-cycle units: ~0.55 us and ~1.1 us)
+    if ((wave_u >> 2) == 3) __builtin_amdgcn_s_sleep(40);
+    if (p < nunits && !early) load_unit(p, F, tid & 63);
+    if (p < nunits) convert();
 
     const float inf = __builtin_inff();
     VQ_STAMP(0);                                               // codebook image copy + first rows + first conversion
@@ -217,6 +255,21 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
     double dacc = 0.0;
 
+    // Many units per wave (pool_pct > 0: the host sets 25 from four units per wave on): the last quarter of the units is not dealt out
+    // to the workgroups.  A wave whose workgroup has used up its share draws from the pool of its group of workgroups (blockIdx % 8 --
+    // the XCD under round-robin dispatch; group x owns the pooled units nlocal + x, + 8, ...), one returning atomic per unit, paid by
+    // a wave that would otherwise be idle.  A unit's time depends on its rows (how many stay open): with every unit dealt out the
+    // slowest workgroup finishes well after the median one (2.1 M rows: 241 -> 231 us with the pool).  With two units per wave the
+    // atomic's round trip costs more than the balance gains (262 144 rows: +1-2 us), and one counter for the whole grid serialises
+    // (~9 ns per atomic: 110 us at 262 144 rows when every unit came from it).  The counters live behind the workspace's flags and are
+    // zero between launches: the last workgroup of a group to leave puts its two words back.
+    const int xng = gridDim.x < 8u ? (int)gridDim.x : 8;
+    const int xg = (int)(blockIdx.x % (unsigned)xng);
+    int *xt = reinterpret_cast<int *>(reinterpret_cast<char *>(const_cast<int *>(flags)) + 256 + xg * 256);
+    int *xdone = xt + 512;                                   // (2 KiB behind the ticket slots)
+    long long npool = nunits > pstride ? nunits * pool_pct / 100 : 0;
+    if (npool > nunits - pstride) npool = nunits - pstride;  // (first units are always dealt out)
+    const long long nlocal = nunits - npool;
     while (p < nunits) {
         const long long r0 = p * RU;
         // lane-derived indices are made opaque once per iteration: hipcc otherwise hoists dozens of per-lane address values
@@ -232,14 +285,27 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #pragma unroll
         for (int t = 0; t < T; ++t) trk::init(L[t], ninf);
         {
+            // (VQ_KO_*: timing-only knock-outs of one resource each -- wrong results; tools/build_vq_variant.sh)
             auto fetch = [&](int ct, u32x4(&a)[4], f32x16 &seed) {
+#ifdef VQ_KO_AREAD
+                if (ct == 0)
+#endif
 #pragma unroll
                 for (int q = 0; q < 4; ++q) a[q] = *reinterpret_cast<const u32x4 *>(ap0 + ct * 256 + q * 64);
+#ifdef VQ_KO_AREAD
+                asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));
+#endif
+#ifdef VQ_KO_SEED
+                if (ct == 0)
+#endif
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 e4 = *reinterpret_cast<const f32x4 *>(sp0 + ct * 32 + 4 * g);
                     seed[4 * g] = e4.x; seed[4 * g + 1] = e4.y; seed[4 * g + 2] = e4.z; seed[4 * g + 3] = e4.w;
                 }
+#ifdef VQ_KO_SEED
+                asm volatile("" : "+v"(seed));
+#endif
             };
             // Round 4: the sweep as a software pipeline over code tiles.  The eight MFMAs of tile ct are issued INTERLEAVED with the
             // 48 vector instructions that track tile ct - 1's accumulators (two accumulator sets, one operand set: the same 96
@@ -248,6 +314,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             // vector work runs -- a 32-cycle MFMA slot has room for about six vector issues (MI355X_MICROARCH.md, "5 fillers
             // per gap"), which is exactly the tracker's budget (24 per 16 values = 6 per MFMA).
             auto mma = [&](f32x16(&acc)[T], const u32x4(&a)[4], const f32x16 &seed) {
+#ifdef VQ_KO_MFMA
+                for (int t = 0; t < T; ++t) { acc[t] = seed; acc[t][0] += __uint_as_float(a[0].x ^ a[1].y ^ a[2].z ^ a[3].w); }
+                return;
+#endif
 #pragma unroll
                 for (int t = 0; t < T; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[t][0], seed, 0, 0, 0);
 #pragma unroll
@@ -260,7 +330,12 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 unsigned cell0 = (unsigned)(2 * ct), cell1 = cell0 + 1u;        // scalars (opaque: else or3(x & mask, cell0, 1))
                 asm volatile("" : "+s"(cell0), "+s"(cell1));
 #pragma unroll
+#ifdef VQ_KO_TRACK
+                for (int t = 0; t < T; ++t) { L[t].S[0] = trk::max3(L[t].S[0], acc[t][0], acc[t][15]); L[t].m1 = trk::max3(L[t].m1, acc[t][7], acc[t][8]); }
+                (void)cell0; (void)cell1;
+#else
                 for (int t = 0; t < T; ++t) trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
+#endif
             };
             // one pipeline step: operands of tile ct, its MFMAs into `accn`, the tracker of tile ct - 1 on `accp` between them
             auto step = [&](int ct, f32x16(&accn)[T], const f32x16(&accp)[T]) {
@@ -298,6 +373,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         }
 
         VQ_STAMP(2);                                           // sweep
+#ifdef VQ_TRACE2
+        if (trace_u == 0) VQ_TR(2);
+#endif
         // ================= threshold, merge of the two lane halves of every row, verdict (vq_unit.h) =========================
         const vqu::Tables tb = vqu::tables(tab_s);
         vqu::Rows R;
@@ -306,6 +384,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         vqu::classify<T>(L, zn2, bound, K, lane, ninf, tb.task_s, R);
 
         VQ_STAMP(3);                                           // threshold + verdict
+#ifdef VQ_TRACE2
+        if (trace_u == 0) VQ_TR(3);
+#endif
         // ================= exact part (rows the screen left open) =========================================================
         // A TASK is (row, code a, code b); four tasks run per pass, one per 16-lane group, on the row's fp32 data (read again
         // from L2: it was loaded a few microseconds ago): ||z||^2 in ATen's summation order and the two c-ordered fmaf
@@ -315,6 +396,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         //   hard rows: the row tile's screen is run again with the row's now-known threshold and every code at or above
         //       it becomes a task (same accumulators as in the sweep)
         //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
+#define VQ_PRE
         {
             vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
             int ntasks = FL.ndirect;
@@ -372,6 +454,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         }
 
         VQ_STAMP(4);                                           // exact part
+#ifdef VQ_TRACE2
+        if (trace_u == 0) VQ_TR(4);
+#endif
         // ================= epilogue: gather, z + (e_k - z), squared error, index, histogram (vq_unit.h) =======================
         {
             const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
@@ -397,11 +482,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         }
 #endif
         VQ_STAMP(5);                                           // epilogue
+#ifdef VQ_TRACE2
+        if (trace_u == 0) VQ_TR(5);
+        ++trace_u;
+#elif defined(VQ_TRACE)
+        if (trace_u < 4) { VQ_TR(2 + trace_u); }
+        ++trace_u;
+#endif
         {
             int q = 0;
             if (lane == 0) q = atomicAdd(ticket_s, 1);
             q = __builtin_amdgcn_readfirstlane(q);
             p = (long long)(q / NW) * pstride + (long long)blockIdx.x * NW + (q % NW);
+            if (p >= nlocal && npool > 0) {                    // the workgroup's own share is used up: the group's pool
+                int t = 0;
+                if (lane == 0) t = atomicAdd(xt, 1);
+                p = nlocal + (long long)xng * __builtin_amdgcn_readfirstlane(t) + xg;
+            }
             if (p < nunits) {
                 load_unit(p, F, lane);
                 convert();                                     // (waits for the rows; the next iteration starts with the sweep)
@@ -417,6 +514,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     if (tid < 8 && blockIdx.x < 64) reinterpret_cast<unsigned long long *>(partials + 512)[blockIdx.x * 8 + tid] = tsum[tid];
     __syncthreads();
 #endif
+    VQ_TR(6);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
     __syncthreads();
@@ -426,11 +524,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         double s = 0.0;
         for (int w = 0; w < NW; ++w) s += red[w];
         partials[blockIdx.x] = s;
+        if (npool > 0) {
+            const int ngroup = ((int)gridDim.x - xg + xng - 1) / xng;   // workgroups of this group
+            if (atomicAdd(xdone, 1) == ngroup - 1) { atomicExch(xt, 0); atomicExch(xdone, 0); }
+        }
     }
     for (int k = tid; k < K; k += NW * 64) {
         const int c = hist_s[k];
         if (c) atomicAdd(&hist[k], c);
     }
+    VQ_TR(7);
 }
 
 size_t vq_track_lds_bytes(int K, int nw = 8) {        // nw = 16: one 32-row tile per unit and wave, nw = 8: two
@@ -453,12 +556,16 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     // 8 / 16 = forced (A/B: tools/vq_ab4.py)
     const bool fits16 = !nchw && vq_track_lds_bytes(K, 16) <= (size_t)kLdsBytes;
     const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
-    const int NW = wide ? 16 : 8, RU = wide ? 32 : 64;
+    // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
+    // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
+    const bool spread = form == 0 && !nchw && (N + 31) / 32 <= 8LL * cus;
+    const int NW = (wide && !spread) ? 16 : 8, RU = (wide || spread) ? 32 : 64;
     const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
     if (grid > cus) grid = cus;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
     *grid_out = (int)grid;
+    const int pool_pct = nunits >= 4 * grid * NW ? 25 : 0;     // (see the kernel: the pooled tail pays from four units per wave on)
     auto launch = [&](auto kfn) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         hipEvent_t e0, e1;
@@ -470,15 +577,22 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
         // that is the form a stream capture (vqvae_amd/graph.py) records
         if (prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1))
             hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, e0, e1, 0, z, cb, imgh, seeds, ee,
-                                  wflags, N, K, p.K32, nunits, zq, idx, hist, partials, HW);
+                                  wflags, N, K, p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
         else
             hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, z, cb, imgh, seeds, ee, wflags, N, K,
-                               p.K32, nunits, zq, idx, hist, partials, HW);
+                               p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
     if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
+    else if (spread) launch(vq_track_kernel_d64<8, false, 1>);
     else if (wide) launch(vq_track_kernel_d64<16, false, 1>);
     else launch(vq_track_kernel_d64<8, false, 2>);
     return (int)hipGetLastError();
 }
 
 }  // namespace vqvae
+
+#ifdef VQ_TRACE
+extern "C" VQVAE_API int vqvae_debug_vq_trace(void *host, size_t bytes) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(vqvae::g_vq_trace), bytes < sizeof(vqvae::g_vq_trace) ? bytes : sizeof(vqvae::g_vq_trace));
+}
+#endif
