@@ -97,7 +97,9 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
 
 #define VQVAE_VQ_UNITS64_8WAVES  0x100 /* vq_track_kernel_d64's launch form, forced (identical outputs; tests and A/B timing): 64-row units on */
 #define VQVAE_VQ_UNITS32_16WAVES 0x200 /* eight waves per CU / 32-row units on sixteen waves per CU (row-major rows, K <= 512).  Default: the
-                                        * sixteen-wave form where a wave gets at most two units (N <= 2 x 16 x CUs x 32 rows), else eight */
+                                        * 32-row units on eight waves up to 8 units per CU (every CU busy before any wave gets a second unit),
+                                        * the sixteen-wave form where a wave gets at most two units (N <= 2 x 16 x CUs x 32 rows), else 64-row
+                                        * units on eight waves */
 
 #define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
                                         kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 512, D = 64: z_e is
