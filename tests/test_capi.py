@@ -123,7 +123,8 @@ def test_host_side_plans_without_gpu():
     # quantizer dispatch (row-major flag 0x1): resident-image sweep for small codebooks, streamed image beyond, exact on request
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "unsupported"              # round 2's tracker (flags 0x10 / 0x20): removed in round 4
-    assert _lib.vq_kernel_name(1024, 64) == "vq_stream_sweep_kernel"
+    assert _lib.vq_kernel_name(1024, 64) == "vq_track_kernel_d64"                 # 128 KiB image beside four waves' tiles (round 4)
+    assert _lib.vq_kernel_name(1056, 64) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"
     assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_track_kernel_d64"           # NCHW rows (maps of 64 k pixels; round 4)

@@ -286,7 +286,10 @@ def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x10) == "unsupported"              # round 2's tracker kernel and its flags: removed in round 4
-    for K, D in ((640, 64), (1024, 64), (16384, 64), (64, 128), (8192, 128)):
+    for K, D in ((640, 64), (1024, 64)):               # the image still fits beside FOUR waves' 32-row tiles (round 4, second session)
+        assert _lib.vq_kernel_name(K, D) == "vq_track_kernel_d64", (K, D)
+        assert _lib.vq_sweeps(K, D) == 1
+    for K, D in ((1025, 64), (3000, 64), (16384, 64), (64, 128), (8192, 128)):
         assert _lib.vq_kernel_name(K, D) == "vq_stream_sweep_kernel", (K, D)
         assert _lib.vq_sweeps(K, D) == 1
     assert _lib.vq_kernel_name(8192, 128, 0x1 | 0x4) == "vq_exact_kernel"      # VQVAE_VQ_EXACT_SWEEP
@@ -294,7 +297,7 @@ def test_vq_stream_kernel_is_the_default_for_large_codebooks():
 
 
 @pytest.mark.parametrize("K,D,p,seed", [(640, 64, 11, 0), (1024, 64, 11, 1), (1024, 64, 11, 2), (2048, 128, 11, 3),
-                                        (8192, 128, 11, 4), (96, 128, 11, 5), (3000, 64, 8, 6)])
+                                        (8192, 128, 11, 4), (96, 128, 11, 5), (3000, 64, 8, 6), (1056, 64, 11, 7), (2048, 64, 11, 8)])
 def test_vq_stream_aligned_rounding_adversarial(K, D, p, seed):
     """tests/adversarial.py through the streamed-codebook kernel (vq_chunk.hip): several LDS chunks, several key
     epochs, D = 128, a K that is not a multiple of 32 -- every row bit for bit against the oracle."""
@@ -311,7 +314,7 @@ def test_vq_stream_aligned_rounding_adversarial(K, D, p, seed):
         np.testing.assert_array_equal(hist, ref["hist"])
 
 
-@pytest.mark.parametrize("K,D", [(1024, 64), (1500, 128)])
+@pytest.mark.parametrize("K,D", [(1024, 64), (2048, 64), (1500, 128)])      # (K = 1024 at D = 64: the stream-tracker kernel's four-wave form)
 def test_vq_stream_near_ties_duplicates_and_nonfinite_rows(K, D):
     """Everything the streamed kernel's task lists exist for: midpoints between codes of different key epochs (pair
     tasks), > 3 exact duplicates and near-duplicates (hard tasks), rows with NaN / Inf / beyond fp16's range (hard

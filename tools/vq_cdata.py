@@ -2,7 +2,7 @@
 """z_e rows of the reference-initialised model (BASELINE config 3 dims) + the reference's indices, as one binary file for the
 torch-free A/B harness tools/ubench/vq_ab.cpp:   int64 N, K, D | z (N, D) f32 | codebook (K, D) f32 | idx (N) int32.
 Computed on the CPU by oracle/torch_port.py (test infrastructure; this tool is a measurement aid, not product code).
-    python tools/vq_cdata.py [n_images=1024] [out=tools/data/vq_c3.bin]      (tools/data/ is not tracked; it travels with gpurun)"""
+    python tools/vq_cdata.py [n_images=1024] [out=tools/data/vq_c3.bin] [K=512]      (tools/data/ is not tracked; it travels with gpurun)"""
 import os, sys
 import numpy as np
 import torch
@@ -11,7 +11,8 @@ from oracle import torch_port as tp
 
 n_images = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 out = sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "vq_c3.bin")
-sd = tp.init_state_dict(128, 32, 512, 64, seed=0)
+K = int(sys.argv[3]) if len(sys.argv) > 3 else 512
+sd = tp.init_state_dict(128, 32, K, 64, seed=0)
 g = torch.Generator().manual_seed(1)
 with torch.no_grad():
     x = torch.randn(n_images, 3, 32, 32, generator=g)

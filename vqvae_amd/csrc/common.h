@@ -69,7 +69,7 @@ constexpr int kVqMaxGrid = 1024;     // persistent grid never exceeds this many 
 constexpr int kVqSlabRows = 1 << 18; // rows per pass of the streamed-codebook kernels (vq_chunk.hip): bounds their scratch
 constexpr int kVqGroupSlabs = 16;    // slabs whose open / hard rows are resolved by ONE launch (their records' scratch: 44.1 B per row of a group)
 
-bool vq_track_ok(int K, int D);          // vq_track.hip: the codebook's fp16 image fits LDS next to eight waves' tiles (D = 64, K <= ~600)
+bool vq_track_ok(int K, int D);          // vq_track.hip: the codebook's fp16 image fits LDS next to four waves' 32-row tiles (D = 64, K <= 1024; row-major rows)
 bool vq_chunk_ok(int K, int D);
 size_t vq_chunk_scratch_bytes(int D);
 

@@ -552,7 +552,7 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
         // NCHW (the module boundary): the stream-tracker kernel on maps whose pixel count is a multiple of 64 (8x8, 56x56, 64x64
         // ...: what this function answers for); other NCHW maps run vq_filter_kernel_d64
-        if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER)) && vq_track_ok(K, D))
+        if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER)) && vq_track_nchw_ok(K, D, 64))
             return "vq_track_kernel_d64";
         if (vq_plan(K, D).filter_ok) return "vq_filter_kernel_d64";
     }

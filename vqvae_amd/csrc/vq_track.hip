@@ -536,13 +536,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     VQ_TR(7);
 }
 
-size_t vq_track_lds_bytes(int K, int nw = 8) {        // nw = 16: one 32-row tile per unit and wave, nw = 8: two
+size_t vq_track_lds_bytes(int K, int nw = 8, int T = 2) {      // nw waves per CU, T 32-row tiles per unit (4 KiB of fp16 rows each)
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nw > 8 ? 4096 : 8192) + 1552);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * (4096 * T + 1552);
 }
 
-bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K, 8) <= (size_t)kLdsBytes; }
-bool vq_track_nchw_ok(int K, int D, int HW) { return vq_track_ok(K, D) && HW >= 64 && HW % 64 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll; }
+// K <= ~600: the image fits beside eight waves' 64-row tiles (every launch form below).  Up to K = 1024 (BASELINE config 4's codebook:
+// a 128 KiB image) it still fits beside FOUR waves' 32-row tiles -- one wave per SIMD, row-major rows only: 2.2x the rate of the
+// streamed-codebook kernels (vq_chunk.hip), which such codebooks took before (profiles/r04b_vq_timeline.txt section 5).
+static bool vq_track_fits8(int K) { return vq_track_lds_bytes(K, 8, 2) <= (size_t)kLdsBytes; }
+bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K, 4, 1) <= (size_t)kLdsBytes; }
+bool vq_track_nchw_ok(int K, int D, int HW) {
+    return D == 64 && K <= 1024 && vq_track_fits8(K) && HW >= 64 && HW % 64 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll;
+}
 
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out, int HW, bool nchw, int form) {
@@ -554,12 +560,14 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     // phases per unit, and four waves per SIMD overlap them four-fold.  With more units per wave the sweep's issue slots
     // dominate and the 64-row form (two tiles share every operand read, half the LDS traffic) wins.  form: 0 = this rule,
     // 8 / 16 = forced (A/B: tools/vq_ab4.py)
-    const bool fits16 = !nchw && vq_track_lds_bytes(K, 16) <= (size_t)kLdsBytes;
+    const bool fits16 = !nchw && vq_track_lds_bytes(K, 16, 1) <= (size_t)kLdsBytes;
+    const bool narrow = !vq_track_fits8(K);                                           // four waves, 32-row units (K up to 1024)
+    if (narrow && (nchw || !vq_track_ok(K, 64))) return VQVAE_ERR_UNSUPPORTED;
     const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
     // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
     // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
     const bool spread = form == 0 && !nchw && (N + 31) / 32 <= 8LL * cus;
-    const int NW = (wide && !spread) ? 16 : 8, RU = (wide || spread) ? 32 : 64;
+    const int NW = narrow ? 4 : ((wide && !spread) ? 16 : 8), RU = (narrow || wide || spread) ? 32 : 64;
     const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
     if (grid > cus) grid = cus;
@@ -576,13 +584,14 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
         // the extended launch only while profiling (it carries the dispatch's start / stop events); the plain one otherwise --
         // that is the form a stream capture (vqvae_amd/graph.py) records
         if (prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1))
-            hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, e0, e1, 0, z, cb, imgh, seeds, ee,
+            hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32), st, e0, e1, 0, z, cb, imgh, seeds, ee,
                                   wflags, N, K, p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
         else
-            hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW), st, z, cb, imgh, seeds, ee, wflags, N, K,
+            hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32), st, z, cb, imgh, seeds, ee, wflags, N, K,
                                p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
-    if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
+    if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
+    else if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
     else if (spread) launch(vq_track_kernel_d64<8, false, 1>);
     else if (wide) launch(vq_track_kernel_d64<16, false, 1>);
     else launch(vq_track_kernel_d64<8, false, 2>);
