@@ -566,7 +566,7 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
     // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
     // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
-    const bool spread = form == 0 && !nchw && (N + 31) / 32 <= 8LL * cus;
+    const bool spread = form == 0 && !nchw && (N + 31) / 32 <= 8LL * cus;     // (beyond that: 27.8 vs 27.4 us at 131 072 rows, 42.9 vs 40.0 at 262 144)
     const int NW = narrow ? 4 : ((wide && !spread) ? 16 : 8), RU = (narrow || wide || spread) ? 32 : 64;
     const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
