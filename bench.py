@@ -383,8 +383,9 @@ HPARAM_LEGS = {
              "main.py --n_embeddings 256, 32x32x3, D=64: the four fused conv kernels, quantizer inside the encoder's last kernel "
              "(32 KiB codebook image)"),
     "k1024": (128, 32, 2, 1024, 64, 4096,
-              "main.py --n_embeddings 1024, 32x32x3, D=64: the four fused conv kernels; the codebook image (128 KiB) does not fit beside "
-              "the conv stages in LDS, so z_e is written and the quantizer runs as its own kernel"),
+              "main.py --n_embeddings 1024, 32x32x3, D=64: the four fused conv kernels, quantizer inside the encoder's last kernel "
+              "(128 KiB codebook image streamed through the weight stages in eight parts; before the second session of round 4 "
+              "z_e was written and the streamed-codebook kernels quantized it)"),
 }
 
 

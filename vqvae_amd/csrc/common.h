@@ -140,7 +140,7 @@ bool res_pair_supported(int H, int W, int C, int Rh, int flags);
 // zero / zero_n (conv_res_pair_forward_impl only): ints the kernel clears for the next kernel of the stream
 // The quantizer inside the encoder's last kernel (conv_res_pair8_h2_kernel<2, true>, models/vqvae.py:33-34 in one launch):
 // the codebook's prepared images (vq_prepare_impl: fp16 image in that kernel's channel order, seeds, ||e||^2, bound
-// statistics), the codebook itself and where the quantizer's outputs go.  K32 must be a multiple of 128, K <= 512, D = 64.
+// statistics), the codebook itself and where the quantizer's outputs go.  K32 must be a multiple of 128, K <= 1024, D = 64.
 struct VqFuse {
     const uint4 *imgf; const float *seeds; const float *ee; const int *flags; const float *cb;
     int K, K32;

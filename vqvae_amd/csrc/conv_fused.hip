@@ -53,7 +53,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     __shared__ u32x4 Wb_all[2 * WBUF];
     // fused quantizer: per-wave tables (vq_unit.h), the workgroup's histogram and loss partials
     __shared__ __attribute__((aligned(16))) unsigned char vq_tab_all[VQ ? CRP_NW * 1040 : 16];
-    __shared__ int vq_hist_s[VQ ? 512 : 1];
+    __shared__ int vq_hist_s[VQ ? 1024 : 1];             // (K <= 1024: 32 code tiles = the tracker's 6-bit cell field; 2 x 80 384 B of LDS per CU)
     // the four weight tensors' per-output-channel scales 2^-kw[c]: front conv [0, 128), residual 3x3 [128, 160), residual 1x1
     // [160, 288), post conv [288, 288 + 32 NT3) (a stage barrier precedes every use)
     __shared__ __attribute__((aligned(16))) float dw_s[288 + 32 * (NT3 > 0 ? NT3 : 1)];
@@ -1259,7 +1259,7 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
     ConvGeom g3;
     if (post && (!post->packed || !post->out || !res_pair_post_supported(C, post->Cout) ||
                  make_geom(VQVAE_CONV_1x1, 1, 8, 8, C, post->Cout, 0, g3) != VQVAE_OK)) return VQVAE_ERR_UNSUPPORTED;
-    if (post && post->vq && (post->Cout != 64 || CRP_NW != 4 || post->vq->K32 % 128 || post->vq->K32 > 512 || !post->vq->partials))
+    if (post && post->vq && (post->Cout != 64 || CRP_NW != 4 || post->vq->K32 % 128 || post->vq->K32 > 1024 || !post->vq->partials))
         return VQVAE_ERR_UNSUPPORTED;
     prof_begin(VQVAE_PROF_RES_LAYER, st);
     if (post) {

@@ -585,7 +585,7 @@ int vqvae_vq_forward_f32(const float *z_e, const float *codebook, int64_t B, int
 bool vqvae::vq_fuse_ok(int K, int D, int64_t B, int flags) {
     const VqPlan p = vq_plan(K > 0 ? K : 1, 64);
     (void)B;
-    return D == 64 && K >= 1 && K <= 512 && p.K32 % 128 == 0 && vq_track_ok(K, D) &&
+    return D == 64 && K >= 1 && K <= 1024 && p.K32 % 128 == 0 && vq_track_ok(K, D) &&
            !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_UNFUSED));
 }
 
