@@ -650,21 +650,30 @@ def test_step_in_parts_on_side_streams_equals_the_single_call(B, parts):
     assert c[0].item() == a[0].item() and torch.equal(c[1].view(torch.int32), a[1].view(torch.int32))
 
 
-@pytest.mark.parametrize("B", [4096, 37, 1, 5000])
-def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B):
+@pytest.mark.parametrize("B,K", [(4096, 512), (37, 512), (1, 512), (5000, 512), (4096, 1024), (37, 1024), (4096, 256), (130, 128)])
+def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B, K):
     """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the
     encoder's last kernel (conv_res_pair8_h2_kernel<2, true>: z_e never leaves the chip).  Same z_e bits, same tracker,
     same exact part as the separate launch (VQVAE_VQ_UNFUSED): indices and x_hat must be BITWISE equal, loss / perplexity
-    equal to summation order (rtol 1e-6); ragged batches leave waves of the four-image workgroups idle."""
-    from vqvae_amd import functional as F
+    equal to summation order (rtol 1e-6); ragged batches leave waves of the four-image workgroups idle.  Round 4: every
+    codebook of 128 k codes up to K = 1024 (eight 128-code parts through the weight stages); the profile hooks say which
+    form ran -- no stand-alone quantizer launch in the fused forward, one in the other."""
+    from vqvae_amd import _lib, functional as F
     from vqvae_amd.modules import VQVAE
     torch.manual_seed(0)
-    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    m = VQVAE(128, 32, 2, K, 64, 0.25).eval().to(dev())
     x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).to(dev())
     with torch.no_grad():
+        m._forward_c(x, want_idx=True)                       # (packs the weights, prepares the codebook)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
         a = m._forward_c(x, want_idx=True)
+        n_fused = _lib.profile_collect('vq_main')[1]
         b = m._forward_c(x, want_idx=True, vq_flags=F.VQ_UNFUSED)
+        n_unfused = _lib.profile_collect('vq_main')[1]
+        _lib.profile_enable(False)
     torch.cuda.synchronize()
+    assert (n_fused, n_unfused) == (0, 1), (n_fused, n_unfused)
     assert torch.equal(a[3], b[3]), f"{int((a[3] != b[3]).sum())} indices differ"
     assert torch.equal(a[1], b[1])
     np.testing.assert_allclose(a[0].item(), b[0].item(), rtol=1e-6)
