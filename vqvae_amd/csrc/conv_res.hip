@@ -536,7 +536,12 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         }
     };
     const u32x4 *w1v = w1img + h * 32 + l31;
+    // (RES_KO_*: timing-only knock-outs of one resource each -- wrong results; tools/build_src_variant.sh, tools/ubench/enc_ab.cpp,
+    // profiles/r04b_halo_knockouts.txt: epilogue 28 %, these per-wave weight loads 21 %, the slice preparation 12 %, the operand reads 5 %)
     auto load_w = [&](int tap, int sl, u32x4(&bw)[2]) {
+#ifdef RES_KO_W
+        if (sl > 0 || tap > 2) { asm volatile("" : "+v"(bw[0]), "+v"(bw[1])); return; }
+#endif
         const u32x4 *p = w1v + (size_t)(tap * cpt + (sl >> 1)) * 256 + (sl & 1) * 64;
         bw[0] = p[0]; bw[1] = p[128];
     };
@@ -561,10 +566,16 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         xscale = __builtin_ldexpf(1.0f, kx);
         d1 = __builtin_ldexpf(1.0f, -kx) * h2_dw(hdr1)[l31];          // this lane's hidden channel: 2^-(kx + kw1[n])
     }
+#ifdef RES_KO_SREAD
+    u32x4 Skeep[2][2] = {};
+#endif
     load_raw(0);
     load_w(0, 0, bw[0]);
     load_w(1, 0, bw[1]);
     auto slice = [&](int sl) {
+#ifdef RES_KO_SLICE
+        if (sl == 0)
+#endif
         {
             u32x4 t1a[2], t2a[2], t1b[2], t2b[2];
 #pragma unroll
@@ -594,11 +605,18 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
             else if (sl + 1 < nslice) load_w(tap + 2 - 9, sl + 1, bw[nxt]);
             const int shift = (tap / 3 - 1) * PW + (tap % 3 - 1);
             u32x4 S[MT][2];
+#ifdef RES_KO_SREAD
+            if (tap == 0)
+                for (int mt = 0; mt < MT; ++mt) { const u32x4 *ap = As + h * HP + spx[mt] + shift; Skeep[mt][0] = ap[0]; Skeep[mt][1] = ap[HP * 2]; }
+            for (int mt = 0; mt < MT; ++mt) { S[mt][0] = Skeep[mt][0]; S[mt][1] = Skeep[mt][1]; }
+            asm volatile("" : "+v"(Skeep[0][0]), "+v"(Skeep[0][1]), "+v"(Skeep[1][0]), "+v"(Skeep[1][1]));
+#else
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const u32x4 *ap = As + h * HP + spx[mt] + shift;
                 S[mt][0] = ap[0]; S[mt][1] = ap[HP * 2];
             }
+#endif
             prod3x2(S[0][0], S[0][1], S[1][0], S[1][1], bw[cur][0], bw[cur][1], acc1[0], acc1[1]);
         }
     };
@@ -696,6 +714,10 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
                 }
             }
         };
+#ifdef RES_KO_EPI
+        if (H1[0][0].x == 0x12345u) out[lane] = __uint_as_float(Hb[1][1].y ^ H1[1][0].z ^ Hb[0][0].w ^ H1[0][1].x ^ Hb[0][1].x ^ Hb[1][0].x ^ H1[1][1].x);
+        else if (false)
+#endif
         if (relu_in && relu_out) finish(std::true_type{}, std::true_type{});
         else if (relu_in) finish(std::true_type{}, std::false_type{});
         else if (relu_out) finish(std::false_type{}, std::true_type{});
