@@ -282,6 +282,25 @@ def test_vq_few_rows_take_the_eight_wave_32_row_form_bit_exact(B):
     np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
 
 
+@pytest.mark.parametrize("B,H,W", [(5, 4, 8), (300, 8, 12), (1500, 12, 8), (1024, 8, 8), (1030, 8, 8)],
+                         ids=["hw32", "hw96", "hw96_144000rows", "hw64_last_of_the_rule", "hw64_first_past_it"])
+def test_vq_nchw_units_of_32_positions_bit_exact(B, H, W):
+    """The module's own NCHW layout on the stream-tracker kernel with units of 32 positions of one image (round 4, second
+    session): maps whose pixel count is a multiple of 32 but not of 64 at any row count, and 8x8 maps while the rule for few rows
+    holds (the 64-position form beyond it) -- against the oracle, bit for bit."""
+    from vqvae_amd import _lib
+    assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_track_kernel_d64"
+    g = torch.Generator().manual_seed(900 + B + H)
+    K, D = 512, 64
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, H, W, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25, n_chunks=min(B, 64))
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, False)
+    np.testing.assert_array_equal(idx, ref_idx)
+    assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+    np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
+
+
 def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"

@@ -42,6 +42,18 @@ int main(int argc, char **argv) {
         for (int c = 0; c < D; ++c) {
             const float zz = z0[r * D + c]; volatile float d = cb[(size_t)idx0[r] * D + c] - zz; zq0[r * D + c] = zz + d;
         }
+    // VQ_AB_NCHW=1: the module's own (B, D, 8, 8) layout in and out (flags without VQVAE_VQ_ROWMAJOR): images of 64 consecutive rows
+    const bool nchw = getenv("VQ_AB_NCHW") && atoi(getenv("VQ_AB_NCHW"));
+    if (nchw) {
+        auto to_nchw = [&](std::vector<float> &v) {
+            std::vector<float> t(v.size());
+            for (int64_t b = 0; b < N0 / 64; ++b)
+                for (int pos = 0; pos < 64; ++pos)
+                    for (int c = 0; c < D; ++c) t[(size_t)(b * D + c) * 64 + pos] = v[(size_t)(b * 64 + pos) * D + c];
+            v.swap(t);
+        };
+        to_nchw(z0); to_nchw(zq0);
+    }
     std::vector<Lib> libs;
     for (int i = 3; i < argc; ++i) {
         Lib L; L.name = argv[i];
@@ -72,7 +84,7 @@ int main(int argc, char **argv) {
         for (size_t l = 0; l < libs.size(); ++l) { wsb[l] = libs[l].ws(N, K, D); CK(hipMalloc(&wss[l], wsb[l])); }
         std::vector<float> hzq((size_t)N0 * D); std::vector<int64_t> hidx(N0);
         for (int form : forms) {
-            const int fl = 0x1 | (form == 8 ? 0x100 : form == 16 ? 0x200 : 0);
+            const int fl = (nchw ? 0x0 : 0x1) | (form == 8 ? 0x100 : form == 16 ? 0x200 : 0);
             std::vector<std::vector<float>> ts(libs.size());
             std::vector<int> ok(libs.size(), 1);
             // correctness + warm-up

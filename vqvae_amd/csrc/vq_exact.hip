@@ -467,7 +467,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
     }
     const bool rowmajor = flags & VQVAE_VQ_ROWMAJOR;
     if constexpr (D == 64) {
-        // NCHW maps whose pixel count is a multiple of 64 (a unit = 64 positions of one image): the stream-tracker kernel reads
+        // NCHW maps whose pixel count is a multiple of 32 (a unit = 64 or 32 positions of one image): the stream-tracker kernel reads
         // and writes the reference's own layout (round 4); other NCHW maps stay on the two-sweep kernel below
         const bool track_nchw = !rowmajor && vq_track_nchw_ok(K, D, HW) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER));
         if (track_nchw || (rowmajor && vq_track_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
@@ -550,7 +550,7 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_track_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_track_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
-        // NCHW (the module boundary): the stream-tracker kernel on maps whose pixel count is a multiple of 64 (8x8, 56x56, 64x64
+        // NCHW (the module boundary): the stream-tracker kernel on maps whose pixel count is a multiple of 32 (8x8, 56x56, 64x64
         // ...: what this function answers for); other NCHW maps run vq_filter_kernel_d64
         if (!(flags & (VQVAE_VQ_ROWMAJOR | VQVAE_VQ_BF16_FILTER)) && vq_track_nchw_ok(K, D, 64))
             return "vq_track_kernel_d64";

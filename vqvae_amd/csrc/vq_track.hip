@@ -69,7 +69,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     long long N, int K, int K32, long long nunits, float *__restrict__ zq, long long *__restrict__ idx,
     int *__restrict__ hist, double *__restrict__ partials, int HW, int pool_pct) {
     constexpr int D = 64, RU = 32 * T;
-    static_assert(!NCHW || T == 2, "the NCHW form turns a 32 x 64 fp32 block around in an 8 KiB tile: 64-row units only");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int ntile = K32 >> 5;
     uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                                  // [ntile][4][2][32] x 16 B
@@ -81,7 +80,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int TILEB = 4096 * T, TABB = 1552;
+    constexpr int TILEB = NCHW ? 8192 : 4096 * T, TABB = 1552;      // (NCHW: a 32 x 64 fp32 block is turned around in the tile, one row tile at a time)
     unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);                // the unit's fp16 rows; later 16 fp32 row slots
     unsigned char *tab_s = tile_s + TILEB;
 #ifdef VQ_TRACE
@@ -536,9 +535,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     VQ_TR(7);
 }
 
-size_t vq_track_lds_bytes(int K, int nw = 8, int T = 2) {      // nw waves per CU, T 32-row tiles per unit (4 KiB of fp16 rows each)
+size_t vq_track_lds_bytes(int K, int nw = 8, int T = 2, bool nchw = false) {      // nw waves per CU, T 32-row tiles per unit (4 KiB of fp16 rows each; NCHW: 8 KiB)
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * (4096 * T + 1552);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nchw ? 8192 : 4096 * T) + 1552);
 }
 
 // K <= ~600: the image fits beside eight waves' 64-row tiles (every launch form below).  Up to K = 1024 (BASELINE config 4's codebook:
@@ -546,8 +545,9 @@ size_t vq_track_lds_bytes(int K, int nw = 8, int T = 2) {      // nw waves per C
 // streamed-codebook kernels (vq_chunk.hip), which such codebooks took before (profiles/r04b_vq_timeline.txt section 5).
 static bool vq_track_fits8(int K) { return vq_track_lds_bytes(K, 8, 2) <= (size_t)kLdsBytes; }
 bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K, 4, 1) <= (size_t)kLdsBytes; }
+// NCHW maps: a unit is 64 consecutive positions of ONE image, or 32 (maps whose pixel count is a multiple of 32 only, and few rows)
 bool vq_track_nchw_ok(int K, int D, int HW) {
-    return D == 64 && K <= 1024 && vq_track_fits8(K) && HW >= 64 && HW % 64 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll;
+    return D == 64 && K <= 1024 && vq_track_fits8(K) && HW >= 32 && HW % 32 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll;
 }
 
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
@@ -566,7 +566,9 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
     const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
     // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
     // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
-    const bool spread = form == 0 && !nchw && (N + 31) / 32 <= 8LL * cus;     // (beyond that: 27.8 vs 27.4 us at 131 072 rows, 42.9 vs 40.0 at 262 144)
+    // (beyond that: 27.8 vs 27.4 us at 131 072 rows, 42.9 vs 40.0 at 262 144).  NCHW maps take the same form then -- and always when
+    // their pixel count is a multiple of 32 but not of 64
+    const bool spread = (form == 0 && (N + 31) / 32 <= 8LL * cus) || (nchw && HW % 64 != 0);
     const int NW = narrow ? 4 : ((wide && !spread) ? 16 : 8), RU = (narrow || wide || spread) ? 32 : 64;
     const long long nunits = (N + RU - 1) / RU;
     long long grid = (nunits + NW - 1) / NW;
@@ -584,13 +586,14 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
         // the extended launch only while profiling (it carries the dispatch's start / stop events); the plain one otherwise --
         // that is the form a stream capture (vqvae_amd/graph.py) records
         if (prof_dispatch(VQVAE_PROF_VQ_MAIN, &e0, &e1))
-            hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32), st, e0, e1, 0, z, cb, imgh, seeds, ee,
+            hipExtLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32, nchw), st, e0, e1, 0, z, cb, imgh, seeds, ee,
                                   wflags, N, K, p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
         else
-            hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32), st, z, cb, imgh, seeds, ee, wflags, N, K,
+            hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32, nchw), st, z, cb, imgh, seeds, ee, wflags, N, K,
                                p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
     if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
+    else if (nchw && spread) launch(vq_track_kernel_d64<8, true, 1>);
     else if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
     else if (spread) launch(vq_track_kernel_d64<8, false, 1>);
     else if (wide) launch(vq_track_kernel_d64<16, false, 1>);

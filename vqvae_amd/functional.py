@@ -49,7 +49,7 @@ def vq_forward(z_e: torch.Tensor, codebook: torch.Tensor, beta: float, *, rowmaj
     Returns (loss 0-dim, z_q like z_e or None, perplexity 0-dim, idx (N,1) int64, hist (K,) int32).
     exact_sweep=True forces the exhaustive fp32-MFMA kernel, bf16_filter=True round 1's two-sweep bf16 filter
     kernel, instead of the default (single-sweep fp16 screen with the stream tracker: D=64 rows, row-major or NCHW maps of
-    64 k pixels); all three produce identical bits, the flags exist for testing and A/B timing.  form: 8 / 16 forces the
+    32 k pixels); all three produce identical bits, the flags exist for testing and A/B timing.  form: 8 / 16 forces the
     stream-tracker kernel's launch form (64-row units on eight waves / 32-row units on sixteen waves per CU; 0 = by row count).
     """
     _check_dev("z_e", z_e)
