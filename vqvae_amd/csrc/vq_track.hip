@@ -1,5 +1,6 @@
 // Fused VectorQuantizer forward for gfx950, round 3: single-sweep fp16 screen with a STREAM TRACKER, exact refine
-// (D = 64, row-major rows, K <= 512 so that the codebook image stays resident in LDS next to eight waves' tiles).
+// (D = 64; the codebook's fp16 image resident in LDS next to the waves' row tiles: K <= ~600 beside eight or sixteen waves' tiles,
+// row-major rows or the module's own NCHW layout; up to K = 1024 beside four waves' tiles, row-major rows).
 //
 // Same contract and the same bits out as vq_exact.hip (indices and z_q bit-identical to the reference,
 // models/quantizer.py:45-74).  What changes against round 2's vq_sweep_kernel_d64 -- which was bound by vector-instruction
@@ -37,7 +38,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 using vqu::lds_order_wave;
 
-// Debug builds (tools/build_variant.py NAME -DVQ_TRACE, tools/ubench/vq_ab.cpp): absolute 100 MHz stamps of every wave --
+// Debug builds (tools/build_vq_variant.sh NAME -DVQ_TRACE, tools/ubench/vq_ab.cpp): absolute 100 MHz stamps of every wave --
 // [0] wave start, [1] past the prologue's barrier, [2..5] end of its first four units, [6] loop exit, [7] last instruction
 #ifdef VQ_TRACE2                 // slots 2..5 = end of the sweep / classification / exact part / epilogue of the wave's FIRST unit
 #define VQ_TRACE 1
@@ -53,8 +54,8 @@ __device__ unsigned long long g_vq_trace[4096 * 8];
 // every codebook operand and seed read from LDS; its first unit is static, later units come from an LDS ticket.  Rows stay
 // in registers in the coalesced load layout (16 lanes x 16 bytes per row) from load to store: HBM traffic is the
 // algorithmic 520 B per row.
-// NCHW (round 4): z / z_q are (B, 64, HW) with HW % 64 == 0 -- the reference's own module boundary (models/quantizer.py:45-46
-// and :74 are its two permute + copy passes).  A unit is 64 consecutive positions of ONE image.  Per row tile the wave reads 8
+// NCHW (round 4): z / z_q are (B, 64, HW) with HW % 32 == 0 -- the reference's own module boundary (models/quantizer.py:45-46
+// and :74 are its two permute + copy passes).  A unit is 64 (HW % 64 == 0) or 32 consecutive positions of ONE image.  Per row tile the wave reads 8
 // channels x 32 positions per instruction (16 bytes per lane = four positions of one channel, whole 128-byte lines), turns the
 // 32 x 64 fp32 block around in its 8 KiB LDS tile (conflict-free both ways: 16-byte chunk c >> 2 of row r sits at slot
 // (c >> 2) ^ (r >> 2)) and continues in the row-major register layout; z_q takes the same way back.  Everything between is the
@@ -62,6 +63,9 @@ __device__ unsigned long long g_vq_trace[4096 * 8];
 // T (round 4): 32-row tiles per unit.  2 = 64-row units on eight waves per CU (the two tiles share every codebook operand read);
 // 1 = 32-row units on SIXTEEN waves per CU (<= 128 registers per lane): four waves per SIMD interleave their latency-bound phases
 // (classification, exact part, epilogue, row loads) with each other's sweeps -- what pays when a wave has only one or two units.
+// Launch forms <NW, NCHW, T> (launch_vq_track_d64 has the rule): <8, ., 2> many rows; <16, false, 1> up to two 32-row units per wave
+// (BASELINE config 3); <8, ., 1> up to 8 units per CU (config 2: every CU busy before any wave gets a second unit) and NCHW maps of
+// 32 (2 k + 1) pixels; <4, false, 1> codebooks whose image only fits beside four waves' tiles (K up to 1024: config 4).
 template <int NW, bool NCHW = false, int T = 2>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
@@ -395,7 +399,6 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         //   hard rows: the row tile's screen is run again with the row's now-known threshold and every code at or above
         //       it becomes a task (same accumulators as in the sweep)
         //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
-#define VQ_PRE
         {
             vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
             int ntasks = FL.ndirect;
