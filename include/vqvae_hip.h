@@ -102,7 +102,7 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
                                         * units on eight waves */
 
 #define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
-                                        kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 512, D = 64: z_e is
+                                        kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 128 k <= 1024, D = 64: z_e is
                                         then never written); identical outputs, A/B timing and tests */
 
 /* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" (codebook image resident in LDS: D = 64,
@@ -464,7 +464,7 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
                                 vqvae_stream_t stream);
 
 /* The same step in PARTS, for callers that spread a large batch over several streams (the default shapes' path only: 32x32
- * images, h_dim 128, two residual layers, K = 512, D = 64; VQVAE_ERR_UNSUPPORTED otherwise -- use vqvae_forward_f32):
+ * images, h_dim 128, two residual layers, K a multiple of 128 up to 1024, D = 64; VQVAE_ERR_UNSUPPORTED otherwise -- use vqvae_forward_f32):
  *   vqvae_forward_begin_f32   codebook images + cleared histogram, on `stream`;
  *   vqvae_forward_part_f32    images [b0, b0 + Bc) of the batch of B, on ANY stream ordered behind the begin (b0 and every Bc
  *                             but the last multiples of 64); x, x_hat, idx and both workspaces are the WHOLE batch's, as
