@@ -355,7 +355,7 @@ def other_workload(name, torch, dev, seconds=1.0):
         t_vq = vq_ms / vq_n * 1e-3
         # (VQVAE.forward hands the quantizer row-major rows with BOTH conv backends -- the torch backend permutes z_e itself,
         # vqvae_amd/conv.py -- so the kernel is the row-major one; round 3 printed the NCHW kernel's name here by mistake)
-        res["vq"] = {"kernel": _lib.vq_kernel_name(K, D, 0x1), "avg_kernel_us": round(t_vq * 1e6, 2),
+        res["vq"] = {"kernel": _lib.vq_kernel_instance(rows, K, D, (HW // 4) ** 2, 0x1), "avg_kernel_us": round(t_vq * 1e6, 2),
                      "hbm_GBps": round(rows * (8 * D + 8) / t_vq / 1e9, 1),
                      "hbm_frac": round(rows * (8 * D + 8) / t_vq / 1e9 / HBM_PEAK_GBPS, 4),
                      # at K >= 1024 the screen is matrix-bound, not HBM-bound
@@ -680,7 +680,7 @@ def main():
                 alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
                 achieved = alg_bytes / t_vq / 1e9
                 line["roofline"] = {
-                    "kernel": _lib.vq_kernel_name(K, D, 0x1) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
+                    "kernel": _lib.vq_kernel_instance(rows, K, D, (H // 4) * (W // 4), 0x1) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
                               "fp32 refine of the surviving codes; bit-exact indices)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),

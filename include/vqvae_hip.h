@@ -30,11 +30,13 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 7   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+#define VQVAE_HIP_ABI_VERSION 8   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
                                     4: forward in parts (begin / part / end), residual layer with hidden output, larger
                                        weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions);
                                     5-6: round 4's headers in front of the two-term images, whole-path product flags, removed
-                                       quantizer flags; 7: data-gradient epilogues (vqvae_conv_forward_ep_f32) */
+                                       quantizer flags; 7: data-gradient epilogues (vqvae_conv_forward_ep_f32);
+                                    8: vqvae_vq_launch_form, unit counters in the quantizer workspace (its size changed: ask
+                                       vqvae_vq_workspace_bytes), K up to 1024 on the resident-image and the fused quantizer */
 
 #define VQVAE_OK               0
 #define VQVAE_ERR_NULL        -1   /* a required pointer is NULL                       */
@@ -112,6 +114,11 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
  * cores per row (0 for the exact-fp32 kernel).  For reporting (bench.py). */
 VQVAE_API const char *vqvae_vq_kernel_name(int K, int D, int flags);
 VQVAE_API int vqvae_vq_screen_sweeps(int K, int D, int flags);
+/* Where vqvae_vq_kernel_name says "vq_track_kernel_d64": the launch form that kernel takes for n_rows rows (HW = pixels per image,
+ * which matters for NCHW maps only) on the CURRENT device -- waves per CU (4 / 8 / 16), rows per unit (32 / 64) and the share of
+ * the units (per cent) that waves draw from per-group pools at the end; VQVAE_ERR_UNSUPPORTED where another kernel runs.
+ * For reporting and tests (bench.py names the template instance that ran). */
+VQVAE_API int vqvae_vq_launch_form(int64_t n_rows, int K, int D, int HW, int flags, int *waves, int *unit_rows, int *pool_pct);
 
 /* Bytes of workspace vqvae_vq_forward_f32 needs (any number of rows: the streamed-codebook kernels work through the rows
  * in slabs of 2^18 and resolve the open rows of up to sixteen slabs per launch, so their scratch -- 221 MB at D = 64,

@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(lib):
     lib.vqvae_strerror.restype = ctypes.c_char_p
     lib.vqvae_vq_workspace_bytes.restype = ctypes.c_size_t
     lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
-    assert lib.vqvae_abi_version() == 7
+    assert lib.vqvae_abi_version() == 8
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
     assert b"NULL" in lib.vqvae_strerror(-1)
@@ -130,6 +130,21 @@ def test_host_side_plans_without_gpu():
     assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_track_kernel_d64"           # NCHW rows (maps of 64 k pixels; round 4)
     assert _lib.vq_kernel_name(1024, 64, 0x0) == "vq_filter_kernel_d64"         # NCHW, codebook beyond the LDS-resident image
     assert _lib.vq_kernel_name(512, 256) == "vq_exact_kernel"
+    # the stream-tracker kernel's launch forms (256 CUs assumed where no device is present): config 2 / config 3 / many rows / K = 1024 /
+    # the module's NCHW layout; the rule scales with the CU count, so only sizes far from its edges are pinned here
+    cus = 256
+    assert _lib.vq_launch_form(8 * cus * 32, 512, 64) == (8, 32, 0)               # BASELINE config 2 on 256 CUs: 32-row units, eight waves
+    assert _lib.vq_launch_form(32 * cus * 32, 512, 64) == (16, 32, 0)             # config 3: sixteen waves
+    assert _lib.vq_launch_form(256 * cus * 32, 512, 64) == (8, 64, 25)            # many rows: 64-row units, pooled tail
+    assert _lib.vq_launch_form(32 * cus * 32, 1024, 64) == (4, 32, 25)            # config 4's codebook: four waves (eight units per wave here: pooled tail)
+    assert _lib.vq_launch_form(256 * cus * 32, 1024, 64)[:2] == (4, 32)
+    assert _lib.vq_launch_form(8 * cus * 32, 512, 64, 64, 0x0) == (8, 32, 0)      # NCHW 8x8 maps, few rows
+    assert _lib.vq_launch_form(256 * cus * 32, 512, 64, 64, 0x0)[:2] == (8, 64)
+    assert _lib.vq_launch_form(256 * cus * 32, 512, 64, 96, 0x0)[:2] == (8, 32)   # 32 (2 k + 1) pixels: 32-position units at any size
+    assert _lib.vq_launch_form(4096, 512, 64, 49, 0x0) is None                    # 7x7 maps: another kernel
+    assert _lib.vq_launch_form(4096, 1024, 64, 64, 0x0) is None and _lib.vq_launch_form(4096, 2048, 64) is None
+    assert _lib.vq_launch_form(32 * cus * 32, 512, 64, 64, 0x1 | 0x100) == (8, 64, 0)     # forced forms
+    assert _lib.vq_kernel_instance(32 * cus * 32, 512, 64) == "vq_track_kernel_d64<16, false, 1>"
     assert _lib.vq_sweeps(512, 64) == 1 and _lib.vq_sweeps(512, 64, 0x1 | 0x8) == 2 and _lib.vq_sweeps(512, 256) == 0
     # the streamed kernels' scratch does not grow with the row count (slabs of 2^18 rows)
     a, b = L.vqvae_vq_workspace_bytes(1000, 8192, 128), L.vqvae_vq_workspace_bytes(10 ** 8, 8192, 128)

@@ -49,6 +49,7 @@ SIGNATURES = {
     "vqvae_calibration_mfma_f16": (_i32, [_i32, _vp, _sz, _vp]),
     "vqvae_vq_kernel_name": (C.c_char_p, [_i32, _i32, _i32]),
     "vqvae_vq_screen_sweeps": (_i32, [_i32, _i32, _i32]),
+    "vqvae_vq_launch_form": (_i32, [_i64, _i32, _i32, _i32, _i32, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "vqvae_vq_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "vqvae_vq_forward_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -125,7 +126,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
-    if lib.vqvae_abi_version() != 7:
+    if lib.vqvae_abi_version() != 8:
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -146,6 +147,24 @@ def vq_kernel_name(K: int, D: int, flags: int = 0x1) -> str:
 
 def vq_sweeps(K: int, D: int, flags: int = 0x1) -> int:
     return load().vqvae_vq_screen_sweeps(K, D, flags)
+
+
+def vq_launch_form(n_rows: int, K: int, D: int, HW: int = 64, flags: int = 0x1):
+    """(waves per CU, rows per unit, pooled tail units in per cent) of vq_track_kernel_d64 for this problem on the current device,
+    or None where another kernel runs"""
+    w, r, p = _i32(), _i32(), _i32()
+    if load().vqvae_vq_launch_form(n_rows, K, D, HW, flags, C.byref(w), C.byref(r), C.byref(p)) != 0:
+        return None
+    return w.value, r.value, p.value
+
+
+def vq_kernel_instance(n_rows: int, K: int, D: int, HW: int = 64, flags: int = 0x1) -> str:
+    """the kernel's name with the template instance that runs for n_rows rows, e.g. vq_track_kernel_d64<16, false, 1>"""
+    name = vq_kernel_name(K, D, flags)
+    f = vq_launch_form(n_rows, K, D, HW, flags)
+    if f is None:
+        return name
+    return f"{name}<{f[0]}, {'false' if flags & 0x1 else 'true'}, {f[1] // 32}>" + (f" (last {f[2]} % of the units pooled)" if f[2] else "")
 
 
 PROF_IDS = {"vq_main": 0, "conv_igemm": 1, "res_layer": 2, "conv_in": 3, "conv_out": 4}

@@ -116,6 +116,8 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 
 // vq_track.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel with the stream tracker (D = 64; row-major rows or NCHW)
 bool vq_track_nchw_ok(int K, int D, int HW);       // NCHW input: maps whose pixel count is a multiple of 64
+struct VqTrackForm { int waves, unit_rows, grid, pool_pct; long long nunits; };     // waves per CU, rows per unit, workgroups, pooled tail units (%)
+bool vq_track_form(long long N, int K, int HW, bool nchw, int form, int cus, VqTrackForm &f);      // false: the kernel does not take this problem
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
                         char *ws, hipStream_t st, int *grid_out, int HW = 0, bool nchw = false, int form = 0);
 void launch_vq_prepare16(const float *cb, int K, int D, char *ws, hipStream_t st);

@@ -561,6 +561,20 @@ const char *vqvae_vq_kernel_name(int K, int D, int flags) {
     return "vq_exact_kernel";
 }
 
+int vqvae_vq_launch_form(int64_t n_rows, int K, int D, int HW, int flags, int *waves, int *unit_rows, int *pool_pct) {
+    if (n_rows < 1 || K < 1 || HW < 1) return VQVAE_ERR_SHAPE;
+    const char *n = vqvae_vq_kernel_name(K, D, flags);
+    VqTrackForm f;
+    const bool nchw = !(flags & VQVAE_VQ_ROWMAJOR);
+    if (D != 64 || n[3] != 't' || !vq_track_form(n_rows, K, HW, nchw, (flags & VQVAE_VQ_UNITS32_16WAVES) ? 16 : ((flags & VQVAE_VQ_UNITS64_8WAVES) ? 8 : 0),
+                                                  num_cus(), f))
+        return VQVAE_ERR_UNSUPPORTED;
+    if (waves) *waves = f.waves;
+    if (unit_rows) *unit_rows = f.unit_rows;
+    if (pool_pct) *pool_pct = f.pool_pct;
+    return VQVAE_OK;
+}
+
 int vqvae_vq_screen_sweeps(int K, int D, int flags) {
     const char *n = vqvae_vq_kernel_name(K, D, flags);
     return (n[3] == 's' || n[3] == 't') ? 1 : (n[3] == 'f' ? 2 : 0);

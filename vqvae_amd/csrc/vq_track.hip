@@ -553,32 +553,42 @@ bool vq_track_nchw_ok(int K, int D, int HW) {
     return D == 64 && K <= 1024 && vq_track_fits8(K) && HW >= 32 && HW % 32 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll;
 }
 
-int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
-                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw, int form) {
-    const VqPlan p = vq_plan(K, 64);
-    const int cus = num_cus();
-    if (nchw && !vq_track_nchw_ok(K, 64, HW)) return VQVAE_ERR_UNSUPPORTED;          // a unit = 64 positions of ONE image
+// The launch form of vq_track_kernel_d64<NW, NCHW, T> for a problem (also behind vqvae_vq_launch_form, include/vqvae_hip.h).
+bool vq_track_form(long long N, int K, int HW, bool nchw, int form, int cus, VqTrackForm &f) {
+    if (nchw ? !vq_track_nchw_ok(K, 64, HW) : !vq_track_ok(K, 64)) return false;     // (NCHW: a unit = 64 or 32 positions of ONE image)
     // Sixteen waves per CU with 32-row units where a wave gets at most two of them (N <= 2 x 16 x CUs x 32 rows: BASELINE
-    // configs 2 and 3) and the codebook image leaves room for sixteen 4 KiB tiles: the kernel is a chain of latency-bound
+    // config 3) and the codebook image leaves room for sixteen 4 KiB tiles: the kernel is a chain of latency-bound
     // phases per unit, and four waves per SIMD overlap them four-fold.  With more units per wave the sweep's issue slots
     // dominate and the 64-row form (two tiles share every operand read, half the LDS traffic) wins.  form: 0 = this rule,
-    // 8 / 16 = forced (A/B: tools/vq_ab4.py)
+    // 8 / 16 = forced (A/B: tools/ubench/vq_ab.cpp)
     const bool fits16 = !nchw && vq_track_lds_bytes(K, 16, 1) <= (size_t)kLdsBytes;
     const bool narrow = !vq_track_fits8(K);                                           // four waves, 32-row units (K up to 1024)
-    if (narrow && (nchw || !vq_track_ok(K, 64))) return VQVAE_ERR_UNSUPPORTED;
     const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
     // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
     // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
     // (beyond that: 27.8 vs 27.4 us at 131 072 rows, 42.9 vs 40.0 at 262 144).  NCHW maps take the same form then -- and always when
     // their pixel count is a multiple of 32 but not of 64
     const bool spread = (form == 0 && (N + 31) / 32 <= 8LL * cus) || (nchw && HW % 64 != 0);
-    const int NW = narrow ? 4 : ((wide && !spread) ? 16 : 8), RU = (narrow || wide || spread) ? 32 : 64;
-    const long long nunits = (N + RU - 1) / RU;
-    long long grid = (nunits + NW - 1) / NW;
+    f.waves = narrow ? 4 : ((wide && !spread) ? 16 : 8);
+    f.unit_rows = (narrow || wide || spread) ? 32 : 64;
+    f.nunits = (N + f.unit_rows - 1) / f.unit_rows;
+    long long grid = (f.nunits + f.waves - 1) / f.waves;
     if (grid > cus) grid = cus;
     if (grid > kVqMaxGrid) grid = kVqMaxGrid;
-    *grid_out = (int)grid;
-    const int pool_pct = nunits >= 4 * grid * NW ? 25 : 0;     // (see the kernel: the pooled tail pays from four units per wave on)
+    f.grid = (int)grid;
+    f.pool_pct = f.nunits >= 4 * grid * f.waves ? 25 : 0;     // (see the kernel: the pooled tail pays from four units per wave on)
+    return true;
+}
+
+int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
+                        char *ws, hipStream_t st, int *grid_out, int HW, bool nchw, int form) {
+    const VqPlan p = vq_plan(K, 64);
+    VqTrackForm tf;
+    if (!vq_track_form(N, K, HW, nchw, form, num_cus(), tf)) return VQVAE_ERR_UNSUPPORTED;
+    const int NW = tf.waves, RU = tf.unit_rows, pool_pct = tf.pool_pct;
+    const long long nunits = tf.nunits, grid = tf.grid;
+    const bool narrow = NW == 4, spread = NW == 8 && RU == 32, wide = NW == 16;
+    *grid_out = tf.grid;
     auto launch = [&](auto kfn) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
         hipEvent_t e0, e1;
