@@ -361,6 +361,31 @@ def other_workload(name, torch, dev, seconds=1.0):
                      # at K >= 1024 the screen is matrix-bound, not HBM-bound
                      "screen_tflops_16bit": round(2.0 * rows * K * D / t_vq / 1e12, 1),
                      "mfma_frac": round(2.0 * rows * K * D / t_vq / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4)}
+    if name == "c2":
+        # the same quantizer at the REFERENCE's own boundary: VectorQuantizer.forward(z) takes NCHW (models/quantizer.py:45-46, :74 are its
+        # permute + copy passes) -- what integration/vqvae_hip_stub.py binds; timed by the dispatch's events like the row-major figure
+        try:
+            from vqvae_amd import functional as F_
+            with torch.no_grad():
+                z_nchw = torch.randn(B, D, HW // 4, HW // 4, generator=torch.Generator().manual_seed(7)).to(dev) * 0.07
+                cbw = model.vector_quantization.embedding.weight.detach().contiguous()
+                ws_n = F_.vq_workspace(K, D, dev)
+                F_.vq_forward(z_nchw, cbw, 0.25, rowmajor=False, workspace=ws_n)
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                for _ in range(20):
+                    F_.vq_forward(z_nchw, cbw, 0.25, rowmajor=False, workspace=ws_n, prepared=True)
+                ms_n, n_n = _lib.profile_collect("vq_main")
+                _lib.profile_enable(False)
+            if n_n:
+                t_n = ms_n / n_n * 1e-3
+                res["vq_nchw_boundary"] = {"kernel": _lib.vq_kernel_instance(rows, K, D, (HW // 4) ** 2, 0x0),
+                                           "avg_kernel_us": round(t_n * 1e6, 2),
+                                           "hbm_frac": round(rows * (8 * D + 8) / t_n / 1e9 / HBM_PEAK_GBPS, 4),
+                                           "data": "N(0, 0.07^2) z_e in the module's (B, D, H, W) layout, this model's codebook"}
+        except Exception as e:                               # (a reporting extra: never take the bench line down with it)
+            _lib.profile_enable(False)
+            res["vq_nchw_boundary"] = {"error": repr(e)[:200]}
     if conv_backend == "hip" and conv_ms > 0:
         t_conv = conv_ms / nprof * 1e-3
         flops_img = conv_flops_per_image(HW, HW, D, ends=True)
