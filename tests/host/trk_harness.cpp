@@ -68,6 +68,25 @@ int main(int argc, char **argv) {
         if (V0.closed != V1.closed || V0.hard != V1.hard || (V0.closed && V0.kbest != V1.kbest)) {
             ++viol; fprintf(stderr, "row %d: halves disagree\n", n);
         }
+        // round 5: the word / speaker form must take the same decisions, and its tasks must cover the same codes
+        {
+            const unsigned ge0 = ~lt_of(L[0], thr, thrB, ninf) & kGeBits, ge1 = ~lt_of(L[1], thr, thrB, ninf) & (kGeBits | 1u << 14);
+            const Spoken S = spoken_of(word_of(L[0], ge0), word_of(L[1], ge1));
+            const bool c2 = spoken_closed(S, K), h2 = !c2 && spoken_hard(S, K);
+            if (c2 != V0.closed || h2 != V0.hard || (c2 && S.kbest != V0.kbest)) {
+                ++viol; fprintf(stderr, "row %d: speaker form disagrees (closed %d/%d hard %d/%d kbest %d/%d)\n", n, (int)c2, (int)V0.closed, (int)h2, (int)V0.hard, S.kbest, V0.kbest);
+            }
+            if (!c2 && !h2) {
+                const Cands A[2] = {cands_of(L[0], H[0], 0, K), cands_of(L[1], H[1], 1, K)};
+                const Cands B[2] = {cands2_of(L[0], ge0, 0, K), cands2_of(L[1], ge1, 1, K)};
+                for (int h = 0; h < 2; ++h) {                   // (the two forms number a half's streams in opposite orders)
+                    std::set<int> sa, sb;
+                    for (int j = 0; j < A[h].ntask; ++j) { sa.insert(A[h].ta[j]); sa.insert(A[h].tb[j]); }
+                    for (int j = 0; j < B[h].ntask; ++j) { sb.insert(B[h].ta[j]); sb.insert(B[h].tb[j]); }
+                    if (A[h].ntask != B[h].ntask || sa != sb) { ++viol; fprintf(stderr, "row %d half %d: tasks differ\n", n, h); }
+                }
+            }
+        }
         if (V0.closed) {
             ++closed;
             if (G.size() != 1 || *G.begin() != V0.kbest) { ++viol; fprintf(stderr, "row %d: closed with |G| = %zu, kbest %d\n", n, G.size(), V0.kbest); }

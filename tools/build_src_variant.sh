@@ -7,6 +7,7 @@ cd "$(dirname "$0")/.."
 src=$1; name=$2; shift 2
 out=vqvae_amd/build/variants; mkdir -p $out/$name
 FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-math -fvisibility=hidden -Wall -Wno-unused-function"
+[ "$src" = vq_track.hip ] && [ -z "$NO_EXTRA" ] && FLAGS="$FLAGS -fno-slp-vectorize"     # (vqvae_amd/build.py EXTRA_FLAGS; NO_EXTRA=1 builds without)
 hipcc $FLAGS "$@" -c vqvae_amd/csrc/$src -o $out/$name/$src.o
 objs=$(ls vqvae_amd/build/*.hip.o | grep -v "/$src.o")
 hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libvqvae_$name.so $objs $out/$name/$src.o

@@ -14,7 +14,7 @@ procs, objs = [], []
 for src in B.sources():
     obj = os.path.join(out, name, os.path.basename(src) + ".o")
     objs.append(obj)
-    procs.append(subprocess.Popen([B.hipcc(), *B.FLAGS, *defs, "-c", src, "-o", obj]))
+    procs.append(subprocess.Popen([B.hipcc(), *B.flags_for(src), *defs, "-c", src, "-o", obj]))
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out, f"libvqvae_{name}.so")
 subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])

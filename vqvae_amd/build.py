@@ -16,6 +16,15 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-ffp-contract=o
          "-fno-fast-math", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
 
 
+# Per-source additions.  vq_track.hip: hipcc's SLP vectoriser packs the epilogue's fp32 adds / multiplies into v_pk_* pairs plus the
+# v_mov shuffles that feed them -- more issue slots, not fewer, on gfx950 (profiles/r05_vq_notes.txt).
+EXTRA_FLAGS = {"vq_track.hip": ["-fno-slp-vectorize"]}
+
+
+def flags_for(src: str):
+    return [*FLAGS, *EXTRA_FLAGS.get(os.path.basename(src), [])]
+
+
 def hipcc() -> str:
     for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if c and os.path.exists(c):
@@ -46,7 +55,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [hipcc(), *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc(), *flags_for(src), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         procs.append((src, subprocess.Popen(cmd)))

@@ -43,6 +43,16 @@ VQT_FN float max3(float a, float b, float c) {
     return std::fmax(std::fmax(a, b), c);
 #endif
 }
+// two operands, ONE instruction and no -inf pad register (the builtin form of a two-operand maximum is canonicalised, see above)
+VQT_FN float max2(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#else
+    return std::fmax(a, b);
+#endif
+}
 VQT_FN float med3(float a, float b, float c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __builtin_amdgcn_fmed3f(a, b, c);
@@ -82,21 +92,25 @@ template <class ACC>
 VQT_FN void tile(Lane &L, const ACC &acc, unsigned cell0, unsigned cell1, unsigned keymask, float ninf, float pinf) {
 #pragma unroll
     for (int a = 0; a < 8; ++a) L.S[a] = max3(L.S[a], acc[a], acc[a + 8]);
-    const float x0 = max3(max3(max3(acc[0], acc[1], acc[2]), max3(acc[3], acc[4], acc[5]), acc[6]), acc[7], ninf);
-    const float x1 = max3(max3(max3(acc[8], acc[9], acc[10]), max3(acc[11], acc[12], acc[13]), acc[14]), acc[15], ninf);
+    // (round 5: the fourth v_max3 of eight values repeats one of them instead of padding with a -inf register, and the largest
+    // key's v_max3 repeats a smaller key: no +-inf registers live through the sweep, and still no two-operand maximum)
+    const float x0 = max3(max3(max3(acc[0], acc[1], acc[2]), max3(acc[3], acc[4], acc[5]), acc[6]), acc[7], acc[0]);
+    const float x1 = max3(max3(max3(acc[8], acc[9], acc[10]), max3(acc[11], acc[12], acc[13]), acc[14]), acc[15], acc[8]);
     const float k0 = u2f((f2u(x0) & keymask) | cell0);
     const float k1 = u2f((f2u(x1) & keymask) | cell1);
     L.m3 = med3(L.m2, L.m3, k0);
     L.m2 = med3(L.m1, L.m2, k0);
-    L.m1 = med3(L.m1, k0, pinf);
+    L.m1 = max3(L.m1, k0, L.m3);                  // (m3 <= m1: the maximum of m1 and k0)
     L.m3 = med3(L.m2, L.m3, k1);
     L.m2 = med3(L.m1, L.m2, k1);
-    L.m1 = med3(L.m1, k1, pinf);
+    L.m1 = max3(L.m1, k1, L.m3);
+    (void)pinf; (void)ninf;
 }
 
 // largest value the lane has seen (exact accumulator bits)
 VQT_FN float lane_max(const Lane &L, float ninf) {
-    return max3(max3(max3(L.S[0], L.S[1], L.S[2]), max3(L.S[3], L.S[4], L.S[5]), L.S[6]), L.S[7], ninf);
+    (void)ninf;
+    return max3(max3(max3(L.S[0], L.S[1], L.S[2]), max3(L.S[3], L.S[4], L.S[5]), L.S[6]), L.S[7], L.S[0]);
 }
 
 VQT_FN int code_of(int a, int cell, int h) { return 32 * (cell >> 1) + (a & 3) + 8 * (a >> 2) + 16 * (cell & 1) + 4 * h; }
@@ -167,6 +181,98 @@ VQT_FN Cands cands_of(const Lane &L, const Half &H, int h, int K) {
     if (k22 >= K) k22 = kv;
     const bool two = H.popA == 2 && H.nB == 2;
     const bool any = H.popA >= 1 && H.nB >= 1 && kv < K;
+    Cands C;
+    C.ntask = any ? (two ? 2 : 1) : 0;
+    C.ta[0] = k11; C.tb[0] = k22;
+    C.ta[1] = k12; C.tb[1] = k21;
+    return C;
+}
+
+// ---- round 5: what a half knows as ONE word, the verdict on the row's SPEAKER lane ---------------------------------------
+// Same decisions as half_of / verdict_of / cands_of above (tests/host/trk_harness.cpp checks both against the brute-force scan
+// and against each other), in a form that costs the kernel ~35 vector instructions per row tile instead of ~110:
+//   * the eight stream tests and the three key tests go into ONE shift register, stream a at bit pos(a) = (a & 3) + 8 (a >> 2)
+//     -- the code's offset inside its cell, code = 16 cell + pos + 4 h, so the highest set stream bit IS the low part of k11 --
+//     the keys m1, m2, m3 at bits 4, 5, 6 (bit 7: a filler that is never set);
+//   * a half's word  w = ge | pos << 12 | h << 14 | cell(m1) << 16  (bits 12..21 = k11) is all the other half ever needs, and only
+//     ONE lane of the row needs both words: the row's speaker (the lane that later owns the row's index, histogram count and
+//     gather).  One v_permlane32_swap hands the speakers of both row tiles their partners' words.
+constexpr unsigned kGeStream = 0xF0Fu, kGeCell = 0x070u, kGeBits = 0xF7Fu;
+
+VQT_FN unsigned ffbh(unsigned x) {                   // v_ffbh_u32: leading zeros, ~0 for 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    unsigned r;                                       // (the C form costs a compare and a select around the same instruction)
+    asm("v_ffbh_u32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+#else
+    return x ? (unsigned)__builtin_clz(x) : ~0u;
+#endif
+}
+
+// bit set = BELOW the threshold (the sign bits of the differences); the caller's ge = ~lt & gemask, gemask = kGeBits | h << 14
+VQT_FN unsigned lt_of(const Lane &L, float thr, float thrB, float ninf) {
+    unsigned lt = f2u(L.S[7] - thr) >> 31;
+    lt = shl1_in(lt, L.S[6] - thr);
+    lt = shl1_in(lt, L.S[5] - thr);
+    lt = shl1_in(lt, L.S[4] - thr);
+    lt = (lt << 1) | 1u;                              // bit 7: never "at or above"
+    (void)ninf;
+    lt = shl1_in(lt, L.m3 - thrB);
+    lt = shl1_in(lt, L.m2 - thrB);
+    lt = shl1_in(lt, L.m1 - thrB);
+    lt = shl1_in(lt, L.S[3] - thr);
+    lt = shl1_in(lt, L.S[2] - thr);
+    lt = shl1_in(lt, L.S[1] - thr);
+    lt = shl1_in(lt, L.S[0] - thr);
+    return lt;
+}
+
+// (a half without a stream at or above thr: pos is garbage and spills into the cell field -- such a word's k11 is never selected)
+VQT_FN unsigned word_of(const Lane &L, unsigned ge) {
+    const unsigned p = 31u ^ ffbh(ge & kGeStream);
+    return ge | (p << 12) | (f2u(L.m1) << 16);
+}
+
+struct Spoken {            // on the row's speaker lane: Wlo / Whi = the words of the row's lower / upper accumulator lane
+    unsigned g;            // the halves' ge bits side by side: lower half at 0..11, upper at 12..23 (bits 24.. garbage)
+    int pT, nT;            // streams / cell keys of the row at or above their thresholds
+    int kbest;             // k11 of the half that has a stream at or above thr (the lower one if both)
+};
+
+VQT_FN Spoken spoken_of(unsigned Wlo, unsigned Whi) {
+    Spoken V;
+    V.g = (Wlo & 0xFFFu) | (Whi << 12);
+    V.pT = popc(V.g & (kGeStream | kGeStream << 12));
+    V.nT = popc(V.g & (kGeCell | kGeCell << 12));
+    const unsigned sel = (Wlo & kGeStream) ? Wlo : Whi;
+    V.kbest = (int)((sel >> 12) & 1023u);
+    return V;
+}
+VQT_FN bool spoken_closed(const Spoken &V, int K) { return V.pT == 1 && V.nT == 1 && V.kbest < K; }
+// (a row closed by its counts whose code is a padding code can only come from a broken screen: it is screened again, as above)
+VQT_FN bool spoken_hard(const Spoken &V, int K) {
+    const int a = popc(V.g & kGeStream), b = popc(V.g & (kGeStream << 12)), c = popc(V.g & kGeCell), d = popc(V.g & (kGeCell << 12));
+    const int m = a > b ? a : b, n = c > d ? c : d;
+    return (m > n ? m : n) > 2 || (V.pT == 1 && V.nT == 1 && V.kbest >= K);
+}
+
+// stage 2 from a half's own ge bits: the products of its (at most two) streams and cells at or above the thresholds
+VQT_FN Cands cands2_of(const Lane &L, unsigned ge, int h, int K) {
+    const unsigned x = ge & kGeStream;
+    const int popA = popc(x), nB = popc(ge & kGeCell);
+    const int p1 = 31 - clz(x | 1u);
+    const unsigned x2 = x & ~(1u << p1);
+    const int p2 = x2 ? 31 - clz(x2) : p1;
+    const int c1 = (int)(f2u(L.m1) & kCellMask);
+    const int c2 = nB >= 2 ? (int)(f2u(L.m2) & kCellMask) : c1;
+    int k11 = 16 * c1 + p1 + 4 * h, k12 = 16 * c2 + p1 + 4 * h, k21 = 16 * c1 + p2 + 4 * h, k22 = 16 * c2 + p2 + 4 * h;
+    const int kv = k11 < K ? k11 : (k12 < K ? k12 : (k21 < K ? k21 : k22));
+    if (k11 >= K) k11 = kv;
+    if (k12 >= K) k12 = kv;
+    if (k21 >= K) k21 = kv;
+    if (k22 >= K) k22 = kv;
+    const bool two = popA == 2 && nB == 2;
+    const bool any = popA >= 1 && nB >= 1 && kv < K;
     Cands C;
     C.ntask = any ? (two ? 2 : 1) : 0;
     C.ta[0] = k11; C.tb[0] = k22;

@@ -26,6 +26,7 @@
 #include "vq_device.h"
 #include "vq_track.h"
 #include "vq_unit.h"
+#include <type_traits>
 #include <hip/hip_ext.h>          // hipExtLaunchKernelGGL: start / stop events on the dispatch itself (prof_dispatch)
 
 namespace vqvae {
@@ -37,6 +38,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 using vqu::lds_order_wave;
+
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
 // Debug builds (tools/build_vq_variant.sh NAME -DVQ_TRACE, tools/ubench/vq_ab.cpp): absolute 100 MHz stamps of every wave --
 // [0] wave start, [1] past the prologue's barrier, [2..5] end of its first four units, [6] loop exit, [7] last instruction
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #define VQ_STAMP(slot) do {} while (0)
 #endif
 
-    const vqu::Bound bound = vqu::load_bound(flags);
+    const vqu::BoundP bound = vqu::load_boundp(flags);
 
     // ---- row I/O: F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the unit (1 KiB contiguous per instruction) ----
     // a buffer descriptor over the unit's 16 KiB clipped at the end of z: rows past the end read zeros (their results are
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     f16x8 zb[T][4];
     float zn2[T];
     auto convert = [&]() {
-        int lane_c = tid & 63;
+        int lane_c = lane_id();                                 // (not tid & 63: threadIdx would stay live through the unit loop and spill)
         asm volatile("" : "+v"(lane_c));
         const int l31 = lane_c & 31, h = lane_c >> 5, j16 = lane_c & 15, g4 = lane_c >> 4;
         if constexpr (NCHW) {
@@ -236,8 +239,18 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 zb[t][q] = __builtin_bit_cast(f16x8, v);
                 sq = sqsum8_f16(v.x, v.y, v.z, v.w, sq);       // (not four fdot2 builtins: miscompiled, common.h)
             }
-            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sq), __float_as_uint(sq), false, false);
-            zn2[t] = sq + __uint_as_float(h ? sw[0] : sw[1]);
+            zn2[t] = sq;
+        }
+        // both halves of a row need its |z^|^2: (lower half's sum) + (upper half's sum) on every lane
+        if constexpr (T == 1) {
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(zn2[0]), __float_as_uint(zn2[0]), false, false);
+            zn2[0] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        } else {
+            const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(zn2[0]), __float_as_uint(zn2[1]), false, false);
+            const float sm = __uint_as_float(sv[0]) + __uint_as_float(sv[1]);      // lower lanes: tile 0's rows, upper lanes: tile 1's
+            const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sm), __float_as_uint(sm), false, false);
+            zn2[0] = __uint_as_float(sw[0]);
+            zn2[1] = __uint_as_float(sw[1]);
         }
     };
     if (p < nunits && early) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * T) : "memory");    // all but the 8 T row requests
@@ -253,10 +266,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
     const float inf = __builtin_inff();
     VQ_STAMP(0);                                               // codebook image copy + first rows + first conversion
-    float pinf = inf, ninf = -inf;                           // opaque: see vq_track.h
-    unsigned keymask = trk::kKeyMask;
-    asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
-    double dacc = 0.0;
+    const float pinf = inf, ninf = -inf;                     // (round 5: the tracker no longer pads with them; plain constants)
+    unsigned keymask = trk::kKeyMask;                        // opaque: see vq_track.h
+    asm volatile("" : "+v"(keymask));
+    // the wave's squared-error sum: one fp32 value per unit; fp64 across units -- except in the sixteen-wave form, which a wave runs
+    // for two or three units (launch rule) and which has no two registers to spare
+    typedef typename std::conditional<NW == 16, float, double>::type acc_t;
+    acc_t dacc = 0;
 
     // Many units per wave (pool_pct > 0: the host sets 25 from four units per wave on): the last quarter of the units is not dealt out
     // to the workgroups.  A wave whose workgroup has used up its share draws from the pool of its group of workgroups (blockIdx % 8 --
@@ -277,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         const long long r0 = p * RU;
         // lane-derived indices are made opaque once per iteration: hipcc otherwise hoists dozens of per-lane address values
         // out of this loop, spills them and reloads them from scratch inside it
-        int lane_v = tid & 63;
+        int lane_v = lane_id();
         asm volatile("" : "+v"(lane_v));
         const int lane = lane_v, l31 = lane_v & 31, h = lane_v >> 5;
         const uint4 *ap0 = Eimg + h * 32 + l31;
@@ -381,10 +397,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #endif
         // ================= threshold, merge of the two lane halves of every row, verdict (vq_unit.h) =========================
         const vqu::Tables tb = vqu::tables(tab_s);
-        vqu::Rows R;
-#pragma unroll
-        for (int t = 0; t < T; ++t) R.valid[t] = r0 + 32 * t + l31 < N;
-        vqu::classify<T>(L, zn2, bound, K, lane, ninf, tb.task_s, R);
+        const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
+        vqu::RowsSp<T> R;
+        vqu::classify_sp<T>(L, zn2, bound, K, lane, nleft, ninf, tb.task_s, R);
 
         VQ_STAMP(3);                                           // threshold + verdict
 #ifdef VQ_TRACE2
@@ -400,7 +415,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         //       it becomes a task (same accumulators as in the sweep)
         //   non-finite rows / unusable codebooks / task overflow: scalar torch.argmin semantics, one lane per row
         {
-            vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
+            vqu::Flagged FL = vqu::exact_begin_sp<T>(R, lane, tb);
             int ntasks = FL.ndirect;
             if (FL.hmask && FL.ndirect <= 64) {
                 // rows with candidates the products do not cover: the tile's screen again, hits (acc >= v1 - DELTA) become tasks
@@ -425,7 +440,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                             }
                         };
                         rfetch(0);
-                        const float thr_t = R.hardf[t] ? R.thr[t] : inf;             // only the hard rows can hit
+                        const float thr_t = (((unsigned)(FL.hmask >> (32 * t)) >> l31) & 1u) ? R.thr[t] : inf;   // only the hard rows can hit
                         for (int ct = 0; ct < ntile; ++ct) {
                             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[0]), zbr[0], rs, 0, 0, 0);
 #pragma unroll
@@ -442,14 +457,14 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             }
             if constexpr (NCHW) {
                 const float *zu = unit_base(p, z);                 // (strided dword reads: ~3 % of the rows, L2-resident)
-                vqu::exact_end(R, FL, ntasks, lane, tb, cb, ee_g, K,
+                vqu::exact_end_sp<T>(R, FL, ntasks, lane, tb, cb, ee_g, K,
                                [&](int rr, int jc) { const float *q = zu + (size_t)(4 * jc) * HW + rr; return f32x4{q[0], q[HW], q[2 * (size_t)HW], q[3 * (size_t)HW]}; },
                                [&](int rr, int c) { return zu[(size_t)c * HW + rr]; });
             } else {
                 const long long left = (N - r0) * (D * 4);
                 const auto zr_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(z + (size_t)r0 * D), 0,
                                                                      (unsigned)(left < RU * 256 ? left : RU * 256), 0x00020000);
-                vqu::exact_end(R, FL, ntasks, lane, tb, cb, ee_g, K,
+                vqu::exact_end_sp<T>(R, FL, ntasks, lane, tb, cb, ee_g, K,
                                [&](int rr, int jc) { return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(zr_rs, (unsigned)rr * 256u + (unsigned)jc * 16u, 0, 0)); },
                                [&](int rr, int c) { const long long grow = r0 + rr; return z[(size_t)(grow < N ? grow : N - 1) * D + c]; });
             }
@@ -461,26 +476,23 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #endif
         // ================= epilogue: gather, z + (e_k - z), squared error, index, histogram (vq_unit.h) =======================
         {
-            const int nleft = (int)(N - r0 < RU ? N - r0 : RU);         // rows of this unit that exist
             float sacc;
             if constexpr (NCHW)
-                sacc = vqu::epilogue<true, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                sacc = vqu::epilogue_sp<true, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                            zq ? const_cast<float *>(unit_base(p, zq)) : nullptr, nleft, idx + r0, hist_s,
                                            reinterpret_cast<float *>(tile_s), HW, (unsigned)(((long long)D * HW - (p * RU) % HW) * 4));
             else
-                sacc = vqu::epilogue<false, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                sacc = vqu::epilogue_sp<false, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                      zq ? zq + (size_t)p * RU * D : nullptr, nleft, idx + r0, hist_s);
-            dacc += (double)sacc;
+            dacc += (acc_t)sacc;
         }
 #ifdef VQ_DEBUG_VERDICT
         // debug build (tools/build_variant.py dbg -DVQ_DEBUG_VERDICT): the classification of every row next to its index --
         // bits 20..23 = open / hard / bad / valid, high word = the row's threshold (float bits)
-        if (h == 0) {
-#pragma unroll
-            for (int t = 0; t < T; ++t)
-                if (R.valid[t])
-                    idx[r0 + 32 * t + l31] = (long long)R.kbest[t] | ((long long)(R.openf[t] ? 1 : 0) << 20) | ((long long)(R.hardf[t] ? 1 : 0) << 21) |
-                                             ((long long)(R.bad[t] ? 1 : 0) << 22) | ((long long)__float_as_uint(VQ_DEBUG_VERDICT == 2 ? zn2[t] : R.thr[t]) << 32);
+        if (R.valid) {
+            const float thr_l = T == 2 && h ? R.thr[T - 1] : R.thr[0], zn2_l = T == 2 && h ? zn2[T - 1] : zn2[0];
+            idx[r0 + lane] = (long long)R.kbest | ((long long)(R.open ? 1 : 0) << 20) | ((long long)(R.hard ? 1 : 0) << 21) |
+                             ((long long)(R.bad ? 1 : 0) << 22) | ((long long)__float_as_uint(VQ_DEBUG_VERDICT == 2 ? zn2_l : thr_l) << 32);
         }
 #endif
         VQ_STAMP(5);                                           // epilogue
@@ -517,10 +529,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     __syncthreads();
 #endif
     VQ_TR(6);
+    double dsum = (double)dacc;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) dacc += __shfl_xor(dacc, o);
+    for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
     __syncthreads();
-    if ((tid & 63) == 0) red[wave_u] = dacc;
+    if ((tid & 63) == 0) red[wave_u] = dsum;
     __syncthreads();
     if (tid == 0) {
         double s = 0.0;

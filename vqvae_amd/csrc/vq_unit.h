@@ -333,5 +333,315 @@ __device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *
     return sacc;
 }
 
+
+// =====================================================================================================================
+// Round 5: the same unit in SPEAKER form (vq_track.h, "round 5"): lane L of the wave speaks for row L of the unit -- the
+// verdict, the index, the histogram count and the gather address of a row live on ONE lane, so nothing is selected per
+// half and nothing is shuffled back.  Same decisions and the same bits out as the functions above (which the encoder's
+// fused kernel still uses); per 32-row tile the classification issues ~60 vector instructions instead of ~250, the
+// epilogue ~115 instead of ~220 (profiles/r05_vq_notes.txt has the census).
+// =====================================================================================================================
+
+// DELTA of classify() as a polynomial in Z = v_sqrt_f32(|z^|^2), every coefficient rounded up:
+//   zh <= s Z (s = 1.00016 covers sqrt(1.0001) * 1.0001 and v_sqrt's ulp), errz = c1 zh + c0, zn = zh + errz = q Z + c0 (q = (1 + c1) s)
+//   DELTA = 2.002 (eps + xi) = (D2 Z + D1) Z + D0,   key slack tB = 8e-6 (zn Ehat + EEh) = T1 Z + T0
+struct BoundP {            // wave-uniform, kept in scalar registers (gfx950 reads ONE scalar register per vector instruction:
+    int cb_bad;            // classify_sp() spends a v_mul + v_add + v_fma on DELTA rather than two live vector registers)
+    float D2, D1, D0, T1, T0;
+};
+
+__device__ __forceinline__ BoundP load_boundp(const int *__restrict__ flags) {
+    const Bound b = load_bound(flags);
+    const float c1 = 4.89e-4f, c0 = 2.5e-7f, s = 1.00016f, q = (1.0f + c1) * s, up = 1.0002f;
+    BoundP p;
+    p.cb_bad = b.cb_bad;
+    p.D2 = up * 2.002f * (1.2e-7f * b.A * q * q);
+    p.D1 = up * 2.002f * (b.Ehat * (c1 * s) + b.dE * ((1.0f + 2.0f * c1) * s) + 7.76e-6f * b.Ehat * q + 3.86e-6f * b.EmaxS * q + 1.2e-7f * b.A * (2.0f * q * c0));
+    p.D0 = up * 2.002f * (b.Ehat * c0 + 2.0f * b.dE * c0 + 7.76e-6f * (b.Ehat * c0 + b.EEh) + 3.86e-6f * b.EmaxS * c0 + 1.2e-7f * (b.A * c0 * c0 + b.EEa));
+    p.T1 = 1.01f * 8.0e-6f * b.Ehat * q;
+    p.T0 = 1.01f * 8.0e-6f * (b.Ehat * c0 + b.EEh);
+    p.cb_bad = __builtin_amdgcn_readfirstlane(p.cb_bad);
+    // (inline assembly: hipcc folds the builtin away on values it knows to be uniform and then cannot place them in scalar registers)
+    int d2, d1, d0, t1, t0;
+    asm volatile("v_readfirstlane_b32 %0, %5\n\tv_readfirstlane_b32 %1, %6\n\tv_readfirstlane_b32 %2, %7\n\t"
+                 "v_readfirstlane_b32 %3, %8\n\tv_readfirstlane_b32 %4, %9"
+                 : "=s"(d2), "=s"(d1), "=s"(d0), "=s"(t1), "=s"(t0) : "v"(p.D2), "v"(p.D1), "v"(p.D0), "v"(p.T1), "v"(p.T0));
+    p.D2 = __int_as_float(d2); p.D1 = __int_as_float(d1); p.D0 = __int_as_float(d0); p.T1 = __int_as_float(t1); p.T0 = __int_as_float(t0);
+    return p;
+}
+
+template <int T>
+struct RowsSp {
+    int kbest;                           // speaker lane L: the index of row L of the unit (closed rows; the exact part fills in the rest)
+    bool valid, bad, open, hard;         // speaker lane L: row L
+    unsigned long long openm, hardm;     // the same as wave masks (bit L = row L)
+    float thr[T];                        // per accumulator lane: the threshold of row l31 of tile t (the rescan needs it)
+    int ncls;                            // tasks the classification wrote (wave-uniform)
+};
+
+// nleft: rows of the unit that exist (wave-uniform)
+template <int T>
+__device__ __forceinline__ void classify_sp(const trk::Lane (&L)[T], const float (&zn2)[T], const BoundP &B, int K, int lane, int nleft,
+                                            float ninf, unsigned *task_s, RowsSp<T> &R) {
+    const int l31 = lane & 31, h = lane >> 5;
+    const unsigned gemask = trk::kGeBits | (((unsigned)lane & 32u) << 9);      // | h << 14: see trk::word_of
+    // ---- the row maxima on every lane ----
+    float v1[T];
+    if constexpr (T == 1) {
+        const float a = trk::lane_max(L[0], ninf);
+        const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(a), false, false);
+        v1[0] = trk::max2(__uint_as_float(sv[0]), __uint_as_float(sv[1]));
+    } else {
+        const float a0 = trk::lane_max(L[0], ninf), a1 = trk::lane_max(L[1], ninf);
+        const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(a0), __float_as_uint(a1), false, false);
+        const float m = trk::max2(__uint_as_float(sv[0]), __uint_as_float(sv[1]));          // lower lanes: tile 0's rows, upper: tile 1's
+        const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        v1[0] = __uint_as_float(sw[0]);
+        v1[1] = __uint_as_float(sw[1]);
+    }
+    // ---- thresholds, words ----
+    unsigned ge[T], w[T];
+    bool badl[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+        const float Z = __builtin_amdgcn_sqrtf(zn2[t]);
+        const float delta = __builtin_fmaf(Z * B.D2 + B.D1, Z, B.D0);
+        const float th = v1[t] - delta;
+        const float thB = __builtin_fmaf(Z, -B.T1, th - B.T0);
+        R.thr[t] = th;
+        // NaN / Inf anywhere in the row, an overflowing bound, or |v1| below 1e-30 (a key could be a denormal whose cell field a
+        // flush would lose -- never on real data): the scalar path
+        const float av = __builtin_fabsf(v1[t]);
+        badl[t] = !(av < 1.0e37f) || !(delta < 1.0e37f) || av < 1.0e-30f;
+        ge[t] = ~trk::lt_of(L[t], th, thB, ninf) & gemask;
+        w[t] = trk::word_of(L[t], ge[t]);
+    }
+    // ---- the speakers get their partners' words: lanes 0..31 speak for tile 0, lanes 32..63 for tile 1 ----
+    unsigned Wlo, Whi;
+    bool bad_sp;                          // (both halves of a row computed the same v1 and delta)
+    if constexpr (T == 1) {
+        unsigned junk;
+        asm volatile("" : "=v"(junk));
+        const auto sv = __builtin_amdgcn_permlane32_swap(w[0], junk, false, false);
+        Wlo = sv[0]; Whi = sv[1];
+        bad_sp = badl[0];
+    } else {
+        const auto sv = __builtin_amdgcn_permlane32_swap(w[0], w[1], false, false);
+        Wlo = sv[0]; Whi = sv[1];
+        bad_sp = h ? badl[T - 1] : badl[0];
+    }
+    const trk::Spoken V = trk::spoken_of(Wlo, Whi);
+    const bool closed = trk::spoken_closed(V, K);
+    R.kbest = V.kbest;
+    R.valid = lane < nleft;
+    R.bad = R.valid && (bad_sp || B.cb_bad);
+    R.open = false; R.hard = false; R.openm = 0ull; R.hardm = 0ull; R.ncls = 0;
+    const bool nonclosed = R.valid && !R.bad && !closed;
+    if (__builtin_amdgcn_ballot_w64(nonclosed)) {
+        R.hard = nonclosed && trk::spoken_hard(V, K);
+        R.open = nonclosed && !R.hard;
+        R.openm = __builtin_amdgcn_ballot_w64(R.open);
+        R.hardm = __builtin_amdgcn_ballot_w64(R.hard);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const unsigned om = (unsigned)(R.openm >> (32 * t));
+            if (om) {
+                // open rows: this half's exact tasks
+                const trk::Cands C = trk::cands2_of(L[t], ge[t], h, K);
+                const int nt = ((om >> l31) & 1u) ? C.ntask : 0;
+                const unsigned long long b1 = __builtin_amdgcn_ballot_w64(nt >= 1), b2 = __builtin_amdgcn_ballot_w64(nt >= 2);
+                const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
+                                  __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
+                const int slot = R.ncls + below;
+                const unsigned rowu = (unsigned)(32 * t + l31);
+                if (nt >= 1 && slot < 64) task_s[slot] = rowu | ((unsigned)C.ta[0] << 6) | ((unsigned)C.tb[0] << 19);
+                if (nt >= 2 && slot + 1 < 64) task_s[slot + 1] = rowu | ((unsigned)C.ta[1] << 6) | ((unsigned)C.tb[1] << 19);
+                R.ncls += __builtin_popcountll(b1) + __builtin_popcountll(b2);
+            }
+        }
+    }
+}
+
+template <int T>
+__device__ __forceinline__ Flagged exact_begin_sp(const RowsSp<T> &R, int lane, const Tables &tb) {
+    Flagged F;
+    F.o_open = R.open; F.o_hard = R.hard; F.o_bad = R.bad;
+    F.fm = __builtin_amdgcn_ballot_w64(R.open || R.hard || R.bad);
+    F.hmask = 0ull;
+    F.ndirect = R.ncls;
+    if (F.fm) {
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        unsigned ones;                       // (made here: hipcc hoists a plain ~0ull pair out of the unit loop and spills it)
+        asm volatile("v_mov_b32 %0, -1" : "=v"(ones));
+        reinterpret_cast<unsigned *>(tb.best_s)[2 * lane] = ones;
+        reinterpret_cast<unsigned *>(tb.best_s)[2 * lane + 1] = ones;
+        // non-finite rows: one task each, for the row's ||z||^2
+        const unsigned long long tmb = __builtin_amdgcn_ballot_w64(F.o_bad);
+        if (F.o_bad && R.ncls + __builtin_popcountll(tmb & lowmask) < 64) tb.task_s[R.ncls + __builtin_popcountll(tmb & lowmask)] = (unsigned)lane;
+        F.ndirect = R.ncls + __builtin_popcountll(tmb);
+        F.hmask = R.hardm;
+        if (F.hmask && lane == 0) tb.cnt_s[0] = 0;
+        lds_order_wave();
+    }
+    return F;
+}
+
+// the chains and the decision of exact_end(); R.kbest of the flagged rows final afterwards
+template <int T, class ZRow, class ZScalar>
+__device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntasks, int lane, const Tables &tb, const float *__restrict__ cb,
+                                             const float *__restrict__ ee_g, int K, ZRow &&zrow, ZScalar &&zscalar) {
+    constexpr int D = 64;
+    if (!F.fm) return;
+    const int j16 = lane & 15, g4 = lane >> 4;
+    if (ntasks > 64) {                      // pathological tie counts: every flagged row takes the scalar path;
+        const unsigned long long lowmask = (1ull << lane) - 1ull;
+        F.o_bad = F.o_bad || F.o_open || F.o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
+        __builtin_amdgcn_wave_barrier();
+        if (F.o_bad) tb.task_s[__builtin_popcountll(F.fm & lowmask)] = (unsigned)lane;
+        ntasks = __builtin_popcountll(F.fm);
+    }
+    lds_order_wave();
+    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
+    for (int base = 0; base < ntasks; base += 4) {
+        const int jj = base + g4;
+        const unsigned task = tb.task_s[jj < ntasks ? jj : 0];
+        const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
+        const f32x4 zv = zrow(rr, j16);
+        const f32x4 ea = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)ka * 256u + (unsigned)j16 * 16u, 0, 0));
+        const f32x4 eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kb2 * 256u + (unsigned)j16 * 16u, 0, 0));
+        const float eea = ee_g[ka], eeb = ee_g[kb2];
+        // ||z||^2 in ATen's order (see exact_end)
+        float Aq[4];
+        const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
+            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
+            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
+            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
+            Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
+        }
+        const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
+        const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
+        const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
+        float ma = 0.0f, mb = 0.0f;
+#pragma unroll
+        for (int sidx = 0; sidx < 16; ++sidx) {
+            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
+            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
+            ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
+            mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
+        }
+        const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
+        const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
+        const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
+        if (j16 == 1 && jj < ntasks) {
+            atomicMin(&tb.best_s[rr], trk::dist_key(da, ka));
+            atomicMin(&tb.best_s[rr], trk::dist_key(db, kb2));
+            tb.zz_s[rr] = zz;
+        }
+    }
+    lds_order_wave();
+    int o_best = 0;
+    if ((F.o_open || F.o_hard) && !F.o_bad) {
+        const unsigned long long bk = tb.best_s[lane];
+        if (bk != ~0ull) o_best = (int)(unsigned)bk; else F.o_bad = true;   // no task came back (cannot happen): scalar path
+    }
+    if (F.o_bad) {
+        // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
+        const float zz = tb.zz_s[lane];                                   // every flagged row had a task
+        int best = 0;
+        if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
+            float bd = 0.0f;
+            for (int k = 0; k < K; ++k) {
+                float m = 0.0f;
+                for (int c = 0; c < D; ++c) m = __builtin_fmaf(zscalar(lane, c), cb[(size_t)k * D + c], m);
+                const float d = (zz + ee_g[k]) - 2.0f * m;
+                const bool dn = d != d, bn = bd != bd;
+                if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
+            }
+        }
+        o_best = best;
+    }
+    if (R.open || R.hard || R.bad) R.kbest = o_best;
+    __builtin_amdgcn_wave_barrier();
+}
+
+// epilogue() with the rows' indices on their speaker lanes: frow / zq_unit / nleft / idx_unit / hist_s / NCHW arguments as there
+template <bool NCHW = false, int T = 2, class FRow>
+__device__ __forceinline__ float epilogue_sp(const RowsSp<T> &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
+                                             float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
+                                             int *__restrict__ hist_s, float *tile_f = nullptr, int HW = 0, unsigned zq_bytes = 0u) {
+    constexpr int D = 64, RU = 32 * T;
+    const int j16 = lane & 15, g4 = lane >> 4;
+    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
+    f32x4 ev[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int kr = __builtin_amdgcn_ds_bpermute((32 * t + 4 * i + g4) << 2, R.kbest);
+            ev[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr * (D * 4) + (unsigned)j16 * 16u, 0, 0));
+        }
+    // index and histogram count of row L from lane L while the gathers are on their way
+    if (R.valid) {
+        idx_unit[lane] = R.kbest;
+        atomicAdd(&hist_s[R.kbest], 1);
+    }
+    const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq_unit ? zq_unit : const_cast<float *>(cb), 0,
+                                                         zq_unit ? (NCHW ? zq_bytes : (unsigned)nleft * (D * 4)) : 0u, 0x00020000);
+    // (store offsets without a scalar offset register: the hazard note in epilogue())
+    unsigned vo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        vo[k] = (unsigned)lane * 16u + 4096u * k;
+        asm volatile("" : "+v"(vo[k]));
+    }
+    float sqv[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const f32x4 zv = frow(t, i), e = ev[t][i];
+            const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
+            f32x4 o;
+            o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
+            sqv[t][i] = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
+            if constexpr (!NCHW) {
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, VQ_ZQ_STORE_AUX);
+            } else {
+                if (i == 0) lds_order_wave();
+                *reinterpret_cast<f32x4 *>(tile_f + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2)) = o;
+                if (i == 7) {
+                    lds_order_wave();
+                    const int cl = lane >> 3, j8 = lane & 7;
+                    unsigned so = (unsigned)(cl * HW + 4 * j8 + 32 * t) * 4u;
+#pragma unroll
+                    for (int c8 = 0; c8 < 8; ++c8) {
+                        f32x4 wv;
+#pragma unroll
+                        for (int e2 = 0; e2 < 4; ++e2) wv[e2] = tile_f[(4 * j8 + e2) * 64 + ((((2 * c8 + (cl >> 2)) ^ j8) & 15) << 2) + (cl & 3)];
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, wv), zq_rs, so, 0, VQ_ZQ_STORE_AUX);
+                        so += (unsigned)(8 * HW) * 4u;
+                    }
+                }
+            }
+        }
+    // fp32 over the unit's 16 groups in the order of epilogue() (one fp64 add per unit in the caller); only a ragged last unit masks
+    float sacc = 0.0f;
+    if (nleft == RU) {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sacc += sqv[t][i];
+    } else {
+#pragma unroll
+        for (int t = 0; t < T; ++t)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sacc += 32 * t + 4 * i + g4 < nleft ? sqv[t][i] : 0.0f;
+    }
+    return sacc;
+}
+
 }  // namespace vqu
 }  // namespace vqvae
