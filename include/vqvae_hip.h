@@ -103,6 +103,8 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
                                         * the sixteen-wave form where a wave gets at most two units (N <= 2 x 16 x CUs x 32 rows), else 64-row
                                         * units on eight waves */
 
+#define VQVAE_VQ_UNITS32_8WAVES  0x400 /* 32-row units on eight waves per CU, forced (the rule takes this form up to 8 units per CU) */
+
 #define VQVAE_VQ_UNFUSED        0x40 /* vqvae_forward_f32 only: run the quantizer as its own launch even where the encoder's last
                                         kernel would quantize its z_e in place (32x32 images, h_dim 128, K = 128 k <= 1024, D = 64: z_e is
                                         then never written); identical outputs, A/B timing and tests */

@@ -135,7 +135,8 @@ def test_host_side_plans_without_gpu():
     cus = 256
     assert _lib.vq_launch_form(8 * cus * 32, 512, 64) == (8, 32, 0)               # BASELINE config 2 on 256 CUs: 32-row units, eight waves
     assert _lib.vq_launch_form(32 * cus * 32, 512, 64) == (16, 32, 0)             # config 3: sixteen waves
-    assert _lib.vq_launch_form(256 * cus * 32, 512, 64) == (8, 64, 25)            # many rows: 64-row units, pooled tail
+    assert _lib.vq_launch_form(256 * cus * 32, 512, 64) == (16, 32, 25)           # many rows: sixteen waves as well (round 5), pooled tail
+    assert _lib.vq_launch_form(256 * cus * 32, 600, 64) == (8, 64, 25)            # a codebook whose image leaves no room for sixteen tiles: 64-row units
     assert _lib.vq_launch_form(32 * cus * 32, 1024, 64) == (4, 32, 25)            # config 4's codebook: four waves (eight units per wave here: pooled tail)
     assert _lib.vq_launch_form(256 * cus * 32, 1024, 64)[:2] == (4, 32)
     assert _lib.vq_launch_form(8 * cus * 32, 512, 64, 64, 0x0) == (8, 32, 0)      # NCHW 8x8 maps, few rows

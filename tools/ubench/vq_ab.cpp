@@ -84,7 +84,7 @@ int main(int argc, char **argv) {
         for (size_t l = 0; l < libs.size(); ++l) { wsb[l] = libs[l].ws(N, K, D); CK(hipMalloc(&wss[l], wsb[l])); }
         std::vector<float> hzq((size_t)N0 * D); std::vector<int64_t> hidx(N0);
         for (int form : forms) {
-            const int fl = (nchw ? 0x0 : 0x1) | (form == 8 ? 0x100 : form == 16 ? 0x200 : 0);
+            const int fl = (nchw ? 0x0 : 0x1) | (form == 8 ? 0x100 : form == 16 ? 0x200 : form == 12 ? 0x300 : form == 32 ? 0x400 : 0);
             std::vector<std::vector<float>> ts(libs.size());
             std::vector<int> ok(libs.size(), 1);
             // correctness + warm-up
@@ -124,7 +124,7 @@ int main(int argc, char **argv) {
                 libs[l].fwd(dz, dcb, B, D, 8, 8, K, 0.25f, fl | 0x2, dzq, didx, dhist, dloss, dloss + 1, wss[l], wsb[l], nullptr);
                 CK(hipDeviceSynchronize());
                 if (libs[l].trace(tr.data(), tr.size() * 8)) continue;
-                int NW = form;
+                int NW = form == 32 ? 8 : form;
                 if (NW == 0) { NW = 8; for (int w = 0; w < 256; ++w) if (tr[(w * 16 + 8) * 8 + 7]) NW = 16; }   // (default rule: which form ran?)
                 if (NW == 16) { bool odd = false; for (int w = 0; w < 256; ++w) if (tr[(w * 16 + 9) * 8 + 7]) odd = true; if (!odd) NW = 8; }
                 const int nwaves = 256 * NW;

@@ -116,6 +116,13 @@ int launch_vq_filter_d64(const float *z, const float *cb, long long N, int HW, i
 
 // vq_track.hip: single-sweep fp16-screened, exactly-refined VectorQuantizer kernel with the stream tracker (D = 64; row-major rows or NCHW)
 bool vq_track_nchw_ok(int K, int D, int HW);       // NCHW input: maps whose pixel count is a multiple of 64
+// launch form forced by the caller's flags: 0 = the rule, 8 / 16 = the two public forms, 12 / 32 = experimental (both bits: 32-row units on
+// twelve waves; VQVAE_VQ_UNITS32_8WAVES: 32-row units on eight waves)
+inline int vq_form_of_flags(int flags) {
+    const bool a = flags & VQVAE_VQ_UNITS64_8WAVES, b = flags & VQVAE_VQ_UNITS32_16WAVES;
+    if (flags & VQVAE_VQ_UNITS32_8WAVES) return 32;
+    return a && b ? 12 : (b ? 16 : (a ? 8 : 0));
+}
 struct VqTrackForm { int waves, unit_rows, grid, pool_pct; long long nunits; };     // waves per CU, rows per unit, workgroups, pooled tail units (%)
 bool vq_track_form(long long N, int K, int HW, bool nchw, int form, int cus, VqTrackForm &f);      // false: the kernel does not take this problem
 int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, float *zq, long long *idx, int *hist,
@@ -157,7 +164,8 @@ int res_pair_forward_impl(const float *x, const float *packed_w1, const float *p
 bool conv_res_pair_supported(int kind, int H, int W, int Cin, int C, int Rh);
 int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_front, const float *bias_front, int Cin,
                                const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C, int Rh, int flags,
-                               float *y, hipStream_t stream, const int *in_amax, int *out_amax, const ResPairPost *post = nullptr);
+                               float *y, hipStream_t stream, const int *in_amax, int *out_amax, const ResPairPost *post = nullptr,
+                               const int64_t *gather_idx = nullptr, int gather_K = 0);     // gather_idx: x = a (K, Cin) table, pixel p takes row gather_idx[p]
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)

@@ -142,10 +142,27 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     {
         const int cpt0 = fc.Cin >> 5;
         const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * fc.Cin;     // this lane's pixel row
+        // decode-from-indices (vqvae_decode_f32; the instances without a fused quantizer, vq.idx given): `in` is the codebook and a
+        // pixel's row is its code's row -- z_q never exists in memory (visualization.ipynb:358-365).  An index outside [0, K)
+        // never reads the codebook: its pixel becomes NaN, as in vqvae_vq_decode_indices_f32
+        bool gbad = false;
+        if constexpr (!VQ) {
+            if (vq.idx) {
+                const long long k = vq.idx[(size_t)(img_ok ? img : 0) * PX + lane];
+                gbad = k < 0 || k >= vq.K;
+                src = in + (size_t)(gbad ? 0 : k) * fc.Cin;
+            }
+        }
+        const bool gany = !VQ && __builtin_amdgcn_ballot_w64(gbad) != 0;
         f32x4 raw[8];
         auto load_raw0 = [&](int cc) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) raw[j] = *reinterpret_cast<const f32x4 *>(src + 32 * cc + 4 * j);
+            if (gany) {
+                const float qn = __builtin_nanf("");
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (gbad) raw[j] = f32x4{qn, qn, qn, qn};
+            }
         };
         float m = 0.0f;
         const int given = (in_amax && img_ok) ? in_amax[img] : -1;
@@ -1234,7 +1251,8 @@ bool vqvae::conv_res_pair_supported(int kind, int H, int W, int Cin, int C, int 
 int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *packed_front, const float *bias_front, int Cin,
                                       const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C, int Rh,
                                       int flags, float *y, hipStream_t st, const int *in_amax, int *out_amax,
-                                      const ResPairPost *post) {
+                                      const ResPairPost *post, const int64_t *gather_idx, int gather_K) {
+    if (gather_idx && (post || gather_K < 1)) return VQVAE_ERR_UNSUPPORTED;      // (the gather rides in the instance without a post conv)
     if (!x || !packed_front || !packed_w1 || !packed_w2 || (!y && !post)) return VQVAE_ERR_NULL;
     if (B < 1 || !conv_res_pair_supported(kind, H, W, Cin, C, Rh)) return VQVAE_ERR_UNSUPPORTED;
     if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(post ? post->out : nullptr)) & 15)
@@ -1281,8 +1299,11 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         }
 #undef CRP_POST
     } else {
+        VqFuse gf{};
+        gf.idx = reinterpret_cast<long long *>(const_cast<int64_t *>(gather_idx));       // (read only; x = the codebook then)
+        gf.K = gather_K;
         hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
-                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, VqFuse{});
+                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, gf);
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

@@ -306,9 +306,18 @@ static bool zq_amax_wanted(const VqvaeDims *d, int h4, int w4) {
 }
 
 // zq_amax_given: the quantizer has already published z_q's maxima into the region's slot
+// gather_idx: z_q = the codebook and the first kernel takes pixel p's row from code gather_idx[p] (decoder_gather_ok shapes only)
+static bool decoder_gather_ok(const VqvaeDims *d, int h4, int w4, int cf) {
+#ifndef VQVAE_NO_FRONT_FUSION
+    return !cf && d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONVT_3x3_S1, h4, w4, d->embedding_dim, d->h_dim, d->res_h_dim);
+#else
+    (void)d; (void)h4; (void)w4; (void)cf;
+    return false;
+#endif
+}
 static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h4, int w4, float *x_hat, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, bool am_exclusive = false, bool zq_amax_given = false,
-                       int cf = 0, float *hid_given = nullptr) {
+                       int cf = 0, float *hid_given = nullptr, const int64_t *gather_idx = nullptr) {
     if (!w || !z_q || !x_hat || !workspace) return VQVAE_ERR_NULL;
     const VqvaeDims *d = &w->dims;
     if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
@@ -331,8 +340,9 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     // decoder.py:28-29 (+ the stack's first in-place ReLU), :30, :31-33, :34-35
     // z_q has no producer that publishes maxima: the 8x8-map kernel measures its image itself, the generic one gets them
     // from one more pass over z_q (array [2 + n_res_layers] of the region)
+    if (gather_idx && !decoder_gather_ok(d, h4, w4, cf)) return VQVAE_ERR_UNSUPPORTED;
     int *amz = nullptr;
-    if (am && zq_amax_wanted(d, h4, w4)) {
+    if (am && !gather_idx && zq_amax_wanted(d, h4, w4)) {
         amz = zq_amax_slot(d, B, am);
         if (!zq_amax_given) act_absmax_impl(z_q, B, (long long)h4 * w4 * d->embedding_dim, amz, st);
     }
@@ -347,7 +357,8 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     if (front) {
         int *aout = am ? am + (size_t)2 * B : nullptr;
         if ((rc = conv_res_pair_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, d->embedding_dim, w->dec_res_w1, w->dec_res_w2, B, h4,
-                                             w4, h, d->res_h_dim, VQVAE_CONV_RELU_OUT, a, st, amz, aout)) != 0) return rc;
+                                             w4, h, d->res_h_dim, VQVAE_CONV_RELU_OUT, a, st, amz, aout, nullptr, gather_idx,
+                                             d->n_embeddings)) != 0) return rc;
         amt = aout;
     } else if ((rc = conv_forward_impl(VQVAE_CONVT_3x3_S1, z_q, w->dec0, w->dec0_b, B, h4, w4, d->embedding_dim, h, VQVAE_CONV_RELU_OUT | cf, a, st, amz, am)) != 0) return rc;
     if (!front && d->n_res_layers > 0) {
@@ -473,6 +484,70 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf, f.hid);    // :36
 }
 
+
+// ---- the index wire format: x -> indices, indices -> x_hat ---------------------------------------------
+// README.md:56 / visualization.ipynb:84-90 (encode_data: the (N, 1) int64 indices are what the PixelCNN prior trains on) and
+// visualization.ipynb:358-365 (generate_samples: one-hot @ embedding -> decoder).  On the default shapes' fused path neither
+// direction touches a latent map: the encoder's last kernel quantizes its own z_e and writes 512 bytes of indices per image
+// (no z_e, no z_q), the decoder's first kernel gathers the codebook rows itself.  Workspace: vqvae_workspace_bytes, as for the forward.
+int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, int64_t *idx, void *workspace,
+                     size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !x || !idx || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    FwdWs f;
+    {
+        const int crc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
+        if (crc != VQVAE_OK) return crc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int cf = conv_scheme(vq_flags);
+    if (cf < 0) return VQVAE_ERR_UNSUPPORTED;
+    const size_t acts_bytes = 2 * align_up(f.act * sizeof(float), 256);
+    const bool fused = fused_c3_path(d, H, W, cf);
+    if (!fused && hipMemsetAsync(f.am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    int rc;
+    bool hist_zeroed = false;
+    if (fused && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
+        if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, f.vqws, f.vqws_bytes, st)) != 0) return rc;
+        VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, f.vqws, nullptr, idx, f.hist);      // no z_q: its stores are dropped
+        vf.partials = reinterpret_cast<double *>(f.z_e);                // (the loss partials and the histogram are by-products nobody reads)
+        return encoder_run(w, x, B, H, W, f.z_e, f.acts, acts_bytes, st, f.am2, f.hist, d->n_embeddings, &hist_zeroed, false, &vf);
+    }
+    // other shapes: encoder -> z_e (workspace) -> the stand-alone quantizer (z_q, loss and perplexity land in the workspace, unread)
+    if ((rc = encoder_run(w, x, B, H, W, f.z_e, f.acts, acts_bytes, st, f.am2, fused ? f.hist : nullptr, d->n_embeddings, &hist_zeroed, false,
+                          nullptr, cf, f.hid)) != 0) return rc;
+    float *scal = reinterpret_cast<float *>(f.idx_ws);                  // (the workspace's index region is free: idx is the caller's)
+    return vq_forward_impl(f.z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
+                           (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_REMOVED_FLAGS)) |
+                               VQVAE_VQ_ROWMAJOR,
+                           f.z_q, idx, f.hist, scal, scal + 1, f.vqws, f.vqws_bytes, stream, hist_zeroed, nullptr, nullptr);
+}
+
+int vqvae_decode_f32(const VqvaeWeights *w, const int64_t *idx, int64_t B, int h4, int w4, int flags, float *x_hat, void *workspace,
+                     size_t workspace_bytes, vqvae_stream_t stream) {
+    if (!w || !idx || !x_hat || !workspace) return VQVAE_ERR_NULL;
+    const VqvaeDims *d = &w->dims;
+    const int cf = conv_scheme(flags);
+    if (cf < 0 || (flags & ~(VQVAE_FWD_CONV_BF16_SPLIT | VQVAE_FWD_CONV_EXACT_FP32))) return VQVAE_ERR_UNSUPPORTED;
+    if (!dims_ok(d) || B < 1 || h4 < 1 || w4 < 1) return VQVAE_ERR_SHAPE;
+    FwdWs f;
+    int vq_flags = VQVAE_VQ_CODEBOOK_PREPARED;                          // (no quantizer workspace is touched here)
+    {
+        const int crc = carve_forward(d, B, 4 * h4, 4 * w4, workspace, workspace_bytes, workspace, 0, vq_flags, f, false);
+        if (crc != VQVAE_OK) return crc;
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t acts_bytes = 2 * align_up(f.act * sizeof(float), 256);
+    int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(f.am2) + amax_bytes(d, B));
+    const bool fused = fused_c3_path(d, 4 * h4, 4 * w4, cf);
+    if (!fused && hipMemsetAsync(am_dec, 0xFF, amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    if (decoder_gather_ok(d, h4, w4, cf))
+        return decoder_run(w, w->codebook, B, h4, w4, x_hat, f.acts, acts_bytes, st, am_dec, false, false, cf, f.hid, idx);
+    // other shapes: the codebook rows of every position into the workspace's z_q (row-major), then the decoder
+    const int rc = vqvae_gather_rows_f32(idx, w->codebook, (int64_t)f.rows, d->embedding_dim, d->n_embeddings, f.z_q, stream);
+    if (rc != 0) return rc;
+    return decoder_run(w, f.z_q, B, h4, w4, x_hat, f.acts, acts_bytes, st, am_dec, false, false, cf, f.hid);
+}
 
 // ---- the same step in PARTS (the default shapes' fused path only) -----------------------------------------------------------
 // vqvae_forward_begin_f32 (codebook images, histogram cleared) -> vqvae_forward_part_f32 for disjoint image ranges, each on

@@ -473,7 +473,7 @@ static int launch_vq(const float *z, const float *cb, long long N, int HW, int K
         if (track_nchw || (rowmajor && vq_track_ok(K, D) && !(flags & (VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER)))) {
             int fgrid = 0;
             const int rc = launch_vq_track_d64(z, cb, N, K, zq, idx, hist, ws, st, &fgrid, HW, track_nchw,
-                                               (flags & VQVAE_VQ_UNITS32_16WAVES) ? 16 : ((flags & VQVAE_VQ_UNITS64_8WAVES) ? 8 : 0));
+                                               vq_form_of_flags(flags));
             if (rc != 0) return rc;
             hipLaunchKernelGGL(vq_finalize_kernel, dim3(1), dim3(256), 0, st, partials, fgrid, hist, K, N, D,
                                beta, loss, ppl);
@@ -566,7 +566,7 @@ int vqvae_vq_launch_form(int64_t n_rows, int K, int D, int HW, int flags, int *w
     const char *n = vqvae_vq_kernel_name(K, D, flags);
     VqTrackForm f;
     const bool nchw = !(flags & VQVAE_VQ_ROWMAJOR);
-    if (D != 64 || n[3] != 't' || !vq_track_form(n_rows, K, HW, nchw, (flags & VQVAE_VQ_UNITS32_16WAVES) ? 16 : ((flags & VQVAE_VQ_UNITS64_8WAVES) ? 8 : 0),
+    if (D != 64 || n[3] != 't' || !vq_track_form(n_rows, K, HW, nchw, vq_form_of_flags(flags),
                                                   num_cus(), f))
         return VQVAE_ERR_UNSUPPORTED;
     if (waves) *waves = f.waves;

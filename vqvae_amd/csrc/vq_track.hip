@@ -269,10 +269,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float pinf = inf, ninf = -inf;                     // (round 5: the tracker no longer pads with them; plain constants)
     unsigned keymask = trk::kKeyMask;                        // opaque: see vq_track.h
     asm volatile("" : "+v"(keymask));
-    // the wave's squared-error sum: one fp32 value per unit; fp64 across units -- except in the sixteen-wave form, which a wave runs
-    // for two or three units (launch rule) and which has no two registers to spare
+    // the wave's squared-error sum: one fp32 value per lane and unit; fp64 across units.  The sixteen-wave form has no two registers to
+    // spare for it through the sweep: there the fp64 sums sit in the spare 512 bytes of the wave's tables and take the fp32 value of
+    // eight units at a time
     typedef typename std::conditional<NW == 16, float, double>::type acc_t;
     acc_t dacc = 0;
+    int nflush = 0;
+    if constexpr (NW == 16) reinterpret_cast<double *>(tab_s + 1032)[tid & 63] = 0.0;
 
     // Many units per wave (pool_pct > 0: the host sets 25 from four units per wave on): the last quarter of the units is not dealt out
     // to the workgroups.  A wave whose workgroup has used up its share draws from the pool of its group of workgroups (blockIdx % 8 --
@@ -289,6 +292,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     long long npool = nunits > pstride ? nunits * pool_pct / 100 : 0;
     if (npool > nunits - pstride) npool = nunits - pstride;  // (first units are always dealt out)
     const long long nlocal = nunits - npool;
+    // the wave's next unit: its workgroup's LDS ticket, then (many units per wave) the group's pool
+    auto next_unit = [&](int lane) -> long long {
+        int q = 0;
+        if (lane == 0) q = atomicAdd(ticket_s, 1);
+        q = __builtin_amdgcn_readfirstlane(q);
+        long long pn = (long long)(q / NW) * pstride + (long long)blockIdx.x * NW + (q % NW);
+        if (pn >= nlocal && npool > 0) {                    // the workgroup's own share is used up: the group's pool
+            int t = 0;
+            if (lane == 0) t = atomicAdd(xt, 1);
+            pn = nlocal + (long long)xng * __builtin_amdgcn_readfirstlane(t) + xg;
+        }
+        return pn;
+    };
     while (p < nunits) {
         const long long r0 = p * RU;
         // lane-derived indices are made opaque once per iteration: hipcc otherwise hoists dozens of per-lane address values
@@ -485,6 +501,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 sacc = vqu::epilogue_sp<false, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                      zq ? zq + (size_t)p * RU * D : nullptr, nleft, idx + r0, hist_s);
             dacc += (acc_t)sacc;
+            if constexpr (NW == 16) {
+                if ((++nflush & 7) == 0) { reinterpret_cast<double *>(tab_s + 1032)[lane] += (double)dacc; dacc = 0; }
+            }
         }
 #ifdef VQ_DEBUG_VERDICT
         // debug build (tools/build_variant.py dbg -DVQ_DEBUG_VERDICT): the classification of every row next to its index --
@@ -503,20 +522,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         if (trace_u < 4) { VQ_TR(2 + trace_u); }
         ++trace_u;
 #endif
-        {
-            int q = 0;
-            if (lane == 0) q = atomicAdd(ticket_s, 1);
-            q = __builtin_amdgcn_readfirstlane(q);
-            p = (long long)(q / NW) * pstride + (long long)blockIdx.x * NW + (q % NW);
-            if (p >= nlocal && npool > 0) {                    // the workgroup's own share is used up: the group's pool
-                int t = 0;
-                if (lane == 0) t = atomicAdd(xt, 1);
-                p = nlocal + (long long)xng * __builtin_amdgcn_readfirstlane(t) + xg;
-            }
-            if (p < nunits) {
-                load_unit(p, F, lane);
-                convert();                                     // (waits for the rows; the next iteration starts with the sweep)
-            }
+        // (round 5 tried requesting the NEXT unit's rows here a unit ahead -- into F, free once the rows are fp16 operands -- with the
+        // epilogue reading the current rows again from L2: 37 -> 44 us at 262 144 rows, slower in every launch form; the second read
+        // misses L2 and waits as long as the first did.  profiles/r05_vq_notes.txt)
+        p = next_unit(lane);
+        if (p < nunits) {
+            load_unit(p, F, lane);
+            convert();                                         // (waits for the rows; the next iteration starts with the sweep)
         }
         VQ_STAMP(1);                                           // next rows landed, fp16 conversion
     }
@@ -530,6 +542,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #endif
     VQ_TR(6);
     double dsum = (double)dacc;
+    if constexpr (NW == 16) dsum += reinterpret_cast<double *>(tab_s + 1032)[tid & 63];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) dsum += __shfl_xor(dsum, o);
     __syncthreads();
@@ -576,14 +589,17 @@ bool vq_track_form(long long N, int K, int HW, bool nchw, int form, int cus, VqT
     // 8 / 16 = forced (A/B: tools/ubench/vq_ab.cpp)
     const bool fits16 = !nchw && vq_track_lds_bytes(K, 16, 1) <= (size_t)kLdsBytes;
     const bool narrow = !vq_track_fits8(K);                                           // four waves, 32-row units (K up to 1024)
-    const bool wide = form == 16 ? fits16 : (form == 8 ? false : (fits16 && (N + 31) / 32 <= 2LL * 16 * cus));
+    // (round 5: with the speaker-form unit the sixteen-wave form is also the faster one for many units per wave -- 2.1 M rows
+    // 207-235 us against 225-233 us -- so the rule takes it whenever its tiles fit)
+    const bool wide = form == 16 ? fits16 : ((form == 8 || form == 12 || form == 32) ? false : fits16);
     // Few rows (N <= 8 x CUs x 32: BASELINE config 2): 32-row units on EIGHT waves per CU -- every CU gets a workgroup before any
     // wave gets a second unit, where sixteen waves would leave half the CUs without one (65 536 rows: 21.5 -> 18 us)
     // (beyond that: 27.8 vs 27.4 us at 131 072 rows, 42.9 vs 40.0 at 262 144).  NCHW maps take the same form then -- and always when
     // their pixel count is a multiple of 32 but not of 64
-    const bool spread = (form == 0 && (N + 31) / 32 <= 8LL * cus) || (nchw && HW % 64 != 0);
-    f.waves = narrow ? 4 : ((wide && !spread) ? 16 : 8);
-    f.unit_rows = (narrow || wide || spread) ? 32 : 64;
+    const bool spread = (form == 0 && (N + 31) / 32 <= 8LL * cus) || (nchw && HW % 64 != 0) || form == 32;
+    const bool twelve = form == 12 && !nchw && !narrow && vq_track_lds_bytes(K, 12, 1) <= (size_t)kLdsBytes;
+    f.waves = narrow ? 4 : (twelve ? 12 : ((wide && !spread) ? 16 : 8));
+    f.unit_rows = (narrow || wide || spread || twelve) ? 32 : 64;
     f.nunits = (N + f.unit_rows - 1) / f.unit_rows;
     long long grid = (f.nunits + f.waves - 1) / f.waves;
     if (grid > cus) grid = cus;
@@ -619,6 +635,7 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
                                p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
     if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
+    else if (NW == 12) launch(vq_track_kernel_d64<12, false, 1>);
     else if (nchw && spread) launch(vq_track_kernel_d64<8, true, 1>);
     else if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
     else if (spread) launch(vq_track_kernel_d64<8, false, 1>);

@@ -43,7 +43,8 @@ __device__ __forceinline__ Bound load_bound(const int *__restrict__ flags) {
     return b;
 }
 
-// per-wave tables (1552 bytes): [64] tasks  row | a << 6 | b << 19;  [64] (distance, index) minima;  [64] ||z||^2;  counter
+// per-wave tables (1552 bytes): [64] tasks  row | a << 6 | b << 19;  [64] (distance, index) minima;  [64] ||z||^2;  counter;
+// from byte 1032: 64 fp64 loss sums (vq_track_kernel_d64's sixteen-wave form)
 constexpr int kTabBytes = 1552;
 struct Tables {
     unsigned *task_s;
