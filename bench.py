@@ -203,6 +203,16 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
+def vq_instance_traffic(pmc, instance: str, rows: int):
+    """HBM bytes per launch of ONE template instance of the quantizer at ONE row count, from the per-instance table
+    tools/pmc_traffic.py writes (`vq_instances`: "<instance>@<rows>" -> read / write bytes per launch), or None: the figure in
+    `roofline.traffic` must describe the kernel the line names and times, not another instance at another size."""
+    if not pmc:
+        return None
+    ent = pmc.get("vq_instances", {}).get(f"{instance}@{rows}")
+    return int(ent["read_bytes"] + ent["write_bytes"]) if ent else None
+
+
 def pmc_traffic(workload: str, vq_kernel: str):
     """HBM bytes per row / per image from the committed rocprofv3 PMC summary for this workload, or None.
     The file is written by tools/pmc_traffic.py from separate FETCH_SIZE / WRITE_SIZE passes (FETCH_SIZE doubled on
@@ -399,6 +409,87 @@ def other_workload(name, torch, dev, seconds=1.0):
     return res
 
 
+# What the quantizer's launch shape can reach when it does NOTHING but move its 520 B per row (one workgroup per CU, codebook image
+# into LDS, rows in, rows + indices out): tools/ubench/vq_floor.hip, profiles/r04b_vq_timeline.txt section 1, as a fraction of the
+# 8 TB/s the roofline is priced against.  The distance between `frac` and this is the kernel's own; the rest is the machine's.
+VQ_COPY_ROOF = {65536: 0.63, 262144: 0.97, 2097152: 0.66}
+
+
+def vq_size_sweep(torch, dev, K=512, D=64):
+    """The stand-alone quantizer at 65 536 / 262 144 / 2 097 152 rows of this model's own z_e (repeated to size), each timed by the
+    dispatch's own events: fraction of the 8 TB/s peak beside the bare-copy roof of the same launch shape at that size."""
+    from vqvae_amd import _lib, conv as conv_mod, conv_hip, functional as F_hip
+    from vqvae_amd.modules import VQVAE
+    conv_mod.set_conv_backend("hip")
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+    out = {}
+    with torch.no_grad():
+        x = torch.randn(1024, 3, 32, 32, generator=torch.Generator().manual_seed(1000)).to(dev)
+        z1 = conv_hip.encoder_forward(model.encoder, x, model.pre_quantization_conv).reshape(-1, D)       # 65 536 rows
+        cbw = model.vector_quantization.embedding.weight.detach()
+        vws = F_hip.vq_workspace(K, D, dev)
+        for mult in (1, 4, 32):
+            z = z1.repeat(mult, 1).view(mult * 1024, 8, 8, D).contiguous()
+            rows = z.shape[0] * 64
+            F_hip.vq_forward(z, cbw, 0.25, rowmajor=True, workspace=vws)
+            for _ in range(3):
+                F_hip.vq_forward(z, cbw, 0.25, rowmajor=True, workspace=vws, prepared=True)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            n = 30 if mult < 32 else 12
+            for _ in range(n):
+                F_hip.vq_forward(z, cbw, 0.25, rowmajor=True, workspace=vws, prepared=True)
+            ms, cnt = _lib.profile_collect("vq_main")
+            _lib.profile_enable(False)
+            t = ms / max(cnt, 1) * 1e-3
+            frac = rows * (8 * D + 8) / t / 1e9 / HBM_PEAK_GBPS
+            out[str(rows)] = {"kernel": _lib.vq_kernel_instance(rows, K, D, 64, 0x1), "avg_kernel_us": round(t * 1e6, 2),
+                              "frac": round(frac, 4), "copy_roof_frac": VQ_COPY_ROOF.get(rows),
+                              "frac_of_copy_roof": round(frac / VQ_COPY_ROOF[rows], 4) if rows in VQ_COPY_ROOF else None}
+            del z
+    del model, x, z1, vws
+    torch.cuda.empty_cache()
+    return out
+
+
+def wire_legs(torch, dev, fwd_ms, seconds=0.6, B=4096, K=512, D=64):
+    """SURVEY.md 8f-1, the index wire format as single entry points at the headline's batch: x -> indices (vqvae_encode_f32: the
+    encoder's last kernel writes 512 B of indices per image, no z_e, no z_q) and indices -> x_hat (vqvae_decode_f32: the decoder's
+    first kernel gathers the codebook rows itself)."""
+    import statistics
+    from vqvae_amd import conv as conv_mod
+    from vqvae_amd.modules import VQVAE
+    conv_mod.set_conv_backend("hip")
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev)
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(1000)).to(dev)
+    res = {}
+    with torch.no_grad():
+        idx = model.encode(x)
+        for name, fn in (("encode", lambda: model.encode(x)), ("decode", lambda: model.decode_indices(idx, B, 8, 8))):
+            def run(n):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t0
+            run(3)
+            steps = max(3, int(seconds / 5 / max(run(3) / 3, 1e-6)) + 1)
+            el = statistics.median([run(steps) for _ in range(5)])
+            ms = el / steps * 1e3
+            res[name] = {"images_per_s": round(B * steps / el, 1), "ms_per_call": round(ms, 4),
+                         "vs_forward": round(fwd_ms / ms, 2) if fwd_ms else None}
+    res["encode"]["boundary_bytes_per_image"] = {"in": 3 * 32 * 32 * 4, "out": 64 * 8}
+    res["decode"]["boundary_bytes_per_image"] = {"in": 64 * 8, "out": 3 * 32 * 32 * 4}
+    res["note"] = ("decode includes the Python layer's range check of the indices (one min / max reduction and a host sync per call: the "
+                   "reference's scatter raises on a bad index, a launch cannot)")
+    del model, x, idx
+    torch.cuda.empty_cache()
+    return res
+
+
 HPARAM_LEGS = {
     # main.py:16-25's other hyper-parameters on 32x32 images (VERDICT r3 item 7): (h_dim, res_h, n_res, K, D, batch, what runs)
     "wide_h256_rh64": (256, 64, 2, 512, 64, 1024,
@@ -537,6 +628,17 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU "
                          "(or drop the launcher and let --gpus spawn them)")
 
+    # one slice of the host's cores per rank (LOCAL_RANK of LOCAL_WORLD_SIZE): eight ranks' launch threads and their helper threads do
+    # not migrate over each other; a no-op for a single rank or where the kernel forbids it
+    try:
+        lws = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+        if lws > 1 and hasattr(os, "sched_setaffinity"):
+            cpus = sorted(os.sched_getaffinity(0))
+            per = len(cpus) // lws
+            if per >= 1:
+                os.sched_setaffinity(0, cpus[local * per:(local + 1) * per])
+    except OSError:
+        pass
     import torch
     dry = args.dry_run
     if not dry and not torch.cuda.is_available():
@@ -597,6 +699,8 @@ def main():
     g = torch.Generator().manual_seed(1000 + rank)
     x = torch.randn(B, 3, H, W, generator=g).to(dev)   # synthetic, resident in HBM before timing
 
+    own_times = []
+
     def timed_repeat():
         sync()
         if dist:
@@ -610,6 +714,7 @@ def main():
             dist.barrier()
         sync()
         el = time.perf_counter() - t0
+        own_times.append(el)                            # this rank's own clock (the line lists every rank's median: a straggler shows)
         if dist:
             t = torch.tensor([el], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -633,6 +738,14 @@ def main():
     assert torch.isfinite(out[1]).all()
     srt = sorted(times)
     elapsed = srt[len(srt) // 2]                       # median repeat
+    # every rank's own median step time and calibration, gathered on all ranks (tiny): rank 0 prints them
+    own_ms = sorted(own_times)[len(own_times) // 2] / args.steps * 1e3
+    per_rank = [{"rank": rank, "ms_per_step": round(own_ms, 4), "calibration_tflops": (calib or {}).get("mfma_fp16_random_tflops"),
+                 "cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}]
+    if dist:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, per_rank[0])
+        per_rank = gathered
 
     # ---- per-kernel time of the fused VQ kernel (and the conv groups), extra steps outside the timed region ----
     extra, vq_ms, vq_n, nprof = {}, 0.0, 0, min(args.steps, 50)
@@ -689,6 +802,7 @@ def main():
                        "ms_per_step_max": round(srt[-1] / args.steps * 1e3, 4),
                        "timed_seconds_total": round(sum(times), 3)},
         }
+        line["per_rank"] = per_rank
         if calib:
             line["calibration"] = calib
             # the same build on the calibration's reference box: value x (reference / measured) -- a first-order correction (the
@@ -704,14 +818,18 @@ def main():
                 t_vq = vq_ms / vq_n * 1e-3                     # seconds per launch
                 alg_bytes = rows * (8 * D + 8)                 # read z_e, write z_q, write int64 idx
                 achieved = alg_bytes / t_vq / 1e9
+                vq_inst = _lib.vq_kernel_instance(rows, K, D, (H // 4) * (W // 4), 0x1)
                 line["roofline"] = {
-                    "kernel": _lib.vq_kernel_instance(rows, K, D, (H // 4) * (W // 4), 0x1) + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
+                    "kernel": vq_inst + " (fused VQ: 16-bit MFMA screen with a rigorous bound + exact "
                               "fp32 refine of the surviving codes; bit-exact indices)",
                     "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": int(pmc["vq_bytes_per_row"] * rows) if pmc and "vq_bytes_per_row" in pmc else None,
-                    "traffic_source": pmc["_path"] if pmc and "vq_bytes_per_row" in pmc else None,
-                    "traffic_stale": pmc_stale,
+                    "traffic": vq_instance_traffic(pmc, vq_inst, rows),
+                    "traffic_over_algorithmic": (round(vq_instance_traffic(pmc, vq_inst, rows) / alg_bytes, 3)
+                                                 if vq_instance_traffic(pmc, vq_inst, rows) else None),
+                    "traffic_source": pmc["_path"] if vq_instance_traffic(pmc, vq_inst, rows) else None,
+                    "traffic_stale": pmc_stale or (None if vq_instance_traffic(pmc, vq_inst, rows) or not pmc else
+                                                   f"{pmc['_path']}: no PMC pass for {vq_inst} at {rows} rows"),
                     "avg_kernel_us": round(t_vq * 1e6, 2), "rows_per_launch": rows,
                     "in_step": "own launch" if vq_in_step else
                                "the step quantizes inside the encoder's last kernel (conv_res_pair8_h2_kernel<2, true>; z_e is never "
@@ -786,6 +904,12 @@ def main():
                 line["other_workloads"]["c3_fp32"] = scheme_leg("fp32", torch, dev)
                 for name in HPARAM_LEGS:
                     line["other_workloads"][name] = hparam_leg(name, torch, dev, seconds=0.6)
+                for name, fn in (("wire_format", lambda: wire_legs(torch, dev, elapsed / args.steps * 1e3)),
+                                 ("vq_sizes", lambda: vq_size_sweep(torch, dev))):
+                    try:                               # next-row / reporting figures: never take the headline line down
+                        line["other_workloads"][name] = fn()
+                    except Exception as e:             # noqa: BLE001
+                        line["other_workloads"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
                 try:                                   # a next-row figure: its failure must not take the headline line with it
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)

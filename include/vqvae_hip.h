@@ -30,13 +30,15 @@
 extern "C" {
 #endif
 
-#define VQVAE_HIP_ABI_VERSION 8   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
+#define VQVAE_HIP_ABI_VERSION 9   /* 2: round 2's packed-weight layout, whole-path entries; 3: quantizer flag 0x10 = VQVAE_VQ_TOP3_KEYS;
                                     4: forward in parts (begin / part / end), residual layer with hidden output, larger
                                        weight-gradient and streamed-quantizer workspaces (always ask the *_bytes functions);
                                     5-6: round 4's headers in front of the two-term images, whole-path product flags, removed
                                        quantizer flags; 7: data-gradient epilogues (vqvae_conv_forward_ep_f32);
                                     8: vqvae_vq_launch_form, unit counters in the quantizer workspace (its size changed: ask
-                                       vqvae_vq_workspace_bytes), K up to 1024 on the resident-image and the fused quantizer */
+                                       vqvae_vq_workspace_bytes), K up to 1024 on the resident-image and the fused quantizer;
+                                    9: round 5 -- vqvae_encode_f32 / vqvae_decode_f32 (the index wire format as fused entry points),
+                                       VQVAE_VQ_UNITS32_8WAVES, the sixteen-wave quantizer form at every size */
 
 #define VQVAE_OK               0
 #define VQVAE_ERR_NULL        -1   /* a required pointer is NULL                       */
@@ -426,6 +428,7 @@ VQVAE_API int vqvae_weights_pack_f32(const VqvaeDims *dims, const VqvaeRawWeight
                                      VqvaeWeights *out, vqvae_stream_t stream);
 /* Bytes of activation workspace for a (B, in_ch, H, W) batch (H, W multiples of 4; 0: unsupported). */
 VQVAE_API size_t vqvae_workspace_bytes(const VqvaeDims *dims, int64_t B, int H, int W);
+VQVAE_API size_t vqvae_workspace_ze_offset(const VqvaeDims *dims, int64_t B, int H, int W);   /* bytes from the workspace's start to z_e (0: unsupported shape) */
 
 /* ResidualStack.forward (models/residual.py:47-51): n_layers applications of the SAME layer, then F.relu if
  * VQVAE_CONV_RELU_OUT; VQVAE_CONV_RELU_IN applies the first layer's in-place ReLU on read.  x, y, tmp row-major
@@ -462,6 +465,11 @@ VQVAE_API int vqvae_decoder_ex_f32(const VqvaeWeights *w, const float *z_q, int6
  * "error bound per output channel") and the honest side-by-side legs of bench.py.  Both at once: VQVAE_ERR_UNSUPPORTED.   */
 #define VQVAE_FWD_CONV_BF16_SPLIT 0x1000
 #define VQVAE_FWD_CONV_EXACT_FP32 0x2000
+/* Test hook (round 5): on the default shapes' fused path -- where the encoder's last kernel quantizes a z_e that never leaves the chip --
+ * vqvae_forward_f32 ALSO writes the very z_e rows that kernel quantizes, row-major (B*H/4*W/4, D), at vqvae_workspace_ze_offset() of the
+ * workspace (a separate instance of the kernel; idx must be given).  tests/test_model_gpu.py feeds those bits to the CPU oracle.
+ * Ignored where the quantizer runs as its own launch (z_e is in the workspace there anyway).                                          */
+#define VQVAE_FWD_DEBUG_ZE        0x4000
 
 /* VQVAE.forward: x -> (embedding_loss, x_hat, perplexity) (models/vqvae.py:44); idx (B*H/4*W/4 int64) is optional.
  * vq_flags: VQVAE_VQ_CODEBOOK_PREPARED (only meaningful with a persistent vq_workspace of vqvae_vq_workspace_bytes),
@@ -471,6 +479,22 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
                                 float *x_hat, float *loss, float *perplexity, int64_t *idx, void *workspace,
                                 size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
                                 vqvae_stream_t stream);
+
+/* The index wire format as single entry points -- what the PixelCNN prior is trained on and sampled into:
+ *   vqvae_encode_f32   x (B,C,H,W) -> min_encoding_indices (B*H/4*W/4 int64), README.md:56 / visualization.ipynb:84-90 (encode_data);
+ *   vqvae_decode_f32   indices -> x_hat (B,C,4h,4w), visualization.ipynb:358-365 / 642-650 (one-hot @ embedding -> decoder).
+ * On the default shapes' fused path (32x32 images, h_dim 128, two residual layers, K a multiple of 128 up to 1024, D = 64) neither
+ * touches a latent map: the encoder's last kernel quantizes its own z_e and writes 512 bytes of indices per image (no z_e, no z_q:
+ * 12 KiB in, 0.5 KiB out), and the decoder's first kernel takes each latent pixel's row straight from the codebook (0.5 KiB in, 12 KiB
+ * out).  Other shapes run encoder -> stand-alone quantizer / row gather -> decoder through the workspace.  Indices equal
+ * vqvae_forward_f32's bit for bit; x_hat equals the decoder's on the same z_q bit for bit.  An index outside [0, K) makes its image's
+ * x_hat NaN (it never reads the codebook).  workspace: vqvae_workspace_bytes(dims, B, H, W) (decode: H = 4h, W = 4w); vq_workspace /
+ * vq_flags as for vqvae_forward_f32; decode's flags: VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32 or 0.                                   */
+VQVAE_API int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, int64_t *idx,
+                               void *workspace, size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
+                               vqvae_stream_t stream);
+VQVAE_API int vqvae_decode_f32(const VqvaeWeights *w, const int64_t *idx, int64_t B, int h, int w_, int flags, float *x_hat,
+                               void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
 
 /* The same step in PARTS, for callers that spread a large batch over several streams (the default shapes' path only: 32x32
  * images, h_dim 128, two residual layers, K a multiple of 128 up to 1024, D = 64; VQVAE_ERR_UNSUPPORTED otherwise -- use vqvae_forward_f32):

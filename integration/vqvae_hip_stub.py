@@ -3,6 +3,7 @@
     import vqvae_hip_stub as hip                       # next to main.py in the reference tree
     model = VQVAE(128, 32, 2, 512, 64, .25).to('cuda').eval()      # the reference's OWN class (models/vqvae.py:10)
     hip.install(model)                                 # model(x) -> (embedding_loss, x_hat, perplexity) on libvqvae_hip.so
+    idx = model.encode(x); x_hat = model.decode_indices(idx, B, 8, 8)     # the index wire format (README.md:56, notebook cells)
     hip.install_quantizer(model.vector_quantization)   # or only VectorQuantizer.forward (models/quantizer.py:29-76)
 
 `install` reads the parameters through `model.state_dict()` -- the 23 keys of SURVEY.md 8b -- so it works on the
@@ -60,6 +61,8 @@ def lib():
                 ("vqvae_weights_pack_f32", _i32, [C.POINTER(Dims), C.POINTER(RawWeights), _vp, _sz, C.POINTER(Weights), _vp]),
                 ("vqvae_workspace_bytes", _sz, [C.POINTER(Dims), _i64, _i32, _i32]),
                 ("vqvae_forward_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32] + [_vp] * 5 + [_sz, _vp, _sz, _vp]),
+                ("vqvae_encode_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp, _sz, _vp]),
+                ("vqvae_decode_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
                 ("vqvae_vq_workspace_bytes", _sz, [_i64, _i32, _i32]),
                 ("vqvae_vq_forward_f32", _i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32] + [_vp] * 6 + [_sz, _vp])):
             fn = getattr(L, name)
@@ -118,7 +121,49 @@ def install(model):
                                        ws.data_ptr(), n, None, 0, torch.cuda.current_stream(x.device).cuda_stream))
         return out[0], x_hat, out[1]                      # (embedding_loss, x_hat, perplexity), models/vqvae.py:44
 
+    def _ws(w, B, H, W, dev):
+        n = lib().vqvae_workspace_bytes(w.dims, B, H, W)
+        if not n:
+            raise RuntimeError(f"image shape ({B}, ., {H}, {W}) not supported")
+        return torch.empty(n, dtype=torch.uint8, device=dev)
+
+    @torch.no_grad()
+    def encode(self, x):
+        """x -> min_encoding_indices (N, 1) int64: what README.md:56 / the notebook's encode_data keep of a forward.  One call
+        (vqvae_encode_f32); on the default shapes no latent map is written at all."""
+        if state["w"] is None:
+            state["w"] = pack(self)
+        w, _keep = state["w"]
+        x = x.contiguous()
+        B, _, H, W = x.shape
+        with torch.cuda.device(x.device):
+            ws = _ws(w, B, H, W, x.device)
+            idx = torch.empty(B * (H // 4) * (W // 4), 1, dtype=torch.int64, device=x.device)
+            _check(lib().vqvae_encode_f32(w, x.data_ptr(), B, H, W, 0, idx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0,
+                                          torch.cuda.current_stream(x.device).cuda_stream))
+        return idx
+
+    @torch.no_grad()
+    def decode_indices(self, idx, B, h, w_):
+        """indices -> x_hat: the notebook's generate_samples (one-hot @ embedding.weight -> view -> permute -> decoder,
+        visualization.ipynb:358-365) as one call (vqvae_decode_f32).  h, w_: the latent map's size."""
+        if state["w"] is None:
+            state["w"] = pack(self)
+        w, _keep = state["w"]
+        idx = idx.contiguous().view(-1)
+        K = w.dims.n_embeddings
+        if idx.numel() != B * h * w_ or int(idx.min()) < 0 or int(idx.max()) >= K:
+            raise IndexError("indices must be B*h*w values in [0, K)")
+        with torch.cuda.device(idx.device):
+            ws = _ws(w, B, 4 * h, 4 * w_, idx.device)
+            x_hat = torch.empty(B, w.dims.in_ch, 4 * h, 4 * w_, dtype=torch.float32, device=idx.device)
+            _check(lib().vqvae_decode_f32(w, idx.data_ptr(), B, h, w_, 0, x_hat.data_ptr(), ws.data_ptr(), ws.numel(),
+                                          torch.cuda.current_stream(idx.device).cuda_stream))
+        return x_hat
+
     model.forward = types.MethodType(forward, model)
+    model.encode = types.MethodType(encode, model)
+    model.decode_indices = types.MethodType(decode_indices, model)
     model.hip_repack = lambda: state.update(w=None)       # after load_state_dict / an optimizer step
     return model
 

@@ -35,6 +35,24 @@ def test_gpus_2_spawns_two_ranks_and_prints_one_line():
         assert key in line
 
 
+def test_gpus_8_dry_run_lists_every_rank_and_pins_cores():
+    """Round 5: the driver's 8-GPU launch shape on gloo -- eight ranks, one line, every rank's own median step
+    time and calibration slot in `per_rank` (a straggler is visible), each rank on its own slice of the host's cores."""
+    p = _run(["--gpus", "8"], timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = _json_lines(p.stdout)
+    assert len(lines) == 1, p.stdout
+    line = lines[0]
+    assert line["n_gpus"] == 8 and line["config"]["global_batch"] == 8 * line["config"]["per_gpu_batch"]
+    pr = line["per_rank"]
+    assert [r["rank"] for r in pr] == list(range(8)) and all(r["ms_per_step"] > 0 for r in pr)
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert all(r["cpus"] == ncpu // 8 for r in pr), pr      # LOCAL_RANK's slice, not the whole host
+    # the whole-job figure is the slowest rank's clock
+    assert line["ms_per_step"] >= max(r["ms_per_step"] for r in pr) * 0.5
+
+
 def test_single_rank_line_and_world_size_mismatch():
     p = _run(["--gpus", "1"])
     assert p.returncode == 0, p.stderr[-2000:]

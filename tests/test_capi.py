@@ -46,7 +46,7 @@ def test_argument_errors_without_gpu(lib):
     lib.vqvae_strerror.restype = ctypes.c_char_p
     lib.vqvae_vq_workspace_bytes.restype = ctypes.c_size_t
     lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
-    assert lib.vqvae_abi_version() == 8
+    assert lib.vqvae_abi_version() == 9
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
     assert b"NULL" in lib.vqvae_strerror(-1)

@@ -84,6 +84,34 @@ def test_installed_forward_matches_reference_golden(golden_models):
 
 
 @pytest.mark.gpu
+def test_installed_encode_decode_wire_format(golden_models):
+    """the stub's encode / decode_indices (vqvae_encode_f32 / vqvae_decode_f32 through ctypes only): indices equal the installed
+    forward's reference-golden indices up to provable near-ties, x_hat of the round trip equals the forward's to fp32 rounding"""
+    from tests.test_model_gpu import build
+    stub = _stub()
+    name = "kat1"
+    h, rh, nl, K, D, beta, B, H, W = cases.MODEL_CASES[name]
+    m, x = build(name)
+    m = m.to("cuda:0")
+    plain = torch.nn.Module.__new__(type("RefLike", (torch.nn.Module,), {}))
+    torch.nn.Module.__init__(plain)
+    for attr in ("encoder", "pre_quantization_conv", "vector_quantization", "decoder"):
+        setattr(plain, attr, getattr(m, attr))
+    stub.install(plain)
+    xd = x.to("cuda:0")
+    with torch.no_grad():
+        idx = plain.encode(xd)
+        x_hat = plain.decode_indices(idx, B, H // 4, W // 4)
+        _, x_hat_f, _ = plain(xd)
+    torch.cuda.synchronize()
+    want = golden_models[f"{name}/idx"].astype(np.int64).reshape(-1)
+    assert (idx.view(-1).cpu().numpy() != want).sum() <= max(1, int(1e-4 * want.size))
+    np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_f.cpu().numpy(), atol=1e-6, rtol=1e-5)
+    with pytest.raises(IndexError):
+        plain.decode_indices(torch.full_like(idx, K), B, H // 4, W // 4)
+
+
+@pytest.mark.gpu
 def test_installed_quantizer_matches_reference_golden(golden_vq):
     stub = _stub()
 

@@ -126,6 +126,111 @@ def test_encode_decode_indices_wire_format(golden_models):
     assert (got != want).sum() <= max(1, int(1e-4 * got.size))
 
 
+@pytest.mark.parametrize("B,K,S", [(64, 512, 32), (37, 512, 32), (1, 1024, 32), (200, 256, 32), (6, 512, 64), (5, 96, 24), (3, 2048, 32)],
+                         ids=["fused_64", "fused_ragged_37", "fused_k1024_1", "fused_k256_200", "halo_64x64", "generic_24x24_k96", "stream_k2048"])
+def test_encode_and_decode_entry_points_equal_the_forward(B, K, S):
+    """Round 5: vqvae_encode_f32 / vqvae_decode_f32 as single entry points.  On the default shapes the encoder's last
+    kernel writes ONLY the indices (no z_e, no z_q) and the decoder's first kernel gathers the codebook rows itself; other shapes go
+    through the workspace.  Indices must equal vqvae_forward_f32's bit for bit; x_hat of decode must equal the decoder's on the
+    gathered z_q bit for bit (e_k against z + (e_k - z) of the forward: equal to fp32 rounding, checked with a tolerance)."""
+    from vqvae_amd import _lib, functional as F
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, K, 64, 0.25).eval().to(dev())
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(5)).to(dev())
+    with torch.no_grad():
+        _, x_hat_f, _, idx_f = m._forward_c(x, want_idx=True)
+        _lib.profile_enable(True)
+        idx = m.encode(x)
+        n_vq = _lib.profile_collect('vq_main')[1]
+        _lib.profile_enable(False)
+        x_hat = m.decode_indices(idx, B, S // 4, S // 4)
+        # the decoder entry on the gathered rows (row-major z_q -> the module's NCHW boundary)
+        z_q = m.vector_quantization.embedding.weight.detach()[idx.view(-1)].view(B, S // 4, S // 4, 64).permute(0, 3, 1, 2).contiguous()
+        x_hat_d = m.decoder(z_q)
+    torch.cuda.synchronize()
+    assert idx.shape == idx_f.shape and idx.dtype == torch.int64
+    assert torch.equal(idx, idx_f), f"{int((idx != idx_f).sum())} indices differ from the forward's"
+    if S == 32 and K % 128 == 0 and K <= 1024:
+        assert n_vq == 0, "the default shapes must quantize inside the encoder's last kernel"
+    assert torch.equal(x_hat, x_hat_d), "decode-from-indices differs from the decoder on the gathered rows"
+    np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_f.cpu().numpy(), atol=1e-6, rtol=1e-5)
+
+
+def test_decode_entry_point_out_of_range_index_is_nan_not_a_read():
+    """An index outside [0, K) never reads the codebook: the C entry makes that image's x_hat NaN (the Python layer raises, as the
+    reference's scatter does)."""
+    from vqvae_amd import _lib
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    B = 8
+    idx = torch.randint(0, 512, (B * 64,), device=dev())
+    with pytest.raises(IndexError):
+        m.decode_indices(torch.where(torch.arange(B * 64, device=dev()) == 70, torch.tensor(512, device=dev()), idx), B, 8, 8)
+    L = _lib.load()
+    with torch.no_grad():
+        good = m.decode_indices(idx, B, 8, 8)
+        bad = idx.clone()
+        bad[70] = 512                                   # image 1
+        bad[5 * 64 + 3] = -1                            # image 5
+        cw, _keep = m._c_weights()
+        ws, stream = m._c_workspace(L, cw, B, 32, 32, dev())
+        out = torch.empty_like(good)
+        _lib.check(L.vqvae_decode_f32(cw, bad.data_ptr(), B, 8, 8, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+    torch.cuda.synchronize()
+    for b in range(B):
+        if b in (1, 5):
+            assert torch.isnan(out[b]).all()
+        else:
+            assert torch.equal(out[b], good[b])
+
+
+def test_fused_quantizer_against_the_oracle_on_its_own_z_e_bits():
+    """Round 5: the quantizer that runs INSIDE the encoder's last kernel met the CPU oracle only through the
+    separate launch.  VQVAE_FWD_DEBUG_ZE makes that kernel write the very z_e rows it quantizes; the C oracle (models/quantizer.py:45-76
+    restated, oracle/vqvae_oracle.c) must give the kernel's indices on exactly those bits -- benign rows, duplicated / near-tied
+    codes (open and hard rows) and rows with Inf / NaN (torch.argmin semantics)."""
+    from oracle import c_oracle
+    from vqvae_amd import _lib, functional as F
+    from vqvae_amd.modules import VQVAE
+    torch.manual_seed(1)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    with torch.no_grad():
+        cb = m.vector_quantization.embedding.weight
+        cb[8:16] = cb[0:8]                                   # exact duplicates: ties, first index wins
+        cb[16:48] = cb[0:1] + 1e-9 * torch.randn(32, 64, device=dev())    # a cluster of 32 near-ties around code 0
+        cb[100:164] = cb[300:301] * (1 + 1e-7 * torch.arange(64, device=dev()).view(-1, 1))
+    m.invalidate_caches()
+    B = 96
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(4)).to(dev())
+    x[5] *= 1e20                                             # z_e overflows: Inf / NaN rows
+    x[9, 0, 0, 0] = float("nan")
+    L = _lib.load()
+    with torch.no_grad():
+        _lib.profile_enable(True)
+        out = m._forward_c(x, want_idx=True, fwd_flags=F.FWD_DEBUG_ZE, parts=1)
+        assert _lib.profile_collect('vq_main')[1] == 0       # the fused kernel ran, not the stand-alone quantizer
+        _lib.profile_enable(False)
+        cw, _keep = m._c_weights()
+        ws, _stream = m._c_workspace(L, cw, B, 32, 32, dev())
+        off = L.vqvae_workspace_ze_offset(cw.dims, B, 32, 32)
+        assert off > 0
+        z_e = ws[off:off + B * 64 * 64 * 4].view(torch.float32).view(B * 64, 64).cpu().numpy().copy()
+    torch.cuda.synchronize()
+    got = out[3].view(-1).cpu().numpy()
+    cbn = m.vector_quantization.embedding.weight.detach().cpu().numpy()
+    want = c_oracle.vq_forward(z_e.reshape(-1, 64, 1, 1), cbn, 0.25)["idx"].reshape(-1)      # (rows as 1x1 maps)
+    assert np.isfinite(z_e).all(axis=1).sum() < B * 64       # the non-finite rows are really there
+    assert (got == want).all(), f"{int((got != want).sum())} of {got.size} indices differ from the oracle's on the kernel's own z_e"
+    # and those bits are the separate encoder launch's bits
+    from vqvae_amd import conv as C_hip
+    with torch.no_grad():
+        z_sep = C_hip.encoder_forward(m.encoder, x, pre_quant=m.pre_quantization_conv).reshape(B * 64, 64).cpu().numpy()
+    fin = np.isfinite(z_sep) & np.isfinite(z_e)
+    assert (np.isfinite(z_sep) == np.isfinite(z_e)).all() and (z_sep[fin] == z_e[fin]).all()
+
+
 def test_forward_only_and_no_cpu_fallback():
     from vqvae_amd._lib import VqvaeHipError
     m, x = build("small")

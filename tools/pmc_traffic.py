@@ -36,7 +36,7 @@ def main():
     wl, B = sys.argv[1], int(sys.argv[2])
     bf, bw, vf, vw = (per_kernel(p) for p in sys.argv[3:7])
     vq_rows, out = int(sys.argv[7]), sys.argv[8]
-    is_vq = lambda k: "vq_" in k and "kernel_d64" in k or "vq_exact_kernel" in k
+    is_vq = lambda k: "vq_" in k and any(t in k for t in ("kernel_d64", "vq_exact_kernel", "vq_stream", "vq_filter", "vq_cand", "vq_refine"))
     vqk = [k for k in vf if is_vq(k)]
     assert vqk, list(vf)
     k = max(vqk, key=lambda n: vf[n][0])
@@ -65,6 +65,24 @@ def main():
         if per_step >= 0.99 and any(t in n for t in ("conv_tile8", "res_tile8", "res_pair8", "conv_res_pair8", "res_layer", "conv_igemm",
                                                      "enc_front8", "dec_tail8", "conv_halo8", "res_halo8")):
             conv += byts
+    # the quantizer per TEMPLATE INSTANCE and ROW COUNT (round 5): bench.py takes `roofline.traffic` from here for
+    # the very instance it names and times -- the bench run's own extra launches of the stand-alone kernel at the workload's rows,
+    # plus the beyond-the-Infinity-Cache stream of tools/vq_traffic.py
+    import re
+    import bench as _bench
+    hw = _bench.WORKLOADS[wl][2]
+    rows_wl = B * (hw // 4) * (hw // 4)
+    inst = {}
+    for tab_f, tab_w, rows in ((bf, bw, rows_wl), (vf, vw, vq_rows)):
+        for n in tab_f:
+            mm = re.search(r"(vq_\w+<[^>]*>)", n)
+            if not mm or not is_vq(n):
+                continue
+            inst[f"{mm.group(1)}@{rows}"] = {"read_bytes": round(2 * tab_f[n][0] * 1024), "write_bytes": round(tab_w.get(n, (0.0, 0))[0] * 1024),
+                                             "algorithmic_bytes": rows * (8 * _bench.WORKLOADS[wl][4] + 8), "dispatches": tab_f[n][1]}
+    for v in inst.values():
+        v["over_algorithmic"] = round((v["read_bytes"] + v["write_bytes"]) / v["algorithmic_bytes"], 4)
+    res["vq_instances"] = inst
     res["conv_bytes_per_image"] = round(conv / B, 1)     # on the fused 32x32 path this includes the quantizer's z_q / index writes
     # stamp: bench.py uses this file only while the kernel sources are the ones it was measured on
     import bench

@@ -92,12 +92,15 @@ SIGNATURES = {
     "vqvae_weights_packed_bytes": (_sz, [_dimsp]),
     "vqvae_weights_pack_f32": (_i32, [_dimsp, _rawp, _vp, _sz, _wp, _vp]),
     "vqvae_workspace_bytes": (_sz, [_dimsp, _i64, _i32, _i32]),
+    "vqvae_workspace_ze_offset": (_sz, [_dimsp, _i64, _i32, _i32]),
     "vqvae_resstack_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "vqvae_encoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_decoder_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_encoder_ex_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_decoder_ex_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_forward_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "vqvae_encode_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp, _sz, _vp]),
+    "vqvae_decode_f32": (_i32, [_wp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
     "vqvae_forward_begin_f32": (_i32, [_wp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_part_f32": (_i32, [_wp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_end_f32": (_i32, [_wp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
@@ -126,7 +129,7 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
-    if lib.vqvae_abi_version() != 8:
+    if lib.vqvae_abi_version() != 9:
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib

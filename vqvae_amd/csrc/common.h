@@ -156,7 +156,7 @@ struct VqFuse {
     float *zq; long long *idx; int *hist; double *partials;
 };
 struct ResPairPost { const float *packed; const float *bias; int Cout; float *out; int *zero = nullptr; int zero_n = 0;
-                     const VqFuse *vq = nullptr; };
+                     const VqFuse *vq = nullptr; bool debug_ze = false; };      // debug_ze: the fused quantizer also writes its z_e rows to `out`
 bool res_pair_post_supported(int C, int Cout);
 int res_pair_forward_impl(const float *x, const float *packed_w1, const float *packed_w2, int64_t B, int H, int W, int C,
                           int Rh, int flags, float *y, hipStream_t stream, const int *in_amax, int *out_amax,

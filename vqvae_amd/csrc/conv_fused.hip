@@ -26,7 +26,7 @@ namespace vqvae {
 #define CRP_MINW 2      // waves per SIMD the register allocation must allow (tools/build_variant.py crp1 -DCRP_MINW=1: 388 registers, no
                         // scratch, one workgroup per CU)
 #endif
-template <int NT3, bool VQ = false>
+template <int NT3, bool VQ = false, bool GATHER = false, bool ZEOUT = false>
 __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kernel(const float *__restrict__ in, FrontConv fc,
                                                                    const u32x4 *__restrict__ w1img, const u32x4 *__restrict__ w2img,
                                                                    float *__restrict__ out, int B, int flags,
@@ -142,18 +142,16 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
     {
         const int cpt0 = fc.Cin >> 5;
         const float *src = in + ((size_t)(img_ok ? img : 0) * PX + lane) * fc.Cin;     // this lane's pixel row
-        // decode-from-indices (vqvae_decode_f32; the instances without a fused quantizer, vq.idx given): `in` is the codebook and a
-        // pixel's row is its code's row -- z_q never exists in memory (visualization.ipynb:358-365).  An index outside [0, K)
-        // never reads the codebook: its pixel becomes NaN, as in vqvae_vq_decode_indices_f32
+        // decode-from-indices (vqvae_decode_f32; the GATHER instance): `in` is the codebook and a pixel's row is its code's row --
+        // z_q never exists in memory (visualization.ipynb:358-365).  An index outside [0, K) never reads the codebook: its
+        // pixel becomes NaN, as in vqvae_vq_decode_indices_f32
         bool gbad = false;
-        if constexpr (!VQ) {
-            if (vq.idx) {
-                const long long k = vq.idx[(size_t)(img_ok ? img : 0) * PX + lane];
-                gbad = k < 0 || k >= vq.K;
-                src = in + (size_t)(gbad ? 0 : k) * fc.Cin;
-            }
+        if constexpr (GATHER) {
+            const long long k = vq.idx[(size_t)(img_ok ? img : 0) * PX + lane];
+            gbad = k < 0 || k >= vq.K;
+            src = in + (size_t)(gbad ? 0 : k) * fc.Cin;
         }
-        const bool gany = !VQ && __builtin_amdgcn_ballot_w64(gbad) != 0;
+        const bool gany = GATHER && __builtin_amdgcn_ballot_w64(gbad) != 0;
         f32x4 raw[8];
         auto load_raw0 = [&](int cc) {
 #pragma unroll
@@ -609,6 +607,13 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     for (int g = 0; g < 4; ++g)
                         *zchunk(32 * mt + l31, 8 * n3 + 2 * g + h) = f32x4{acc3[mt][n3][4 * g], acc3[mt][n3][4 * g + 1], acc3[mt][n3][4 * g + 2], acc3[mt][n3][4 * g + 3]};
             lds_order_wave();
+            if constexpr (ZEOUT) {
+                // debug instance (VQVAE_FWD_DEBUG_ZE): the z_e rows the quantizer works on, bit for bit, for the oracle (tests only)
+                if (img_ok)
+#pragma unroll
+                    for (int c16 = 0; c16 < 16; ++c16)
+                        *reinterpret_cast<f32x4 *>(out3 + ((size_t)img * PX + lane) * 64 + 4 * c16) = *zchunk(lane, c16);
+            }
             vqu::exact_end(R, FL, ntasks, lane, tb, vq.cb, vq.ee, vq.K,
                            [&](int rr, int jc) { return *zchunk(rr, jc); },
                            [&](int rr, int c) { return reinterpret_cast<const float *>(zchunk(rr, c >> 2))[c & 3]; });
@@ -1287,7 +1292,10 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
 #define CRP_POST(NT3_)                                                                                                          \
     hipLaunchKernelGGL((conv_res_pair8_h2_kernel<NT3_>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2, \
                        in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n, VqFuse{})
-        if (post->vq) {
+        if (post->vq && post->debug_ze) {
+            hipLaunchKernelGGL((conv_res_pair8_h2_kernel<2, true, false, true>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags,
+                               hd1, hd2, in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n, *post->vq);
+        } else if (post->vq) {
             // the quantizer rides behind the 1x1 conv: z_e is never written (post->out unused)
             hipLaunchKernelGGL((conv_res_pair8_h2_kernel<2, true>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags,
                                hd1, hd2, in_amax, out_amax, w3h, hd3, post->bias, post->out, post->zero, post->zero_n, *post->vq);
@@ -1299,11 +1307,15 @@ int vqvae::conv_res_pair_forward_impl(int kind, const float *x, const float *pac
         }
 #undef CRP_POST
     } else {
-        VqFuse gf{};
-        gf.idx = reinterpret_cast<long long *>(const_cast<int64_t *>(gather_idx));       // (read only; x = the codebook then)
-        gf.K = gather_K;
+        if (gather_idx) {
+            VqFuse gf{};
+            gf.idx = reinterpret_cast<long long *>(const_cast<int64_t *>(gather_idx));       // (read only; x = the codebook)
+            gf.K = gather_K;
+            hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0, false, true>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags,
+                               hd1, hd2, in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, gf);
+        } else
         hipLaunchKernelGGL((conv_res_pair8_h2_kernel<0>), dim3(gtc), dim3(CRP_NW * 64), 0, st, x, fc, w1h, w2h, y, (int)B, flags, hd1, hd2,
-                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, gf);
+                           in_amax, out_amax, nullptr, nullptr, nullptr, nullptr, nullptr, 0, VqFuse{});
     }
     prof_end(VQVAE_PROF_RES_LAYER, st);
     return (int)hipGetLastError();

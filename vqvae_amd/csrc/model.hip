@@ -8,6 +8,8 @@
 namespace vqvae {
 namespace {
 
+constexpr int kVqFormFlags = VQVAE_VQ_UNITS64_8WAVES | VQVAE_VQ_UNITS32_16WAVES | VQVAE_VQ_UNITS32_8WAVES;
+
 struct Carve {
     char *p;
     size_t left;
@@ -163,6 +165,11 @@ int vqvae_weights_pack_f32(const VqvaeDims *d, const VqvaeRawWeights *raw, void 
     return VQVAE_OK;
 }
 
+size_t vqvae_workspace_ze_offset(const VqvaeDims *d, int64_t B, int H, int W) {
+    if (vqvae_workspace_bytes(d, B, H, W) == 0) return 0;
+    return 2 * align_up(act_elems(d, B, H, W) * sizeof(float), 256) + 2 * amax_bytes(d, B);      // (carve_forward's order)
+}
+
 size_t vqvae_workspace_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
     if (!dims_ok(d) || B < 1 || H < 4 || W < 4 || H % 4 || W % 4) return 0;
     const size_t vq = vqvae_vq_workspace_bytes(B * (int64_t)(H / 4) * (W / 4), d->n_embeddings, d->embedding_dim);
@@ -191,7 +198,7 @@ int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2, const flo
 static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, float *z_e, void *workspace,
                        size_t workspace_bytes, hipStream_t st, int *am_given, int *zero_buf = nullptr, int zero_n = 0,
                        bool *zeroed = nullptr, bool am_exclusive = false, const VqFuse *vq = nullptr, int cf = 0,
-                       float *hid_given = nullptr) {
+                       float *hid_given = nullptr, bool debug_ze = false) {
     // cf: 0 = the default product scheme (two-term fp16 where the kernels have it), VQVAE_CONV_BF16_SPLIT / VQVAE_CONV_EXACT_FP32 =
     // every layer through the per-layer kernels of that scheme (no fused kernels: they exist for the fp16 products only)
     if (!w || !x || !z_e || !workspace) return VQVAE_ERR_NULL;
@@ -235,7 +242,7 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     // 3x3 conv + ReLU, both residual layers and the pre-quantisation conv; none of the three intermediate maps is written
     if (!cf && d->n_res_layers == 2 && conv_res_pair_supported(VQVAE_CONV_3x3_S1, H / 4, W / 4, h, h, d->res_h_dim) &&
         res_pair_post_supported(h, d->embedding_dim)) {
-        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, vq ? nullptr : zero_buf, vq ? 0 : zero_n, vq};
+        const ResPairPost post{w->pre, w->pre_b, d->embedding_dim, z_e, vq ? nullptr : zero_buf, vq ? 0 : zero_n, vq, vq && debug_ze};
         if (zeroed) *zeroed = zero_buf != nullptr;
         return conv_res_pair_forward_impl(VQVAE_CONV_3x3_S1, b, w->enc4, w->enc4_b, h, w->enc_res_w1, w->enc_res_w2, B, H / 4, W / 4, h,
                                           d->res_h_dim, VQVAE_CONV_RELU_OUT, nullptr, st, am1, nullptr, &post);
@@ -460,14 +467,21 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
     int *am_dec = reinterpret_cast<int *>(reinterpret_cast<char *>(am2) + amax_bytes(d, B));
     int rc;
     bool hist_zeroed = false;
-    if (fused && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
+    // (a forced launch form of the stand-alone quantizer -- VQVAE_VQ_UNITS* -- means the stand-alone quantizer: ADVICE r4)
+    if (fused && !(vq_flags & kVqFormFlags) && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
         // vqvae.py:31-34 in TWO launches: the encoder's last kernel quantizes its own z_e (never written); the codebook's
         // images are prepared first, the histogram is cleared by the encoder's first kernel, loss / perplexity by the finalize
         if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, vqws, vqws_bytes, st)) != 0) return rc;
         VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, vqws, z_q, idx ? idx : idx_ws, hist);
         // one loss partial per workgroup of four images: they go where z_e would have gone (any batch size)
         vf.partials = reinterpret_cast<double *>(z_e);
-        if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, hist, d->n_embeddings, &hist_zeroed, false, &vf)) != 0) return rc;
+        // VQVAE_FWD_DEBUG_ZE (tests): the fused kernel also writes the z_e rows it quantizes (vqvae_workspace_ze_offset); the
+        // partials move to the workspace's index region, which the caller's own idx buffer leaves free
+        const bool debug_ze = vq_flags & VQVAE_FWD_DEBUG_ZE;
+        if (debug_ze && !idx) return VQVAE_ERR_NULL;
+        if (debug_ze) vf.partials = reinterpret_cast<double *>(idx_ws);
+        if ((rc = encoder_run(w, x, B, H, W, z_e, acts, acts_bytes, st, am2, hist, d->n_embeddings, &hist_zeroed, false, &vf, 0, nullptr,
+                              debug_ze)) != 0) return rc;
         if ((rc = vq_finalize_impl(vf.partials, (int)((B + 3) / 4), hist, d->n_embeddings, (int64_t)rows, d->embedding_dim, d->beta, loss,
                                    perplexity, st)) != 0) return rc;
         return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec);                         // :36
@@ -478,7 +492,7 @@ int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, i
         return rc;                                                                                              // vqvae.py:31-33
     if ((rc = vq_forward_impl(z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
                               (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER |
-                                           VQVAE_VQ_REMOVED_FLAGS)) | VQVAE_VQ_ROWMAJOR,
+                                           VQVAE_VQ_REMOVED_FLAGS | kVqFormFlags)) | VQVAE_VQ_ROWMAJOR,
                               z_q, idx ? idx : idx_ws, hist, loss, perplexity, vqws, vqws_bytes, stream, hist_zeroed,
                               zq_amax_wanted(d, H / 4, W / 4) ? zq_amax_slot(d, B, am_dec) : nullptr, &zq_amax_done)) != 0) return rc;   // :34
     return decoder_run(w, z_q, B, H / 4, W / 4, x_hat, acts, acts_bytes, st, am_dec, false, zq_amax_done, cf, f.hid);    // :36
@@ -507,7 +521,7 @@ int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, in
     if (!fused && hipMemsetAsync(f.am2, 0xFF, 2 * amax_bytes(d, B), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
     int rc;
     bool hist_zeroed = false;
-    if (fused && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
+    if (fused && !(vq_flags & kVqFormFlags) && vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) {
         if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, f.vqws, f.vqws_bytes, st)) != 0) return rc;
         VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, f.vqws, nullptr, idx, f.hist);      // no z_q: its stores are dropped
         vf.partials = reinterpret_cast<double *>(f.z_e);                // (the loss partials and the histogram are by-products nobody reads)
@@ -518,8 +532,8 @@ int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, in
                           nullptr, cf, f.hid)) != 0) return rc;
     float *scal = reinterpret_cast<float *>(f.idx_ws);                  // (the workspace's index region is free: idx is the caller's)
     return vq_forward_impl(f.z_e, w->codebook, B, d->embedding_dim, H / 4, W / 4, d->n_embeddings, d->beta,
-                           (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_REMOVED_FLAGS)) |
-                               VQVAE_VQ_ROWMAJOR,
+                           (vq_flags & (VQVAE_VQ_CODEBOOK_PREPARED | VQVAE_VQ_EXACT_SWEEP | VQVAE_VQ_BF16_FILTER | VQVAE_VQ_REMOVED_FLAGS |
+                                        kVqFormFlags)) | VQVAE_VQ_ROWMAJOR,
                            f.z_q, idx, f.hist, scal, scal + 1, f.vqws, f.vqws_bytes, stream, hist_zeroed, nullptr, nullptr);
 }
 

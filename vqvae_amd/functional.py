@@ -19,6 +19,8 @@ VQ_UNITS32_16WAVES = 0x200
 # whole-path product scheme (vqvae_forward_f32 / vqvae_encoder_ex_f32 / vqvae_decoder_ex_f32)
 FWD_CONV_BF16_SPLIT = 0x1000
 FWD_CONV_EXACT_FP32 = 0x2000
+FWD_DEBUG_ZE = 0x4000            # tests: the fused encoder+quantizer kernel also writes its z_e (include/vqvae_hip.h)
+VQ_UNITS32_8WAVES = 0x400
 
 
 def _stream_ptr(t: torch.Tensor) -> int:

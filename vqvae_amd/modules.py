@@ -378,16 +378,68 @@ class VQVAE(nn.Module):
         return embedding_loss, x_hat, perplexity
 
     # ---- "next" rows of SURVEY.md 8f-1: the index wire format -------------------
+    def _c_workspace(self, L, cw, B, H, W, dev):
+        """(workspace tensor, stream handle) of the whole-path C entry points for this device's current stream (see _forward_c)."""
+        nws = L.vqvae_workspace_bytes(cw.dims, B, H, W)
+        if nws == 0:
+            raise VqvaeHipError(f"shape ({B}, {cw.dims.in_ch}, {H}, {W}) not supported by the gfx950 whole-path entry points")
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        table = _cache.side(self).setdefault("c_ws", {})
+        ws = _cache.lru_get(table, (str(dev), stream))
+        if ws is None or ws.numel() < nws:
+            ws = torch.empty(nws, dtype=torch.uint8, device=dev)
+            _cache.lru_put(table, (str(dev), stream), ws, 4)
+        return ws, stream
+
     @torch.no_grad()
-    def encode(self, x):
-        """x -> min_encoding_indices (N,1) int64 (README.md:56; notebook encode_data)."""
-        from . import conv as C_hip
-        z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
-        _, _, _, idx, _ = self.vector_quantization.quantize(z_e, rowmajor=True, want_zq=False)
+    def encode(self, x, vq_flags=0):
+        """x -> min_encoding_indices (N,1) int64 (README.md:56; notebook encode_data) as ONE call into libvqvae_hip.so
+        (vqvae_encode_f32): on the default shapes the encoder's last kernel quantizes its own z_e and only the indices are
+        written -- no z_e, no z_q."""
+        from . import _lib, conv as C_hip
+        if C_hip.get_conv_backend() != "hip" or not x.is_cuda or x.dtype != torch.float32:
+            z_e = C_hip.encoder_forward(self.encoder, x, pre_quant=self.pre_quantization_conv)
+            _, _, _, idx, _ = self.vector_quantization.quantize(z_e, rowmajor=True, want_zq=False)
+            return idx
+        L = _lib.load()
+        x = x.contiguous()
+        B, Cin, H, W = x.shape
+        cw, _keep = self._c_weights()
+        if Cin != cw.dims.in_ch or H % 4 or W % 4:
+            raise ValueError(f"expected (B, {cw.dims.in_ch}, 4k, 4m) images, got {tuple(x.shape)}")
+        dev = x.device
+        with torch.cuda.device(dev):
+            ws, stream = self._c_workspace(L, cw, B, H, W, dev)
+            vq = self.vector_quantization
+            vws, prepared, key, slot = vq._workspace()
+            if not prepared:
+                slot[1] = None
+            idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev)
+            _lib.check(L.vqvae_encode_f32(cw, x.data_ptr(), B, H, W, (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags,
+                                          idx.data_ptr(), ws.data_ptr(), ws.numel(), vws.data_ptr(), vws.numel(), stream))
+            slot[1] = key
         return idx
 
     @torch.no_grad()
-    def decode_indices(self, idx, B, H, W):
-        """indices -> x_hat (visualization.ipynb:358-365 generate_samples)."""
-        z_q = F_hip.vq_decode_indices(idx, self.vector_quantization.embedding.weight.detach(), B, H, W)
-        return self.decoder(z_q)
+    def decode_indices(self, idx, B, H, W, fwd_flags=0):
+        """indices -> x_hat (visualization.ipynb:358-365 generate_samples) as ONE call (vqvae_decode_f32): on the default shapes
+        the decoder's first kernel takes every latent pixel's row straight from the codebook -- z_q is never written.
+        H, W: the LATENT map's size.  Indices outside [0, K) raise, as the reference's one-hot scatter does."""
+        from . import _lib, conv as C_hip
+        K = self.vector_quantization.n_e
+        if idx.numel() != B * H * W:
+            raise ValueError(f"expected {B * H * W} indices, got {idx.numel()}")
+        if C_hip.get_conv_backend() != "hip" or not idx.is_cuda:
+            z_q = F_hip.vq_decode_indices(idx, self.vector_quantization.embedding.weight.detach(), B, H, W)
+            return self.decoder(z_q)
+        idx = idx.contiguous().view(-1).to(torch.int64)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= K):
+            raise IndexError(f"code index out of range [0, {K})")
+        L = _lib.load()
+        cw, _keep = self._c_weights()
+        dev = idx.device
+        with torch.cuda.device(dev):
+            ws, stream = self._c_workspace(L, cw, B, 4 * H, 4 * W, dev)
+            x_hat = torch.empty((B, cw.dims.in_ch, 4 * H, 4 * W), dtype=torch.float32, device=dev)
+            _lib.check(L.vqvae_decode_f32(cw, idx.data_ptr(), B, H, W, fwd_flags, x_hat.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        return x_hat
