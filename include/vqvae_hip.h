@@ -421,6 +421,19 @@ typedef struct VqvaeWeights {       /* what the whole-path entry points consume:
     const float *dec0, *dec0_b, *dec_res_w1, *dec_res_w2, *dec2, *dec2_b, *dec4, *dec4_b;
 } VqvaeWeights;
 
+/* Which product scheme do these WEIGHTS call for?  (round 5)  The default two-term fp16 scheme carries one power-of-two scale per output
+ * channel of every weight tensor and one per image of every activation map; a layer whose INPUT channels still differ by many binades
+ * after that normalisation pairs its largest weights with activations far below their image's maximum, whose second fp16 term
+ * underflows -- the regime in which the default path is 100x further from fp64 than the reference's fp32.  That is a
+ * property of the checkpoint: this call measures, per layer, log2(max_c r[c] / min_c r[c]) with r[c] = max over (o, taps) of
+ * |w[o, c]| / max |w[o, ., .]| (spread_log2_host: 11 floats in VqvaeRawWeights' order of the weight tensors, may be NULL) and sets
+ * *recommended_flags to VQVAE_FWD_CONV_BF16_SPLIT when any layer behind the first exceeds VQVAE_RANGE_SPREAD_LIMIT_LOG2 binades, else 0.
+ * OR it into vqvae_forward_f32's vq_flags / the _ex_ entries' flags (the Python layer and integration/vqvae_hip_stub.py do, once per
+ * weight version).  Launches 11 one-workgroup kernels on `stream` and SYNCHRONISES it; scratch_device: >= 64 bytes of device memory. */
+#define VQVAE_RANGE_SPREAD_LIMIT_LOG2 10.0f
+VQVAE_API int vqvae_weights_range_check_f32(const VqvaeDims *dims, const VqvaeRawWeights *raw, float *spread_log2_host,
+                                            int *recommended_flags, void *scratch_device, size_t scratch_bytes, vqvae_stream_t stream);
+
 /* Bytes of the one buffer that holds every packed weight image (0: unsupported dims). */
 VQVAE_API size_t vqvae_weights_packed_bytes(const VqvaeDims *dims);
 /* Packs every layer into `packed` and fills `out` (its bias / codebook pointers alias `raw`'s: keep those alive). */
@@ -437,7 +450,9 @@ VQVAE_API int vqvae_resstack_f32(const float *packed_w1, const float *packed_w2,
                                  int C, int Rh, int n_layers, int flags, float *y, float *tmp, vqvae_stream_t stream);
 
 /* Encoder + pre_quantization_conv: x (B,in_ch,H,W) NCHW -> z_e (B,H/4,W/4,D) ROW-MAJOR (the layout vqvae_vq_forward_f32
- * takes with VQVAE_VQ_ROWMAJOR).  workspace: at least the two activation buffers of vqvae_workspace_bytes.
+ * takes with VQVAE_VQ_ROWMAJOR).  workspace: vqvae_workspace_bytes(dims, B, H, W) is always enough; the entry itself needs the two
+ * activation buffers, plus -- where h_dim is not 32 / 64 / 128 or res_h_dim > 32 (the generic residual path) -- one hidden map of
+ * B * H/4 * W/4 * res_h_dim floats, and uses room beyond that for the per-image maxima (without them every layer measures its own).
  * On 32x32 RGB images with h_dim 128 and two residual layers (the reference's defaults) the encoder is two launches
  * (models/encoder.py:29-34, then :35-38 + models/vqvae.py:33) and the decoder two (models/decoder.py:28-30, :31-35): no
  * intermediate map is written inside a launch; other shapes run layer by layer through the kernels of the per-layer
@@ -487,8 +502,9 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
  * touches a latent map: the encoder's last kernel quantizes its own z_e and writes 512 bytes of indices per image (no z_e, no z_q:
  * 12 KiB in, 0.5 KiB out), and the decoder's first kernel takes each latent pixel's row straight from the codebook (0.5 KiB in, 12 KiB
  * out).  Other shapes run encoder -> stand-alone quantizer / row gather -> decoder through the workspace.  Indices equal
- * vqvae_forward_f32's bit for bit; x_hat equals the decoder's on the same z_q bit for bit.  An index outside [0, K) makes its image's
- * x_hat NaN (it never reads the codebook).  workspace: vqvae_workspace_bytes(dims, B, H, W) (decode: H = 4h, W = 4w); vq_workspace /
+ * vqvae_forward_f32's bit for bit; x_hat equals the decoder's on the same z_q bit for bit.  An index outside [0, K) never reads the
+ * codebook: that latent pixel enters the first conv as NaN (the fused ReLUs flush NaN to 0, so its image's x_hat is unspecified; no
+ * other image is affected) -- validate foreign indices on the host, as the Python layer does.  workspace: vqvae_workspace_bytes(dims, B, H, W) (decode: H = 4h, W = 4w); vq_workspace /
  * vq_flags as for vqvae_forward_f32; decode's flags: VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32 or 0.                                   */
 VQVAE_API int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, int64_t *idx,
                                void *workspace, size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,

@@ -91,6 +91,7 @@ SIGNATURES = {
     "vqvae_relu_backward_f32": (_i32, [_vp, _vp, _i64, _vp, _vp]),
     "vqvae_weights_packed_bytes": (_sz, [_dimsp]),
     "vqvae_weights_pack_f32": (_i32, [_dimsp, _rawp, _vp, _sz, _wp, _vp]),
+    "vqvae_weights_range_check_f32": (_i32, [_dimsp, _rawp, _vp, C.POINTER(C.c_int), _vp, _sz, _vp]),
     "vqvae_workspace_bytes": (_sz, [_dimsp, _i64, _i32, _i32]),
     "vqvae_workspace_ze_offset": (_sz, [_dimsp, _i64, _i32, _i32]),
     "vqvae_resstack_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

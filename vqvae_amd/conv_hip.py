@@ -33,11 +33,16 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
     cache = _cache.side(mod).setdefault("packed", {})
     hit = cache.get(kind)
     if hit is not None and hit[0] == key:
-        if hit[2] is not None:                       # packed on some stream a moment ago: wait for it from another stream, and
-            if hit[2][0].query():                    # forget the event once it has completed (no per-call cost from then on)
+        if hit[2] is not None:                       # packed on some stream a moment ago
+            cur = torch.cuda.current_stream(w.device)
+            if cur.cuda_stream == hit[2][1]:
+                pass                                 # the packing stream itself: ordered behind the pack kernels already
+            elif torch.cuda.is_current_stream_capturing():
+                cur.wait_event(hit[2][0])            # an event QUERY is not capturable: the wait is, and costs nothing replayed
+            elif hit[2][0].query():                  # forget the event once it has completed (no per-call cost from then on)
                 cache[kind] = (hit[0], hit[1], None)
             else:
-                _cache.wait_ready(hit[2], w.device)
+                cur.wait_event(hit[2][0])
         return hit[1]
     n = nbytes_fn()
     if n == 0:

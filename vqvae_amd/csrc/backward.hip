@@ -388,11 +388,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_map8_h2_kernel(const float 
         __syncthreads();                                    // + every wave is done with the previous image's operands
         ma = fmaxf(fmaxf(red[0], red[2]), fmaxf(red[4], red[6]));
         mb = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
-        auto scale_exp = [](float m) {                      // -> the power of two that puts m into [2^14, 2^15); 0 for 0 / non-finite
+        auto scale_exp = [](float m) {                      // -> the power of two that puts m into [2^14, 2^15); 0 for 0 / Inf / NaN
             int e = 15;
-            if (m > 0.0f && m < 3.0e38f) (void)__builtin_frexpf(m, &e);
+            // (round 5, ADVICE r4: every FINITE maximum is scaled, also one above 3e38 -- it used to fall through to "unscaled", become
+            // Inf in fp16 and NaN in the residual term where the fp32 kernel stays finite; the clamp below is +-113, fp32's own range)
+            if (m > 0.0f && m <= 3.4028234e38f) (void)__builtin_frexpf(m, &e);
             e = 15 - e;
-            return e > 100 ? 100 : (e < -100 ? -100 : e);
+            return e > 113 ? 113 : (e < -113 ? -113 : e);
         };
         const int ka = scale_exp(ma);
         int kb = scale_exp(mb);

@@ -111,6 +111,53 @@ int vqvae_profile_collect(int kernel_id, double *total_ms, int *launches) {
 
 int vqvae_abi_version(void) { return VQVAE_HIP_ABI_VERSION; }
 
+}  // extern "C"
+
+namespace vqvae {
+// one workgroup per weight tensor (at most 256 x 256 x 16 elements, once per weight version): a[o] = max |w[o, ., .]|, then
+// r[c] = max over (o, taps) of |w[o, c, .]| / a[o], then log2(max r / min r) over the channels that are not all zero
+__global__ __launch_bounds__(1024) void weight_spread_kernel(const float *__restrict__ w, int Cout, int Cin, int taps, int transposed,
+                                                             float *__restrict__ out) {
+    __shared__ float a_s[1024], r_s[1024];
+    __shared__ float red_hi[16], red_lo[16];
+    const int tid = threadIdx.x;
+    if (!w) { if (tid == 0) out[0] = 0.0f; return; }
+    auto at = [&](int o, int c, int t) { return transposed ? w[((size_t)c * Cout + o) * taps + t] : w[((size_t)o * Cin + c) * taps + t]; };
+    for (int o = tid; o < Cout; o += 1024) {
+        float m = 0.0f;
+        for (int c = 0; c < Cin; ++c)
+            for (int t = 0; t < taps; ++t) m = fmaxf(m, __builtin_fabsf(at(o, c, t)));
+        a_s[o] = m;
+    }
+    __syncthreads();
+    float hi = 0.0f, lo = 3.0e38f;
+    for (int c = tid; c < Cin; c += 1024) {
+        float r = 0.0f;
+        for (int o = 0; o < Cout; ++o) {
+            const float a = a_s[o];
+            if (!(a > 0.0f) || !(a < 3.0e38f)) continue;
+            for (int t = 0; t < taps; ++t) r = fmaxf(r, __builtin_fabsf(at(o, c, t)) / a);
+        }
+        r_s[c] = r;
+        if (r > 0.0f) { hi = fmaxf(hi, r); lo = fminf(lo, r); }
+    }
+    for (int o = 32; o > 0; o >>= 1) { hi = fmaxf(hi, __shfl_xor(hi, o)); lo = fminf(lo, __shfl_xor(lo, o)); }
+    if ((tid & 63) == 0) { red_hi[tid >> 6] = hi; red_lo[tid >> 6] = lo; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 1; i < 16; ++i) { hi = fmaxf(hi, red_hi[i]); lo = fminf(lo, red_lo[i]); }
+        hi = fmaxf(hi, red_hi[0]); lo = fminf(lo, red_lo[0]);
+        out[0] = (hi > 0.0f && lo < 3.0e38f) ? __builtin_log2f(hi / lo) : 0.0f;
+    }
+}
+
+void weight_spread_impl(const float *w, int Cout, int Cin, int taps, bool transposed, float *out, hipStream_t st) {
+    hipLaunchKernelGGL(weight_spread_kernel, dim3(1), dim3(1024), 0, st, w, Cout, Cin, taps, transposed ? 1 : 0, out);
+}
+}  // namespace vqvae
+
+extern "C" {
+
 // ---- box calibration (round 4): a bare stream of v_mfma_f32_32x32x16_f16 on RANDOM operands, two waves
 // per SIMD, what tools/ubench/mfma_power.hip measures: the chip's sustained matrix rate on this data is set by the clock it
 // holds at its power limit, and that differs from box to box (profiles/r03_notes.txt section 10).  bench.py runs it for a

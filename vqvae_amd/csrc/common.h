@@ -168,6 +168,8 @@ int conv_res_pair_forward_impl(int kind, const float *x, const float *packed_fro
                                const int64_t *gather_idx = nullptr, int gather_K = 0);     // gather_idx: x = a (K, Cin) table, pixel p takes row gather_idx[p]
 int convt_out_forward_impl(const float *x, const float *packed, const float *bias, int64_t B, int H, int W, int Cin, int Cout,
                            int flags, float *y_nchw, hipStream_t stream, const int *in_amax);
+// log2 of the spread of a conv weight's INPUT channels after per-output-channel normalisation -> out[0] (device); w == NULL: 0
+void weight_spread_impl(const float *w, int Cout, int Cin, int taps, bool transposed, float *out, hipStream_t st);
 void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *amax, hipStream_t st);   // amax[b] = max(amax[b], max |x_b|)
 // the pieces of vq_forward_impl around its main kernel, for the whole-path entry that quantizes inside the encoder's last kernel
 bool vq_fuse_ok(int K, int D, int64_t B, int flags);

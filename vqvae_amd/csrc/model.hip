@@ -165,6 +165,43 @@ int vqvae_weights_pack_f32(const VqvaeDims *d, const VqvaeRawWeights *raw, void 
     return VQVAE_OK;
 }
 
+// ---- round 5: which product scheme the WEIGHTS call for ("nothing at runtime tells a caller their data is in that regime")
+// The default two-term fp16 scheme scales every weight tensor per OUTPUT channel and every activation map per image.  What it cannot
+// absorb is a layer whose INPUT channels differ by many binades after that normalisation: the activations that meet the large
+// weights are then tiny beside their image's maximum, their second fp16 term drops below fp16's window, and the terms that carry
+// the result arrive with 11 bits (tests/hetero.py builds such checkpoints on purpose: 20 binades).  The spread is a property of the
+// checkpoint, so it is measured ONCE per weight version: per layer, r[c] = max over (o, taps) of |w[o, c]| / max|w[o, .]|, spread =
+// log2(max r / min r).  Default-initialised and ordinarily trained layers sit at 0-3 binades.
+int vqvae_weights_range_check_f32(const VqvaeDims *d, const VqvaeRawWeights *raw, float *spread_log2_host, int *recommended_flags,
+                                  void *scratch_device, size_t scratch_bytes, vqvae_stream_t stream) {
+    if (!d || !raw || !recommended_flags || !scratch_device) return VQVAE_ERR_NULL;
+    if (!dims_ok(d)) return VQVAE_ERR_UNSUPPORTED;
+    if (scratch_bytes < 16 * sizeof(float)) return VQVAE_ERR_WORKSPACE;
+    const int h = d->h_dim, D = d->embedding_dim, Rh = d->res_h_dim;
+    struct Lay { const float *w; int Cout, Cin, taps; bool transposed; };
+    const Lay lay[11] = {{raw->enc0_w, h / 2, d->in_ch, 16, false}, {raw->enc2_w, h, h / 2, 16, false}, {raw->enc4_w, h, h, 9, false},
+                         {raw->enc_res_w1, Rh, h, 9, false},         {raw->enc_res_w2, h, Rh, 1, false},  {raw->pre_w, D, h, 1, false},
+                         {raw->dec0_w, h, D, 9, true},               {raw->dec_res_w1, Rh, h, 9, false},  {raw->dec_res_w2, h, Rh, 1, false},
+                         {raw->dec2_w, h / 2, h, 16, true},          {raw->dec4_w, d->in_ch, h / 2, 16, true}};
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float *out = static_cast<float *>(scratch_device);
+    for (int i = 0; i < 11; ++i) {
+        if (!lay[i].w) return VQVAE_ERR_NULL;
+        if (d->n_res_layers == 0 && (i == 3 || i == 4 || i == 7 || i == 8)) { weight_spread_impl(nullptr, 0, 0, 0, false, out + i, st); continue; }
+        if (lay[i].Cout > 1024 || lay[i].Cin > 1024) return VQVAE_ERR_UNSUPPORTED;
+        weight_spread_impl(lay[i].w, lay[i].Cout, lay[i].Cin, lay[i].taps, lay[i].transposed, out + i, st);
+    }
+    float host[11];
+    hipError_t e = hipMemcpyAsync(host, out, sizeof(host), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);                  // (once per weight version: the decision is the host's)
+    if (e != hipSuccess) return (int)e;
+    float worst = 0.0f;
+    for (int i = 1; i < 11; ++i) worst = host[i] > worst ? host[i] : worst;     // (layer 0 reads the image itself: its channels are the caller's)
+    if (spread_log2_host) for (int i = 0; i < 11; ++i) spread_log2_host[i] = host[i];
+    *recommended_flags = worst > VQVAE_RANGE_SPREAD_LIMIT_LOG2 ? VQVAE_FWD_CONV_BF16_SPLIT : 0;
+    return VQVAE_OK;
+}
+
 size_t vqvae_workspace_ze_offset(const VqvaeDims *d, int64_t B, int H, int W) {
     if (vqvae_workspace_bytes(d, B, H, W) == 0) return 0;
     return 2 * align_up(act_elems(d, B, H, W) * sizeof(float), 256) + 2 * amax_bytes(d, B);      // (carve_forward's order)
@@ -208,6 +245,13 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
     const size_t act = act_elems(d, B, H, W);
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    // residual widths outside the fused kernels: the hidden map's scratch (given by the forward entry, else carved here -- BEFORE the
+    // optional maxima, so that a short workspace loses only those: ADVICE r4)
+    float *hid = hid_given;
+    if (!hid && res_hidden_bytes(d, B, H, W)) {
+        hid = static_cast<float *>(c.raw(res_hidden_bytes(d, B, H, W)));
+        if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    }
     // optional: the per-image maxima (a workspace of the documented size has room; without them every consumer measures
     // its own image)
     int *am = am_given;
@@ -215,12 +259,6 @@ static int encoder_run(const VqvaeWeights *w, const float *x, int64_t B, int H, 
         am = static_cast<int *>(c.raw(amax_bytes(d, B)));
         // (no fill where every array that is read has a one-wave-per-image producer with plain stores: fused_c3_path)
         if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
-    }
-    // residual widths outside the fused kernels: the hidden map's scratch (given by the forward entry, else carved here)
-    float *hid = hid_given;
-    if (!hid && res_hidden_bytes(d, B, H, W)) {
-        hid = static_cast<float *>(c.raw(res_hidden_bytes(d, B, H, W)));
-        if (!c.ok) return VQVAE_ERR_WORKSPACE;
     }
     int *am0 = am, *am1 = am ? am + B : nullptr, *am2 = am ? am + 2 * B : nullptr;     // conv_in, enc2, enc4 (+ residual layers)
     const int h = d->h_dim;
@@ -332,15 +370,15 @@ static int decoder_run(const VqvaeWeights *w, const float *z_q, int64_t B, int h
     const size_t act = act_elems(d, B, 4 * h4, 4 * w4);
     float *a = c.f32(act), *b = c.f32(act);
     if (!c.ok) return VQVAE_ERR_WORKSPACE;
-    int *am = am_given;                                                       // optional, see encoder_run
-    if (!am) {
-        am = static_cast<int *>(c.raw(amax_bytes(d, B)));
-        if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
-    }
     float *hid = hid_given;
     if (!hid && res_hidden_bytes(d, B, 4 * h4, 4 * w4)) {
         hid = static_cast<float *>(c.raw(res_hidden_bytes(d, B, 4 * h4, 4 * w4)));
         if (!c.ok) return VQVAE_ERR_WORKSPACE;
+    }
+    int *am = am_given;                                                       // optional, see encoder_run
+    if (!am) {
+        am = static_cast<int *>(c.raw(amax_bytes(d, B)));
+        if (am && !am_exclusive && hipMemsetAsync(am, 0xFF, amax_bytes(d, B), st) != hipSuccess) am = nullptr;
     }
     const int h = d->h_dim;
     int rc;

@@ -258,9 +258,24 @@ class VQVAE(nn.Module):
         with torch.cuda.device(w0.device):
             _lib.check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, cw,
                                                 torch.cuda.current_stream(w0.device).cuda_stream))
+            # which product scheme this checkpoint calls for (vqvae_weights_range_check_f32: once per weight version, one sync)
+            import ctypes
+            rec = ctypes.c_int(0)
+            spreads = (ctypes.c_float * 11)()
+            scratch = torch.empty(16, dtype=torch.float32, device=w0.device)
+            _lib.check(L.vqvae_weights_range_check_f32(dims, raw, spreads, ctypes.byref(rec), scratch.data_ptr(), 64,
+                                                       torch.cuda.current_stream(w0.device).cuda_stream))
             ready = _cache.mark_ready(w0.device)
         _cache.side(self)["c_weights"] = (key, cw, (keep, packed), ready)
+        _cache.side(self)["c_scheme_hint"] = (int(rec.value), [float(v) for v in spreads])
         return cw, (keep, packed)
+
+    def scheme_hint(self):
+        """-> (flags, per-layer input-channel spread in binades): FWD_CONV_BF16_SPLIT when this checkpoint's weights put the default
+        two-term fp16 products outside their range (include/vqvae_hip.h, vqvae_weights_range_check_f32), else 0.  forward / encode /
+        decode_indices apply it unless the caller names a scheme."""
+        self._c_weights()
+        return _cache.side(self)["c_scheme_hint"]
 
     # The step can run as n parts on n side streams (vqvae_forward_begin / part / end; _forward_c(x, parts=n)): the kernels of
     # different parts fill each other's ramp-up and tail.  NOT the default: measured -2 % per step on one MI355X box and +9 % on
@@ -307,17 +322,20 @@ class VQVAE(nn.Module):
         _lib.check(L.vqvae_forward_end_f32(cw, B, H, W, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), nws, stream))
         return True
 
-    def _forward_c(self, x, want_idx=False, vq_flags=0, parts=None, fwd_flags=0):
+    def _forward_c(self, x, want_idx=False, vq_flags=0, parts=None, fwd_flags=None):
         """VQVAE.forward as ONE call into libvqvae_hip.so (vqvae_forward_f32).  vq_flags: extra quantizer flags for tests and
         A/B runs (functional.VQ_UNFUSED: the quantizer as its own launch where the encoder's last kernel would quantize).
         parts: None = the default policy (FORWARD_PARTS side streams for large batches), 1 = always the single call, n = n parts.
         fwd_flags: functional.FWD_CONV_BF16_SPLIT / FWD_CONV_EXACT_FP32 = the whole path on the three-term bf16 / exact-fp32 MFMA
-        kernels instead of the default two-term fp16 products."""
+        kernels instead of the default two-term fp16 products; 0 = the two-term fp16 products whatever the weights; None (default) =
+        what vqvae_weights_range_check_f32 recommends for this checkpoint (scheme_hint())."""
         from . import _lib
         L = _lib.load()
         x = x.contiguous()
         B, Cin, H, W = x.shape
         cw, _keep = self._c_weights()
+        if fwd_flags is None:
+            fwd_flags = _cache.side(self)["c_scheme_hint"][0]
         if Cin != cw.dims.in_ch or H % 4 or W % 4:
             raise ValueError(f"expected (B, {cw.dims.in_ch}, 4k, 4m) images, got {tuple(x.shape)}")
         dev = x.device
@@ -415,13 +433,14 @@ class VQVAE(nn.Module):
             if not prepared:
                 slot[1] = None
             idx = torch.empty((B * (H // 4) * (W // 4), 1), dtype=torch.int64, device=dev)
-            _lib.check(L.vqvae_encode_f32(cw, x.data_ptr(), B, H, W, (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags,
+            _lib.check(L.vqvae_encode_f32(cw, x.data_ptr(), B, H, W, (F_hip.VQ_CODEBOOK_PREPARED if prepared else 0) | vq_flags |
+                                          (_cache.side(self)["c_scheme_hint"][0] if not (vq_flags & 0x3000) else 0),
                                           idx.data_ptr(), ws.data_ptr(), ws.numel(), vws.data_ptr(), vws.numel(), stream))
             slot[1] = key
         return idx
 
     @torch.no_grad()
-    def decode_indices(self, idx, B, H, W, fwd_flags=0):
+    def decode_indices(self, idx, B, H, W, fwd_flags=None):
         """indices -> x_hat (visualization.ipynb:358-365 generate_samples) as ONE call (vqvae_decode_f32): on the default shapes
         the decoder's first kernel takes every latent pixel's row straight from the codebook -- z_q is never written.
         H, W: the LATENT map's size.  Indices outside [0, K) raise, as the reference's one-hot scatter does."""
@@ -437,6 +456,8 @@ class VQVAE(nn.Module):
             raise IndexError(f"code index out of range [0, {K})")
         L = _lib.load()
         cw, _keep = self._c_weights()
+        if fwd_flags is None:
+            fwd_flags = _cache.side(self)["c_scheme_hint"][0]
         dev = idx.device
         with torch.cuda.device(dev):
             ws, stream = self._c_workspace(L, cw, B, 4 * H, 4 * W, dev)

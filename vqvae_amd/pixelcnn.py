@@ -103,13 +103,19 @@ class GatedMaskedConv2d(nn.Module):
         self._htaps = [(0, kx - k // 2) for kx in range(k // 2 + 1)]
 
     def make_causal(self):                                      # models.py:60-62 (in place, like the reference)
-        self.vert_stack.weight.data[:, :, -1].zero_()
-        self.horiz_stack.weight.data[:, :, :, -1].zero_()
+        # through the parameter under no_grad, NOT `.data`: a `.data` write leaves `_version` alone, and the packed-weight cache
+        # (conv_hip._packed, keyed on (data_ptr, _version)) would keep an image packed from un-masked or re-initialised weights
+        #  -- e.g. after the reference's own `weights_init`, which writes through `.data`
+        # The write bumps the version on EVERY call, so the one mask-'A' layer re-packs per forward (two small pack launches, also
+        # inside a stream capture) -- the price of never serving a stale image for the layer whose weights the forward itself edits.
+        with torch.no_grad():
+            self.vert_stack.weight[:, :, -1].zero_()
+            self.horiz_stack.weight[:, :, :, -1].zero_()
 
     def _masked(self, x_rows, conv, taps, tag):
         """One masked conv (bias included): the conv kernels over the tap list."""
-        # (mask 'A' zeroes weights in place on every call: the version bump re-packs, conv_hip._packed; its 4 x 7 vertical stack is
-        # two slices of 14 taps, the second launch adding to the first)
+        # (mask 'A': make_causal's in-place zeroing bumps the version and re-packs, conv_hip._packed; its 4 x 7 vertical stack is two
+        # slices of 14 taps, the second launch adding to the first)
         return conv_hip.conv_taps(x_rows, conv, conv.weight, conv.bias, taps)
 
     def forward_rows(self, x_v, x_h, label):
