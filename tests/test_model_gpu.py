@@ -230,10 +230,11 @@ def test_fused_quantizer_against_the_oracle_on_its_own_z_e_bits():
     # flushed by the encoder's fused ReLUs, v_max_f32(NaN, 0) = 0, so its rows are ordinary)
     assert (np.abs(z_e) > 65504.0).any(axis=1).sum() >= 32
     assert (got == want).all(), f"{int((got != want).sum())} of {got.size} indices differ from the oracle's on the kernel's own z_e"
-    # and those bits are the separate encoder launch's bits
-    from vqvae_amd import conv as C_hip
+    # and those bits are the bits of the encoder ENTRY (vqvae_encoder_f32: the same kernel without the quantizer behind the 1x1 conv)
     with torch.no_grad():
-        z_sep = C_hip.encoder_forward(m.encoder, x, pre_quant=m.pre_quantization_conv).reshape(B * 64, 64).cpu().numpy()
+        z_dev = torch.empty(B, 8, 8, 64, device=dev())
+        _lib.check(L.vqvae_encoder_f32(cw, x.contiguous().data_ptr(), B, 32, 32, z_dev.data_ptr(), ws.data_ptr(), ws.numel(), _stream))
+        z_sep = z_dev.reshape(B * 64, 64).cpu().numpy()
     fin = np.isfinite(z_sep) & np.isfinite(z_e)
     assert (np.isfinite(z_sep) == np.isfinite(z_e)).all() and (z_sep[fin] == z_e[fin]).all()
 

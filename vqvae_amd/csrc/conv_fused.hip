@@ -510,9 +510,9 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                 zn2[mt] = sq + __uint_as_float(h ? sw[0] : sw[1]);
             }
             const float inf = __builtin_inff();
-            float pinf = inf, ninf = -inf;
+            const float pinf = inf, ninf = -inf;             // (round 5: the tracker pads with neither; plain constants)
             unsigned keymask = trk::kKeyMask;
-            asm volatile("" : "+v"(pinf), "+v"(ninf), "+v"(keymask));
+            asm volatile("" : "+v"(keymask));
             trk::Lane L[MT];
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) trk::init(L[mt], ninf);
@@ -551,13 +551,12 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                 });
             }
             // ---- verdicts; exact tasks
+            // (round 5: the unit in speaker form, vq_unit.h -- lane L speaks for row L of the image; the same decisions and bits)
             vqu::Tables tb = vqu::tables(vq_tab_all + wave_u * 1040);
-            const vqu::Bound bound = vqu::load_bound(vq.flags);
-            vqu::Rows R;
-            R.valid[0] = img_ok;
-            R.valid[1] = img_ok;
-            vqu::classify(L, zn2, bound, vq.K, lane, ninf, tb.task_s, R);
-            vqu::Flagged FL = vqu::exact_begin(R, lane, tb);
+            const vqu::BoundP bound = vqu::load_boundp(vq.flags);
+            vqu::RowsSp<MT> R;
+            vqu::classify_sp<MT>(L, zn2, bound, vq.K, lane, img_ok ? PX : 0, ninf, tb.task_s, R);
+            vqu::Flagged FL = vqu::exact_begin_sp<MT>(R, lane, tb);
             int ntasks = FL.ndirect;
             // rows whose candidates the stream x cell products do not cover (~0.01 %) need the codebook image once more: the
             // workgroup votes, and if any of its waves has one, all four stream the stages again (the others only keep the barriers)
@@ -573,7 +572,7 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             if ((unsigned)(FL.hmask >> (32 * mt))) {
-                                const float thr_t = R.hardf[mt] ? R.thr[mt] : inf;
+                                const float thr_t = (((unsigned)(FL.hmask >> (32 * mt)) >> l31) & 1u) ? R.thr[mt] : inf;
                                 sweep_stage(wb, sd, j, [&](int ct, const u32x4(&a)[4], const f32x16 &seed) {
                                     f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), __builtin_bit_cast(f16x8, zb[mt][0]), seed, 0, 0, 0);
 #pragma unroll
@@ -614,11 +613,11 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
                     for (int c16 = 0; c16 < 16; ++c16)
                         *reinterpret_cast<f32x4 *>(out3 + ((size_t)img * PX + lane) * 64 + 4 * c16) = *zchunk(lane, c16);
             }
-            vqu::exact_end(R, FL, ntasks, lane, tb, vq.cb, vq.ee, vq.K,
+            vqu::exact_end_sp<MT>(R, FL, ntasks, lane, tb, vq.cb, vq.ee, vq.K,
                            [&](int rr, int jc) { return *zchunk(rr, jc); },
                            [&](int rr, int c) { return reinterpret_cast<const float *>(zchunk(rr, c >> 2))[c & 3]; });
             const int j16 = lane & 15, g4 = lane >> 4;
-            const float sacc = vqu::epilogue(R, lane, vq.cb, vq.K, [&](int t, int i) { return *zchunk(32 * t + 4 * i + g4, j16); },
+            const float sacc = vqu::epilogue_sp<false, MT>(R, lane, vq.cb, vq.K, [&](int t, int i) { return *zchunk(32 * t + 4 * i + g4, j16); },
                                              (img_ok && vq.zq) ? vq.zq + (size_t)img * PX * 64 : nullptr, img_ok ? PX : 0,
                                              vq.idx + (size_t)(img_ok ? img : 0) * PX, vq_hist_s);
             // loss partial and histogram of the workgroup (fixed order: run-to-run bitwise loss / perplexity)

@@ -57,67 +57,6 @@ __device__ __forceinline__ Tables tables(unsigned char *tab_s) {
                   reinterpret_cast<float *>(tab_s + 768), reinterpret_cast<int *>(tab_s + 1024)};
 }
 
-struct Rows {                        // per lane, per row tile t: row 32 t + (lane & 31) of the unit
-    int kbest[2];
-    bool valid[2], bad[2], openf[2], hardf[2];
-    float thr[2];
-    int ncls;                        // tasks the classification wrote (wave-uniform)
-};
-
-// ---- threshold, merge of the two lane halves of every row, verdict --------------------------------------------------
-// zn2[t]: |z^|^2 of the lane's row (both halves hold the full sum); R.valid[] set by the caller
-// T: 32-row tiles per unit (2: the 64-row units of eight-wave workgroups and of the fused conv kernel; 1: the 32-row units of
-// vq_track_kernel_d64's sixteen-wave form, round 4)
-template <int T = 2>
-__device__ __forceinline__ void classify(const trk::Lane (&L)[T], const float (&zn2)[T], const Bound &B, int K, int lane,
-                                         float ninf, unsigned *task_s, Rows &R) {
-    const int l31 = lane & 31, h = lane >> 5;
-    R.ncls = 0;
-    if (T == 1) { R.openf[1] = false; R.hardf[1] = false; R.bad[1] = false; R.valid[1] = false; R.kbest[1] = 0; R.thr[1] = 0.0f; }
-    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int t = 0; t < T; ++t) {
-        const float vA = trk::lane_max(L[t], ninf);
-        const auto sv = __builtin_amdgcn_permlane32_swap(__float_as_uint(vA), __float_as_uint(vA), false, false);
-        const float v1 = trk::max3(vA, __uint_as_float(h ? sv[0] : sv[1]), ninf);
-        // DELTA in accumulator units, every factor rounded up
-        const float zs = zn2[t] * 1.0001f;                                         // |z^|^2
-        const float zh = __builtin_sqrtf(zs) * 1.0001f;                            // |z^|
-        const float errz = zh * 4.89e-4f + 2.5e-7f;                                // |z - z^| <= u |z| + 2^-22, |z| <= |z^| / (1 - u)
-        const float zn = zh + errz;                                                // |z| <= |z^| + |z - z^|
-        const float mag = zn * B.Ehat + B.EEh;                                     // bounds every |acc|
-        const float eps = errz * B.Ehat + (zn + errz) * B.dE + 7.76e-6f * mag;
-        const float xi = 3.86e-6f * zn * B.EmaxS + 1.2e-7f * (B.A * zn * zn + B.EEa);   // g = 64 * 2^-24 * 1.01; 2^-23
-        const float delta = (2.0f * eps + 2.0f * xi) * 1.001f;
-        const float th = v1 - delta;
-        R.thr[t] = th;
-        // |v1| below 1e-30: a key could be a denormal whose cell field a flush would lose -- never on real data
-        R.bad[t] = R.valid[t] && (B.cb_bad || !(zs < 1.0e30f) || !(v1 > -1.0e37f) || !(v1 < 1.0e37f) || !(delta < 1.0e37f) ||
-                                  (v1 > -1.0e-30f && v1 < 1.0e-30f));
-        const trk::Half H = trk::half_of(L[t], th, th - 8.0e-6f * mag, h);
-        const unsigned mine = trk::pack(H);
-        const auto so = __builtin_amdgcn_permlane32_swap(mine, mine, false, false);
-        const trk::Verdict V = trk::verdict_of(H, h ? so[0] : so[1], K);
-        const bool live = R.valid[t] && !R.bad[t];
-        R.openf[t] = live && !V.closed && !V.hard;
-        R.hardf[t] = live && V.hard;
-        R.kbest[t] = V.closed ? V.kbest : 0;
-        if (__builtin_amdgcn_ballot_w64(R.openf[t])) {
-            // open rows: this half's exact tasks
-            const trk::Cands C = trk::cands_of(L[t], H, h, K);
-            const int nt = R.openf[t] ? C.ntask : 0;
-            const unsigned long long b1 = __builtin_amdgcn_ballot_w64(nt >= 1), b2 = __builtin_amdgcn_ballot_w64(nt >= 2);
-            const int below = __builtin_amdgcn_mbcnt_hi((unsigned)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b1, 0)) +
-                              __builtin_amdgcn_mbcnt_hi((unsigned)(b2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b2, 0));
-            const int slot = R.ncls + below;
-            const unsigned rowu = (unsigned)(32 * t + l31);
-            if (nt >= 1 && slot < 64) task_s[slot] = rowu | ((unsigned)C.ta[0] << 6) | ((unsigned)C.tb[0] << 19);
-            if (nt >= 2 && slot + 1 < 64) task_s[slot + 1] = rowu | ((unsigned)C.ta[1] << 6) | ((unsigned)C.tb[1] << 19);
-            R.ncls += __builtin_popcountll(b1) + __builtin_popcountll(b2);
-        }
-    }
-}
-
 // ---- exact part, first half: who is flagged; table entries of the non-finite rows -------------------------------------
 // lane L of the wave speaks for row L of the unit (tile L >> 5, row L & 31)
 struct Flagged {
@@ -125,29 +64,6 @@ struct Flagged {
     unsigned long long fm, hmask;    // flagged rows / rows to be screened again (wave-uniform)
     int ndirect;                     // tasks so far: classification + one per non-finite row
 };
-
-__device__ __forceinline__ Flagged exact_begin(const Rows &R, int lane, const Tables &tb) {
-    const int h = lane >> 5;
-    Flagged F;
-    F.o_open = h ? R.openf[1] : R.openf[0];
-    F.o_hard = h ? R.hardf[1] : R.hardf[0];
-    F.o_bad = h ? R.bad[1] : R.bad[0];
-    F.fm = __builtin_amdgcn_ballot_w64(F.o_open || F.o_hard || F.o_bad);
-    F.hmask = 0ull;
-    F.ndirect = R.ncls;
-    if (F.fm) {
-        const unsigned long long lowmask = (1ull << lane) - 1ull;
-        tb.best_s[lane] = ~0ull;
-        // non-finite rows: one task each, for the row's ||z||^2
-        const unsigned long long tmb = __builtin_amdgcn_ballot_w64(F.o_bad);
-        if (F.o_bad && R.ncls + __builtin_popcountll(tmb & lowmask) < 64) tb.task_s[R.ncls + __builtin_popcountll(tmb & lowmask)] = (unsigned)lane;
-        F.ndirect = R.ncls + __builtin_popcountll(tmb);
-        F.hmask = __builtin_amdgcn_ballot_w64(F.o_hard);
-        if (F.hmask && lane == 0) tb.cnt_s[0] = 0;
-        lds_order_wave();
-    }
-    return F;
-}
 
 // one 32-code tile of a row tile screened again: every code at or above the row's threshold becomes a task
 __device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int ct, int t, int lane, int K, int ndirect, float ninf,
@@ -167,173 +83,6 @@ __device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int 
         }
     }
 }
-
-// ---- exact part, second half: chains, decision, scalar path; R.kbest[] final afterwards ------------------------------------
-// ntasks: ndirect + what the caller's rescan appended.  zrow(rr, j16) -> floats 4 j16 .. +3 of row rr of the unit;
-// zscalar(rr, c) -> one float of it (non-finite rows only)
-template <class ZRow, class ZScalar>   // (T = 1 units: rows 32..63 do not exist; their flags are false and R.kbest[1] is never read)
-__device__ __forceinline__ void exact_end(Rows &R, Flagged &F, int ntasks, int lane, const Tables &tb, const float *__restrict__ cb,
-                                          const float *__restrict__ ee_g, int K, ZRow &&zrow, ZScalar &&zscalar) {
-    constexpr int D = 64;
-    if (!F.fm) return;
-    const int l31 = lane & 31, j16 = lane & 15, g4 = lane >> 4;
-    const float inf = __builtin_inff();
-    if (ntasks > 64) {                      // pathological tie counts: every open row takes the scalar path;
-        const unsigned long long lowmask = (1ull << lane) - 1ull;
-        F.o_bad = F.o_bad || F.o_open || F.o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
-        __builtin_amdgcn_wave_barrier();
-        if (F.o_bad) tb.task_s[__builtin_popcountll(F.fm & lowmask)] = (unsigned)lane;
-        ntasks = __builtin_popcountll(F.fm);
-    }
-    lds_order_wave();
-    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
-    for (int base = 0; base < ntasks; base += 4) {
-        const int jj = base + g4;
-        const unsigned task = tb.task_s[jj < ntasks ? jj : 0];
-        const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
-        const f32x4 zv = zrow(rr, j16);
-        const f32x4 ea = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)ka * 256u + (unsigned)j16 * 16u, 0, 0));
-        const f32x4 eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kb2 * 256u + (unsigned)j16 * 16u, 0, 0));
-        const float eea = ee_g[ka], eeb = ee_g[kb2];
-        // ||z||^2 in ATen's order (lane j16 holds elements 4 j16 .. +3): P = v_q + v_{q+4} (lane j + lane j+8),
-        // A = ((P0 + P1) + P2) + P3 (lanes b, b+2, b+4, b+6), then A0..A7 in order (lane 0, then lane 1)
-        float Aq[4];
-        const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
-            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
-            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
-            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
-            Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
-        }
-        const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
-        const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
-        const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
-        // c-ordered fmaf chains: lane j continues lane j-1's partial sum (row_shr:1, 0 enters lane 0)
-        float ma = 0.0f, mb = 0.0f;
-#pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
-            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
-            ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
-            mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
-        }
-        const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
-        const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
-        const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
-        if (j16 == 1 && jj < ntasks) {
-            atomicMin(&tb.best_s[rr], trk::dist_key(da, ka));
-            atomicMin(&tb.best_s[rr], trk::dist_key(db, kb2));
-            tb.zz_s[rr] = zz;
-        }
-    }
-    lds_order_wave();
-    int o_best = 0;
-    if ((F.o_open || F.o_hard) && !F.o_bad) {
-        const unsigned long long bk = tb.best_s[lane];
-        if (bk != ~0ull) o_best = (int)(unsigned)bk; else F.o_bad = true;   // no task came back (cannot happen): scalar path
-    }
-    if (F.o_bad) {
-        // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
-        const float zz = tb.zz_s[lane];                                   // every flagged row had a task
-        int best = 0;
-        if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
-            float bd = 0.0f;
-            for (int k = 0; k < K; ++k) {
-                float m = 0.0f;
-                for (int c = 0; c < D; ++c) m = __builtin_fmaf(zscalar(lane, c), cb[(size_t)k * D + c], m);
-                const float d = (zz + ee_g[k]) - 2.0f * m;
-                const bool dn = d != d, bn = bd != bd;
-                if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
-            }
-        }
-        o_best = best;
-    }
-    const int k0n = __shfl(o_best, l31), k1n = __shfl(o_best, 32 + l31);
-    if (R.openf[0] || R.hardf[0] || R.bad[0]) R.kbest[0] = k0n;
-    if (R.openf[1] || R.hardf[1] || R.bad[1]) R.kbest[1] = k1n;
-    (void)inf;
-    __builtin_amdgcn_wave_barrier();
-}
-
-// ---- epilogue: gather, z + (e_k - z), squared error, z_q stores, index, histogram -> the unit's squared error (this lane) ---
-// frow(t, i) -> floats 4 j16 .. +3 of row 32 t + 4 i + g4 of the unit (the coalesced load layout); zq_unit: z_q of the
-// unit's first row (or NULL); nleft: rows of the unit that exist; idx_unit: index of its first row
-// NCHW (vq_track_kernel_d64<., true>): zq_unit = the unit's first position of channel 0 in a (B, 64, HW) tensor, zq_bytes = bytes from
-// there to the end of its image; the values leave through the wave's 8 KiB LDS tile `tile_f` (one row tile at a time, the layout
-// of the kernel's input transposition) as 16-byte stores of four positions of one channel.
-template <bool NCHW = false, int T = 2, class FRow>
-__device__ __forceinline__ float epilogue(const Rows &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
-                                          float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
-                                          int *__restrict__ hist_s, float *tile_f = nullptr, int HW = 0, unsigned zq_bytes = 0u) {
-    constexpr int D = 64, RU = 32 * T;
-    const int l31 = lane & 31, h = lane >> 5, j16 = lane & 15, g4 = lane >> 4;
-    const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
-    f32x4 ev[T][8];
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int kr = __builtin_amdgcn_ds_bpermute((4 * i + g4) << 2, R.kbest[t]);
-            ev[t][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kr * (D * 4) + (unsigned)j16 * 16u, 0, 0));
-        }
-    // the descriptor covers exactly the unit's existing rows: stores of rows past the end are dropped by the hardware
-    const auto zq_rs = __builtin_amdgcn_make_buffer_rsrc(zq_unit ? zq_unit : const_cast<float *>(cb), 0,
-                                                         zq_unit ? (NCHW ? zq_bytes : (unsigned)nleft * (D * 4)) : 0u, 0x00020000);
-    // Store offsets: four lane bases 4 KiB apart + an immediate, NO scalar offset register.  hipcc (ROCm 7.2) does not
-    // guard a 16-byte buffer store whose soffset is an SGPR against the next vector instruction overwriting its data
-    // registers (LLVM exempts that form from the store-data hazard); on gfx950 the overwrite corrupted the last dword
-    // of lanes 12..15 of each row here.  Without an soffset register the compiler inserts the wait states itself
-    // (tools/hazard_scan.py checks the assembly of every source for this pattern; tests/test_build_hazards.py runs it).
-    unsigned vo[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        vo[k] = (unsigned)lane * 16u + 4096u * k;
-        asm volatile("" : "+v"(vo[k]));
-    }
-    float sacc = 0.0f;
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const f32x4 zv = frow(t, i), e = ev[t][i];
-            const float d0 = e.x - zv.x, d1 = e.y - zv.y, d2 = e.z - zv.z, d3 = e.w - zv.w;
-            f32x4 o;
-            o.x = zv.x + d0; o.y = zv.y + d1; o.z = zv.z + d2; o.w = zv.w + d3;
-            const float sq = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
-            if (nleft == RU) sacc += sq;                   // fp32 over the unit's 16 groups, one fp64 add per unit
-            else sacc += 32 * t + 4 * i + g4 < nleft ? sq : 0.0f;
-            if constexpr (!NCHW) {
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, VQ_ZQ_STORE_AUX);
-            } else {
-                // row tile t: rows in, [channel][four positions] out (conflict-free both ways, see the kernel's convert())
-                if (i == 0) lds_order_wave();              // the previous row tile's reads are behind us
-                *reinterpret_cast<f32x4 *>(tile_f + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2)) = o;
-                if (i == 7) {
-                    lds_order_wave();
-                    const int cl = lane >> 3, j8 = lane & 7;
-                    unsigned so = (unsigned)(cl * HW + 4 * j8 + 32 * t) * 4u;           // (offsets in the VECTOR operand: the hazard note above)
-#pragma unroll
-                    for (int c8 = 0; c8 < 8; ++c8) {
-                        f32x4 w;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) w[e] = tile_f[(4 * j8 + e) * 64 + ((((2 * c8 + (cl >> 2)) ^ j8) & 15) << 2) + (cl & 3)];
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, w), zq_rs, so, 0, VQ_ZQ_STORE_AUX);
-                        so += (unsigned)(8 * HW) * 4u;
-                    }
-                }
-            }
-        }
-#pragma unroll
-    for (int t = 0; t < T; ++t)
-        if (R.valid[t] && h == 0) {
-            idx_unit[32 * t + l31] = R.kbest[t];
-            atomicAdd(&hist_s[R.kbest[t]], 1);
-        }
-    return sacc;
-}
-
 
 // =====================================================================================================================
 // Round 5: the same unit in SPEAKER form (vq_track.h, "round 5"): lane L of the wave speaks for row L of the unit -- the
@@ -493,7 +242,7 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
                                              const float *__restrict__ ee_g, int K, ZRow &&zrow, ZScalar &&zscalar) {
     constexpr int D = 64;
     if (!F.fm) return;
-    const int j16 = lane & 15, g4 = lane >> 4;
+    const int j8 = lane & 7, g8 = lane >> 3;
     if (ntasks > 64) {                      // pathological tie counts: every flagged row takes the scalar path;
         const unsigned long long lowmask = (1ull << lane) - 1ull;
         F.o_bad = F.o_bad || F.o_open || F.o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
@@ -503,43 +252,45 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
     }
     lds_order_wave();
     const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
+    // Four tasks per pass as before, but ONE code per group of EIGHT lanes (group g: task g >> 1, code a or b), lane j of a group
+    // holding channels 8 j .. 8 j + 7 of the row and of the code: the c-ordered fmaf chain passes through the group in 8 steps of
+    // 8 fmaf instead of through 16 lanes in 16 steps of 2 x 4 -- the same 64 sequential fmaf per (row, code), half the instructions
+    // per pass (72 against 160: what counts is the step count, every lane issues every step).
     for (int base = 0; base < ntasks; base += 4) {
-        const int jj = base + g4;
+        const int jj = base + (g8 >> 1);
         const unsigned task = tb.task_s[jj < ntasks ? jj : 0];
         const int rr = (int)(task & 63u), ka = (int)((task >> 6) & 8191u), kb2 = (int)(task >> 19);
-        const f32x4 zv = zrow(rr, j16);
-        const f32x4 ea = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)ka * 256u + (unsigned)j16 * 16u, 0, 0));
-        const f32x4 eb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kb2 * 256u + (unsigned)j16 * 16u, 0, 0));
-        const float eea = ee_g[ka], eeb = ee_g[kb2];
-        // ||z||^2 in ATen's order (see exact_end)
-        float Aq[4];
-        const float sq[4] = {zv.x * zv.x, zv.y * zv.y, zv.z * zv.z, zv.w * zv.w};
+        const int kc = (g8 & 1) ? kb2 : ka;
+        const f32x4 z0 = zrow(rr, 2 * j8), z1 = zrow(rr, 2 * j8 + 1);
+        const f32x4 e0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kc * 256u + (unsigned)j8 * 32u, 0, 0));
+        const f32x4 e1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)kc * 256u + (unsigned)j8 * 32u + 16u, 0, 0));
+        const float eek = ee_g[kc];
+        // ||z||^2 in ATen's order (vq_device.h, aten_sqsum_full<64>): lane j holds vector j (elements 8 j + t): part[q][t] = v_q[t] +
+        // v_{q+4}[t] (lane q + lane q + 4), a_t = ((part_0 + part_1) + part_2) + part_3 (lanes 0..3 of the group), then a_0..a_7 in order
+        const float sq[8] = {z0.x * z0.x, z0.y * z0.y, z0.z * z0.z, z0.w * z0.w, z1.x * z1.x, z1.y * z1.y, z1.z * z1.z, z1.w * z1.w};
+        float zz = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float P = sq[e] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[e]), 0x108, 0xf, 0xf, true));
-            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
-            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x104, 0xf, 0xf, true));
-            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x106, 0xf, 0xf, true));
-            Aq[e] = ((P + p1) + p2) + p3;                                 // valid on lanes 0, 1 of the group
+        for (int t = 0; t < 8; ++t) {
+            const float P = sq[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[t]), 0x104, 0xf, 0xf, true));
+            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x101, 0xf, 0xf, true));
+            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
+            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x103, 0xf, 0xf, true));
+            zz = zz + (((P + p1) + p2) + p3);                             // valid on lane 0 of the group
         }
-        const float fin0 = (((0.0f + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];   // lane 0: A0..A3
-        const float f0 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(fin0), 0x111, 0xf, 0xf, true));
-        const float zz = (((f0 + Aq[0]) + Aq[1]) + Aq[2]) + Aq[3];       // lane 1: + A4..A7
-        float ma = 0.0f, mb = 0.0f;
+        // the chain: lane j continues lane j - 1's partial sum (row_shr:1; every partial sum is 0 before the first step, and lane s's
+        // value after step s only depends on lanes below it in its own group)
+        float m = 0.0f;
 #pragma unroll
-        for (int sidx = 0; sidx < 16; ++sidx) {
-            const float ia = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x111, 0xf, 0xf, true));
-            const float ib = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x111, 0xf, 0xf, true));
-            ma = __builtin_fmaf(zv.w, ea.w, __builtin_fmaf(zv.z, ea.z, __builtin_fmaf(zv.y, ea.y, __builtin_fmaf(zv.x, ea.x, ia))));
-            mb = __builtin_fmaf(zv.w, eb.w, __builtin_fmaf(zv.z, eb.z, __builtin_fmaf(zv.y, eb.y, __builtin_fmaf(zv.x, eb.x, ib))));
+        for (int sidx = 0; sidx < 8; ++sidx) {
+            const float im = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(m), 0x111, 0xf, 0xf, true));
+            m = __builtin_fmaf(z1.w, e1.w, __builtin_fmaf(z1.z, e1.z, __builtin_fmaf(z1.y, e1.y, __builtin_fmaf(z1.x, e1.x,
+                __builtin_fmaf(z0.w, e0.w, __builtin_fmaf(z0.z, e0.z, __builtin_fmaf(z0.y, e0.y, __builtin_fmaf(z0.x, e0.x, im))))))));
         }
-        const float ma1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ma), 0x122, 0xf, 0xf, true));   // lane 1 <- lane 15
-        const float mb1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mb), 0x122, 0xf, 0xf, true));
-        const float da = (zz + eea) - 2.0f * ma1, db = (zz + eeb) - 2.0f * mb1;     // valid on lane 1
-        if (j16 == 1 && jj < ntasks) {
-            atomicMin(&tb.best_s[rr], trk::dist_key(da, ka));
-            atomicMin(&tb.best_s[rr], trk::dist_key(db, kb2));
-            tb.zz_s[rr] = zz;
+        const float zz7 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(zz), 0x117, 0xf, 0xf, true));   // lane 7 <- lane 0
+        const float d = (zz7 + eek) - 2.0f * m;                                       // valid on lane 7 of the group
+        if (j8 == 7 && jj < ntasks) {
+            atomicMin(&tb.best_s[rr], trk::dist_key(d, kc));
+            tb.zz_s[rr] = zz7;
         }
     }
     lds_order_wave();
