@@ -522,9 +522,11 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         if (trace_u < 4) { VQ_TR(2 + trace_u); }
         ++trace_u;
 #endif
-        // (round 5 tried requesting the NEXT unit's rows here a unit ahead -- into F, free once the rows are fp16 operands -- with the
-        // epilogue reading the current rows again from L2: 37 -> 44 us at 262 144 rows, slower in every launch form; the second read
-        // misses L2 and waits as long as the first did.  profiles/r05_vq_notes.txt)
+        // (round 5 tried two ways of asking for rows a unit ahead; both lost.  (1) The NEXT unit's rows into F as soon as the current rows
+        // are fp16 operands, the epilogue reading the current rows again from L2: 37 -> 44 us at 262 144 rows -- the second read misses
+        // L2 and waits as long as the first did.  (2) One 4-byte load per 128-byte line of the unit after the next ("touch"), so that
+        // the real loads find their lines in L2: 36.9 -> 38.4 us, 216 -> 259 us at 2.1 M rows -- the lines are requested twice and the
+        // request path, not the latency, is what the rows wait on.  profiles/r05_vq_notes.txt)
         p = next_unit(lane);
         if (p < nunits) {
             load_unit(p, F, lane);
