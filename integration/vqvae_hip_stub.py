@@ -61,6 +61,7 @@ def lib():
                 ("vqvae_weights_pack_f32", _i32, [C.POINTER(Dims), C.POINTER(RawWeights), _vp, _sz, C.POINTER(Weights), _vp]),
                 ("vqvae_workspace_bytes", _sz, [C.POINTER(Dims), _i64, _i32, _i32]),
                 ("vqvae_forward_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32] + [_vp] * 5 + [_sz, _vp, _sz, _vp]),
+                ("vqvae_weights_range_check_f32", _i32, [C.POINTER(Dims), C.POINTER(RawWeights), _vp, C.POINTER(_i32), _vp, _sz, _vp]),
                 ("vqvae_encode_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp, _sz, _vp]),
                 ("vqvae_decode_f32", _i32, [C.POINTER(Weights), _vp, _i64, _i32, _i32, _i32, _vp, _vp, _sz, _vp]),
                 ("vqvae_vq_workspace_bytes", _sz, [_i64, _i32, _i32]),
@@ -92,9 +93,14 @@ def pack(model):
     packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     w = Weights()
     raw = RawWeights(**{f: t.data_ptr() for f, t in keep.items()})
+    rec = _i32(0)
     with torch.cuda.device(dev):
-        _check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, w, torch.cuda.current_stream(dev).cuda_stream))
-    return w, (keep, packed)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        _check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, w, st))
+        # which product scheme this checkpoint calls for (once per pack; synchronises the stream)
+        scratch = torch.empty(16, dtype=torch.float32, device=dev)
+        _check(L.vqvae_weights_range_check_f32(dims, raw, None, C.byref(rec), scratch.data_ptr(), 64, st))
+    return w, (keep, packed, int(rec.value))
 
 
 def install(model):
@@ -117,7 +123,7 @@ def install(model):
             ws = torch.empty(n, dtype=torch.uint8, device=x.device)
             x_hat = torch.empty_like(x)
             out = torch.empty(2, dtype=torch.float32, device=x.device)
-            _check(L.vqvae_forward_f32(w, x.data_ptr(), B, H, W, 0, x_hat.data_ptr(), out.data_ptr(), out.data_ptr() + 4, None,
+            _check(L.vqvae_forward_f32(w, x.data_ptr(), B, H, W, _keep[2], x_hat.data_ptr(), out.data_ptr(), out.data_ptr() + 4, None,
                                        ws.data_ptr(), n, None, 0, torch.cuda.current_stream(x.device).cuda_stream))
         return out[0], x_hat, out[1]                      # (embedding_loss, x_hat, perplexity), models/vqvae.py:44
 
@@ -139,7 +145,7 @@ def install(model):
         with torch.cuda.device(x.device):
             ws = _ws(w, B, H, W, x.device)
             idx = torch.empty(B * (H // 4) * (W // 4), 1, dtype=torch.int64, device=x.device)
-            _check(lib().vqvae_encode_f32(w, x.data_ptr(), B, H, W, 0, idx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0,
+            _check(lib().vqvae_encode_f32(w, x.data_ptr(), B, H, W, _keep[2], idx.data_ptr(), ws.data_ptr(), ws.numel(), None, 0,
                                           torch.cuda.current_stream(x.device).cuda_stream))
         return idx
 
@@ -157,7 +163,7 @@ def install(model):
         with torch.cuda.device(idx.device):
             ws = _ws(w, B, 4 * h, 4 * w_, idx.device)
             x_hat = torch.empty(B, w.dims.in_ch, 4 * h, 4 * w_, dtype=torch.float32, device=idx.device)
-            _check(lib().vqvae_decode_f32(w, idx.data_ptr(), B, h, w_, 0, x_hat.data_ptr(), ws.data_ptr(), ws.numel(),
+            _check(lib().vqvae_decode_f32(w, idx.data_ptr(), B, h, w_, _keep[2], x_hat.data_ptr(), ws.data_ptr(), ws.numel(),
                                           torch.cuda.current_stream(idx.device).cuda_stream))
         return x_hat
 
