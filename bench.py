@@ -228,7 +228,9 @@ def pmc_traffic(workload: str, vq_kernel: str):
     rel = os.path.relpath(path, ROOT)
     if d.get("source_sha") != source_sha():
         return None, f"{rel}: measured on kernel sources {d.get('source_sha')}, running {source_sha()}"
-    if vq_kernel and vq_kernel not in d.get("vq_kernel", ""):
+    # (files with a per-instance table are looked up by template instance and row count, vq_instance_traffic; older files carried one
+    # kernel's figure and are only good for that kernel)
+    if "vq_instances" not in d and vq_kernel and vq_kernel not in d.get("vq_kernel", ""):
         return None, f"{rel}: measured on {d.get('vq_kernel')!r}, running {vq_kernel}"
     d["_path"] = rel
     return d, None

@@ -145,7 +145,8 @@ def test_host_side_plans_without_gpu():
     assert _lib.vq_launch_form(4096, 512, 64, 49, 0x0) is None                    # 7x7 maps: another kernel
     assert _lib.vq_launch_form(4096, 1024, 64, 64, 0x0) is None and _lib.vq_launch_form(4096, 2048, 64) is None
     assert _lib.vq_launch_form(32 * cus * 32, 512, 64, 64, 0x1 | 0x100) == (8, 64, 0)     # forced forms
-    assert _lib.vq_kernel_instance(32 * cus * 32, 512, 64) == "vq_track_kernel_d64<16, false, 1>"
+    assert _lib.vq_kernel_instance(32 * cus * 32, 512, 64) == "vq_track_kernel_d64<16, false, 1, 16>"      # (the unrolled-sweep instance, round 5)
+    assert _lib.vq_kernel_instance(32 * cus * 32, 448, 64) == "vq_track_kernel_d64<16, false, 1>"
     assert _lib.vq_sweeps(512, 64) == 1 and _lib.vq_sweeps(512, 64, 0x1 | 0x8) == 2 and _lib.vq_sweeps(512, 256) == 0
     # the streamed kernels' scratch does not grow with the row count (slabs of 2^18 rows)
     a, b = L.vqvae_vq_workspace_bytes(1000, 8192, 128), L.vqvae_vq_workspace_bytes(10 ** 8, 8192, 128)

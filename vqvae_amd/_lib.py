@@ -168,7 +168,10 @@ def vq_kernel_instance(n_rows: int, K: int, D: int, HW: int = 64, flags: int = 0
     f = vq_launch_form(n_rows, K, D, HW, flags)
     if f is None:
         return name
-    return f"{name}<{f[0]}, {'false' if flags & 0x1 else 'true'}, {f[1] // 32}>" + (f" (last {f[2]} % of the units pooled)" if f[2] else "")
+    # (codebooks of exactly sixteen 32-code tiles, K in 481 .. 512, run instances with the sweep fully unrolled -- every launch form
+    # but 64-row units on eight waves of row-major rows, which the rule no longer picks for such codebooks)
+    unrolled = ", 16" if 480 < K <= 512 and not (f[0] == 8 and f[1] == 64 and flags & 0x1) and f[0] != 12 else ""
+    return f"{name}<{f[0]}, {'false' if flags & 0x1 else 'true'}, {f[1] // 32}{unrolled}>" + (f" (last {f[2]} % of the units pooled)" if f[2] else "")
 
 
 PROF_IDS = {"vq_main": 0, "conv_igemm": 1, "res_layer": 2, "conv_in": 3, "conv_out": 4}

@@ -266,6 +266,27 @@ def encoder_forward_train(enc, x, pre_quant):
     return ConvFn.apply(t, pre_quant.weight, pre_quant.bias, pre_quant, CONV_1x1, False, fs, False)
 
 
+def encoder_stack_forward_train(enc, x):
+    """Encoder.forward alone under autograd (models/encoder.py:42-43): NCHW image -> NCHW (B, h_dim, H/4, W/4), every layer
+    forward and backward on the HIP kernels (round 5: sub-modules are differentiable like the reference's)."""
+    cs = enc.conv_stack
+    c0, c2, c4, stack = cs[0], cs[2], cs[4], cs[5]
+    f = FUSE_EPILOGUES
+    layers = list(stack.stack)
+    fs = f and len(layers) > 0
+    a0 = ConvInFn.apply(x, c0.weight, c0.bias, c0, f)
+    a1 = ConvFn.apply(a0, c2.weight, c2.bias, c2, CONV_4x4_S2, True, f, f)
+    a2 = ConvFn.apply(a1, c4.weight, c4.bias, c4, CONV_3x3_S1, True, f, fs)
+    t = _res_stack_train(a2, layers, False, True, fs, False)         # (no consumer kernel behind the stack: it masks itself)
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def residual_stack_forward_train(x_nchw, layers, final_relu):
+    """ResidualStack / ResidualLayer.forward alone under autograd (models/residual.py:28, :47-51): NCHW in, NCHW out."""
+    t = _res_stack_train(x_nchw.permute(0, 2, 3, 1).contiguous(), layers, True, final_relu, False, False)
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
 def decoder_forward_train(dec, z_q_rows):
     """models/decoder.py:27-39 under autograd; z_q row-major (B,h,w,D) -> x_hat NCHW."""
     ds = dec.inverse_conv_stack

@@ -69,7 +69,10 @@ __device__ unsigned long long g_vq_trace[4096 * 8];
 // Launch forms <NW, NCHW, T> (launch_vq_track_d64 has the rule): <8, ., 2> many rows; <16, false, 1> up to two 32-row units per wave
 // (BASELINE config 3); <8, ., 1> up to 8 units per CU (config 2: every CU busy before any wave gets a second unit) and NCHW maps of
 // 32 (2 k + 1) pixels; <4, false, 1> codebooks whose image only fits beside four waves' tiles (K up to 1024: config 4).
-template <int NW, bool NCHW = false, int T = 2>
+// NTILE (round 5): 0 = the number of 32-code tiles is a run-time value; 16 = K in 481 .. 512 (the reference's default codebook) with the sweep
+// fully unrolled -- every tile index a compile-time constant, so LDS offsets are immediates, cell ids inline constants, and the
+// sweep carries no scalar bookkeeping and no branches (~95 instructions per 32-row unit less)
+template <int NW, bool NCHW = false, int T = 2, int NTILE = 0>
 __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     const float *__restrict__ z, const float *__restrict__ cb, const uint4 *__restrict__ img_g,
     const float *__restrict__ seeds_g, const float *__restrict__ ee_g, const int *__restrict__ flags,
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     int *__restrict__ hist, double *__restrict__ partials, int HW, int pool_pct) {
     constexpr int D = 64, RU = 32 * T;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int ntile = K32 >> 5;
+    const int ntile = NTILE ? NTILE : K32 >> 5;
     uint4 *Eimg = reinterpret_cast<uint4 *>(smem_raw);                                  // [ntile][4][2][32] x 16 B
     float *seeds = reinterpret_cast<float *>(Eimg + (size_t)ntile * 256);               // [ntile][2][16]
     int *hist_s = reinterpret_cast<int *>(seeds + (size_t)ntile * 32);                  // [K]
@@ -193,6 +196,16 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
     // row 4 i + g4, chunk j16 >> 1: the slot is (j16 >> 1) ^ (g4 >> 1) ^ 2 (i & 3) -- one lane constant, one immediate
     f16x8 zb[T][4];
     float zn2[T];
+    // the conversion's two lane-dependent tile offsets, computed ONCE (round 5): ~20 vector instructions per unit less for two live
+    // registers -- where registers are not the limit (the sixteen-wave form keeps recomputing them: it would spill)
+    constexpr bool HOIST = NW != 16;
+    unsigned cvt_wbase = 0u, cvt_rbase = 0u;
+    if constexpr (HOIST) {
+        const unsigned l = (unsigned)tid & 63u, j16h = l & 15u, g4h = l >> 4, l31h = l & 31u, hh = l >> 5;
+        cvt_wbase = g4h * 128u + (((j16h >> 1) ^ (g4h >> 1)) << 4) + ((j16h & 1u) << 3);
+        cvt_rbase = l31h * 128u + (((hh ^ (l31h >> 1)) & 7u) << 4);
+        asm volatile("" : "+v"(cvt_wbase), "+v"(cvt_rbase));
+    }
     auto convert = [&]() {
         int lane_c = lane_id();                                 // (not tid & 63: threadIdx would stay live through the unit loop and spill)
         asm volatile("" : "+v"(lane_c));
@@ -216,7 +229,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                     F[t][i] = *reinterpret_cast<const f32x4 *>(tf + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2));
             }
         }
-        const unsigned wbase = (unsigned)g4 * 128u + ((((unsigned)j16 >> 1) ^ ((unsigned)g4 >> 1)) << 4) + (((unsigned)j16 & 1u) << 3);
+        const unsigned wbase = HOIST ? cvt_wbase : (unsigned)g4 * 128u + ((((unsigned)j16 >> 1) ^ ((unsigned)g4 >> 1)) << 4) + (((unsigned)j16 & 1u) << 3);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -229,7 +242,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 *reinterpret_cast<u32x2 *>(tile_s + t * 4096 + i * 512 + (wbase ^ ((unsigned)(2 * (i & 3)) << 4))) = w;
             }
         lds_order_wave();
-        const unsigned rbase = (unsigned)l31 * 128u + ((((unsigned)h ^ ((unsigned)l31 >> 1)) & 7u) << 4);
+        const unsigned rbase = HOIST ? cvt_rbase : (unsigned)l31 * 128u + ((((unsigned)h ^ ((unsigned)l31 >> 1)) & 7u) << 4);
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             float sq = 0.0f;
@@ -361,9 +374,9 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                     for (int t = 0; t < T; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[t][q], acc[t], 0, 0, 0);
             };
-            auto track = [&](int ct, const f32x16(&acc)[T]) {
+            auto track = [&](int ct, const f32x16(&acc)[T], bool known = false) {
                 unsigned cell0 = (unsigned)(2 * ct), cell1 = cell0 + 1u;        // scalars (opaque: else or3(x & mask, cell0, 1))
-                asm volatile("" : "+s"(cell0), "+s"(cell1));
+                if (!known) asm volatile("" : "+s"(cell0), "+s"(cell1));       // (known: compile-time tile index -> inline constants)
 #pragma unroll
 #ifdef VQ_KO_TRACK
                 for (int t = 0; t < T; ++t) { L[t].S[0] = trk::max3(L[t].S[0], acc[t][0], acc[t][15]); L[t].m1 = trk::max3(L[t].m1, acc[t][7], acc[t][8]); }
@@ -373,13 +386,13 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 #endif
             };
             // one pipeline step: operands of tile ct, its MFMAs into `accn`, the tracker of tile ct - 1 on `accp` between them
-            auto step = [&](int ct, f32x16(&accn)[T], const f32x16(&accp)[T]) {
+            auto step = [&](int ct, f32x16(&accn)[T], const f32x16(&accp)[T], bool known = false) {
                 u32x4 a[4];
                 f32x16 seed;
                 fetch(ct, a, seed);
                 __builtin_amdgcn_sched_barrier(0);
                 mma(accn, a, seed);
-                track(ct - 1, accp);
+                track(ct - 1, accp, known);
 #pragma unroll
                 for (int i = 0; i < 4 * T; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);          // one MFMA
@@ -394,6 +407,15 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 fetch(0, a, seed);
                 mma(accA, a, seed);
             }
+            if constexpr (NTILE == 16) {
+#pragma unroll
+                for (int c2 = 0; c2 < 7; ++c2) {
+                    step(1 + 2 * c2, accB, accA, true);
+                    step(2 + 2 * c2, accA, accB, true);
+                }
+                step(15, accB, accA, true);
+                track(15, accB, true);
+            } else {
             int ct = 1;
             for (; ct + 1 < ntile; ct += 2) {
                 step(ct, accB, accA);
@@ -404,6 +426,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                 track(ct, accB);
             } else {
                 track(ct - 1, accA);
+            }
             }
         }
 
@@ -636,11 +659,16 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
             hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(NW * 64), vq_track_lds_bytes(K, NW, RU / 32, nchw), st, z, cb, imgh, seeds, ee, wflags, N, K,
                                p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
+    const bool k512 = p.K32 == 512;                          // sixteen code tiles: the instances with the unrolled sweep
     if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
     else if (NW == 12) launch(vq_track_kernel_d64<12, false, 1>);
+    else if (nchw && spread && k512) launch(vq_track_kernel_d64<8, true, 1, 16>);
     else if (nchw && spread) launch(vq_track_kernel_d64<8, true, 1>);
+    else if (nchw && k512) launch(vq_track_kernel_d64<8, true, 2, 16>);
     else if (nchw) launch(vq_track_kernel_d64<8, true, 2>);
+    else if (spread && k512) launch(vq_track_kernel_d64<8, false, 1, 16>);
     else if (spread) launch(vq_track_kernel_d64<8, false, 1>);
+    else if (wide && k512) launch(vq_track_kernel_d64<16, false, 1, 16>);
     else if (wide) launch(vq_track_kernel_d64<16, false, 1>);
     else launch(vq_track_kernel_d64<8, false, 2>);
     return (int)hipGetLastError();

@@ -268,15 +268,20 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
         // ||z||^2 in ATen's order (vq_device.h, aten_sqsum_full<64>): lane j holds vector j (elements 8 j + t): part[q][t] = v_q[t] +
         // v_{q+4}[t] (lane q + lane q + 4), a_t = ((part_0 + part_1) + part_2) + part_3 (lanes 0..3 of the group), then a_0..a_7 in order
         const float sq[8] = {z0.x * z0.x, z0.y * z0.y, z0.z * z0.z, z0.w * z0.w, z1.x * z1.x, z1.y * z1.y, z1.z * z1.z, z1.w * z1.w};
+        // (the eight t-chains level by level, not one after the other: a DPP read needs two instructions between it and the write
+        // of its source -- back to back, hipcc pads every level of every chain with an s_nop)
+        float P[8], A[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) P[t] = sq[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[t]), 0x104, 0xf, 0xf, true));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) A[t] = P[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t]), 0x101, 0xf, 0xf, true));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) A[t] = A[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t]), 0x102, 0xf, 0xf, true));
+#pragma unroll
+        for (int t = 0; t < 8; ++t) A[t] = A[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P[t]), 0x103, 0xf, 0xf, true));
         float zz = 0.0f;
 #pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float P = sq[t] + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(sq[t]), 0x104, 0xf, 0xf, true));
-            const float p1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x101, 0xf, 0xf, true));
-            const float p2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x102, 0xf, 0xf, true));
-            const float p3 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(P), 0x103, 0xf, 0xf, true));
-            zz = zz + (((P + p1) + p2) + p3);                             // valid on lane 0 of the group
-        }
+        for (int t = 0; t < 8; ++t) zz = zz + A[t];                       // valid on lane 0 of the group
         // the chain: lane j continues lane j - 1's partial sum (row_shr:1; every partial sum is 0 before the first step, and lane s's
         // value after step s only depends on lanes below it in its own group)
         float m = 0.0f;

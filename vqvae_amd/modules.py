@@ -31,17 +31,26 @@ from . import functional as F_hip
 from ._lib import VqvaeHipError
 
 
-def _require_forward_only(*tensors):
-    """The HIP conv / residual kernels have no backward: refuse to run them while a graph is recorded."""
+def _records_graph(*tensors):
+    """Is a graph being recorded through the HIP conv path?  (round 5: the sub-modules then run autograd_conv's Functions --
+    forward AND backward on the HIP kernels -- as VQVAE.forward does; models/encoder.py:42-43, decoder.py:38-39,
+    residual.py:47-51 are differentiable upstream, and so are they here)"""
     from . import conv as C_hip
-    if C_hip.get_conv_backend() == "torch":
-        return                                          # torch's own convs carry their autograd
-    if torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+    return C_hip.get_conv_backend() == "hip" and torch.is_grad_enabled() and any(t.requires_grad for t in tensors)
+
+
+def _require_forward_only(*tensors):
+    """The whole-path / fused forward entries keep no activations: refuse to run them while a graph is recorded."""
+    if _records_graph(*tensors):
         raise VqvaeHipError(
-            "the HIP conv kernels are forward-only: call them under torch.no_grad() (or "
-            "model.requires_grad_(False)).  For training, select set_conv_backend('torch'): the "
-            "VectorQuantizer then runs its HIP forward and backward, the convs use torch autograd. "
+            "this entry point is forward-only: call it under torch.no_grad() (or model.requires_grad_(False)); "
+            "VQVAE.forward, Encoder / Decoder / ResidualStack.forward record a graph on the HIP kernels by themselves.  "
             "There is no silent fallback")
+
+
+def _need_hip_f32(x, who):
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise VqvaeHipError(f"{who} needs a CUDA(HIP) fp32 input: there is no CPU path")
 
 
 class VectorQuantizer(nn.Module):
@@ -129,7 +138,12 @@ class ResidualStack(nn.Module):
     @staticmethod
     def _run(x, layers, final_relu, mutate_input):
         from . import conv as C_hip
-        _require_forward_only(x, *[p for l in layers for p in l.parameters()])
+        if _records_graph(x, *[p for l in layers for p in l.parameters()]):
+            # under autograd the caller's tensor is NOT rewritten to relu(x) (upstream's in-place nn.ReLU does that through
+            # autograd's version counter; an out-of-graph write here would corrupt other consumers' gradients): use the return value
+            from . import autograd_conv as A_hip
+            _need_hip_f32(x, "ResidualStack.forward")
+            return A_hip.residual_stack_forward_train(x, layers, final_relu)
         y = C_hip.residual_stack_nchw(x, layers, final_relu=final_relu)
         if mutate_input:
             # nn.ReLU(True) upstream rewrites the caller's tensor to relu(x) (residual.py:19)
@@ -157,7 +171,10 @@ class Encoder(nn.Module):
 
     def forward(self, x):
         from . import conv as C_hip
-        _require_forward_only(x, *self.parameters())
+        if _records_graph(x, *self.parameters()):
+            from . import autograd_conv as A_hip
+            _need_hip_f32(x, "Encoder.forward")
+            return A_hip.encoder_stack_forward_train(self, x)
         return C_hip.encoder_forward(self, x, pre_quant=None)
 
 
@@ -177,7 +194,10 @@ class Decoder(nn.Module):
 
     def forward(self, x):
         from . import conv as C_hip
-        _require_forward_only(x, *self.parameters())
+        if _records_graph(x, *self.parameters()):
+            from . import autograd_conv as A_hip
+            _need_hip_f32(x, "Decoder.forward")
+            return A_hip.decoder_forward_train(self, x.permute(0, 2, 3, 1).contiguous())
         return C_hip.decoder_forward(self, x, rowmajor_in=False)
 
 
