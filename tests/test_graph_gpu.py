@@ -51,3 +51,35 @@ def test_graph_replay_of_the_unfused_paths(dims, B, HW):
         out = g(x)
         torch.cuda.synchronize()
         assert all(torch.equal(a, b) for a, b in zip(out, e))
+
+
+def test_graph_capture_of_a_sub_module_through_the_per_layer_cache():
+    """Encoder / Decoder on their own go through conv_hip's per-layer packed-weight cache, whose entries carry the event
+    recorded behind their pack launches.  A hit inside a stream capture must not QUERY that event (not a capturable call): the
+    packing stream is recognised as such, any other stream waits on the event.  Capture right after the warm-up that packed the
+    weights (their events are still attached), on the capture stream and from a cache filled on ANOTHER stream."""
+    from vqvae_amd import conv
+    from vqvae_amd.graph import GraphedForward
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    dev = torch.device("cuda:0")
+    torch.manual_seed(2)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).to(dev).eval()
+    x1 = torch.randn(16, 3, 32, 32, device=dev)
+    x2 = torch.randn(16, 3, 32, 32, device=dev)
+    g = GraphedForward(m.encoder, x1, warmup=1)          # packs on the capture stream, captures at once
+    with torch.no_grad():
+        e1, e2 = m.encoder(x1).clone(), m.encoder(x2).clone()
+    for x, e in ((x2, e2), (x1, e1)):
+        out = g(x)
+        torch.cuda.synchronize()
+        assert torch.equal(out, e)
+    # the decoder's images are packed on a side stream first; the capture (another stream) then meets entries with foreign events
+    z = torch.randn(16, 64, 8, 8, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    with torch.no_grad(), torch.cuda.stream(side):
+        d_ref = m.decoder(z).clone()
+    g2 = GraphedForward(m.decoder, z, warmup=1)
+    out = g2(z)
+    torch.cuda.synchronize()
+    assert torch.equal(out, d_ref)
