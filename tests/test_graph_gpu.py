@@ -77,9 +77,11 @@ def test_graph_capture_of_a_sub_module_through_the_per_layer_cache():
     # the decoder's images are packed on a side stream first; the capture (another stream) then meets entries with foreign events
     z = torch.randn(16, 64, 8, 8, device=dev)
     side = torch.cuda.Stream(device=dev)
+    side.wait_stream(torch.cuda.current_stream(dev))
     with torch.no_grad(), torch.cuda.stream(side):
         d_ref = m.decoder(z).clone()
-    g2 = GraphedForward(m.decoder, z, warmup=1)
+    g2 = GraphedForward(m.decoder, z, warmup=1)      # (its warm-up waits on the side stream's pack events; the capture itself does not)
+    torch.cuda.current_stream(dev).wait_stream(side)
     out = g2(z)
     torch.cuda.synchronize()
     assert torch.equal(out, d_ref)

@@ -38,7 +38,10 @@ def _packed(mod, kind, weight, nbytes_fn, pack_fn):
             if cur.cuda_stream == hit[2][1]:
                 pass                                 # the packing stream itself: ordered behind the pack kernels already
             elif torch.cuda.is_current_stream_capturing():
-                cur.wait_event(hit[2][0])            # an event QUERY is not capturable: the wait is, and costs nothing replayed
+                # neither an event query nor a wait on an event from outside the capture belongs in a capture.  Nothing to
+                # do: a capture is preceded by an eager warm-up on the capture stream (GraphedForward; torch's own rule for its
+                # allocator), which met this entry in the branch below and ordered the stream behind the pack kernels
+                pass
             elif hit[2][0].query():                  # forget the event once it has completed (no per-call cost from then on)
                 cache[kind] = (hit[0], hit[1], None)
             else:
