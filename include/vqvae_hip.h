@@ -525,11 +525,12 @@ VQVAE_API int vqvae_decode_f32(const VqvaeWeights *w, const int64_t *idx, int64_
  * (profiles/r03_notes.txt section 11), which is why the Python host layer does not do it by default.
  * The library creates no streams or events: ordering between the streams is the caller's (hipStreamWaitEvent / torch
  * wait_stream).
- * PRECONDITIONS the library does not (and, allocating nothing, cannot cheaply) verify -- violating them gives wrong loss /
- * perplexity or races, not an error code: begin / every part / end get the SAME B, H, W, flags and workspaces; the parts cover
- * [0, B) exactly once (no overlap, no gap: a part leaves one loss partial per four images and adds to the histogram
- * atomically); with vq_workspace == NULL the codebook images live inside `workspace`, prepared by begin -- parts never
- * prepare them; every buffer stays alive, and untouched by other work, until the stream of `end` has passed it. */
+ * Checked on the host since round 5 (a record per workspace pointer, opened by begin and closed by end; VQVAE_ERR_SHAPE on violation):
+ * every part repeats begin's B, H, W, flags and quantizer workspace; parts do not overlap; end finds [0, B) covered exactly once (a part
+ * leaves one loss partial per four images and adds to the histogram atomically: a gap or a repeat would give wrong loss / perplexity).
+ * What stays the caller's, because no launch-time check can see it: begin / parts / end are ORDERED on their streams as described, and
+ * every buffer stays alive, untouched by other work, until the stream of `end` has passed it.  With vq_workspace == NULL the codebook
+ * images live inside `workspace`, prepared by begin -- parts never prepare them. */
 VQVAE_API int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int vq_flags, void *workspace,
                                       size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,
                                       vqvae_stream_t stream);

@@ -779,6 +779,45 @@ def test_step_in_parts_on_side_streams_equals_the_single_call(B, parts):
     assert c[0].item() == a[0].item() and torch.equal(c[1].view(torch.int32), a[1].view(torch.int32))
 
 
+def test_step_in_parts_protocol_violations_are_errors():
+    """Round 5: the parts protocol is checked on the host -- a part without a begin, a part whose shapes differ
+    from begin's, overlapping parts, and an end before [0, B) is covered all return VQVAE_ERR_SHAPE instead of wrong loss / perplexity."""
+    from vqvae_amd import _lib, conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    B = 256
+    x = torch.randn(B, 3, 32, 32, device=dev())
+    L = _lib.load()
+    ERR_SHAPE = -2
+    with torch.no_grad():
+        m._forward_c(x)                                              # packs weights, prepares the codebook
+        cw, _keep = m._c_weights()
+        ws, st = m._c_workspace(L, cw, B, 32, 32, dev())
+        ws2 = torch.empty_like(ws)
+        vws = m.vector_quantization._workspace()[0]
+        x_hat = torch.empty_like(x)
+        scal = torch.empty(2, device=dev())
+
+        def part(b0, bc, Bt=B, w=ws):
+            return L.vqvae_forward_part_f32(cw, x.data_ptr(), Bt, b0, bc, 32, 32, 0x2, x_hat.data_ptr(), None, w.data_ptr(), w.numel(),
+                                            vws.data_ptr(), vws.numel(), st)
+
+        assert part(0, 128, w=ws2) == ERR_SHAPE                      # no begin on this workspace
+        _lib.check(L.vqvae_forward_begin_f32(cw, B, 32, 32, 0x2, ws.data_ptr(), ws.numel(), vws.data_ptr(), vws.numel(), st))
+        assert part(0, 128, Bt=B - 64) == ERR_SHAPE                  # another batch size than begin's
+        _lib.check(part(0, 128))
+        assert part(64, 128) == ERR_SHAPE                            # overlaps the first part
+        assert L.vqvae_forward_end_f32(cw, B, 32, 32, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), ws.numel(), st) == ERR_SHAPE   # gap
+        _lib.check(part(128, 128))
+        _lib.check(L.vqvae_forward_end_f32(cw, B, 32, 32, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), ws.numel(), st))
+        assert L.vqvae_forward_end_f32(cw, B, 32, 32, scal.data_ptr(), scal.data_ptr() + 4, ws.data_ptr(), ws.numel(), st) == ERR_SHAPE   # closed
+        ref = m._forward_c(x, parts=1)
+    torch.cuda.synchronize()
+    assert torch.equal(x_hat, ref[1]) and scal[0].item() == ref[0].item() and scal[1].item() == ref[2].item()
+
+
 @pytest.mark.parametrize("B,K", [(4096, 512), (37, 512), (1, 512), (5000, 512), (4096, 1024), (37, 1024), (4096, 256), (130, 128)])
 def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B, K):
     """Round 3: on the default shapes (32x32 RGB, h_dim 128, K = 512, D = 64) vqvae_forward_f32 quantizes inside the

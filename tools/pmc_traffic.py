@@ -80,6 +80,15 @@ def main():
                 continue
             inst[f"{mm.group(1)}@{rows}"] = {"read_bytes": round(2 * tab_f[n][0] * 1024), "write_bytes": round(tab_w.get(n, (0.0, 0))[0] * 1024),
                                              "algorithmic_bytes": rows * (8 * _bench.WORKLOADS[wl][4] + 8), "dispatches": tab_f[n][1]}
+    # the quantizer FAMILY of one bench step (the streamed-codebook kernels run four launches per slab of 2^18 rows: bench.py times them
+    # together and names the family by its sweep kernel): every dispatch of a quantizer kernel in the bench passes, per step
+    once_v = [n for n in bf if "dec_tail8" in n or "convt_out_kernel" in n]
+    steps_v = max(bf[n][1] for n in once_v) if once_v else 1
+    fam_r = sum(2 * bf[n][0] * 1024 * bf[n][1] / steps_v for n in bf if is_vq(n))
+    fam_w = sum(bw.get(n, (0.0, 0))[0] * 1024 * bf[n][1] / steps_v for n in bf if is_vq(n))
+    if fam_r + fam_w > 0:
+        inst[f"vq_step@{rows_wl}"] = {"read_bytes": round(fam_r), "write_bytes": round(fam_w), "algorithmic_bytes": rows_wl * (8 * _bench.WORKLOADS[wl][4] + 8),
+                                      "dispatches": sum(bf[n][1] for n in bf if is_vq(n)), "note": "all quantizer launches of one step"}
     for v in inst.values():
         v["over_algorithmic"] = round((v["read_bytes"] + v["write_bytes"]) / v["algorithmic_bytes"], 4)
     res["vq_instances"] = inst

@@ -4,9 +4,26 @@
 // points of this library on the caller's stream and carve the caller's workspace; they allocate nothing and never
 // synchronise.  A C / C++ caller needs nothing from the Python package.
 #include "common.h"
+#include <map>
+#include <mutex>
+#include <utility>
+#include <vector>
 
 namespace vqvae {
 namespace {
+
+// Host-side bookkeeping of a step in PARTS (vqvae_forward_begin / part / end), keyed by the caller's workspace pointer (round 5; ADVICE
+// r3 item 5): begin opens a record, every part must repeat begin's B / H / W / flags / quantizer workspace and
+// claim images no other part of the step has claimed, end must find [0, B) covered exactly and closes the record.  What stays the
+// caller's: the ORDER of the streams and the lifetime of the buffers -- nothing a launch-time check can see.
+struct PartsRecord {
+    int64_t B;
+    int H, W, flags;
+    const void *vqws;
+    std::vector<std::pair<int64_t, int64_t>> claimed;
+};
+std::mutex g_parts_mu;
+std::map<const void *, PartsRecord> g_parts;
 
 constexpr int kVqFormFlags = VQVAE_VQ_UNITS64_8WAVES | VQVAE_VQ_UNITS32_16WAVES | VQVAE_VQ_UNITS32_8WAVES;
 
@@ -619,6 +636,10 @@ int vqvae_forward_begin_f32(const VqvaeWeights *w, int64_t B, int H, int W, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     if ((rc = vq_prepare_impl(w->codebook, d->n_embeddings, d->embedding_dim, vq_flags, f.vqws, f.vqws_bytes, st)) != 0) return rc;
     if (hipMemsetAsync(f.hist, 0, (size_t)d->n_embeddings * sizeof(int32_t), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+    {
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        g_parts[workspace] = PartsRecord{B, H, W, vq_flags, vq_workspace, {}};      // (a begin without an end is simply replaced)
+    }
     return VQVAE_OK;
 }
 
@@ -633,6 +654,17 @@ int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int64_t B, int
     int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, vq_workspace, vq_workspace_bytes, vq_flags, f);
     if (rc != VQVAE_OK) return rc;
     if (!fused_c3_path(d, H, W, conv_scheme(vq_flags)) || !vq_fuse_ok(d->n_embeddings, d->embedding_dim, B, vq_flags)) return VQVAE_ERR_UNSUPPORTED;
+    {
+        // this part against the step's record: same shapes / flags / quantizer workspace as begin, images nobody has claimed
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        auto it = g_parts.find(workspace);
+        if (it == g_parts.end()) return VQVAE_ERR_SHAPE;                                   // no vqvae_forward_begin_f32 on this workspace
+        PartsRecord &r = it->second;
+        if (r.B != B || r.H != H || r.W != W || r.flags != vq_flags || r.vqws != vq_workspace) return VQVAE_ERR_SHAPE;
+        for (const auto &c : r.claimed)
+            if (b0 < c.second && c.first < b0 + Bc) return VQVAE_ERR_SHAPE;                // overlaps another part of this step
+        r.claimed.emplace_back(b0, b0 + Bc);
+    }
     hipStream_t st = static_cast<hipStream_t>(stream);
     const size_t per_img = f.act / (size_t)B, lat = (size_t)(H / 4) * (W / 4);
     // this part's own two activation buffers and maxima regions inside the whole batch's
@@ -658,6 +690,16 @@ int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float 
     int flags = 0;
     int rc = carve_forward(d, B, H, W, workspace, workspace_bytes, nullptr, 0, flags, f, false);
     if (rc != VQVAE_OK) return rc;
+    {
+        // the step's record: opened by begin with these shapes, [0, B) claimed exactly once -- else loss / perplexity would be wrong
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        auto it = g_parts.find(workspace);
+        if (it == g_parts.end() || it->second.B != B || it->second.H != H || it->second.W != W) return VQVAE_ERR_SHAPE;
+        int64_t covered = 0;
+        for (const auto &c : it->second.claimed) covered += c.second - c.first;            // (parts never overlap: checked when claimed)
+        if (covered != B) return VQVAE_ERR_SHAPE;
+        g_parts.erase(it);
+    }
     return vq_finalize_impl(reinterpret_cast<const double *>(f.z_e), (int)((B + 3) / 4), f.hist, d->n_embeddings, (int64_t)f.rows,
                             d->embedding_dim, d->beta, loss, perplexity, static_cast<hipStream_t>(stream));
 }
