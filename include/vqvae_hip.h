@@ -112,7 +112,8 @@ VQVAE_API int vqvae_calibration_mfma_f16(int iters, void *scratch, size_t scratc
                                         then never written); identical outputs, A/B timing and tests */
 
 /* Which kernel vqvae_vq_forward_f32 launches for this shape / flags ("vq_track_kernel_d64" (codebook image resident in LDS: D = 64,
- * K <= ~600, row-major rows or NCHW maps whose pixel count is a multiple of 32; row-major rows up to K = 1024 with four waves per CU),
+ * K <= 1024 -- up to ~600 beside eight or sixteen waves' tiles, beyond that with four waves per CU; row-major rows or, since round 5 for
+ * every such K, NCHW maps whose pixel count is a multiple of 32),
  * "vq_stream_sweep_kernel" (image streamed through LDS: D = 64 / 128, K <= 16384),
  * "vq_filter_kernel_d64", "vq_exact_kernel"), and how many times that kernel sweeps the codebook on the 16-bit matrix
  * cores per row (0 for the exact-fp32 kernel).  For reporting (bench.py). */

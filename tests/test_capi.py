@@ -128,7 +128,9 @@ def test_host_side_plans_without_gpu():
     assert _lib.vq_kernel_name(8192, 128) == "vq_stream_sweep_kernel"
     assert _lib.vq_kernel_name(512, 64, 0x1 | 0x8) == "vq_filter_kernel_d64"
     assert _lib.vq_kernel_name(512, 64, 0x0) == "vq_track_kernel_d64"           # NCHW rows (maps of 64 k pixels; round 4)
-    assert _lib.vq_kernel_name(1024, 64, 0x0) == "vq_filter_kernel_d64"         # NCHW, codebook beyond the LDS-resident image
+    assert _lib.vq_kernel_name(1024, 64, 0x0) == "vq_track_kernel_d64"          # NCHW, K up to 1024: four waves, half-tile transposition (round 5)
+    assert _lib.vq_kernel_name(1056, 64, 0x0) == "vq_exact_kernel"              # NCHW, codebook beyond the LDS-resident image
+    assert _lib.vq_kernel_name(1024, 64, 0x8) == "vq_filter_kernel_d64"         # (round 1's two-sweep kernel stays reachable by its flag)
     assert _lib.vq_kernel_name(512, 256) == "vq_exact_kernel"
     # the stream-tracker kernel's launch forms (256 CUs assumed where no device is present): config 2 / config 3 / many rows / K = 1024 /
     # the module's NCHW layout; the rule scales with the CU count, so only sizes far from its edges are pinned here
@@ -143,7 +145,7 @@ def test_host_side_plans_without_gpu():
     assert _lib.vq_launch_form(256 * cus * 32, 512, 64, 64, 0x0)[:2] == (8, 64)
     assert _lib.vq_launch_form(256 * cus * 32, 512, 64, 96, 0x0)[:2] == (8, 32)   # 32 (2 k + 1) pixels: 32-position units at any size
     assert _lib.vq_launch_form(4096, 512, 64, 49, 0x0) is None                    # 7x7 maps: another kernel
-    assert _lib.vq_launch_form(4096, 1024, 64, 64, 0x0) is None and _lib.vq_launch_form(4096, 2048, 64) is None
+    assert _lib.vq_launch_form(4096, 1024, 64, 64, 0x0)[:2] == (4, 32) and _lib.vq_launch_form(4096, 2048, 64) is None
     assert _lib.vq_launch_form(32 * cus * 32, 512, 64, 64, 0x1 | 0x100) == (8, 64, 0)     # forced forms
     assert _lib.vq_kernel_instance(32 * cus * 32, 512, 64) == "vq_track_kernel_d64<16, false, 1, 16>"      # (the unrolled-sweep instance, round 5)
     assert _lib.vq_kernel_instance(32 * cus * 32, 448, 64) == "vq_track_kernel_d64<16, false, 1>"

@@ -301,6 +301,27 @@ def test_vq_nchw_units_of_32_positions_bit_exact(B, H, W):
     np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
 
 
+@pytest.mark.parametrize("K,B,H,W", [(1024, 2, 56, 56), (1024, 37, 8, 8), (640, 9, 8, 12), (1000, 3, 16, 16)],
+                         ids=["config4_56x56_k1024", "k1024_8x8_ragged", "k640_hw96", "k1000_padding_codes"])
+def test_vq_nchw_large_codebooks_on_the_four_wave_form_bit_exact(K, B, H, W):
+    """Round 5: the module's NCHW layout with codebooks whose fp16 image leaves 4 KiB of LDS per wave (K up to 1024,
+    BASELINE config 4's codebook) runs vq_track_kernel_d64<4, true, 1> -- the 32 x 64 fp32 block is turned around in two halves of 32
+    channels through a 32 x 32 tile, in and out -- instead of round 1's two-sweep filter kernel; against the oracle, bit for bit
+    (indices, z_q, histogram), incl. a K that is not a multiple of 32 (padding codes) and a ragged number of units."""
+    from vqvae_amd import _lib
+    assert _lib.vq_kernel_name(K, 64, 0x0) == "vq_track_kernel_d64"
+    assert _lib.vq_launch_form(B * H * W, K, 64, H * W, 0x0)[:2] == (4, 32)
+    g = torch.Generator().manual_seed(1300 + K + B)
+    D = 64
+    cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+    z = torch.randn(B, D, H, W, generator=g) * 0.066
+    ref_idx, ref_zq = _oracle_vq_chunked(z, cb, 0.25, n_chunks=min(B, 8))
+    loss, zq, ppl, idx, hist = _run(z, cb, 0.25, False)
+    np.testing.assert_array_equal(idx, ref_idx)
+    assert np.array_equal(zq.view(np.uint32), ref_zq.view(np.uint32))
+    np.testing.assert_array_equal(hist, np.bincount(ref_idx.reshape(-1), minlength=K))
+
+
 def test_vq_stream_kernel_is_the_default_for_large_codebooks():
     from vqvae_amd import _lib
     assert _lib.vq_kernel_name(512, 64) == "vq_track_kernel_d64"

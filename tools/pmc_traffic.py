@@ -97,7 +97,7 @@ def main():
     import bench
     res["source_sha"] = bench.source_sha()
     try:
-        res["git_head"] = subprocess.check_output(["git", "-C", bench.ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        res["git_head"] = subprocess.check_output(["git", "-C", bench.ROOT, "rev-parse", "--short=12", "HEAD"], text=True, stderr=subprocess.DEVNULL).strip()
     except Exception:
         res["git_head"] = None
     rsrc = resources(sys.argv[3])

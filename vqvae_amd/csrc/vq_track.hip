@@ -90,7 +90,10 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
     const int tid = threadIdx.x;
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int TILEB = NCHW ? 8192 : 4096 * T, TABB = 1552;      // (NCHW: a 32 x 64 fp32 block is turned around in the tile, one row tile at a time)
+    // NCHW: a 32 x 64 fp32 block is turned around in the tile, one row tile at a time -- in the four-wave form (codebooks whose 128 KiB image
+    // leaves 4 KiB per wave: K up to 1024, round 5) in two halves of 32 channels through a 32 x 32 tile
+    constexpr bool HALF = NCHW && NW == 4;
+    constexpr int TILEB = NCHW ? (HALF ? 4096 : 8192) : 4096 * T, TABB = 1552;
     unsigned char *tile_s = wave_base + (size_t)wave_u * (TILEB + TABB);                // the unit's fp16 rows; later 16 fp32 row slots
     unsigned char *tab_s = tile_s + TILEB;
 #ifdef VQ_TRACE
@@ -210,11 +213,34 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         int lane_c = lane_id();                                 // (not tid & 63: threadIdx would stay live through the unit loop and spill)
         asm volatile("" : "+v"(lane_c));
         const int l31 = lane_c & 31, h = lane_c >> 5, j16 = lane_c & 15, g4 = lane_c >> 4;
+        f32x4 Fh[8];                                   // (HALF only: the turned block is collected here -- F is still being read)
+        (void)Fh;
         if constexpr (NCHW) {
             // (32 positions x 64 channels) fp32 through the tile, one row tile at a time: in as [channel][4 positions] per lane,
             // out as F[t][i] = floats 4 j16 .. +3 of row 32 t + 4 i + g4 -- the row-major layout everything below works on
             float *tf = reinterpret_cast<float *>(tile_s);
             const int cl = lane_c >> 3, j8 = lane_c & 7;
+            if constexpr (HALF) {
+                // channels 32 hh .. 32 hh + 31 at a time: rows of 32 floats, the 16-byte chunk c of row r at slot c ^ (r >> 2) (conflict-free
+                // both ways as in the 64-channel tile); the lanes whose output chunk j16 lies in the half read, the others keep their registers
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    lds_order_wave();
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            tf[(4 * j8 + e) * 32 + ((((2 * i + (cl >> 2)) ^ j8) & 7) << 2) + (cl & 3)] = F[0][4 * hh + i][e];
+                    lds_order_wave();
+                    if ((j16 >> 3) == hh) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i)
+                            Fh[i] = *reinterpret_cast<const f32x4 *>(tf + (4 * i + g4) * 32 + ((((j16 & 7) ^ i) & 7) << 2));
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) F[0][i] = Fh[i];
+            } else
 #pragma unroll
             for (int t = 0; t < T; ++t) {
                 lds_order_wave();
@@ -517,7 +543,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
         {
             float sacc;
             if constexpr (NCHW)
-                sacc = vqu::epilogue_sp<true, T>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
+                sacc = vqu::epilogue_sp<true, T, HALF>(R, lane, cb, K, [&](int t, int i) { return F[t][i]; },
                                            zq ? const_cast<float *>(unit_base(p, zq)) : nullptr, nleft, idx + r0, hist_s,
                                            reinterpret_cast<float *>(tile_s), HW, (unsigned)(((long long)D * HW - (p * RU) % HW) * 4));
             else
@@ -591,7 +617,8 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
 
 size_t vq_track_lds_bytes(int K, int nw = 8, int T = 2, bool nchw = false) {      // nw waves per CU, T 32-row tiles per unit (4 KiB of fp16 rows each; NCHW: 8 KiB)
     const int K32 = (K + 31) / 32 * 32;
-    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 + (size_t)nw * ((nchw ? 8192 : 4096 * T) + 1552);
+    return (size_t)K32 * 128 + (size_t)K32 * 4 + (size_t)((K + 3) / 4 * 4) * 4 + (size_t)nw * 8 + 16 +
+           (size_t)nw * ((nchw ? (nw == 4 ? 4096 : 8192) : 4096 * T) + 1552);
 }
 
 // K <= ~600: the image fits beside eight waves' 64-row tiles (every launch form below).  Up to K = 1024 (BASELINE config 4's codebook:
@@ -601,7 +628,10 @@ static bool vq_track_fits8(int K) { return vq_track_lds_bytes(K, 8, 2) <= (size_
 bool vq_track_ok(int K, int D) { return D == 64 && K <= 1024 && vq_track_lds_bytes(K, 4, 1) <= (size_t)kLdsBytes; }
 // NCHW maps: a unit is 64 consecutive positions of ONE image, or 32 (maps whose pixel count is a multiple of 32 only, and few rows)
 bool vq_track_nchw_ok(int K, int D, int HW) {
-    return D == 64 && K <= 1024 && vq_track_fits8(K) && HW >= 32 && HW % 32 == 0 && (long long)HW * 256 < 0x7FFFFFF0ll;
+    // (round 5: codebooks whose image does not fit beside eight waves' tiles -- K up to 1024, BASELINE config 4 -- take the four-wave form
+    // with the block turned around in halves)
+    return D == 64 && K <= 1024 && (vq_track_fits8(K) || vq_track_lds_bytes(K, 4, 1, true) <= (size_t)kLdsBytes) && HW >= 32 && HW % 32 == 0 &&
+           (long long)HW * 256 < 0x7FFFFFF0ll;
 }
 
 // The launch form of vq_track_kernel_d64<NW, NCHW, T> for a problem (also behind vqvae_vq_launch_form, include/vqvae_hip.h).
@@ -660,7 +690,8 @@ int launch_vq_track_d64(const float *z, const float *cb, long long N, int K, flo
                                p.K32, nunits, zq, idx, hist, partials, HW, pool_pct);
     };
     const bool k512 = p.K32 == 512;                          // sixteen code tiles: the instances with the unrolled sweep
-    if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
+    if (narrow && nchw) launch(vq_track_kernel_d64<4, true, 1>);
+    else if (narrow) launch(vq_track_kernel_d64<4, false, 1>);
     else if (NW == 12) launch(vq_track_kernel_d64<12, false, 1>);
     else if (nchw && spread && k512) launch(vq_track_kernel_d64<8, true, 1, 16>);
     else if (nchw && spread) launch(vq_track_kernel_d64<8, true, 1>);

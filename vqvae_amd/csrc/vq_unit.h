@@ -325,7 +325,8 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
 }
 
 // epilogue() with the rows' indices on their speaker lanes: frow / zq_unit / nleft / idx_unit / hist_s / NCHW arguments as there
-template <bool NCHW = false, int T = 2, class FRow>
+// HALF (NCHW, four-wave form): `tile_f` holds 32 x 32 floats only -- z_q leaves in two halves of 32 channels
+template <bool NCHW = false, int T = 2, bool HALF = false, class FRow>
 __device__ __forceinline__ float epilogue_sp(const RowsSp<T> &R, int lane, const float *__restrict__ cb, int K, FRow &&frow,
                                              float *__restrict__ zq_unit, int nleft, long long *__restrict__ idx_unit,
                                              int *__restrict__ hist_s, float *tile_f = nullptr, int HW = 0, unsigned zq_bytes = 0u) {
@@ -355,6 +356,8 @@ __device__ __forceinline__ float epilogue_sp(const RowsSp<T> &R, int lane, const
         asm volatile("" : "+v"(vo[k]));
     }
     float sqv[T][8];
+    f32x4 oh[8];
+    (void)oh;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -366,6 +369,8 @@ __device__ __forceinline__ float epilogue_sp(const RowsSp<T> &R, int lane, const
             sqv[t][i] = ((d0 * d0 + d1 * d1) + d2 * d2) + d3 * d3;
             if constexpr (!NCHW) {
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, o), zq_rs, vo[(t * 8 + i) >> 2] + (unsigned)((t * 8 + i) & 3) * 1024u, 0, VQ_ZQ_STORE_AUX);
+            } else if constexpr (HALF) {
+                oh[i] = o;                                  // (collected: the tile takes them in two halves below)
             } else {
                 if (i == 0) lds_order_wave();
                 *reinterpret_cast<f32x4 *>(tile_f + (4 * i + g4) * 64 + (((j16 ^ i) & 15) << 2)) = o;
@@ -384,6 +389,30 @@ __device__ __forceinline__ float epilogue_sp(const RowsSp<T> &R, int lane, const
                 }
             }
         }
+    if constexpr (NCHW && HALF) {
+        // rows in (the lanes whose 16-byte chunk j16 lies in the half), [channel][four positions] out: 32-float rows, chunk c of row r
+        // at slot c ^ (r >> 2) as in the kernel's convert()
+        static_assert(T == 1, "the half-tile form has one row tile per unit");
+        const int cl = lane >> 3, j8 = lane & 7;
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            lds_order_wave();
+            if ((j16 >> 3) == hh) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4 *>(tile_f + (4 * i + g4) * 32 + ((((j16 & 7) ^ i) & 7) << 2)) = oh[i];
+            }
+            lds_order_wave();
+            unsigned so = (unsigned)((32 * hh + cl) * HW + 4 * j8) * 4u;
+#pragma unroll
+            for (int c8 = 0; c8 < 4; ++c8) {
+                f32x4 wv;
+#pragma unroll
+                for (int e2 = 0; e2 < 4; ++e2) wv[e2] = tile_f[(4 * j8 + e2) * 32 + ((((2 * c8 + (cl >> 2)) ^ j8) & 7) << 2) + (cl & 3)];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4v, wv), zq_rs, so, 0, VQ_ZQ_STORE_AUX);
+                so += (unsigned)(8 * HW) * 4u;
+            }
+        }
+    }
     // fp32 over the unit's 16 groups in the order of epilogue() (one fp64 add per unit in the caller); only a ragged last unit masks
     float sacc = 0.0f;
     if (nleft == RU) {
