@@ -211,15 +211,10 @@ def calibrate(torch, dev, seconds=0.6):
 
 def source_sha():
     """Fingerprint of the kernel sources the running library was built from (vqvae_amd/csrc/*): ties a committed
-    profile to the build it was taken on."""
-    import glob
-    import hashlib
-    h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "vqvae_amd", "csrc", "*"))):
-        if os.path.isfile(f):
-            h.update(os.path.basename(f).encode())
-            h.update(open(f, "rb").read())
-    return h.hexdigest()[:16]
+    profile to the build it was taken on (vqvae_amd.build.source_fingerprint; `_lib.load()` refuses or rebuilds a library whose
+    own fingerprint differs from it)."""
+    from vqvae_amd import build as _build
+    return _build.source_fingerprint()
 
 
 def vq_instance_traffic(pmc, instance: str, rows: int):

@@ -56,6 +56,10 @@ typedef void *vqvae_stream_t;      /* hipStream_t */
 #endif
 
 VQVAE_API int vqvae_abi_version(void);
+/* sha256 (16 hex digits) over the names and bytes of the kernel sources (vqvae_amd/csrc) this library was built from; the same string
+ * follows the marker "VQVAE_SRC_FP=" inside the library FILE, so a loader can tell a stale build without loading it (vqvae_amd/_lib.py
+ * rebuilds or refuses; bench.py stamps its profiles with it).  Round 5; no ABI change for existing callers.                          */
+VQVAE_API const char *vqvae_source_fingerprint(void);
 VQVAE_API const char *vqvae_strerror(int code);
 
 /* ---------------------------------------------------------------- profiling

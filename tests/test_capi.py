@@ -197,3 +197,19 @@ def test_modules_pickle_and_deepcopy_like_the_reference(tmp_path):
         st = a.encoder.conv_stack[5].stack
         assert st[0].res_block[1].weight is st[1].res_block[1].weight
     assert not any(k.startswith("_c_") or "vqvae_amd" in k for k in m.__dict__)
+
+
+def test_library_carries_the_fingerprint_of_its_sources_and_a_stale_one_is_refused(monkeypatch):
+    """Round 5: a library left over from OTHER sources (an experiment reverted without a rebuild) must never be the thing tests and
+    bench measure.  The build links the sources' fingerprint in; `_lib.load()` reads it from the file and rebuilds -- or, without
+    hipcc, refuses."""
+    from vqvae_amd import _lib, build
+    want = build.source_fingerprint()
+    assert build.library_fingerprint() == want and not build.stale()
+    assert _lib.load().vqvae_source_fingerprint().decode() == want
+    # the same check, failing: other sources, no compiler
+    monkeypatch.setattr(build, "source_fingerprint", lambda: "0" * 16)
+    monkeypatch.setattr(build, "hipcc", lambda: (_ for _ in ()).throw(RuntimeError("no hipcc")))
+    monkeypatch.delenv("VQVAE_HIP_LIB_OVERRIDE", raising=False)
+    with pytest.raises(_lib.VqvaeHipError, match="built from other sources"):
+        _lib._open_checked()

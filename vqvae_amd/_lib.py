@@ -41,6 +41,7 @@ _dimsp, _rawp, _wp = C.POINTER(VqvaeDims), C.POINTER(VqvaeRawWeights), C.POINTER
 # name -> (restype, argtypes); mirrors include/vqvae_hip.h one to one
 SIGNATURES = {
     "vqvae_abi_version": (_i32, []),
+    "vqvae_source_fingerprint": (C.c_char_p, []),
     "vqvae_strerror": (C.c_char_p, [_i32]),
     "vqvae_profile_enable": (_i32, [_i32]),
     "vqvae_profile_collect": (_i32, [_i32, C.POINTER(C.c_double), C.POINTER(_i32)]),
@@ -126,7 +127,7 @@ def load():
         raise VqvaeHipError(
             f"{LIB_PATH} is missing: build it with `python -m vqvae_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU or PyTorch fallback for this path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = _open_checked()
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the ABI drifted
         fn.restype, fn.argtypes = res, args
@@ -134,6 +135,26 @@ def load():
         raise VqvaeHipError("libvqvae_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def _open_checked():
+    """dlopen the in-tree library after making sure it was built from the csrc/ that lies next to it: a library left over from other
+    sources (an experiment reverted without a rebuild, a checkout) is rebuilt where hipcc exists and refused where it does not --
+    never silently measured or tested.  The library carries its sources' fingerprint as a marked string, read from the FILE: the
+    stale one is never loaded.  (VQVAE_HIP_LIB_OVERRIDE names an A/B build on purpose: not checked.)"""
+    if not os.environ.get("VQVAE_HIP_LIB_OVERRIDE"):
+        from . import build as _build
+        want, have = _build.source_fingerprint(), _build.library_fingerprint(LIB_PATH)
+        if have != want:
+            try:
+                _build.hipcc()
+            except RuntimeError:
+                raise VqvaeHipError(f"{LIB_PATH} was built from other sources (fingerprint {have}, csrc/ is {want}) and hipcc is "
+                                    "not here to rebuild it: run `python -m vqvae_amd.build -f` where it is") from None
+            _build.build(force=True)
+            if _build.library_fingerprint(LIB_PATH) != want:
+                raise VqvaeHipError(f"{LIB_PATH}: rebuilt, and its fingerprint still differs from csrc/")
+    return C.CDLL(LIB_PATH)
 
 
 ERR_UNSUPPORTED = -3      # VQVAE_ERR_UNSUPPORTED (include/vqvae_hip.h)

@@ -36,8 +36,31 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+FP_MARKER = "VQVAE_SRC_FP="        # in front of the fingerprint inside the library file: readable without loading the library
+
+
+def library_fingerprint(path: str = LIB):
+    """the fingerprint a built library carries (None: built before round 5's guard, or not ours)"""
+    with open(path, "rb") as f:
+        blob = f.read()
+    i = blob.find(FP_MARKER.encode())
+    return blob[i + len(FP_MARKER):i + len(FP_MARKER) + 16].decode(errors="replace") if i >= 0 else None
+
+
+def source_fingerprint() -> str:
+    """sha256 (16 hex digits) over the names and bytes of vqvae_amd/csrc/*: what the library is built from.  The build links it in
+    (vqvae_source_fingerprint()), `_lib.load()` compares it with the sources it finds, bench.py stamps profiles with it."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(CSRC, "*"))):
+        if os.path.isfile(f):
+            h.update(os.path.basename(f).encode())
+            h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def stale() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or library_fingerprint() != source_fingerprint():
         return True
     t = os.path.getmtime(LIB)
     deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
@@ -62,7 +85,14 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+    # the fingerprint of the sources, as a function of the library (a generated one-line translation unit: no object above depends on it)
+    fp_src = os.path.join(objdir, "source_fingerprint.cpp")
+    with open(fp_src, "w") as f:
+        f.write('extern "C" __attribute__((visibility("default"))) const char *vqvae_source_fingerprint(void) '
+                f'{{ return "{FP_MARKER}{source_fingerprint()}" + {len(FP_MARKER)}; }}\n')
+    fp_obj = os.path.join(objdir, "source_fingerprint.o")
+    subprocess.check_call([hipcc(), "-O1", "-fPIC", "-x", "c++", "-c", fp_src, "-o", fp_obj])
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, fp_obj]
     subprocess.check_call(cmd)
     return LIB
 
