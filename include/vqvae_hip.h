@@ -153,7 +153,11 @@ VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);
  * Bit-exactness contract (tests/test_vq_gpu.py): idx and z_q are bit-identical
  * to the reference's for identical z_e bits, including first-index tie-breaking
  * and NaN-counts-as-minimum; loss / perplexity agree to rtol 1e-6.
- * Supported: D in {32, 64, 128, 256}, 1 <= K <= 16384.
+ * Supported: 1 <= K <= 16384; D in {32, 64, 128, 256} on the matrix cores (the kernels named by vqvae_vq_kernel_name), any other
+ * 1 <= D <= 256 on an exact-fp32 vector kernel with the same contract (vq_generic_kernel, round 5: main.py:21 leaves
+ * --embedding_dim free and the reference "just runs"; correct, not fast -- the kernel-selection flags select nothing there).
+ * D > 256 stays VQVAE_ERR_UNSUPPORTED: from D = 384 on the reference's own z @ E^T is no longer one k-ordered fmaf chain (its sgemm
+ * blocks the reduction), so there are no pinned bits to be exact against.
  */
 VQVAE_API int vqvae_vq_forward_f32(const float *z_e, const float *codebook,
                          int64_t B, int D, int H, int W, int K, float beta, int flags,
@@ -163,6 +167,12 @@ VQVAE_API int vqvae_vq_forward_f32(const float *z_e, const float *codebook,
 
 /* min_encodings, the (N,K) fp32 one-hot (models/quantizer.py:55-57).  Optional:
  * VQVAE.forward discards it (models/vqvae.py:34); N*K must fit in int64.       */
+/* Test hook (round 5): out[r] = torch.sum(x[r] ** 2) of `rows` row-major rows of any width D <= 1024, in the order ATen's CPU kernel
+ * uses (models/quantizer.py:49-50 delegates it; the tests' CPU oracle restates it) -- mode 0: one thread per row (the codebook term of
+ * vq_generic_kernel), mode 1: the workgroup-cooperative form (its row term).  tests/test_vq_generic_gpu.py compares both with
+ * torch.sum bit for bit.                                                                                                               */
+VQVAE_API int vqvae_debug_row_sqnorm_f32(const float *x, int64_t rows, int D, int mode, float *out, vqvae_stream_t stream);
+
 VQVAE_API int vqvae_vq_onehot_f32(const int64_t *idx, int64_t N, int K, float *onehot,
                         vqvae_stream_t stream);
 

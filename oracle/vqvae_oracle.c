@@ -85,6 +85,18 @@ static void vqo_multi_row_sum8x4(const float *x, int64_t size_ilp, float acc_out
 
 VQO_API float vqo_aten_row_sum(const float *x, int64_t n)
 {
+    if (n < 8) {
+        /* shorter than one vector: cascade_sum takes scalar_inner_sum -> row_sum<float> (aten/native/cpu/SumKernel.cpp): four
+         * partial sums over elements 4 i + k, leftovers into slot 0, then slots 1..3 into slot 0.  n = 5: ((x0 + x4) + x1 + x2) + x3,
+         * NOT the sequential sum (round 5: the widths below 8 were never pinned before; tests/test_oracle.py d = 1 .. 7). */
+        float p[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int64_t si = n / 4;
+        for (int64_t i = 0; i < si; ++i)
+            for (int k = 0; k < 4; ++k) p[k] += x[i * 4 + k];
+        for (int64_t i = si * 4; i < n; ++i) p[0] += x[i];
+        for (int k = 1; k < 4; ++k) p[0] += p[k];
+        return p[0];
+    }
     const int64_t vec_size = n / 8;          /* number of whole 8-float vectors */
     const int64_t size_ilp = vec_size / 4;
     float part[4][8];

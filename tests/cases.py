@@ -29,6 +29,15 @@ VQ_CASES = {
     "ties":             (96, 64, 2, 8, 8, 0.25, "ties"),
     # NaN / Inf rows: torch.argmin treats NaN as minimal (first NaN wins)
     "nonfinite":        (64, 64, 1, 8, 8, 0.25, "nonfinite"),
+    # round 5: embedding widths outside {32, 64, 128, 256} (main.py:21 leaves --embedding_dim free): the exact-fp32 vector kernel.
+    # 48 = the width VERDICT r4 names; 7 = no 16-byte pieces and ATen's scalar row sum; 200 = ragged vector tail; ties / non-finite rows
+    # (D <= 256: beyond 383 the reference's own matmul stops being one fmaf chain -- MKL blocks the reduction)
+    "k96_d48_ragged":   (96, 48, 3, 5, 7, 0.25, "normal"),
+    "k300_d48_init":    (300, 48, 2, 8, 8, 0.25, "init"),
+    "k50_d7":           (50, 7, 2, 3, 5, 0.5, "normal"),
+    "k40_d200":         (40, 200, 1, 4, 4, 0.25, "normal"),
+    "ties_d48":         (96, 48, 2, 8, 8, 0.25, "ties"),
+    "nonfinite_d72":    (64, 72, 1, 8, 8, 0.25, "nonfinite"),
 }
 
 
@@ -80,6 +89,8 @@ MODEL_CASES = {
     "kat1":      (128, 32, 2, 512, 64, 0.25, 32, 32, 32),
     # small, non-square, 3 residual layers, K not a power of two
     "small":     (64, 16, 3, 96, 32, 0.25, 3, 16, 24),
+    # round 5: --embedding_dim 48 (the quantizer's exact-fp32 vector kernel inside the whole model)
+    "d48":       (128, 32, 2, 512, 48, 0.25, 4, 32, 32),
 }
 
 

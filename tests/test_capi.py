@@ -48,7 +48,8 @@ def test_argument_errors_without_gpu(lib):
     lib.vqvae_vq_workspace_bytes.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int]
     assert lib.vqvae_abi_version() == 9
     assert lib.vqvae_vq_workspace_bytes(2048, 512, 64) > 512 * 64 * 4
-    assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) == 0          # unsupported D
+    assert lib.vqvae_vq_workspace_bytes(2048, 512, 48) > 0           # any width up to 256 (round 5: the exact-fp32 vector kernel)
+    assert lib.vqvae_vq_workspace_bytes(2048, 512, 257) == 0         # unsupported D
     assert b"NULL" in lib.vqvae_strerror(-1)
     f = lib.vqvae_vq_forward_f32
     f.restype = ctypes.c_int
@@ -57,7 +58,7 @@ def test_argument_errors_without_gpu(lib):
     assert f(None, None, 1, 64, 8, 8, 512, 0.25, 0, None, None, None, None, None, None, 0, None) == -1
     one = ctypes.c_void_p(16)
     assert f(one, one, 0, 64, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 1 << 30, None) == -2
-    assert f(one, one, 1, 48, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 1 << 30, None) == -3
+    assert f(one, one, 1, 257, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 1 << 30, None) == -3    # (D <= 256: any width, round 5)
     assert f(one, one, 1, 64, 8, 8, 512, 0.25, 0, one, one, one, one, one, one, 16, None) == -4
 
 

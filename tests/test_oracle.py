@@ -35,7 +35,7 @@ def test_c_oracle_vq_matches_reference_golden(name, golden_vq):
     assert out["hist"].sum() == out["idx"].size
 
 
-@pytest.mark.parametrize("d", [8, 16, 24, 32, 40, 48, 64, 96, 100, 128, 200, 256, 512, 1024, 4096])
+@pytest.mark.parametrize("d", [1, 2, 3, 4, 5, 6, 7, 8, 9, 15, 16, 24, 31, 32, 33, 40, 48, 63, 64, 96, 100, 128, 200, 256, 511, 512, 513, 600, 1000, 1024, 4096])
 def test_row_sqnorm_order_matches_torch(d):
     g = torch.Generator().manual_seed(d)
     for scale in (1.0, 1e-3):
@@ -46,7 +46,7 @@ def test_row_sqnorm_order_matches_torch(d):
             f"sum(x**2) order differs from ATen on this host for D={d}"
 
 
-@pytest.mark.parametrize("K,D", [(512, 64), (1024, 64), (8192, 128), (100, 32), (64, 256)])
+@pytest.mark.parametrize("K,D", [(512, 64), (1024, 64), (8192, 128), (100, 32), (64, 256), (96, 48), (50, 7), (33, 5), (40, 200), (77, 255), (64, 1)])
 def test_distance_matrix_bitwise_vs_torch(K, D):
     """d = sum(z^2) + sum(e^2) - 2 z@E^T element-for-element (models/quantizer.py:49-51)."""
     g = torch.Generator().manual_seed(K + D)

@@ -16,6 +16,8 @@ CASES = [  # B, D, H, W, K
     (3, 32, 5, 7, 100),
     (2, 128, 4, 4, 1024),
     (16, 64, 8, 8, 37),
+    (5, 48, 6, 6, 96),       # round 5: widths outside {32, 64, 128, 256} (the exact-fp32 vector kernel in front of the same backward)
+    (3, 7, 4, 5, 50),
 ]
 
 
@@ -577,7 +579,8 @@ def test_fused_backward_epilogues_equal_separate_passes_bitwise():
 
 @pytest.mark.parametrize("dims,HW,B", [((64, 16, 1, 64, 32), 16, 6),        # 4x4 latent maps, one residual layer, D = 32
                                        ((32, 32, 3, 100, 64), 24, 3),       # 6x6 maps, three layers, K not a multiple of 32
-                                       ((256, 64, 2, 512, 64), 32, 4)])     # widths outside the fused residual kernel
+                                       ((256, 64, 2, 512, 64), 32, 4),      # widths outside the fused residual kernel
+                                       ((128, 32, 2, 512, 48), 32, 4)])     # --embedding_dim 48 (round 5)
 def test_full_model_backward_other_shapes(dims, HW, B):
     """The autograd path away from main.py's defaults: maps that are not 8x8 (generic conv kernels, per-tap weight-gradient kernel,
     data-gradient epilogues where the kernel has them and separate passes where it has not), other widths and codebooks --

@@ -55,6 +55,7 @@ SIGNATURES = {
     "vqvae_vq_forward_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _f32, _i32,
                                     _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "vqvae_vq_onehot_f32": (_i32, [_vp, _i64, _i32, _vp, _vp]),
+    "vqvae_debug_row_sqnorm_f32": (_i32, [_vp, _i64, _i32, _i32, _vp, _vp]),
     "vqvae_vq_decode_indices_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "vqvae_conv_packed_bytes": (_sz, [_i32, _i32, _i32]),
     "vqvae_conv_term_products": (_i32, [_i32] * 6),

@@ -545,8 +545,11 @@ using namespace vqvae;
 
 extern "C" {
 
+static bool vq_mfma_dim(int D) { return D == 32 || D == 64 || D == 128 || D == 256; }
+
 const char *vqvae_vq_kernel_name(int K, int D, int flags) {
-    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256) || (flags & VQVAE_VQ_REMOVED_FLAGS)) return "unsupported";
+    if (K < 1 || K > 16384 || (flags & VQVAE_VQ_REMOVED_FLAGS)) return "unsupported";
+    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? "vq_generic_kernel" : "unsupported";       // any other width: exact fp32 on the vector units (round 5)
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_track_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_track_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
@@ -581,8 +584,9 @@ int vqvae_vq_screen_sweeps(int K, int D, int flags) {
 }
 
 size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D) {
+    if (K < 1 || K > 16384) return 0;
     (void)n_rows;
-    if (K < 1 || K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return 0;
+    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? vq_generic_workspace_bytes(K) : 0;
     return vq_plan(K, D).total;
 }
 
@@ -642,7 +646,8 @@ int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, i
     if (zq_amax_done) *zq_amax_done = false;
     if (!z_e || !codebook || !idx || !hist || !loss || !perplexity) return VQVAE_ERR_NULL;
     if (B < 1 || D < 1 || H < 1 || W < 1 || K < 1) return VQVAE_ERR_SHAPE;
-    if (K > 16384 || !(D == 32 || D == 64 || D == 128 || D == 256)) return VQVAE_ERR_UNSUPPORTED;
+    const bool generic = !(D == 32 || D == 64 || D == 128 || D == 256);
+    if (K > 16384 || (generic && !vq_generic_ok(K, D))) return VQVAE_ERR_UNSUPPORTED;
     if ((int64_t)H * W > (int64_t)1 << 30) return VQVAE_ERR_OVERFLOW;
     const int64_t N = B * (int64_t)H * W;
     if (N / ((int64_t)H * W) != B || N > ((int64_t)1 << 40)) return VQVAE_ERR_OVERFLOW;
@@ -653,6 +658,11 @@ int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, i
     char *ws = static_cast<char *>(workspace);
     const int HW = H * W;
     long long *idx_ll = reinterpret_cast<long long *>(idx);
+    // any other embedding width (main.py:21 leaves it free): exact fp32 on the vector units, the same bits (vq_generic.hip); the
+    // kernel-selection flags have nothing to select there
+    if (generic)
+        return launch_vq_generic(z_e, codebook, N, HW, K, D, beta, (flags & VQVAE_VQ_ROWMAJOR) != 0, z_q, idx_ll, hist, loss, perplexity, ws, st,
+                                 hist_zeroed);
     switch (D) {
         case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
         case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);

@@ -38,7 +38,7 @@ def vq_workspace(K: int, D: int, device) -> torch.Tensor:
     n = _lib.load().vqvae_vq_workspace_bytes(0, K, D)
     if n == 0:
         raise _lib.VqvaeHipError(f"VectorQuantizer shape K={K}, D={D} not supported by the gfx950 kernels "
-                                 "(D in {32,64,128,256}, K <= 16384)")
+                                 "(D <= 256, K <= 16384)")
     return torch.empty(n, dtype=torch.uint8, device=device)
 
 
