@@ -152,7 +152,15 @@ def _open_checked():
             except RuntimeError:
                 raise VqvaeHipError(f"{LIB_PATH} was built from other sources (fingerprint {have}, csrc/ is {want}) and hipcc is "
                                     "not here to rebuild it: run `python -m vqvae_amd.build -f` where it is") from None
-            _build.build(force=True)
+            # (several ranks of one node may get here at once: one of them builds, the others find the fresh library under the lock)
+            import fcntl
+            with open(LIB_PATH + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if _build.library_fingerprint(LIB_PATH) != want:
+                        _build.build(force=True)
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
             if _build.library_fingerprint(LIB_PATH) != want:
                 raise VqvaeHipError(f"{LIB_PATH}: rebuilt, and its fingerprint still differs from csrc/")
     return C.CDLL(LIB_PATH)

@@ -89,7 +89,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     fp_src = os.path.join(objdir, "source_fingerprint.cpp")
     with open(fp_src, "w") as f:
         f.write('extern "C" __attribute__((visibility("default"))) const char *vqvae_source_fingerprint(void) '
-                f'{{ return "{FP_MARKER}{source_fingerprint()}" + {len(FP_MARKER)}; }}\n')
+                f'{{ static const char s[] = "{FP_MARKER}{source_fingerprint()}"; return &s[{len(FP_MARKER)}]; }}\n')
     fp_obj = os.path.join(objdir, "source_fingerprint.o")
     subprocess.check_call([hipcc(), "-O1", "-fPIC", "-x", "c++", "-c", fp_src, "-o", fp_obj])
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, fp_obj]
