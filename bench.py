@@ -536,6 +536,9 @@ HPARAM_LEGS = {
               "main.py --n_embeddings 1024, 32x32x3, D=64: the four fused conv kernels, quantizer inside the encoder's last kernel "
               "(128 KiB codebook image streamed through the weight stages in eight parts; before the second session of round 4 "
               "z_e was written and the streamed-codebook kernels quantized it)"),
+    "d48": (128, 32, 2, 512, 48, 4096,
+            "main.py --embedding_dim 48, 32x32x3, K=512 (round 5: any embedding width up to 256): conv kernels outside the 64-channel fused "
+            "forms, the quantizer on the exact-fp32 vector kernel vq_generic_kernel (correct, not fast)"),
 }
 
 
