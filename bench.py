@@ -935,18 +935,21 @@ def main():
                 line["cpu_baseline"] = cpu_baseline(args.cpu_seconds, torch)
             if n_gpus == 1 and args.workload == "c3" and not args.no_other_workloads and not args.batch:
                 del out
-                line["other_workloads"] = {w: other_workload(w, torch, dev) for w in ("c2", "c4", "c5")}
-                # the headline's step in the two exacter product schemes, same box and batch (the headline itself = "fp16x2")
-                line["other_workloads"]["c3_bf16x3"] = scheme_leg("bf16x3", torch, dev)
-                line["other_workloads"]["c3_fp32"] = scheme_leg("fp32", torch, dev)
-                for name in HPARAM_LEGS:
-                    line["other_workloads"][name] = hparam_leg(name, torch, dev, seconds=0.6)
-                for name, fn in (("wire_format", lambda: wire_legs(torch, dev, elapsed / args.steps * 1e3)),
-                                 ("vq_sizes", lambda: vq_size_sweep(torch, dev))):
-                    try:                               # next-row / reporting figures: never take the headline line down
+                # side figures of the line -- the other BASELINE configs, the headline's step in the two exacter product schemes (the
+                # headline itself = "fp16x2"), main.py's other hyper-parameters, the wire format, the quantizer's size sweep: none of
+                # them may take the headline line down with it (an error is reported in its place, not swallowed)
+                legs = [(w, (lambda w=w: other_workload(w, torch, dev))) for w in ("c2", "c4", "c5")]
+                legs += [("c3_bf16x3", lambda: scheme_leg("bf16x3", torch, dev)), ("c3_fp32", lambda: scheme_leg("fp32", torch, dev))]
+                legs += [(name, (lambda name=name: hparam_leg(name, torch, dev, seconds=0.6))) for name in HPARAM_LEGS]
+                legs += [("wire_format", lambda: wire_legs(torch, dev, elapsed / args.steps * 1e3)),
+                         ("vq_sizes", lambda: vq_size_sweep(torch, dev))]
+                line["other_workloads"] = {}
+                for name, fn in legs:
+                    try:
                         line["other_workloads"][name] = fn()
                     except Exception as e:             # noqa: BLE001
                         line["other_workloads"][name] = {"error": f"{type(e).__name__}: {e}"[:300]}
+                        torch.cuda.empty_cache()
                 try:                                   # a next-row figure: its failure must not take the headline line with it
                     line["training_step"] = training_step(torch, dev)
                 except Exception as e:                 # noqa: BLE001  (reported in the line, not swallowed)
