@@ -214,3 +214,47 @@ def test_library_carries_the_fingerprint_of_its_sources_and_a_stale_one_is_refus
     monkeypatch.delenv("VQVAE_HIP_LIB_OVERRIDE", raising=False)
     with pytest.raises(_lib.VqvaeHipError, match="built from other sources"):
         _lib._open_checked()
+
+
+def test_fingerprint_ignores_files_that_are_not_sources_and_prebuilt_trees_can_opt_out(monkeypatch, tmp_path):
+    """only csrc/*.hip and *.h make the fingerprint (an editor backup or a patch's .orig file must not make the library
+    'stale'); VQVAE_HIP_TRUST_PREBUILT=1 and a tree without csrc/ skip the comparison; the link goes through a temporary name."""
+    import os
+    from vqvae_amd import _lib, build
+    want = build.source_fingerprint()
+    junk = os.path.join(build.CSRC, "vq_track.hip.orig~")
+    try:
+        with open(junk, "w") as f:
+            f.write("not a source")
+        assert build.source_fingerprint() == want
+    finally:
+        os.remove(junk)
+    # other sources + no compiler, but the deployment says "use it as it is"
+    monkeypatch.setattr(build, "source_fingerprint", lambda: "0" * 16)
+    monkeypatch.setattr(build, "hipcc", lambda: (_ for _ in ()).throw(RuntimeError("no hipcc")))
+    monkeypatch.delenv("VQVAE_HIP_LIB_OVERRIDE", raising=False)
+    monkeypatch.setenv("VQVAE_HIP_TRUST_PREBUILT", "1")
+    assert _lib._open_checked() is not None
+    monkeypatch.delenv("VQVAE_HIP_TRUST_PREBUILT")
+    monkeypatch.setattr(build, "have_sources", lambda: False)            # an installed tree: nothing to compare with
+    assert _lib._open_checked() is not None
+    # build.link never leaves a partial file under the final name
+    import inspect
+    assert "os.replace" in inspect.getsource(build.link)
+
+
+def test_variant_builds_export_every_symbol_load_binds():
+    """tools/build_variant.py / build_src_variant.sh link the generated fingerprint object too, so a library named by
+    VQVAE_HIP_LIB_OVERRIDE passes `_lib.load()`'s symbol loop (the A/B tooling of profiles/ depends on it)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from vqvae_amd import build
+    build.build()
+    out = subprocess.check_output(["bash", os.path.join(root, "tools/build_src_variant.sh"), "capi.hip", "capitest"], cwd=root).decode()
+    lib = os.path.join(root, out.strip().splitlines()[-1])
+    code = ("import os, sys; sys.path.insert(0, %r); from vqvae_amd import _lib; L = _lib.load(); "
+            "assert _lib.LIB_PATH.endswith('libvqvae_capitest.so'); print(L.vqvae_source_fingerprint().decode())" % root)
+    got = subprocess.check_output([sys.executable, "-c", code], env={**os.environ, "VQVAE_HIP_LIB_OVERRIDE": lib}).decode().strip()
+    assert got == build.source_fingerprint()

@@ -10,5 +10,6 @@ FLAGS="-O3 -std=c++17 --offload-arch=gfx950 -fPIC -ffp-contract=off -fno-fast-ma
 [ "$src" = vq_track.hip ] && [ -z "$NO_EXTRA" ] && FLAGS="$FLAGS -fno-slp-vectorize"     # (vqvae_amd/build.py EXTRA_FLAGS; NO_EXTRA=1 builds without)
 hipcc $FLAGS "$@" -c vqvae_amd/csrc/$src -o $out/$name/$src.o
 objs=$(ls vqvae_amd/build/*.hip.o | grep -v "/$src.o")
-hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libvqvae_$name.so $objs $out/$name/$src.o
+# (_lib.load() wants vqvae_source_fingerprint in every library it opens: the generated object of the last full build)
+hipcc --offload-arch=gfx950 -shared -fPIC -o $out/libvqvae_$name.so $objs $out/$name/$src.o vqvae_amd/build/source_fingerprint.o
 echo $out/libvqvae_$name.so

@@ -17,5 +17,5 @@ for src in B.sources():
     procs.append(subprocess.Popen([B.hipcc(), *B.flags_for(src), *defs, "-c", src, "-o", obj]))
 assert all(p.wait() == 0 for p in procs)
 lib = os.path.join(out, f"libvqvae_{name}.so")
-subprocess.check_call([B.hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib, *objs])
+B.link([*objs, B.fingerprint_object(os.path.join(out, name))], lib)      # (_lib.load() wants vqvae_source_fingerprint in every library)
 print(lib)

@@ -142,28 +142,41 @@ def _open_checked():
     """dlopen the in-tree library after making sure it was built from the csrc/ that lies next to it: a library left over from other
     sources (an experiment reverted without a rebuild, a checkout) is rebuilt where hipcc exists and refused where it does not --
     never silently measured or tested.  The library carries its sources' fingerprint as a marked string, read from the FILE: the
-    stale one is never loaded.  (VQVAE_HIP_LIB_OVERRIDE names an A/B build on purpose: not checked.)"""
-    if not os.environ.get("VQVAE_HIP_LIB_OVERRIDE"):
-        from . import build as _build
-        want, have = _build.source_fingerprint(), _build.library_fingerprint(LIB_PATH)
+    stale one is never loaded.  Not checked: VQVAE_HIP_LIB_OVERRIDE (names an A/B build on purpose), VQVAE_HIP_TRUST_PREBUILT=1
+    (a deployment that ships the built library and does not want its sources looked at), and a tree without csrc/*.hip at all
+    (an installed package: there is nothing to compare with)."""
+    if (os.environ.get("VQVAE_HIP_LIB_OVERRIDE") or os.environ.get("VQVAE_HIP_TRUST_PREBUILT", "0") not in ("", "0")):
+        return C.CDLL(LIB_PATH)
+    from . import build as _build
+    if not _build.have_sources():
+        return C.CDLL(LIB_PATH)
+    want = _build.source_fingerprint()
+    # Several ranks of one node may get here at once.  The comparison, a rebuild and the dlopen all happen under one lock, and
+    # the build renames the finished file into place (build.link): nobody maps a half-written library.
+    import fcntl
+    try:
+        lock = open(LIB_PATH + ".lock", "w")
+    except OSError:                                   # read-only tree: nobody can be rebuilding it either
+        lock = None
+    try:
+        if lock is not None:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+        have = _build.library_fingerprint(LIB_PATH)
         if have != want:
             try:
                 _build.hipcc()
             except RuntimeError:
                 raise VqvaeHipError(f"{LIB_PATH} was built from other sources (fingerprint {have}, csrc/ is {want}) and hipcc is "
-                                    "not here to rebuild it: run `python -m vqvae_amd.build -f` where it is") from None
-            # (several ranks of one node may get here at once: one of them builds, the others find the fresh library under the lock)
-            import fcntl
-            with open(LIB_PATH + ".lock", "w") as lock:
-                fcntl.flock(lock, fcntl.LOCK_EX)
-                try:
-                    if _build.library_fingerprint(LIB_PATH) != want:
-                        _build.build(force=True)
-                finally:
-                    fcntl.flock(lock, fcntl.LOCK_UN)
+                                    "not here to rebuild it: run `python -m vqvae_amd.build -f` where it is, or set "
+                                    "VQVAE_HIP_TRUST_PREBUILT=1 to use the library as it is") from None
+            _build.build(force=True)
             if _build.library_fingerprint(LIB_PATH) != want:
                 raise VqvaeHipError(f"{LIB_PATH}: rebuilt, and its fingerprint still differs from csrc/")
-    return C.CDLL(LIB_PATH)
+        return C.CDLL(LIB_PATH)
+    finally:
+        if lock is not None:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+            lock.close()
 
 
 ERR_UNSUPPORTED = -3      # VQVAE_ERR_UNSUPPORTED (include/vqvae_hip.h)

@@ -47,16 +47,48 @@ def library_fingerprint(path: str = LIB):
     return blob[i + len(FP_MARKER):i + len(FP_MARKER) + 16].decode(errors="replace") if i >= 0 else None
 
 
+def have_sources() -> bool:
+    """is this a source tree (csrc/ with the kernels) or an installed one that only carries the built library?"""
+    return bool(sources())
+
+
 def source_fingerprint() -> str:
-    """sha256 (16 hex digits) over the names and bytes of vqvae_amd/csrc/*: what the library is built from.  The build links it in
+    """sha256 (16 hex digits) over the names and bytes of vqvae_amd/csrc/*.hip and *.h -- what the library is built from, and
+    nothing else that may lie there (editor backups, .orig files of a patch).  The build links it in
     (vqvae_source_fingerprint()), `_lib.load()` compares it with the sources it finds, bench.py stamps profiles with it."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(CSRC, "*"))):
+    for f in sorted(glob.glob(os.path.join(CSRC, "*.hip")) + glob.glob(os.path.join(CSRC, "*.h"))):
         if os.path.isfile(f):
             h.update(os.path.basename(f).encode())
             h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
+
+
+def fingerprint_object(objdir: str) -> str:
+    """compile the one-line translation unit that makes the sources' fingerprint a function of the library
+    (vqvae_source_fingerprint(); every library `_lib.load()` opens must export it -- the A/B variants of tools/ too) -> object path"""
+    os.makedirs(objdir, exist_ok=True)
+    fp_src = os.path.join(objdir, "source_fingerprint.cpp")
+    with open(fp_src, "w") as f:
+        f.write('extern "C" __attribute__((visibility("default"))) const char *vqvae_source_fingerprint(void) '
+                f'{{ static const char s[] = "{FP_MARKER}{source_fingerprint()}"; return &s[{len(FP_MARKER)}]; }}\n')
+    fp_obj = os.path.join(objdir, "source_fingerprint.o")
+    subprocess.check_call([hipcc(), "-O1", "-fPIC", "-x", "c++", "-c", fp_src, "-o", fp_obj])
+    return fp_obj
+
+
+def link(objs, out: str) -> str:
+    """link to a temporary name and rename into place: a process that opens `out` meanwhile (another rank of the same node) sees
+    the old library or the new one, never a half-written file"""
+    tmp = f"{out}.tmp.{os.getpid()}"
+    try:
+        subprocess.check_call([hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", tmp, *objs])
+        os.replace(tmp, out)
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
+    return out
 
 
 def stale() -> bool:
@@ -85,15 +117,8 @@ def build(force: bool = False, verbose: bool = False) -> str:
     for src, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {src}")
-    # the fingerprint of the sources, as a function of the library (a generated one-line translation unit: no object above depends on it)
-    fp_src = os.path.join(objdir, "source_fingerprint.cpp")
-    with open(fp_src, "w") as f:
-        f.write('extern "C" __attribute__((visibility("default"))) const char *vqvae_source_fingerprint(void) '
-                f'{{ static const char s[] = "{FP_MARKER}{source_fingerprint()}"; return &s[{len(FP_MARKER)}]; }}\n')
-    fp_obj = os.path.join(objdir, "source_fingerprint.o")
-    subprocess.check_call([hipcc(), "-O1", "-fPIC", "-x", "c++", "-c", fp_src, "-o", fp_obj])
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, fp_obj]
-    subprocess.check_call(cmd)
+    # the fingerprint of the sources, as a function of the library (a generated translation unit: no object above depends on it)
+    link([*objs, fingerprint_object(objdir)], LIB)
     return LIB
 
 
