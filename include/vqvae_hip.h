@@ -518,8 +518,9 @@ VQVAE_API int vqvae_forward_f32(const VqvaeWeights *w, const float *x, int64_t B
  * 12 KiB in, 0.5 KiB out), and the decoder's first kernel takes each latent pixel's row straight from the codebook (0.5 KiB in, 12 KiB
  * out).  Other shapes run encoder -> stand-alone quantizer / row gather -> decoder through the workspace.  Indices equal
  * vqvae_forward_f32's bit for bit; x_hat equals the decoder's on the same z_q bit for bit.  An index outside [0, K) never reads the
- * codebook: that latent pixel enters the first conv as NaN (the fused ReLUs flush NaN to 0, so its image's x_hat is unspecified; no
- * other image is affected) -- validate foreign indices on the host, as the Python layer does.  workspace: vqvae_workspace_bytes(dims, B, H, W) (decode: H = 4h, W = 4w); vq_workspace /
+ * codebook: that latent pixel enters the first conv as NaN on EVERY path (fused gather and workspace gather alike) and -- the fused
+ * ReLUs keep a NaN as nn.ReLU does -- shows as NaN pixels of its image's x_hat; no other image is affected.  The Python layer
+ * validates foreign indices on the host and raises, as the reference's scatter does.  workspace: vqvae_workspace_bytes(dims, B, H, W) (decode: H = 4h, W = 4w); vq_workspace /
  * vq_flags as for vqvae_forward_f32; decode's flags: VQVAE_FWD_CONV_BF16_SPLIT / _EXACT_FP32 or 0.                                   */
 VQVAE_API int vqvae_encode_f32(const VqvaeWeights *w, const float *x, int64_t B, int H, int W, int vq_flags, int64_t *idx,
                                void *workspace, size_t workspace_bytes, void *vq_workspace, size_t vq_workspace_bytes,

@@ -4,7 +4,7 @@
 
 The reference publishes no golden vectors for this path, so
 the reference itself, run here on seeded inputs (tests/cases.py), is the anchor:
-    python oracle/gen_golden.py            # writes tests/golden/{vq_cases,model_cases}.npz
+    python oracle/gen_golden.py [vq] [models] [trained]   # writes tests/golden/{vq_cases,model_cases,trained_cases}.npz
 The reference tree cannot travel to the GPU box; these fixtures do.
 """
 from __future__ import annotations
@@ -80,7 +80,41 @@ def gen_models():
     np.savez_compressed(os.path.join(ROOT, "tests/golden/model_cases.npz"), **out)
 
 
+def gen_trained():
+    """Round 6: REALLY TRAINED checkpoints (tools/train_checkpoint.py: main.py:67-98's loop on the HIP training path, run on the
+    GPU box; the 23 state_dict tensors are committed as tests/golden/<name>_state.npz) loaded into the UNMODIFIED reference model
+    and run on seeded structured validation images (tests/synthdata.py).  -> tests/golden/trained_cases.npz"""
+    from tests import synthdata
+    out = {}
+    for name, (h, rh, nl, K, D, beta, B, seed) in cases.TRAINED_CASES.items():
+        sd = cases.trained_state(name)
+        m = VQVAE(h, rh, nl, K, D, beta).eval()
+        missing = m.load_state_dict(sd, strict=True)
+        assert not missing.missing_keys and not missing.unexpected_keys
+        x = synthdata.normalised(B, seed)
+        with torch.no_grad():
+            loss, x_hat, ppl = m(x)
+            z_e = m.pre_quantization_conv(m.encoder(x))
+            _, z_q, _, _, idx = m.vector_quantization(z_e)
+            x_hat2 = m.decoder(z_q)
+        assert torch.equal(x_hat, x_hat2)
+        out[f"{name}/idx"] = idx.numpy().astype(np.int32).reshape(-1)
+        out[f"{name}/loss"] = loss.numpy()
+        out[f"{name}/perplexity"] = ppl.numpy()
+        out[f"{name}/z_e"] = z_e.numpy()
+        out[f"{name}/x_hat"] = x_hat.numpy()
+        out[f"{name}/sha"] = np.array([cases.sha(x), cases.sha(z_e), cases.sha(z_q), cases.sha(x_hat), cases.sha(idx)])
+        print(f"trn {name:22s} loss={loss.item():.9g} ppl={ppl.item():.9g} distinct={idx.unique().numel()} "
+              f"max|z_e|={z_e.abs().max().item():.4g} max|x_hat|={x_hat.abs().max().item():.4g} recon mse={((x_hat - x) ** 2).mean().item():.5f}")
+    np.savez_compressed(os.path.join(ROOT, "tests/golden/trained_cases.npz"), **out)
+
+
 if __name__ == "__main__":
     os.makedirs(os.path.join(ROOT, "tests/golden"), exist_ok=True)
-    gen_vq()
-    gen_models()
+    which = sys.argv[1:] or ["vq", "models", "trained"]
+    if "vq" in which:
+        gen_vq()
+    if "models" in which:
+        gen_models()
+    if "trained" in which:
+        gen_trained()

@@ -99,3 +99,29 @@ def model_inputs(name):
     torch.manual_seed(0), exactly as KAT-1 prescribes.  Call AFTER building the model."""
     h, rh, nl, K, D, beta, B, H, W = MODEL_CASES[name]
     return torch.randn(B, 3, H, W)
+
+
+# Round 6: really trained checkpoints.  name -> (h_dim, res_h_dim, n_res_layers, K, D, beta, B of the golden run, seed of its images).
+# The weights come from tools/train_checkpoint.py (the loop of main.py:67-98 -- Adam amsgrad lr 3e-4, recon / x_train_var +
+# embedding loss -- on the HIP training path, structured synthetic 32x32x3 images of tests/synthdata.py; logs in profiles/r06_train_*):
+#   trained_main_defaults   main.py's own hyperparameters: batch 32, 5 000 updates  (perplexity 2.7 -> 42.5 over the run)
+#   trained_b128x20k        batch 128, 20 000 updates                               (perplexity -> 114.7, 134 codes in use)
+TRAINED_CASES = {
+    "trained_main_defaults": (128, 32, 2, 512, 64, 0.25, 32, 4242),
+    "trained_b128x20k":      (128, 32, 2, 512, 64, 0.25, 32, 4243),
+}
+
+
+def trained_state(name):
+    """-> state_dict (reference layout, the aliased residual keys sharing storage again) of a committed trained checkpoint"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", f"{name}_state.npz"))
+    sd = {k: torch.from_numpy(z[k].copy()) for k in z.files}
+    for pre in ("encoder.conv_stack.5.stack.", "decoder.inverse_conv_stack.1.stack."):
+        l = 1
+        while f"{pre}{l}.res_block.1.weight" in sd:
+            for blk in ("res_block.1.weight", "res_block.3.weight"):
+                assert torch.equal(sd[f"{pre}{l}.{blk}"], sd[f"{pre}0.{blk}"]), "aliased residual weights diverged in the checkpoint"
+                sd[f"{pre}{l}.{blk}"] = sd[f"{pre}0.{blk}"]
+            l += 1
+    return sd

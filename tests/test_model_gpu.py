@@ -161,34 +161,42 @@ def test_encode_and_decode_entry_points_equal_the_forward(B, K, S):
     np.testing.assert_allclose(x_hat.cpu().numpy(), x_hat_f.cpu().numpy(), atol=1e-6, rtol=1e-5)
 
 
-def test_decode_entry_point_out_of_range_index_is_not_a_read():
-    """An index outside [0, K) never reads the codebook: the C entry feeds that latent pixel as NaN and leaves every other image
-    alone (the Python layer raises, as the reference's scatter does)."""
+@pytest.mark.parametrize("K,D,S", [(512, 64, 32), (96, 64, 24), (512, 48, 32), (300, 50, 32)],
+                         ids=["fused_gather", "workspace_gather_24x24", "workspace_gather_d48", "workspace_gather_d50"])
+def test_decode_entry_point_out_of_range_index_is_not_a_read(K, D, S):
+    """An index outside [0, K) never reads the codebook: the C entry feeds that latent pixel as NaN -- on the fused gather AND on
+    the workspace gather of the other shapes (that one used to clamp the index and decode a wrong code silently, and
+    refused D % 4 != 0) -- and leaves every other image alone (the Python layer raises, as the reference's scatter does)."""
     from vqvae_amd import _lib
     from vqvae_amd.modules import VQVAE
     torch.manual_seed(0)
-    m = VQVAE(128, 32, 2, 512, 64, 0.25).eval().to(dev())
+    m = VQVAE(128, 32, 2, K, D, 0.25).eval().to(dev())
     B = 8
-    idx = torch.randint(0, 512, (B * 64,), device=dev())
+    h = S // 4
+    idx = torch.randint(0, K, (B * h * h,), device=dev())
     with pytest.raises(IndexError):
-        m.decode_indices(torch.where(torch.arange(B * 64, device=dev()) == 70, torch.tensor(512, device=dev()), idx), B, 8, 8)
+        m.decode_indices(torch.where(torch.arange(B * h * h, device=dev()) == h * h + 6, torch.tensor(K, device=dev()), idx), B, h, h)
     L = _lib.load()
     with torch.no_grad():
-        good = m.decode_indices(idx, B, 8, 8)
+        good = m.decode_indices(idx, B, h, h)
         bad = idx.clone()
-        bad[70] = 512                                   # image 1
-        bad[5 * 64 + 3] = -1                            # image 5
+        bad[h * h + 6] = K                              # image 1
+        bad[5 * h * h + 3] = -1                         # image 5
         cw, _keep = m._c_weights()
-        ws, stream = m._c_workspace(L, cw, B, 32, 32, dev())
+        ws, stream = m._c_workspace(L, cw, B, S, S, dev())
         out = torch.empty_like(good)
-        _lib.check(L.vqvae_decode_f32(cw, bad.data_ptr(), B, 8, 8, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        _lib.check(L.vqvae_decode_f32(cw, bad.data_ptr(), B, h, h, 0, out.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+        # the decoder on explicitly gathered rows: what decode_indices must equal on the good indices
+        z_q = m.vector_quantization.embedding.weight.detach()[idx].view(B, h, h, D).permute(0, 3, 1, 2).contiguous()
+        x_ref = m.decoder(z_q)
     torch.cuda.synchronize()
-    # the bad images' x_hat is unspecified (their NaN pixels meet the decoder's fused ReLUs, which flush NaN to 0 like v_max_f32);
-    # what the entry guarantees: no read outside the codebook, and no other image is touched
+    assert torch.equal(good, x_ref)
+    # what the entry guarantees: no read outside the codebook, no other image is touched -- and (round 6: the fused ReLUs keep a NaN,
+    # as nn.ReLU does) the bad latent pixel shows as NaN in its image's x_hat instead of as a silently wrong code
     for b in range(B):
         if b not in (1, 5):
             assert torch.equal(out[b], good[b])
-    assert not torch.equal(out[1], good[1]) and not torch.equal(out[5], good[5])
+    assert torch.isnan(out[1]).any() and torch.isnan(out[5]).any()
 
 
 def test_fused_quantizer_against_the_oracle_on_its_own_z_e_bits():
@@ -226,8 +234,8 @@ def test_fused_quantizer_against_the_oracle_on_its_own_z_e_bits():
     got = out[3].view(-1).cpu().numpy()
     cbn = m.vector_quantization.embedding.weight.detach().cpu().numpy()
     want = c_oracle.vq_forward(z_e.reshape(-1, 64, 1, 1), cbn, 0.25)["idx"].reshape(-1)      # (rows as 1x1 maps)
-    # (image 5's rows overflow fp16 -- the screen's operands are Inf there: the scalar torch.argmin path; image 9's NaN pixel is
-    # flushed by the encoder's fused ReLUs, v_max_f32(NaN, 0) = 0, so its rows are ordinary)
+    # (image 5's rows overflow fp16 -- the screen's operands are Inf there: the scalar torch.argmin path; image 9's NaN pixel travels
+    # through the encoder's fused ReLUs -- round 6: v_maximum3_f32 keeps a NaN as nn.ReLU does -- and makes NaN rows)
     assert (np.abs(z_e) > 65504.0).any(axis=1).sum() >= 32
     assert (got == want).all(), f"{int((got != want).sum())} of {got.size} indices differ from the oracle's on the kernel's own z_e"
     # and those bits are the bits of the encoder ENTRY (vqvae_encoder_f32: the same kernel without the quantizer behind the 1x1 conv)
@@ -237,6 +245,50 @@ def test_fused_quantizer_against_the_oracle_on_its_own_z_e_bits():
         z_sep = z_dev.reshape(B * 64, 64).cpu().numpy()
     fin = np.isfinite(z_sep) & np.isfinite(z_e)
     assert (np.isfinite(z_sep) == np.isfinite(z_e)).all() and (z_sep[fin] == z_e[fin]).all()
+
+
+@pytest.mark.parametrize("scheme", ["fp16x2", "bf16x3", "fp32"])
+@pytest.mark.parametrize("B,K,S,nl", [(8, 512, 32, 2), (3, 512, 64, 2), (2, 96, 24, 2), (4, 512, 32, 3)],
+                         ids=["fused_32x32", "halo_64x64", "generic_24x24_k96", "per_layer_3_res"])
+def test_nan_pixel_propagates_as_in_the_reference(B, K, S, nl, scheme):
+    """Round 6 (VERDICT r5 "missing" 3): nn.ReLU keeps a NaN activation (models/residual.py:19,22, encoder.py:31,34,
+    decoder.py:33); the fused ReLUs used to flush it to 0 (v_max_f32).  They are v_maximum3_f32 now (IEEE-754-2019 maximum: a NaN
+    operand makes a NaN).  One NaN pixel per poisoned image through vqvae_forward_f32 against oracle/torch_port.py: the SAME set of
+    NaN outputs (x_hat pixels, z_q rows -> index 0 by torch.argmin's rule, a NaN loss), every other value within the usual tolerance,
+    the clean images untouched."""
+    from oracle import torch_port
+    from vqvae_amd import conv, functional as F
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    flags = {"fp16x2": 0, "bf16x3": F.FWD_CONV_BF16_SPLIT, "fp32": F.FWD_CONV_EXACT_FP32}[scheme]
+    torch.manual_seed(0)
+    m = VQVAE(128, 32, nl, K, 64, 0.25).eval()
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(11))
+    clean = x.clone()
+    x[0, 1, S // 2, S // 2 + 1] = float("nan")               # the middle of image 0
+    if B > 2:
+        x[2, 0, 0, S - 1] = float("nan")                     # a corner of image 2
+    loss_r, xh_r, ppl_r, ze_r, zq_r, idx_r = torch_port.forward(sd, x.clone(), 0.25, nl, full=True)
+    m = m.to(dev())
+    with torch.no_grad():
+        loss, x_hat, ppl, idx = m._forward_c(x.to(dev()), want_idx=True, fwd_flags=flags)
+        _, x_hat_clean, _, idx_clean = m._forward_c(clean.to(dev()), want_idx=True, fwd_flags=flags)
+    torch.cuda.synchronize()
+    xh, xr = x_hat.cpu().numpy(), xh_r.numpy()
+    assert np.isnan(xr).any() and not np.isnan(xr).all()
+    assert np.array_equal(np.isnan(xh), np.isnan(xr)), \
+        f"NaN pattern of x_hat differs from the reference's: {int(np.isnan(xh).sum())} vs {int(np.isnan(xr).sum())} NaN pixels"
+    fin = ~np.isnan(xr)
+    np.testing.assert_allclose(xh[fin], xr[fin], atol=1e-5, rtol=1e-4)
+    got, want = idx.cpu().numpy().reshape(-1), idx_r.numpy().reshape(-1)
+    nan_rows = np.isnan(ze_r.permute(0, 2, 3, 1).reshape(-1, 64).numpy()).any(1)
+    assert nan_rows.any() and (got[nan_rows] == want[nan_rows]).all() and (want[nan_rows] == 0).all()
+    assert (got != want).sum() <= 1                                             # (a near-tie may flip, as everywhere)
+    assert np.isnan(loss.item()) and np.isnan(loss_r.item())
+    np.testing.assert_allclose(ppl.item(), ppl_r.item(), rtol=1e-4)
+    untouched = [b for b in range(B) if b not in (0, 2)]
+    assert torch.equal(x_hat[untouched], x_hat_clean[untouched])
 
 
 def test_forward_only_and_no_cpu_fallback():

@@ -163,3 +163,57 @@ def test_hetero_unit_fixture_is_the_oracle():
     assert np.array_equal(out["idx"].reshape(-1), d["idx"]) and np.array_equal(out["z_q"].view(np.uint32), d["z_q"].view(np.uint32))
     t = torch_port.quantize(torch.from_numpy(z), torch.from_numpy(d["codebook"]), 0.25)
     assert np.array_equal(t[4].numpy().reshape(-1), d["idx"]) and np.array_equal(t[1].numpy().view(np.uint32), d["z_q"].view(np.uint32))
+
+
+# ---- round 6: really trained checkpoints (tests/golden/<name>_state.npz + trained_cases.npz, generated by oracle/gen_golden.py
+# from the UNMODIFIED reference loaded with the checkpoint) ------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def golden_trained():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_cases.npz"))
+
+
+@pytest.mark.parametrize("name", list(cases.TRAINED_CASES))
+def test_oracles_on_a_trained_checkpoint(name, golden_trained):
+    """The C oracle's quantizer on the reference's z_e bits: indices and z_q bit-exact on a checkpoint whose codebook and z_e are
+    what TRAINING made them (max|z_e| ~ 6, 57 / 125 codes in use) -- not the U(+-1/K) init every other golden rests on; torch_port
+    on the same weights and images reproduces the reference's whole forward."""
+    from tests import synthdata
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    sd = cases.trained_state(name)
+    assert len(sd) == 23
+    x = synthdata.normalised(B, seed)
+    sha = golden_trained[f"{name}/sha"]
+    assert cases.sha(x) == sha[0], "synthetic image generator drifted"
+    g_ze = golden_trained[f"{name}/z_e"]
+    out = c_oracle.vq_forward(g_ze, sd["vector_quantization.embedding.weight"].numpy(), beta)
+    np.testing.assert_array_equal(out["idx"].reshape(-1), golden_trained[f"{name}/idx"].astype(np.int64))
+    assert cases.sha(out["z_q"]) == sha[2], "z_q not bit-exact"
+    np.testing.assert_allclose(out["loss"], golden_trained[f"{name}/loss"], rtol=1e-6)
+    np.testing.assert_allclose(out["perplexity"], golden_trained[f"{name}/perplexity"], rtol=1e-6)
+    loss, x_hat, ppl, z_e, z_q, idx = torch_port.forward(sd, x, beta, nl, full=True)
+    np.testing.assert_array_equal(idx.numpy().reshape(-1), golden_trained[f"{name}/idx"])
+    cmax = np.abs(g_ze).max()
+    np.testing.assert_allclose(z_e.numpy(), g_ze, atol=2e-6 * cmax, rtol=0)
+    np.testing.assert_allclose(x_hat.numpy(), golden_trained[f"{name}/x_hat"], atol=1e-5, rtol=1e-4)
+    np.testing.assert_allclose(loss.numpy(), golden_trained[f"{name}/loss"], rtol=1e-6)
+    # the C oracle's own convs (plain k-ordered loops, not oneDNN's order): whole model within the fp32 tolerance
+    ref = c_oracle.Model(sd, beta, nl).forward(x.numpy())
+    np.testing.assert_allclose(ref["z_e"], g_ze, atol=2e-6 * cmax, rtol=0)
+
+
+@pytest.mark.skipif(not have_reference(), reason="needs /root/reference (build container only)")
+@pytest.mark.parametrize("name", list(cases.TRAINED_CASES))
+def test_trained_goldens_reproduce_from_the_unmodified_reference(name, golden_trained):
+    from tests import synthdata
+    sys.path.insert(0, os.environ.get("VQVAE_REFERENCE", "/root/reference"))
+    sys.dont_write_bytecode = True
+    import models.quantizer as ref_q
+    from models.vqvae import VQVAE
+    ref_q.device = torch.device("cpu")
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = VQVAE(h, rh, nl, K, D, beta).eval()
+    m.load_state_dict(cases.trained_state(name), strict=True)
+    with torch.no_grad():
+        loss, x_hat, ppl = m(synthdata.normalised(B, seed))
+    assert cases.sha(x_hat) == golden_trained[f"{name}/sha"][3]
+    assert loss.item() == golden_trained[f"{name}/loss"].item()

@@ -1,0 +1,219 @@
+"""GPU parity tests (-m gpu) on REALLY TRAINED checkpoints (VERDICT r5 "next round" item 1).
+
+Every other weight set in tests/ is the default init (torch.manual_seed(0)) or a synthetic "trained-like" construction
+(tests/hetero.py).  These two were trained: tools/train_checkpoint.py ran the loop of main.py:67-98 (Adam amsgrad lr 3e-4,
+recon / x_train_var + embedding loss) on the HIP training path over structured synthetic 32x32x3 images (tests/synthdata.py) --
+5 000 updates at batch 32 (main.py's defaults; perplexity 2.7 -> 42) and 20 000 at batch 128 (perplexity -> 115) -- the state_dicts
+came back from the GPU box (tests/golden/<name>_state.npz) and the UNMODIFIED reference, loaded with them in the build container,
+produced tests/golden/trained_cases.npz (oracle/gen_golden.py trained; tests/test_oracle.py re-runs it where /root/reference is).
+
+Checked here, through the C ABI:
+  * P0: the quantizer on the REFERENCE's z_e bits -- indices and z_q bit-exact (z_e of a trained encoder: |z| up to 6, a codebook
+    that moved to where z_e lives, 57 / 125 codes in use; the init's U(+-1/K) codebook exercises none of that);
+  * P1: the whole forward in ALL THREE product schemes and the guard's own choice -- z_e and x_hat per output channel
+    (|got - ref| <= 1e-5 max|ref channel| + 1e-4 |ref|), the decoder on the reference's z_q bits, index flips counted and each one
+    explained by the z_e tolerance, loss / perplexity;
+  * what vqvae_weights_range_check_f32 measures on a trained checkpoint (printed: <= 1.5 binades on both; the limit is 10) and
+    that the module's default call therefore IS the two-term fp16 path, bit for bit;
+  * BASELINE config-3 size (B = 4096 validation images, every one of the 262 144 rows) against oracle/torch_port.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests import cases, hetero, synthdata
+
+pytestmark = pytest.mark.gpu
+
+NAMES = list(cases.TRAINED_CASES)
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def golden_trained():
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "trained_cases.npz"))
+
+
+def _model(name):
+    from vqvae_amd import conv
+    from vqvae_amd.modules import VQVAE
+    conv.set_conv_backend("hip")
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = VQVAE(h, rh, nl, K, D, beta).eval()
+    m.load_state_dict(cases.trained_state(name), strict=True)
+    return m.to(dev())
+
+
+def _flags(scheme):
+    from vqvae_amd import functional as F
+    return {"guard": None, "fp16x2": 0, "bf16x3": F.FWD_CONV_BF16_SPLIT, "fp32": F.FWD_CONV_EXACT_FP32}[scheme]
+
+
+def _explain_flips(got, want, z_ref_rows64, cb64, cmax):
+    """every index flip against the reference must be explained by the z_e tolerance: fp64 gap of the two codes
+    <= 8 eps32 (|z|^2 + |e|^2) + 2 sum_c tol_c |e_a,c - e_b,c|  with tol_c the per-channel z_e tolerance.  -> (flip rows, worst ratio)"""
+    flips = np.nonzero(got != want)[0]
+    worst = 0.0
+    for r in flips:
+        z = z_ref_rows64[r]
+        d = ((z[None, :] - cb64) ** 2).sum(1)
+        tol_c = 1e-5 * cmax + 1e-4 * np.abs(z)
+        bound = 8 * 2.0 ** -24 * ((z ** 2).sum() + (cb64[want[r]] ** 2).sum()) + 2 * (tol_c * np.abs(cb64[got[r]] - cb64[want[r]])).sum()
+        worst = max(worst, abs(d[got[r]] - d[want[r]]) / bound)
+    return flips, worst
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_quantizer_bit_exact_on_the_reference_ze_bits(name, golden_trained):
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = _model(name)
+    g_ze = torch.from_numpy(golden_trained[f"{name}/z_e"]).to(dev())
+    sha = golden_trained[f"{name}/sha"]
+    with torch.no_grad():
+        loss, z_q, ppl, onehot, idx = m.vector_quantization(g_ze)                                      # the module's NCHW boundary
+        l2, zq2, p2, idx2, _ = m.vector_quantization.quantize(g_ze.permute(0, 2, 3, 1).contiguous(), rowmajor=True)   # the fused path's rows
+    np.testing.assert_array_equal(idx.cpu().numpy().reshape(-1), golden_trained[f"{name}/idx"])
+    np.testing.assert_array_equal(idx2.cpu().numpy().reshape(-1), golden_trained[f"{name}/idx"])
+    assert cases.sha(z_q) == sha[2], "z_q (NCHW) not bit-exact"
+    assert cases.sha(zq2.permute(0, 3, 1, 2).contiguous()) == sha[2], "z_q (rows) not bit-exact"
+    np.testing.assert_allclose(loss.item(), golden_trained[f"{name}/loss"], rtol=1e-6)
+    np.testing.assert_allclose(ppl.item(), golden_trained[f"{name}/perplexity"], rtol=1e-6)
+    assert onehot.shape == (B * 64, K) and float(onehot.sum()) == B * 64
+    # the decoder on the quantizer's (= the reference's) z_q bits
+    with torch.no_grad():
+        x_hat = m.decoder(z_q)
+    hetero.per_channel_check(x_hat.cpu().numpy(), golden_trained[f"{name}/x_hat"], "x_hat(decoder on reference z_q)", per_image=False)
+
+
+@pytest.mark.parametrize("scheme", ["guard", "fp16x2", "bf16x3", "fp32"])
+@pytest.mark.parametrize("name", NAMES)
+def test_whole_forward_vs_reference_golden(name, scheme, golden_trained, capsys):
+    from vqvae_amd import _lib
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = _model(name)
+    L = _lib.load()
+    x = synthdata.normalised(B, seed)
+    assert cases.sha(x) == golden_trained[f"{name}/sha"][0]
+    xd = x.to(dev())
+    flags = _flags(scheme)
+    with torch.no_grad():
+        loss, x_hat, ppl, idx = m._forward_c(xd, want_idx=True, fwd_flags=flags)
+        cw, _keep = m._c_weights()
+        eff = m.scheme_hint()[0] if flags is None else flags
+        nws = L.vqvae_workspace_bytes(cw.dims, B, 32, 32)
+        ws = torch.empty(nws, dtype=torch.uint8, device=dev())
+        st = torch.cuda.current_stream().cuda_stream
+        z_e = torch.empty(B, 8, 8, D, device=dev())
+        _lib.check(L.vqvae_encoder_ex_f32(cw, xd.data_ptr(), B, 32, 32, eff, z_e.data_ptr(), ws.data_ptr(), nws, st))
+        idx_enc = m.encode(xd) if flags is None else None
+    torch.cuda.synchronize()
+    g_ze = golden_trained[f"{name}/z_e"]
+    ze = z_e.permute(0, 3, 1, 2).cpu().numpy()
+    w_ze = hetero.per_channel_check(ze, g_ze, f"z_e [{scheme}]", per_image=False)
+    got = idx.cpu().numpy().reshape(-1)
+    want = golden_trained[f"{name}/idx"].astype(np.int64)
+    cb64 = m.vector_quantization.embedding.weight.detach().cpu().double().numpy()
+    zr = np.transpose(g_ze, (0, 2, 3, 1)).reshape(-1, D).astype(np.float64)
+    cmax = np.abs(g_ze).max(axis=(0, 2, 3))
+    flips, worst = _explain_flips(got, want, zr, cb64, cmax)
+    assert worst <= 1.0, f"an index flip is not explained by the z_e tolerance: gap = {worst:.3g} x the bound"
+    assert len(flips) <= max(1, int(1e-3 * got.size)), f"{len(flips)} flips in {got.size} rows"
+    clean = np.setdiff1d(np.arange(B), np.unique(flips // 64))
+    w_xh = hetero.per_channel_check(x_hat.cpu().numpy()[clean], golden_trained[f"{name}/x_hat"][clean], f"x_hat [{scheme}]", per_image=False)
+    if len(flips) == 0:
+        np.testing.assert_allclose(loss.item(), golden_trained[f"{name}/loss"], rtol=2e-5)
+        np.testing.assert_allclose(ppl.item(), golden_trained[f"{name}/perplexity"], rtol=1e-5)
+    if idx_enc is not None:
+        assert torch.equal(idx_enc, idx)
+    with capsys.disabled():
+        print(f"\n   [{name} / {scheme}] worst error in units of the channel maximum: z_e {w_ze:.2e}, x_hat {w_xh:.2e}; "
+              f"{len(flips)} index flips / {got.size} rows (worst {worst:.2f} x the bound)")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_range_guard_on_a_trained_checkpoint(name, capsys):
+    """What the 10-binade limit of vqvae_weights_range_check_f32 (include/vqvae_hip.h) means for checkpoints training actually
+    produces: the largest per-layer input-channel spread is 1.3-1.5 binades (default init: 0.1; tests/hetero.py's constructions:
+    16-19), the guard recommends nothing, and the module's default call is the two-term fp16 path bit for bit."""
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = _model(name)
+    flags, spreads = m.scheme_hint()
+    xd = synthdata.normalised(64, seed + 100).to(dev())
+    with torch.no_grad():
+        auto = m._forward_c(xd, want_idx=True)
+        named = m._forward_c(xd, want_idx=True, fwd_flags=0)
+    torch.cuda.synchronize()
+    with capsys.disabled():
+        print(f"\n   [{name}] input-channel spread per layer (binades): " + " ".join(f"{v:.2f}" for v in spreads)
+              + f" -> {'bf16x3' if flags else 'fp16x2'}")
+    assert flags == 0, (flags, spreads)
+    assert max(spreads) < 3.0, spreads                      # 7 binades of room below the limit
+    assert torch.equal(auto[3], named[3]) and torch.equal(auto[1].view(torch.int32), named[1].view(torch.int32))
+
+
+@pytest.mark.parametrize("scheme", ["guard", "bf16x3"])
+@pytest.mark.parametrize("name", NAMES)
+def test_config3_batch_every_row_vs_reference_port(name, scheme, capsys):
+    """B = 4096 validation images, every one of the 262 144 latent rows against oracle/torch_port.py (bitwise the imported
+    reference, tests/test_oracle.py)."""
+    from oracle import torch_port
+    h, rh, nl, K, D, beta, _, seed = cases.TRAINED_CASES[name]
+    B = 4096
+    m = _model(name)
+    sd = cases.trained_state(name)
+    x = synthdata.normalised(B, seed + 7)
+    xd = x.to(dev())
+    with torch.no_grad():
+        loss, x_hat, ppl, idx = m._forward_c(xd, want_idx=True, fwd_flags=_flags(scheme))
+        z_e_ref = torch.cat([torch_port.encode(sd, x[i:i + 512].clone(), nl) for i in range(0, B, 512)])
+        cbk = sd["vector_quantization.embedding.weight"]
+        outs = [torch_port.quantize(z_e_ref[i:i + 512], cbk, beta) for i in range(0, B, 512)]
+        z_q_ref = torch.cat([o[1] for o in outs])
+        idx_ref = torch.cat([o[4] for o in outs])
+        x_hat_ref = torch.cat([torch_port.decode(sd, z_q_ref[i:i + 512].clone(), nl) for i in range(0, B, 512)])
+    got, want = idx.cpu().numpy().reshape(-1), idx_ref.numpy().reshape(-1)
+    zr = z_e_ref.permute(0, 2, 3, 1).reshape(-1, D).double().numpy()
+    cmax = z_e_ref.abs().amax(dim=(0, 2, 3)).double().numpy()
+    flips, worst = _explain_flips(got, want, zr, cbk.double().numpy(), cmax)
+    assert worst <= 1.0, f"an index flip is not explained by the z_e tolerance: gap = {worst:.3g} x the bound"
+    assert len(flips) <= int(1e-4 * got.size), f"{len(flips)} flips in {got.size} rows (SURVEY 8c expects <= 1e-4)"
+    clean = np.setdiff1d(np.arange(B), np.unique(flips // 64))
+    w_xh = hetero.per_channel_check(x_hat.cpu().numpy()[clean], x_hat_ref.numpy()[clean], f"x_hat [{scheme}]", per_image=False)
+    # merged scalars of the reference's 512-image slabs: loss = mean of slab losses (equal sizes); perplexity from the index histogram
+    loss_ref = float(np.mean([o[0].item() for o in outs]))
+    if len(flips) == 0:
+        np.testing.assert_allclose(loss.item(), loss_ref, rtol=2e-5)
+    p = np.bincount(want, minlength=K).astype(np.float64) / want.size
+    ppl_ref = float(np.exp(-(p * np.log(p + 1e-10)).sum()))
+    np.testing.assert_allclose(ppl.item(), ppl_ref, rtol=1e-4)
+    with capsys.disabled():
+        print(f"\n   [{name} / {scheme} / B=4096] {len(flips)} index flips / {got.size} rows (worst {worst:.2f} x the bound); x_hat worst "
+              f"{w_xh:.2e} of its channel maximum; perplexity {ppl.item():.3f}, {len(np.unique(got))} codes in use")
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_wire_format_and_checkpoint_file_on_a_trained_checkpoint(name, golden_trained, tmp_path):
+    """encode -> indices -> decode_indices on trained weights, and the checkpoint FILE layout of utils.py:109-113
+    ({'model', 'results', 'hyperparameters'}) round-trips through torch.save / load_state_dict."""
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    m = _model(name)
+    path = tmp_path / "vqvae_data_test.pth"
+    torch.save({"model": m.state_dict(), "results": {"n_updates": 0}, "hyperparameters": {}}, path)
+    from vqvae_amd.modules import VQVAE
+    m2 = VQVAE(h, rh, nl, K, D, beta).eval()
+    m2.load_state_dict(torch.load(path, map_location="cpu")["model"])
+    m2 = m2.to(dev())
+    xd = synthdata.normalised(B, seed).to(dev())
+    with torch.no_grad():
+        idx = m2.encode(xd)
+        x_dec = m2.decode_indices(idx, B, 8, 8)
+        _, x_hat, _, idx_f = m._forward_c(xd, want_idx=True)
+    assert torch.equal(idx, idx_f)
+    # decode_indices gathers e_k itself, forward decodes z + (e_k - z): equal up to that rounding of z_q
+    scale = float(x_hat.abs().max())
+    np.testing.assert_allclose(x_dec.cpu().numpy(), x_hat.cpu().numpy(), atol=2e-6 * scale, rtol=1e-5)

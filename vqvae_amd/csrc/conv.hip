@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const float *__restrict
                     const int n = (nb * NT + nt) * 32 + l31;
                     if (n < g.Cout) {
                         float v = acc[mt][nt][r] + bv[nt];
-                        if (relu_out) v = fmaxf(v, 0.0f);
+                        if (relu_out) v = relu1(v);
                         out[off + n] = v;
                     }
                 }
@@ -553,7 +553,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_bf3_kernel(const float *__r
                 const int n = (nb * NT + nt) * 32 + l31;
                 if (n < g.Cout) {
                     float v = (H2 ? acc[nt][r] * drow * wd[nt] : acc[nt][r]) + bv[nt];
-                    if (relu_out) v = fmaxf(v, 0.0f);
+                    if (relu_out) v = relu1(v);
                     rmax = fmaxf(rmax, __builtin_fabsf(v));
                     if (ep) v = em[r][nt] > 0.0f ? v + ea[r][nt] : 0.0f;
                     out[off + n] = v;
@@ -880,7 +880,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     v[r] = (H2 ? acc[mt][nt][r] * wd[nt] : acc[mt][nt][r]) + bv[nt];
-                    if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                    if (relu_out) v[r] = relu1(v[r]);
                     omax = fmaxf(omax, __builtin_fabsf(v[r]));
                 }
                 tile_epilogue(tile, v, lane, (nb * NT + nt) * 32, [&](int p, int n, f32x4 a, int k) {
@@ -909,7 +909,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_tile8_bf3_kernel(const float 
                     const int n = (nb * NT + nt) * 32 + l31;
                     if (n < g.Cout) {
                         float v = (H2 ? acc[mt][nt][r] * wd[nt] : acc[mt][nt][r]) + bv[nt];
-                        if (relu_out) v = fmaxf(v, 0.0f);
+                        if (relu_out) v = relu1(v);
                         omax = fmaxf(omax, __builtin_fabsf(v));
                         out[off + n] = ep_apply1(g, off + n, v);
                     }
@@ -1195,7 +1195,7 @@ __global__ __launch_bounds__(256, 2) void conv_halo8_h2_kernel(const float *__re
                         // acc * 2^-k + bias: the product is exact, so the fused form rounds once like the separate add
                         const f32x2v y = __builtin_elementwise_fma(f32x2v{acc[mt][v][r], acc[mt][v][r + 1]}, d2, b2);
                         float v0 = y.x, v1 = y.y;
-                        if (ro) { v0 = vmax(v0, 0.0f); v1 = vmax(v1, 0.0f); }
+                        if (ro) { v0 = relu1(v0); v1 = relu1(v1); }
                         vmax3_abs(omax, v0, v1);
                         tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
                         tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;

@@ -74,6 +74,15 @@ __device__ __forceinline__ float vmax(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b));
     return o;
 }
+// ReLU that KEEPS a NaN, as nn.ReLU does (models/residual.py:19,22, encoder.py:31,34, decoder.py:33: torch's relu of a NaN is a
+// NaN).  v_max_f32 returns the other operand for a quiet NaN and would flush it to 0; gfx950 has the IEEE-754-2019 `maximum`
+// (v_maximum3_f32: any NaN operand makes the result NaN) at the same one-instruction cost.  The activation MAXIMA that make the
+// per-image scales stay on v_max / v_max3 on purpose: a NaN pixel must not become its image's scale.
+__device__ __forceinline__ float relu1(float a) {
+    float o;
+    asm("v_maximum3_f32 %0, %1, 0, 0" : "=v"(o) : "v"(a));
+    return o;
+}
 __device__ __forceinline__ void vmax3_abs(float &m, float a, float b) {       // m = max(m, |a|, |b|)
     asm("v_max3_f32 %0, %0, |%1|, |%2|" : "+v"(m) : "v"(a), "v"(b));
 }
@@ -86,15 +95,15 @@ __device__ __forceinline__ void vmax3(float &m, float a, float b) {           //
 __device__ __forceinline__ f32x2v scale_bias_relu2(float a0, float a1, float d, float b0, float b1, float &m) {
     // (two scalar FMAs, not a packed one: v_pk_fma_f32 wants aligned register pairs, and with 128 accumulator registers live
     // that constraint cost conv_res_pair8_h2_kernel<2, true> 500 spilled registers)
-    const f32x2v r = {vmax(__builtin_fmaf(a0, d, b0), 0.0f), vmax(__builtin_fmaf(a1, d, b1), 0.0f)};
+    const f32x2v r = {relu1(__builtin_fmaf(a0, d, b0)), relu1(__builtin_fmaf(a1, d, b1))};
     vmax3(m, r.x, r.y);
     return r;
 }
 // the same with one scale per value (round 4: the weight rows' own powers of two)
 #define SCALE2_BIAS_RELU2(A0, A1, D0, D1, B0, B1, M)                             \
     do {                                                                         \
-        const float r0_ = vmax(__builtin_fmaf((A0), (D0), (B0)), 0.0f);          \
-        const float r1_ = vmax(__builtin_fmaf((A1), (D1), (B1)), 0.0f);          \
+        const float r0_ = relu1(__builtin_fmaf((A0), (D0), (B0)));          \
+        const float r1_ = relu1(__builtin_fmaf((A1), (D1), (B1)));          \
         vmax3((M), r0_, r1_);                                                    \
         (A0) = r0_;                                                              \
         (A1) = r1_;                                                              \
@@ -106,7 +115,7 @@ __device__ __forceinline__ f32x2v scale_bias_relu2(float a0, float a1, float d, 
         (A1) = r_.y;                                                             \
     } while (0)
 __device__ __forceinline__ f32x4 relu4(f32x4 v) {
-    v.x = vmax(v.x, 0.0f); v.y = vmax(v.y, 0.0f); v.z = vmax(v.z, 0.0f); v.w = vmax(v.w, 0.0f);
+    v.x = relu1(v.x); v.y = relu1(v.y); v.z = relu1(v.z); v.w = relu1(v.w);
     return v;
 }
 

@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float *__restrict__ 
                     const int n = nt * 32 + l31;
                     if (n < Cout) {
                         float v = acc[mt][nt][r] + (bias ? bias[n] : 0.0f);
-                        if (relu_out) v = fmaxf(v, 0.0f);
+                        if (relu_out) v = relu1(v);
                         out[prow * Cout + n] = v;
                     }
                 }
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                     for (int r = 0; r < 16; r += 2) {
                         const f32x2v y = f32x2v{acc[mt][nt][r], acc[mt][nt][r + 1]} + b2;
                         float v0 = y.x, v1 = y.y;
-                        if (ro) { v0 = vmax(v0, 0.0f); v1 = vmax(v1, 0.0f); }
+                        if (ro) { v0 = relu1(v0); v1 = relu1(v1); }
                         if (cok) vmax3_abs(omax, v0, v1);
                         tile[((r & 3) + 8 * (r >> 2) + 4 * h) * 32 + l31] = v0;
                         tile[(((r + 1) & 3) + 8 * ((r + 1) >> 2) + 4 * h) * 32 + l31] = v1;
@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256, 3) void conv_in_rows_kernel(const float *__res
                 const int n = nt * 32 + l31;
                 if (n < Cout) {
                     float v = acc[mt][nt][r] + bv[nt];
-                    if (relu_out) v = fmaxf(v, 0.0f);
+                    if (relu_out) v = relu1(v);
                     omax = fmaxf(omax, __builtin_fabsf(v));
                     if (ep_mask) v = ep_mask[prow * Cout + n] > 0.0f ? v : 0.0f;
                     out[prow * Cout + n] = v;

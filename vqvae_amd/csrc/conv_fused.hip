@@ -392,8 +392,8 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
                         for (int q = 0; q < 4; q += 2) {
                             const int r = 4 * g + q;
-                            const float y0 = vmax(__builtin_fmaf(acc2[mt][r], dv[q], Y[mt][nt][r]), 0.0f);
-                            const float y1 = vmax(__builtin_fmaf(acc2[mt][r + 1], dv[q + 1], Y[mt][nt][r + 1]), 0.0f);
+                            const float y0 = relu1(__builtin_fmaf(acc2[mt][r], dv[q], Y[mt][nt][r]));
+                            const float y1 = relu1(__builtin_fmaf(acc2[mt][r + 1], dv[q + 1], Y[mt][nt][r + 1]));
                             Y[mt][nt][r] = y0;
                             Y[mt][nt][r + 1] = y1;
                             vmax3(nmax, y0, y1);

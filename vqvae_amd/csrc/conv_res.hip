@@ -139,7 +139,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
         for (int r = 0; r < 16; ++r) {
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
             const float dr = H2 ? __shfl(d1[mt], prow) * w1d : 1.0f;  // the row's 3x3 accumulator scale 2^-(kx + kw1[n])
-            Hs[wave][mt][prow * 33 + l31] = fmaxf(H2 ? acc1[mt][r] * dr : acc1[mt][r], 0.0f);
+            Hs[wave][mt][prow * 33 + l31] = relu1(H2 ? acc1[mt][r] * dr : acc1[mt][r]);
         }
     lds_order_wave();
     u32x4 H1[MT][2], Hb[MT][2], H3[MT][2];
@@ -203,9 +203,9 @@ __global__ __launch_bounds__(256, 2) void res_layer_bf3_kernel(const float *__re
                 float rmax = 0.0f;
                 if (prow < M && n < C) {
                     float u = in[prow * C + n];
-                    if (relu_in) u = fmaxf(u, 0.0f);
+                    if (relu_in) u = relu1(u);
                     float v = u + (H2 ? acc2[mt][r] * dr : acc2[mt][r]);
-                    if (relu_out) v = fmaxf(v, 0.0f);
+                    if (relu_out) v = relu1(v);
                     rmax = __builtin_fabsf(v);
                     out[prow * C + n] = v;
                 }
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256, H2 ? 4 : 3) void res_tile8_bf3_kernel(const fl
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-            Hs[prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+            Hs[prow * 33 + l31] = relu1(acc1[mt][r]);
         }
         lds_order_wave();
         float a2[16];
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256, 3) void res_halo8_h2_kernel(const float *__res
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                acc1[mt][r] = vmax(acc1[mt][r] * d1, 0.0f);
+                acc1[mt][r] = relu1(acc1[mt][r] * d1);
                 m = vmax(m, acc1[mt][r]);
             }
         const int kh = wave_scale_exp(m);
@@ -912,8 +912,8 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
             for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float u0 = relu_in ? fmaxf(u[r], 0.0f) : u[r];
-                    Y[mt][nt][r] = fmaxf(u0 + acc2[mt][r] * d2n, 0.0f);      // + the second layer's in-place ReLU
+                    const float u0 = relu_in ? relu1(u[r]) : u[r];
+                    Y[mt][nt][r] = relu1(u0 + acc2[mt][r] * d2n);      // + the second layer's in-place ReLU
                 }
                 if (mt + 1 < MT) {
 #pragma unroll
@@ -988,7 +988,7 @@ __global__ __launch_bounds__(256, 2) void res_pair8_h2_kernel(const float *__res
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         v[r] = Y[mt][nt][r] + acc2[mt][r] * d2n;
-                        if (relu_out) v[r] = fmaxf(v[r], 0.0f);
+                        if (relu_out) v[r] = relu1(v[r]);
                         omax = fmaxf(omax, __builtin_fabsf(v[r]));
                     }
                     if constexpr (NT3 > 0) {
@@ -1181,7 +1181,7 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int prow = (r & 3) + 8 * (r >> 2) + 4 * h;
-            Hs[wave][mt][prow * 33 + l31] = fmaxf(acc1[mt][r], 0.0f);
+            Hs[wave][mt][prow * 33 + l31] = relu1(acc1[mt][r]);
         }
     lds_order_wave();
     float a2[MT][16];
@@ -1227,9 +1227,9 @@ __global__ __launch_bounds__(256, 2) void res_layer_kernel(const float *__restri
                         const int n = (n0 + nt) * 32 + l31;
                         if (n < C) {
                             float u = in[prow * C + n];
-                            if (relu_in) u = fmaxf(u, 0.0f);
+                            if (relu_in) u = relu1(u);
                             float v = u + acc2[mt][nt][r];
-                            if (relu_out) v = fmaxf(v, 0.0f);
+                            if (relu_out) v = relu1(v);
                             out[prow * C + n] = v;
                         }
                     }

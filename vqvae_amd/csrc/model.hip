@@ -107,6 +107,19 @@ size_t res_hidden_bytes(const VqvaeDims *d, int64_t B, int H, int W) {
 // z_q where the decoder's first layer is a generic kernel, dec2)
 size_t amax_bytes(const VqvaeDims *d, int64_t B) { return align_up((size_t)(4 + d->n_res_layers) * B * sizeof(int), 256); }
 
+// vqvae_decode_f32 on shapes without the gathering decoder kernel: z_q[i][:] = codebook[idx[i]][:] for ANY row length, and -- the
+// contract of the fused gather, include/vqvae_hip.h -- an index outside [0, K) never reads the codebook: its latent pixel becomes NaN
+__global__ __launch_bounds__(256) void decode_gather_kernel(const long long *__restrict__ idx, const float *__restrict__ codebook,
+                                                            long long rows, int D, int K, float *__restrict__ z_q) {
+    const long long total = rows * D;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long i = e / D;
+        const int c = (int)(e - i * D);
+        const long long k = idx[i];
+        z_q[e] = (k >= 0 && k < K) ? codebook[(size_t)k * D + c] : __builtin_nanf("");
+    }
+}
+
 }  // namespace
 }  // namespace vqvae
 
@@ -613,8 +626,15 @@ int vqvae_decode_f32(const VqvaeWeights *w, const int64_t *idx, int64_t B, int h
     if (decoder_gather_ok(d, h4, w4, cf))
         return decoder_run(w, w->codebook, B, h4, w4, x_hat, f.acts, acts_bytes, st, am_dec, false, false, cf, f.hid, idx);
     // other shapes: the codebook rows of every position into the workspace's z_q (row-major), then the decoder
-    const int rc = vqvae_gather_rows_f32(idx, w->codebook, (int64_t)f.rows, d->embedding_dim, d->n_embeddings, f.z_q, stream);
-    if (rc != 0) return rc;
+    {
+        const long long total = (long long)f.rows * d->embedding_dim;
+        const long long blocks = (total + 255) / 256;
+        hipLaunchKernelGGL(decode_gather_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, st,
+                           reinterpret_cast<const long long *>(idx), w->codebook, (long long)f.rows, d->embedding_dim, d->n_embeddings,
+                           f.z_q);
+        const int lrc = (int)hipGetLastError();
+        if (lrc != 0) return lrc;
+    }
     return decoder_run(w, f.z_q, B, h4, w4, x_hat, f.acts, acts_bytes, st, am_dec, false, false, cf, f.hid);
 }
 
