@@ -98,6 +98,8 @@ def gen_trained():
             _, z_q, _, _, idx = m.vector_quantization(z_e)
             x_hat2 = m.decoder(z_q)
         assert torch.equal(x_hat, x_hat2)
+        # (the images are committed too: bicubic / sin / exp of tests/synthdata.py round differently on another host's ISA)
+        out[f"{name}/x"] = x.numpy()
         out[f"{name}/idx"] = idx.numpy().astype(np.int32).reshape(-1)
         out[f"{name}/loss"] = loss.numpy()
         out[f"{name}/perplexity"] = ppl.numpy()

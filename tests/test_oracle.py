@@ -181,9 +181,11 @@ def test_oracles_on_a_trained_checkpoint(name, golden_trained):
     h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
     sd = cases.trained_state(name)
     assert len(sd) == 23
-    x = synthdata.normalised(B, seed)
+    x = torch.from_numpy(golden_trained[f"{name}/x"])          # (committed: the generator's transcendental ops round per host ISA)
     sha = golden_trained[f"{name}/sha"]
-    assert cases.sha(x) == sha[0], "synthetic image generator drifted"
+    assert cases.sha(x) == sha[0]
+    if have_reference():                                         # the build container: the generator still makes these very images
+        assert cases.sha(synthdata.normalised(B, seed)) == sha[0], "synthetic image generator drifted"
     g_ze = golden_trained[f"{name}/z_e"]
     out = c_oracle.vq_forward(g_ze, sd["vector_quantization.embedding.weight"].numpy(), beta)
     np.testing.assert_array_equal(out["idx"].reshape(-1), golden_trained[f"{name}/idx"].astype(np.int64))
@@ -214,6 +216,6 @@ def test_trained_goldens_reproduce_from_the_unmodified_reference(name, golden_tr
     m = VQVAE(h, rh, nl, K, D, beta).eval()
     m.load_state_dict(cases.trained_state(name), strict=True)
     with torch.no_grad():
-        loss, x_hat, ppl = m(synthdata.normalised(B, seed))
+        loss, x_hat, ppl = m(torch.from_numpy(golden_trained[f"{name}/x"]))
     assert cases.sha(x_hat) == golden_trained[f"{name}/sha"][3]
     assert loss.item() == golden_trained[f"{name}/loss"].item()
