@@ -613,6 +613,76 @@ def scheme_leg(scheme, torch, dev, seconds=1.0):
     return res
 
 
+def trained_leg(name, torch, dev, seconds=1.0):
+    """BASELINE config 3 on a REALLY TRAINED checkpoint (round 6; tests/golden/<name>_state.npz: main.py:67-98's loop on the HIP
+    training path, tools/train_checkpoint.py) and structured images (tests/synthdata.py), through the module's DEFAULT call: the
+    product scheme is whatever vqvae_weights_range_check_f32 recommends for this checkpoint.  Beside the rate: the guard's per-layer
+    spreads and its pick, every index against the reference's algorithm, the stand-alone quantizer's time on THIS z_e (its speed is
+    data-dependent: open / hard rows take the exact part), and the row classes of that z_e measured with the VQ_DEBUG_VERDICT build
+    (tools/r06_row_classes.py -> profiles/vq_row_classes.json; not measurable in the product library)."""
+    import statistics
+    from tests import cases, synthdata
+    from vqvae_amd import _lib, conv as conv_mod, conv_hip, functional as F_hip
+    from vqvae_amd.modules import VQVAE
+    desc, B, HW, K, D, _ = WORKLOADS["c3"]
+    h, rh, nl, K, D, beta, _, seed = cases.TRAINED_CASES[name]
+    conv_mod.set_conv_backend("hip")
+    model = VQVAE(h, rh, nl, K, D, beta).eval()
+    model.load_state_dict(cases.trained_state(name))
+    model = model.to(dev)
+    x = synthdata.normalised(B, seed + 7).to(dev)
+    flags, spreads = model.scheme_hint()
+
+    def run(n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for _ in range(n):
+                model(x)                                   # the default call: the guard's scheme
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    run(2)
+    steps = max(2, int(seconds / 5 / max(run(2) / 2, 1e-6)) + 1)
+    times = [run(steps) for _ in range(5)]
+    el = statistics.median(times)
+    with torch.no_grad():
+        loss, _, ppl, idx = model._forward_c(x, want_idx=True)
+        z_e = conv_hip.encoder_forward(model.encoder, x, model.pre_quantization_conv)
+        cbw = model.vector_quantization.embedding.weight.detach()
+        vws = F_hip.vq_workspace(K, D, dev)
+        F_hip.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=vws)
+        for _ in range(3):
+            F_hip.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=vws, prepared=True)
+        torch.cuda.synchronize()
+        _lib.profile_enable(True)
+        for _ in range(30):
+            F_hip.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=vws, prepared=True)
+        ms, cnt = _lib.profile_collect("vq_main")
+        _lib.profile_enable(False)
+    rows = B * 64
+    t_vq = ms / max(cnt, 1) * 1e-3
+    classes = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "vq_row_classes.json")) as f:
+            classes = json.load(f).get(name)
+    except (OSError, ValueError):
+        pass
+    res = {"workload": desc + f" -- weights: {name} (trained, tests/golden/{name}_state.npz), images: tests/synthdata.py",
+           "scheme_picked_by_guard": "bf16x3 (VQVAE_FWD_CONV_BF16_SPLIT)" if flags else "fp16x2 (default two-term fp16 products)",
+           "guard_input_channel_spread_binades": [round(v, 2) for v in spreads], "guard_limit_binades": 10.0,
+           "per_gpu_batch": B, "images_per_s": round(B * steps / el, 1), "ms_per_step": round(el / steps * 1e3, 4),
+           "timed_seconds": round(sum(times), 3), "steps_per_repeat": steps,
+           "embedding_loss": round(float(loss), 6), "perplexity": round(float(ppl), 3), "codes_in_use": int(idx.unique().numel()),
+           "index_flips_vs_reference": index_flips(model, x, torch, flags),
+           "standalone_vq_on_this_z_e": {"kernel": _lib.vq_kernel_instance(rows, K, D, 64, 0x1), "avg_kernel_us": round(t_vq * 1e6, 2),
+                                         "frac": round(rows * (8 * D + 8) / t_vq / 1e9 / HBM_PEAK_GBPS, 4)},
+           "row_classes": classes if classes else "profiles/vq_row_classes.json has no entry for this checkpoint"}
+    del model, x, z_e, vws
+    torch.cuda.empty_cache()
+    return res
+
+
 def pixelcnn_leg(torch, dev, seconds=0.6):
     """one GatedPixelCNN forward (pixelcnn/models.py:118-127; 15 gated layers, dim 64, 512 codes) over the
     8x8 latent index maps of 1024 images, and the ancestral sampler (:129-146, 64 forwards) for 64 samples replayed from a hipGraph."""
@@ -940,6 +1010,8 @@ def main():
                 # them may take the headline line down with it (an error is reported in its place, not swallowed)
                 legs = [(w, (lambda w=w: other_workload(w, torch, dev))) for w in ("c2", "c4", "c5")]
                 legs += [("c3_bf16x3", lambda: scheme_leg("bf16x3", torch, dev)), ("c3_fp32", lambda: scheme_leg("fp32", torch, dev))]
+                legs += [("c3_trained", lambda: trained_leg("trained_main_defaults", torch, dev)),
+                         ("c3_trained_b128x20k", lambda: trained_leg("trained_b128x20k", torch, dev, seconds=0.6))]
                 legs += [(name, (lambda name=name: hparam_leg(name, torch, dev, seconds=0.6))) for name in HPARAM_LEGS]
                 legs += [("wire_format", lambda: wire_legs(torch, dev, elapsed / args.steps * 1e3)),
                          ("vq_sizes", lambda: vq_size_sweep(torch, dev))]
