@@ -217,3 +217,75 @@ def test_wire_format_and_checkpoint_file_on_a_trained_checkpoint(name, golden_tr
     # decode_indices gathers e_k itself, forward decodes z + (e_k - z): equal up to that rounding of z_q
     scale = float(x_hat.abs().max())
     np.testing.assert_allclose(x_dec.cpu().numpy(), x_hat.cpu().numpy(), atol=2e-6 * scale, rtol=1e-5)
+
+
+@pytest.mark.parametrize("form", [0, 8, 16], ids=["default_form", "units64_8waves", "units32_16waves"])
+@pytest.mark.parametrize("rowmajor", [False, True], ids=["nchw", "rows"])
+@pytest.mark.parametrize("name", NAMES)
+def test_rows_at_the_dead_code_cluster_bit_exact(name, rowmajor, form, golden_trained):
+    """What training leaves behind and no synthetic codebook of tests/ had: ~450 of the 512 codes never moved from their U(+-1/K)
+    init -- at the scale of a trained |z| ~ 10 they are ONE point, so a row near the origin finds hundreds of codes above the
+    screen's threshold, the task table (64 entries) overflows and the row takes torch.argmin over all codes.  Round 6 gave that
+    path to the whole wave (it was one lane: 33 such rows made the kernel 14x slower).  Half of these rows are aimed at the cluster;
+    indices and z_q against the C oracle, bit for bit."""
+    from oracle import c_oracle
+    from vqvae_amd import functional as F
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    cb = cases.trained_state(name)["vector_quantization.embedding.weight"]
+    g = torch.Generator().manual_seed(99)
+    z = torch.from_numpy(golden_trained[f"{name}/z_e"]).clone()                 # (32, 64, 8, 8)
+    zr = z.permute(0, 2, 3, 1).reshape(-1, D)
+    n = zr.shape[0]
+    pick = torch.rand(n, generator=g) < 0.5
+    scale = 10.0 ** (torch.rand(n, 1, generator=g) * 3 - 3)                     # |z| element scale 1e-3 .. 1
+    zr[pick] = (torch.randn(n, D, generator=g) * scale)[pick]
+    zr[::97] = 0.0                                                               # the origin itself
+    z = zr.view(32, 8, 8, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), beta)
+    dead = (cb.norm(dim=1) < 0.05).numpy()
+    assert dead.sum() > 300 and dead[ref["idx"].reshape(-1)].mean() > 0.2       # the cluster exists and wins many rows
+    zd = z.to(dev())
+    if rowmajor:
+        zd = zd.permute(0, 2, 3, 1).contiguous()
+    loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(dev()), beta, rowmajor=rowmajor, form=form)
+    torch.cuda.synchronize()
+    if rowmajor:
+        zq = zq.permute(0, 3, 1, 2).contiguous()
+    np.testing.assert_array_equal(idx.cpu().numpy(), ref["idx"])
+    assert np.array_equal(zq.cpu().numpy().view(np.uint32), ref["z_q"].view(np.uint32))
+    np.testing.assert_allclose(loss.item(), ref["loss"], rtol=1e-6)
+    np.testing.assert_array_equal(hist.cpu().numpy(), ref["hist"])
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_quantizer_time_on_trained_z_e_stays_near_the_init_models(name, capsys):
+    """The stand-alone quantizer's time is data-dependent (open / hard / wide rows take the exact part).  On a trained checkpoint's
+    own z_e (B = 4096: 262 144 rows) it must stay within 2x of the default-init model's (measured 1.1-1.3x; it was 14x before
+    round 6's wave-wide path)."""
+    from vqvae_amd import _lib, conv_hip, functional as F
+    from vqvae_amd.modules import VQVAE
+    h, rh, nl, K, D, beta, _, seed = cases.TRAINED_CASES[name]
+
+    def time_vq(model, x):
+        with torch.no_grad():
+            z_e = conv_hip.encoder_forward(model.encoder, x, model.pre_quantization_conv)
+            cbw = model.vector_quantization.embedding.weight.detach()
+            ws = F.vq_workspace(K, D, dev())
+            F.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=ws)
+            for _ in range(3):
+                F.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=ws, prepared=True)
+            torch.cuda.synchronize()
+            _lib.profile_enable(True)
+            for _ in range(20):
+                F.vq_forward(z_e, cbw, beta, rowmajor=True, workspace=ws, prepared=True)
+            ms, cnt = _lib.profile_collect("vq_main")
+            _lib.profile_enable(False)
+        return ms / cnt * 1e3
+
+    torch.manual_seed(0)
+    init = VQVAE(h, rh, nl, K, D, beta).eval().to(dev())
+    t_init = time_vq(init, torch.randn(4096, 3, 32, 32, generator=torch.Generator().manual_seed(1000)).to(dev()))
+    t_tr = time_vq(_model(name), synthdata.normalised(4096, seed + 7).to(dev()))
+    with capsys.disabled():
+        print(f"\n   [{name}] stand-alone quantizer, 262 144 rows: {t_tr:.1f} us on the trained z_e, {t_init:.1f} us on the default-init model's")
+    assert t_tr <= 2.0 * t_init

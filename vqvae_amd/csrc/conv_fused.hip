@@ -561,12 +561,13 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
             // rows whose candidates the stream x cell products do not cover (~0.01 %) need the codebook image once more: the
             // workgroup votes, and if any of its waves has one, all four stream the stages again (the others only keep the barriers)
             const bool rescan_me = FL.hmask && FL.ndirect <= 64;
+            int nres = 0;                               // tasks of the second screen (wave-uniform)
             if (__syncthreads_or(rescan_me ? 1 : 0)) {
                 dma_stage(18 + NT3, 0);
                 for (int j = 0; j < nvq; ++j) {
                     dma_wait_sync();
                     if (j + 1 < nvq) dma_stage(18 + NT3 + j + 1, (j + 1) & 1);
-                    if (rescan_me) {
+                    if (rescan_me && FL.ndirect + nres <= 64) {         // (past 64: the hard rows go wide anyway; the stages still stream)
                         const u32x4 *wb = Wb_all + (j & 1) * WBUF + lane;
                         const float *sd = reinterpret_cast<const float *>(Wb_all + (j & 1) * WBUF + 16 * 64);
 #pragma unroll
@@ -578,14 +579,14 @@ __global__ __launch_bounds__(CRP_NW * 64, CRP_MINW) void conv_res_pair8_h2_kerne
 #pragma unroll
                                     for (int ks = 1; ks < 4; ++ks)
                                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[ks]), __builtin_bit_cast(f16x8, zb[mt][ks]), acc, 0, 0, 0);
-                                    vqu::rescan_tile(acc, thr_t, ct, mt, lane, vq.K, FL.ndirect, ninf, tb);
+                                    vqu::rescan_tile(acc, thr_t, ct, mt, lane, vq.K, FL.ndirect, ninf, tb, nres);
                                 });
                             }
                     }
                 }
                 if (rescan_me) {
                     lds_order_wave();
-                    ntasks = FL.ndirect + tb.cnt_s[0];
+                    ntasks = FL.ndirect + nres;
                 }
             }
             __syncthreads();                        // every wave is done with the weight buffers: they hold half of the rows now

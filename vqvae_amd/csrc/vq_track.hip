@@ -483,6 +483,7 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
             vqu::Flagged FL = vqu::exact_begin_sp<T>(R, lane, tb);
             int ntasks = FL.ndirect;
             if (FL.hmask && FL.ndirect <= 64) {
+                int nres = 0;                                       // tasks of the second screen (wave-uniform)
                 // rows with candidates the products do not cover: the tile's screen again, hits (acc >= v1 - DELTA) become tasks
 #pragma unroll
                 for (int t = 0; t < T; ++t) {
@@ -506,19 +507,19 @@ __global__ __launch_bounds__(NW * 64, NW / 4) void vq_track_kernel_d64(
                         };
                         rfetch(0);
                         const float thr_t = (((unsigned)(FL.hmask >> (32 * t)) >> l31) & 1u) ? R.thr[t] : inf;   // only the hard rows can hit
-                        for (int ct = 0; ct < ntile; ++ct) {
+                        for (int ct = 0; ct < ntile && FL.ndirect + nres <= 64; ++ct) {      // (past 64: the hard rows go wide anyway)
                             f32x16 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[0]), zbr[0], rs, 0, 0, 0);
 #pragma unroll
                             for (int q = 1; q < 4; ++q)
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ra[q]), zbr[q], acc, 0, 0, 0);
                             rfetch(ct + 1 < ntile ? ct + 1 : ct);
-                            vqu::rescan_tile(acc, thr_t, ct, t, lane, K, FL.ndirect, ninf, tb);
+                            vqu::rescan_tile(acc, thr_t, ct, t, lane, K, FL.ndirect, ninf, tb, nres);
                             asm volatile("" : "+v"(ra[0]), "+v"(ra[1]), "+v"(ra[2]), "+v"(ra[3]));
                         }
                     }
                 }
                 lds_order_wave();
-                ntasks = FL.ndirect + tb.cnt_s[0];
+                ntasks = FL.ndirect + nres;
             }
             if constexpr (NCHW) {
                 const float *zu = unit_base(p, z);                 // (strided dword reads: ~3 % of the rows, L2-resident)

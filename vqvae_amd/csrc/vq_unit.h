@@ -65,9 +65,12 @@ struct Flagged {
     int ndirect;                     // tasks so far: classification + one per non-finite row
 };
 
-// one 32-code tile of a row tile screened again: every code at or above the row's threshold becomes a task
+// one 32-code tile of a row tile screened again: every code at or above the row's threshold becomes a task.  nres (wave-uniform):
+// tasks the second screen has produced so far -- slots by ballot prefix (round 6: it was one LDS atomic per hit, and a row at a
+// trained checkpoint's dead-code cluster has 450 hits); once ndirect + nres passes the table's 64 entries the caller stops
+// screening: the unit's hard rows then take the wave-wide argmin of exact_end_sp() whatever else turns up.
 __device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int ct, int t, int lane, int K, int ndirect, float ninf,
-                                            const Tables &tb) {
+                                            const Tables &tb, int &nres) {
     const int l31 = lane & 31, h = lane >> 5;
     const float x0 = trk::max3(trk::max3(acc[0], acc[1], acc[2]), trk::max3(acc[3], acc[4], acc[5]), trk::max3(acc[6], acc[7], acc[8]));
     const float x1 = trk::max3(trk::max3(acc[9], acc[10], acc[11]), trk::max3(acc[12], acc[13], acc[14]), acc[15]);
@@ -76,9 +79,12 @@ __device__ __forceinline__ void rescan_tile(const f32x16 &acc, float thr_t, int 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int code = ct * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (acc[r] >= thr_t && code < K) {
-                const int sl = ndirect + atomicAdd(&tb.cnt_s[0], 1);
-                if (sl < 64) tb.task_s[sl] = (unsigned)(32 * t + l31) | ((unsigned)code << 6) | ((unsigned)code << 19);
+            const bool hit = acc[r] >= thr_t && code < K;
+            const unsigned long long b = __builtin_amdgcn_ballot_w64(hit);
+            if (b) {
+                const int sl = ndirect + nres + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(b >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)b, 0));
+                if (hit && sl < 64) tb.task_s[sl] = (unsigned)(32 * t + l31) | ((unsigned)code << 6) | ((unsigned)code << 19);
+                nres += __builtin_popcountll(b);
             }
         }
     }
@@ -243,12 +249,23 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
     constexpr int D = 64;
     if (!F.fm) return;
     const int j8 = lane & 7, g8 = lane >> 3;
-    if (ntasks > 64) {                      // pathological tie counts: every flagged row takes the scalar path;
+    // Rows that take torch.argmin over ALL codes with the whole wave (below): non-finite rows -- and, when a unit's candidates overflow
+    // the 64-entry task table, its HARD rows (the rows whose second screen found the many candidates); the open rows keep the tasks
+    // the classification wrote.  The tasks only produce a wide row's ||z||^2.
+    bool o_wide = F.o_bad;
+    if (ntasks > 64) {
         const unsigned long long lowmask = (1ull << lane) - 1ull;
-        F.o_bad = F.o_bad || F.o_open || F.o_hard;  // the tasks only produce its ||z||^2 (<= 64 rows, so they fit)
+        const int nh = __builtin_popcountll(F.hmask);
         __builtin_amdgcn_wave_barrier();
-        if (F.o_bad) tb.task_s[__builtin_popcountll(F.fm & lowmask)] = (unsigned)lane;
-        ntasks = __builtin_popcountll(F.fm);
+        if (F.hmask && F.ndirect + nh <= 64) {
+            if (F.o_hard) tb.task_s[F.ndirect + __builtin_popcountll(F.hmask & lowmask)] = (unsigned)lane;   // (over the second screen's tasks)
+            o_wide = o_wide || F.o_hard;
+            ntasks = F.ndirect + nh;
+        } else {                            // more tasks than entries from the open rows alone: every flagged row goes wide
+            o_wide = o_wide || F.o_open || F.o_hard;
+            if (o_wide) tb.task_s[__builtin_popcountll(F.fm & lowmask)] = (unsigned)lane;
+            ntasks = __builtin_popcountll(F.fm);
+        }
     }
     lds_order_wave();
     const auto cb_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(cb), 0, (unsigned)K * (D * 4), 0x00020000);
@@ -300,25 +317,59 @@ __device__ __forceinline__ void exact_end_sp(RowsSp<T> &R, Flagged &F, int ntask
     }
     lds_order_wave();
     int o_best = 0;
-    if ((F.o_open || F.o_hard) && !F.o_bad) {
+    if ((F.o_open || F.o_hard) && !o_wide) {
         const unsigned long long bk = tb.best_s[lane];
-        if (bk != ~0ull) o_best = (int)(unsigned)bk; else F.o_bad = true;   // no task came back (cannot happen): scalar path
+        if (bk != ~0ull) o_best = (int)(unsigned)bk; else o_wide = true;   // no task came back (cannot happen): the wide path
     }
-    if (F.o_bad) {
-        // torch.argmin semantics (NaN is minimal, first index wins), one lane per row
-        const float zz = tb.zz_s[lane];                                   // every flagged row had a task
-        int best = 0;
-        if (zz == zz) {                                                   // NaN ||z||^2: every distance is NaN -> index 0
-            float bd = 0.0f;
-            for (int k = 0; k < K; ++k) {
-                float m = 0.0f;
-                for (int c = 0; c < D; ++c) m = __builtin_fmaf(zscalar(lane, c), cb[(size_t)k * D + c], m);
-                const float d = (zz + ee_g[k]) - 2.0f * m;
-                const bool dn = d != d, bn = bd != bd;
-                if ((k == 0) || (dn ? !bn : (!bn && d < bd))) { best = k; bd = d; }
+    // torch.argmin over ALL codes (NaN is minimal, first index wins) for the rows the tasks cannot decide.  The overflow kind is what
+    // a TRAINED checkpoint produces -- its hundreds of dead codes still sit within 1/K of the origin, nearly one point at the scale of
+    // |z| ~ 10, so a row near them finds hundreds of codes above its threshold.  Round 6: the WAVE takes such a row -- lane l the codes
+    // l, l + 64, ... four at a time, each the same c-ordered fmaf chain on the row's fp32 data (broadcast from the 256 bytes of the task
+    // table, which nobody reads any more), (distance, index) keys folded by the 64-bit LDS minimum -- instead of one lane running K x D
+    // serial fmaf: 33 such rows among 262 144 made the kernel 14 times slower on the trained checkpoints (profiles/r06_vq_trained.txt).
+    unsigned long long wm = __builtin_amdgcn_ballot_w64(o_wide);
+    if (wm) {
+        float *zrow_s = reinterpret_cast<float *>(tb.task_s);
+        do {
+            const int r = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wm));
+            wm &= wm - 1ull;
+            __builtin_amdgcn_wave_barrier();
+            zrow_s[lane] = zscalar(r, lane);
+            if (lane == 0) tb.best_s[r] = ~0ull;
+            lds_order_wave();
+            const float zz = tb.zz_s[r];                                  // every wide row had a task
+            int best = 0;
+            if (zz == zz) {                                               // NaN ||z||^2: every distance is NaN -> index 0
+                unsigned long long key = ~0ull;
+                for (int kb = lane; kb < K; kb += 256) {                  // codes kb, kb + 64, kb + 128, kb + 192 (past K: zeros, dropped)
+                    float m[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll 2
+                    for (int c4 = 0; c4 < D / 4; ++c4) {
+                        const f32x4 zv = *reinterpret_cast<const f32x4 *>(zrow_s + 4 * c4);
+                        f32x4 e[4];
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            e[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(cb_rs, (unsigned)(kb + 64 * i) * (D * 4) + (unsigned)c4 * 16u, 0, 0));
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            m[i] = __builtin_fmaf(zv.w, e[i].w, __builtin_fmaf(zv.z, e[i].z, __builtin_fmaf(zv.y, e[i].y, __builtin_fmaf(zv.x, e[i].x, m[i]))));
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const int k = kb + 64 * i;
+                        if (k < K) {
+                            const float d = (zz + ee_g[k]) - 2.0f * m[i];
+                            const unsigned long long kk = d != d ? (unsigned long long)(unsigned)k : trk::dist_key(d, k);   // NaN below every distance
+                            key = kk < key ? kk : key;
+                        }
+                    }
+                }
+                atomicMin(&tb.best_s[r], key);
+                lds_order_wave();
+                best = (int)(unsigned)tb.best_s[r];
             }
-        }
-        o_best = best;
+            if (lane == r) o_best = best;
+        } while (wm);
     }
     if (R.open || R.hard || R.bad) R.kbest = o_best;
     __builtin_amdgcn_wave_barrier();
