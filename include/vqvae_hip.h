@@ -555,6 +555,11 @@ VQVAE_API int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int6
                                      void *vq_workspace, size_t vq_workspace_bytes, vqvae_stream_t stream);
 VQVAE_API int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float *loss, float *perplexity,
                                     void *workspace, size_t workspace_bytes, vqvae_stream_t stream);
+/* Host-side state of the step in parts (the only state the library keeps): one record per `workspace` pointer in a process-wide table,
+ * opened by begin, closed by end.  A part whose launches fail gives its claim back (it may be retried); a step that will not be
+ * finished is dropped with vqvae_forward_abort_f32(workspace) -- otherwise its record stays until the next begin on the same pointer
+ * replaces it (a freed and reused pointer would inherit it only until that begin).  Always VQVAE_OK. */
+VQVAE_API int vqvae_forward_abort_f32(void *workspace);
 
 #ifdef __cplusplus
 }

@@ -575,3 +575,27 @@ def test_vq_heterogeneous_rows_on_every_kernel_family(K, D, N, rowmajor):
     np.testing.assert_array_equal(idx, ref["idx"])
     assert np.array_equal(zq.view(np.uint32), ref["z_q"].view(np.uint32))
     np.testing.assert_allclose(loss, ref["loss"], rtol=1e-5)
+
+
+def test_min_encodings_is_materialised_lazily():
+    """`min_encodings` (the (N, K) one-hot of models/quantizer.py:55-57; 512 MiB at BASELINE config 3's size) is built
+    on first use -- neither caller of the reference reads it (models/vqvae.py:34, visualization.ipynb:87).  The stand-in knows its
+    shape / dtype / device without a launch and is the real tensor for everything else."""
+    from vqvae_amd.modules import LazyOneHot, VectorQuantizer
+    torch.manual_seed(3)
+    vq = VectorQuantizer(96, 64, 0.25).to(_dev())
+    z = torch.randn(4, 64, 8, 8, device=_dev()) * 0.01
+    with torch.no_grad():
+        loss, z_q, ppl, oh, idx = vq(z)
+    assert isinstance(oh, LazyOneHot) and oh._t is None
+    assert oh.shape == (256, 96) and oh.dtype == torch.float32 and oh.device == idx.device and len(oh) == 256 and oh.numel() == 256 * 96
+    assert oh._t is None                                              # nothing above launched vqvae_vq_onehot_f32
+    want = torch.zeros(256, 96, device=_dev()).scatter_(1, idx, 1)
+    assert torch.equal(torch.matmul(oh, vq.embedding.weight.detach()), torch.matmul(want, vq.embedding.weight.detach()))   # a torch function
+    assert oh._t is not None
+    assert torch.equal(oh.cpu(), want.cpu()) and float(oh.sum()) == 256 and torch.equal(oh[3], want[3]) and torch.equal(oh * 2, want * 2)
+    assert torch.equal(torch.mean(oh, dim=0), torch.mean(want, dim=0))
+    vq.LAZY_MIN_ENCODINGS = False
+    with torch.no_grad():
+        oh2 = vq(z)[3]
+    assert isinstance(oh2, torch.Tensor) and torch.equal(oh2, want)

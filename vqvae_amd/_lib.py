@@ -107,6 +107,7 @@ SIGNATURES = {
     "vqvae_forward_begin_f32": (_i32, [_wp, _i64, _i32, _i32, _i32, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_part_f32": (_i32, [_wp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
     "vqvae_forward_end_f32": (_i32, [_wp, _i64, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "vqvae_forward_abort_f32": (_i32, [_vp]),
     "vqvae_gather_rows_f32": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp, _vp]),
     "vqvae_im2col_rows_f32": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vqvae_gated_activation_f32": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _vp, _vp]),

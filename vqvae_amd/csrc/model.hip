@@ -698,8 +698,27 @@ int vqvae_forward_part_f32(const VqvaeWeights *w, const float *x, int64_t B, int
     VqFuse vf = vq_fuse_args(w->codebook, d->n_embeddings, f.vqws, z_q_p, idx_p, f.hist);
     vf.partials = reinterpret_cast<double *>(f.z_e) + b0 / 4;
     const float *x_p = x + (size_t)b0 * d->in_ch * H * W;
-    if ((rc = encoder_run(w, x_p, Bc, H, W, f.z_e, acts_p, acts_p_bytes, st, am_p, nullptr, 0, nullptr, false, &vf)) != 0) return rc;
-    return decoder_run(w, z_q_p, Bc, H / 4, W / 4, x_hat + (size_t)b0 * d->in_ch * H * W, acts_p, acts_p_bytes, st, am_dec_p);
+    rc = encoder_run(w, x_p, Bc, H, W, f.z_e, acts_p, acts_p_bytes, st, am_p, nullptr, 0, nullptr, false, &vf);
+    if (rc == 0) rc = decoder_run(w, z_q_p, Bc, H / 4, W / 4, x_hat + (size_t)b0 * d->in_ch * H * W, acts_p, acts_p_bytes, st, am_dec_p);
+    if (rc != 0) {
+        // a part whose launches failed gives its claim back: the caller may retry [b0, b0 + Bc)
+        std::lock_guard<std::mutex> lk(g_parts_mu);
+        auto it = g_parts.find(workspace);
+        if (it != g_parts.end()) {
+            auto &cl = it->second.claimed;
+            for (size_t i = 0; i < cl.size(); ++i)
+                if (cl[i].first == b0 && cl[i].second == b0 + Bc) { cl.erase(cl.begin() + (long)i); break; }
+        }
+    }
+    return rc;
+}
+
+// Drops the host-side record of a step in parts that will not be finished (a begin without an end otherwise stays in the process-wide
+// table, keyed by the workspace pointer, until the next begin on that pointer replaces it).  Always VQVAE_OK.
+int vqvae_forward_abort_f32(void *workspace) {
+    std::lock_guard<std::mutex> lk(g_parts_mu);
+    g_parts.erase(workspace);
+    return VQVAE_OK;
 }
 
 int vqvae_forward_end_f32(const VqvaeWeights *w, int64_t B, int H, int W, float *loss, float *perplexity, void *workspace,

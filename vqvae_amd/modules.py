@@ -53,8 +53,82 @@ def _need_hip_f32(x, who):
         raise VqvaeHipError(f"{who} needs a CUDA(HIP) fp32 input: there is no CPU path")
 
 
+class LazyOneHot:
+    """`min_encodings` of VectorQuantizer.forward (models/quantizer.py:55-57): the (N, K) fp32 one-hot -- 512 MiB at BASELINE config
+    3's size, 128 GiB at config 5's -- which neither caller of the reference reads (models/vqvae.py:34 and visualization.ipynb:87
+    both discard it).  SURVEY.md 8b: materialise lazily.  This stands in the return tuple, knows its shape / dtype / device, and
+    becomes the real tensor (vqvae_vq_onehot_f32, once) the moment anything is done with it: attribute access, indexing, arithmetic,
+    or being passed to a torch function.  `VectorQuantizer.LAZY_MIN_ENCODINGS = False` returns the tensor itself as before."""
+
+    def __init__(self, idx, n_e):
+        self._idx, self._n_e, self._t = idx, n_e, None
+
+    def materialize(self):
+        if self._t is None:
+            self._t = F_hip.vq_onehot(self._idx, self._n_e)
+        return self._t
+
+    @property
+    def shape(self):
+        return torch.Size((self._idx.shape[0], self._n_e))
+
+    @property
+    def dtype(self):
+        return torch.float32
+
+    @property
+    def device(self):
+        return self._idx.device
+
+    def size(self, dim=None):
+        return self.shape if dim is None else self.shape[dim]
+
+    def dim(self):
+        return 2
+
+    def numel(self):
+        return self._idx.shape[0] * self._n_e
+
+    def __len__(self):
+        return self._idx.shape[0]
+
+    def __getattr__(self, name):                      # anything else: the tensor's
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        def real(a):
+            if isinstance(a, LazyOneHot):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(v) for v in a)
+            return a
+        return func(*real(args), **{k: real(v) for k, v in (kwargs or {}).items()})
+
+    def __repr__(self):
+        return f"LazyOneHot(shape={tuple(self.shape)}, materialized={self._t is not None})"
+
+
+def _delegate(name):
+    def op(self, *a, **k):
+        return getattr(self.materialize(), name)(*[v.materialize() if isinstance(v, LazyOneHot) else v for v in a], **k)
+    op.__name__ = name
+    return op
+
+
+for _n in ("__getitem__", "__iter__", "__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__matmul__",
+           "__rmatmul__", "__eq__", "__ne__", "__lt__", "__le__", "__gt__", "__ge__", "__neg__", "__bool__", "__float__", "__int__",
+           "__array__"):
+    setattr(LazyOneHot, _n, _delegate(_n))
+LazyOneHot.__hash__ = object.__hash__
+
+
 class VectorQuantizer(nn.Module):
     """Discretisation bottleneck; mirrors models/quantizer.py:10-76."""
+
+    LAZY_MIN_ENCODINGS = True          # forward()'s fourth output: LazyOneHot (the (N, K) one-hot on first use) or the tensor itself
 
     def __init__(self, n_e, e_dim, beta):
         super().__init__()
@@ -106,7 +180,7 @@ class VectorQuantizer(nn.Module):
 
     def forward(self, z):
         loss, z_q, perplexity, idx, _ = self.quantize(z)
-        min_encodings = F_hip.vq_onehot(idx, self.n_e)                         # quantizer.py:55-57
+        min_encodings = LazyOneHot(idx, self.n_e) if self.LAZY_MIN_ENCODINGS else F_hip.vq_onehot(idx, self.n_e)   # quantizer.py:55-57
         return loss, z_q, perplexity, min_encodings, idx
 
 
@@ -232,6 +306,11 @@ class VQVAE(nn.Module):
             if isinstance(mod, VectorQuantizer):
                 mod.invalidate()
 
+    # forward / encode / decode_indices follow vqvae_weights_range_check_f32's recommendation for the checkpoint (scheme_hint()) unless
+    # the caller names a scheme.  False: never check (no host sync per weight version -- an eval forward after every optimizer step
+    # pays one otherwise), always the default two-term fp16 products unless a scheme is named.
+    AUTO_SCHEME = True
+
     # ---- whole-path C ABI (include/vqvae_hip.h: vqvae_forward_f32) ------------------------------------------------
     _RAW = {"enc0_w": "encoder.conv_stack.0.weight", "enc0_b": "encoder.conv_stack.0.bias",
             "enc2_w": "encoder.conv_stack.2.weight", "enc2_b": "encoder.conv_stack.2.bias",
@@ -278,16 +357,36 @@ class VQVAE(nn.Module):
         with torch.cuda.device(w0.device):
             _lib.check(L.vqvae_weights_pack_f32(dims, raw, packed.data_ptr(), nbytes, cw,
                                                 torch.cuda.current_stream(w0.device).cuda_stream))
-            # which product scheme this checkpoint calls for (vqvae_weights_range_check_f32: once per weight version, one sync)
+            # which product scheme this checkpoint calls for (vqvae_weights_range_check_f32: once per weight version, one sync).
+            # Not while a stream capture is recording (the check synchronises): the previous version's hint stands, or none.
             import ctypes
             rec = ctypes.c_int(0)
             spreads = (ctypes.c_float * 11)()
-            scratch = torch.empty(16, dtype=torch.float32, device=w0.device)
-            _lib.check(L.vqvae_weights_range_check_f32(dims, raw, spreads, ctypes.byref(rec), scratch.data_ptr(), 64,
-                                                       torch.cuda.current_stream(w0.device).cuda_stream))
+            hint = None
+            if self.AUTO_SCHEME and not torch.cuda.is_current_stream_capturing():
+                scratch = torch.empty(16, dtype=torch.float32, device=w0.device)
+                _lib.check(L.vqvae_weights_range_check_f32(dims, raw, spreads, ctypes.byref(rec), scratch.data_ptr(), 64,
+                                                           torch.cuda.current_stream(w0.device).cuda_stream))
+                hint = (int(rec.value), [float(v) for v in spreads])
+            elif self.AUTO_SCHEME:
+                hint = _cache.side(self).get("c_scheme_hint")
+                import warnings
+                warnings.warn("VQVAE: new weights met inside a stream capture -- the range check (a host sync) is skipped and "
+                              + ("the previous weights' product scheme is kept" if hint else "the default two-term fp16 scheme is used")
+                              + "; run one forward outside the capture first, or name a scheme (fwd_flags)", RuntimeWarning, stacklevel=3)
             ready = _cache.mark_ready(w0.device)
+        if hint is None:
+            hint = (0, [0.0] * 11)
+        old = _cache.side(self).get("c_scheme_hint")
+        if hint[0] and (old is None or old[0] != hint[0]):
+            # the whole path changes kernels, numerics and speed with this: say so once per flip, never silently
+            import warnings
+            warnings.warn(f"VQVAE: this checkpoint's weights spread over {max(hint[1]):.1f} binades of input-channel magnitude in one layer "
+                          "(limit 10): forward / encode / decode_indices run the three-term bf16 scheme (VQVAE_FWD_CONV_BF16_SPLIT, about "
+                          "half the speed of the default two-term fp16 products).  Name a scheme (fwd_flags=...) or set "
+                          "VQVAE.AUTO_SCHEME = False to decide yourself", RuntimeWarning, stacklevel=3)
         _cache.side(self)["c_weights"] = (key, cw, (keep, packed), ready)
-        _cache.side(self)["c_scheme_hint"] = (int(rec.value), [float(v) for v in spreads])
+        _cache.side(self)["c_scheme_hint"] = hint
         return cw, (keep, packed)
 
     def scheme_hint(self):
@@ -334,6 +433,9 @@ class VQVAE(nn.Module):
                                                     idx.data_ptr() if idx is not None else None, ws.data_ptr(), nws, vws.data_ptr(),
                                                     vws.numel(), s.cuda_stream))
                 b0 += bc
+        except BaseException:
+            L.vqvae_forward_abort_f32(ws.data_ptr())              # the step will not be finished: drop its host-side record
+            raise
         finally:
             # ALWAYS: the caller's stream must not free or reuse x_hat / ws / idx while a side stream still writes them, also
             # when a part raised
@@ -460,10 +562,12 @@ class VQVAE(nn.Module):
         return idx
 
     @torch.no_grad()
-    def decode_indices(self, idx, B, H, W, fwd_flags=None):
+    def decode_indices(self, idx, B, H, W, fwd_flags=None, validate=True):
         """indices -> x_hat (visualization.ipynb:358-365 generate_samples) as ONE call (vqvae_decode_f32): on the default shapes
         the decoder's first kernel takes every latent pixel's row straight from the codebook -- z_q is never written.
-        H, W: the LATENT map's size.  Indices outside [0, K) raise, as the reference's one-hot scatter does."""
+        H, W: the LATENT map's size.  Indices outside [0, K) raise, as the reference's one-hot scatter does -- that check reads
+        idx.min() / idx.max() on the host (one sync per call); validate=False skips it for indices that come from encode(): the C
+        entry never reads outside the codebook either way, a bad index shows as NaN pixels of its image (include/vqvae_hip.h)."""
         from . import _lib, conv as C_hip
         K = self.vector_quantization.n_e
         if idx.numel() != B * H * W:
@@ -472,7 +576,7 @@ class VQVAE(nn.Module):
             z_q = F_hip.vq_decode_indices(idx, self.vector_quantization.embedding.weight.detach(), B, H, W)
             return self.decoder(z_q)
         idx = idx.contiguous().view(-1).to(torch.int64)
-        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= K):
+        if validate and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= K):
             raise IndexError(f"code index out of range [0, {K})")
         L = _lib.load()
         cw, _keep = self._c_weights()
