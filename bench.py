@@ -90,6 +90,7 @@ def parse():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="lower bound on the timed work (sets the repeats)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-power", action="store_true", help="skip the ~3.5 s power / clock sampling run behind the timed region")
     ap.add_argument("--no-other-workloads", action="store_true",
                     help="skip the appended measurements of BASELINE configs 2 / 4 / 5 (default line, 1 GPU, c3 only)")
     ap.add_argument("--dry-run", action="store_true",
@@ -199,6 +200,114 @@ def cpu_baseline(seconds: float, torch):
             "survey_8d": survey_8d,
             "sample": "VQVAE.forward 32x32x3 K=512 D=64 fp32 eval/no_grad on the host CPU (" + cpu +
                       f", {ncpu} logical cpus); ~{per:.1f}s per (threads,batch) point, img/s: " + " ".join(detail)}
+
+
+class PowerSampler:
+    """Package power (W) and shader clock (MHz) of the GPU, sampled in a thread while something runs: the amdgpu hwmon files where the
+    box exposes them (power1_average / power1_input in microwatt, freq1_input in Hz: a read costs microseconds), else `rocm-smi
+    --showpower --showclocks --json` (~0.4 s per sample).  bench.py samples a SEPARATE sustained run of the step behind the timed
+    region (a subprocess per sample beside the timed loop would be a perturbation of its own)."""
+
+    def __init__(self, pci: str | None = None, period: float = 0.05):
+        """pci: the device's PCI address ("0000:c1:00.0"; PowerSampler.pci_of(torch, dev)) -- a box shows the hwmon files of EVERY GPU of
+        the node, also of those this process cannot open"""
+        import glob
+        self.period, self.samples, self._stop, self._thread = period, [], None, None
+        self.power_file = self.freq_file = None
+        self.pci = pci
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        if pci:
+            cards = [c for c in cards if os.path.basename(os.path.realpath(c)).lower() == pci.lower()]
+        for hw in [h for c in cards for h in sorted(glob.glob(os.path.join(c, "hwmon/hwmon*")))]:
+            for name in ("power1_average", "power1_input"):
+                f = os.path.join(hw, name)
+                if self.power_file is None and os.path.exists(f) and self._read(f) is not None:
+                    self.power_file = f
+            f = os.path.join(hw, "freq1_input")
+            if self.freq_file is None and os.path.exists(f) and self._read(f) is not None:
+                self.freq_file = f
+            if self.power_file:
+                break
+        self.mode = "hwmon" if self.power_file else "rocm-smi"
+
+    @staticmethod
+    def pci_of(torch, dev):
+        try:
+            p = torch.cuda.get_device_properties(dev)
+            return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except Exception:                          # noqa: BLE001
+            return None
+
+    @staticmethod
+    def _read(path):
+        try:
+            with open(path) as f:
+                return float(f.read().strip())
+        except (OSError, ValueError):
+            return None
+
+    def describe(self):
+        return (f"{self.mode} of {self.pci}: power={self.power_file} sclk={self.freq_file}" if self.mode == "hwmon" else
+                "rocm-smi --showpower --showclocks --json")
+
+    def _one(self):
+        if self.mode == "hwmon":
+            p = self._read(self.power_file)
+            f = self._read(self.freq_file) if self.freq_file else None
+            return (p / 1e6 if p is not None else None, f / 1e6 if f is not None else None)
+        try:
+            out = subprocess.run(["rocm-smi", "--showpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=10).stdout
+            card = next(iter(json.loads(out).values()))
+            p = next((float(v) for k, v in card.items() if "power" in k.lower() and "(w)" in k.lower()), None)
+            f = next((float(str(v).strip("()").lower().replace("mhz", "")) for k, v in card.items() if k.lower().startswith("sclk clock speed")), None)
+            return (p, f)
+        except Exception:                          # noqa: BLE001  (a sample is optional)
+            return (None, None)
+
+    def start(self):
+        import threading
+        self.samples, self._stop = [], threading.Event()
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append(self._one())
+                self._stop.wait(self.period)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self):
+        self._stop.set()
+        self._thread.join(timeout=15)
+        ps = [p for p, _ in self.samples if p is not None]
+        fs = [f for _, f in self.samples if f is not None]
+        r1 = lambda v: round(v, 1)                  # noqa: E731
+        return {"source": self.describe(), "samples": len(self.samples),
+                "power_w_avg": r1(sum(ps) / len(ps)) if ps else None, "power_w_min": r1(min(ps)) if ps else None, "power_w_max": r1(max(ps)) if ps else None,
+                "sclk_mhz_avg": r1(sum(fs) / len(fs)) if fs else None, "sclk_mhz_min": r1(min(fs)) if fs else None, "sclk_mhz_max": r1(max(fs)) if fs else None}
+
+
+def step_power(step, torch, dev, seconds=3.0):
+    """Average package power and shader clock while the step runs back to back for `seconds` (a run of its own behind the timed region)."""
+    S = PowerSampler(PowerSampler.pci_of(torch, dev))
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < 0.5:          # ramp: the clock needs a moment of load to settle
+        step()
+    torch.cuda.synchronize()
+    S.start()
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for _ in range(20):
+            step()
+        torch.cuda.synchronize()
+        n += 20
+    el = time.perf_counter() - t0
+    r = S.stop()
+    r["ms_per_step_during_sampling"] = round(el / n * 1e3, 4)
+    r["seconds"] = round(el, 2)
+    if r.get("sclk_mhz_avg"):
+        # work per shader cycle: what stays of the step when the clock a box holds at its power cap is divided out
+        r["us_per_step_x_ghz"] = round(el / n * 1e6 * r["sclk_mhz_avg"] / 1e3, 1)
+    return r
 
 
 def calibrate(torch, dev, seconds=0.6):
@@ -428,6 +537,37 @@ def other_workload(name, torch, dev, seconds=1.0):
                      # at K >= 1024 the screen is matrix-bound, not HBM-bound
                      "screen_tflops_16bit": round(2.0 * rows * K * D / t_vq / 1e12, 1),
                      "mfma_frac": round(2.0 * rows * K * D / t_vq / 1e12 / MFMA_16BIT_PEAK_TFLOPS, 4)}
+    if name == "c2" and vq_n:
+        # The same launch STAND-ALONE on the step's own z_e (back-to-back launches, warm L2 / clocks) beside the in-situ figure above
+        # (one launch per step between MIOpen's convs: the codebook image and the kernel's code are cold, the clock follows the convs'
+        # load): VERDICT r5 weak 6 -- 41.5 us in situ against 17.5 us stand-alone on the driver's box.  README quotes the in-situ one
+        # for config 2 (it is what the step pays) and says so.
+        try:
+            from vqvae_amd import conv_hip as _ch, functional as F_
+            with torch.no_grad():
+                z_rows = model.pre_quantization_conv(model.encoder(x)).permute(0, 2, 3, 1).contiguous() if conv_backend == "torch" else \
+                    _ch.encoder_forward(model.encoder, x, model.pre_quantization_conv)
+                cbw = model.vector_quantization.embedding.weight.detach().contiguous()
+                ws_s = F_.vq_workspace(K, D, dev)
+                F_.vq_forward(z_rows, cbw, 0.25, rowmajor=True, workspace=ws_s)
+                for _ in range(3):
+                    F_.vq_forward(z_rows, cbw, 0.25, rowmajor=True, workspace=ws_s, prepared=True)
+                torch.cuda.synchronize()
+                _lib.profile_enable(True)
+                for _ in range(30):
+                    F_.vq_forward(z_rows, cbw, 0.25, rowmajor=True, workspace=ws_s, prepared=True)
+                ms_s, n_s = _lib.profile_collect("vq_main")
+                _lib.profile_enable(False)
+            t_s = ms_s / max(n_s, 1) * 1e-3
+            res["vq"]["timing"] = "in situ: one launch per step between the torch (MIOpen) convs"
+            res["vq_standalone"] = {"kernel": res["vq"]["kernel"], "avg_kernel_us": round(t_s * 1e6, 2),
+                                    "hbm_frac": round(rows * (8 * D + 8) / t_s / 1e9 / HBM_PEAK_GBPS, 4),
+                                    "timing": "30 back-to-back launches on the step's own z_e (warm L2, steady clock)",
+                                    "in_situ_over_standalone": round(t_vq / t_s, 2)}
+            del z_rows, ws_s
+        except Exception as e:                               # noqa: BLE001
+            _lib.profile_enable(False)
+            res["vq_standalone"] = {"error": repr(e)[:200]}
     if name == "c2":
         # the same quantizer at the REFERENCE's own boundary: VectorQuantizer.forward(z) takes NCHW (models/quantizer.py:45-46, :74 are its
         # permute + copy passes) -- what integration/vqvae_hip_stub.py binds; timed by the dispatch's events like the row-major figure
@@ -939,6 +1079,11 @@ def main():
         }
         line["per_rank"] = per_rank
         if calib:
+            # next to `value`: the box's bare-MFMA rate and clock, and the value on the calibration's reference box
+            line = {k: v for k, v in list(line.items())[:2]} | {
+                "value_normalised": round(line["value"] * CALIB_REFERENCE_TFLOPS / max(calib["mfma_fp16_random_tflops"], 1.0), 1),
+                "calibration_mfma_fp16_random_tflops": calib["mfma_fp16_random_tflops"], "calibration_sclk_ghz": calib["sclk_ghz"],
+                "calibration_reference_tflops": CALIB_REFERENCE_TFLOPS} | {k: v for k, v in list(line.items())[2:]}
             line["calibration"] = calib
             # the same build on the calibration's reference box: value x (reference / measured) -- a first-order correction (the
             # step is matrix-bound: 93 % of it is conv kernels at 60-70 % of this stream's rate)
@@ -1027,6 +1172,13 @@ def main():
                                                                    "~10 % to a step; profiles/ holds the rocprofv3 figures)")
                                for k, v in extra.items()}
             line["source_sha"] = source_sha()
+            if n_gpus == 1 and not args.no_power:
+                # package power / shader clock while the SAME step runs back to back (its own ~3 s run behind the timed region: the
+                # hwmon files of this GPU, 50 ms apart).  The step sits at the package limit -- that, not issue slots, is its ceiling
+                try:
+                    line["power"] = step_power(step, torch, dev)
+                except Exception as e:                 # noqa: BLE001
+                    line["power"] = {"error": f"{type(e).__name__}: {e}"[:200]}
             if n_gpus == 1 and not args.no_cpu_baseline:
                 if args.workload == "c3" and conv_backend == "hip":
                     line["index_flips_vs_reference"] = index_flips(model, x, torch)
