@@ -159,6 +159,32 @@ def vq_forward(z_nchw, codebook, beta, want_dist=False):
     return out
 
 
+def vq_indices_rows(z_rows, codebook, threads=None, slab=8192):
+    """min_encoding_indices (N,) int64 of row-major rows (N, D): vqo_vq_indices_rows -- the arithmetic of vq_forward, eight codes per
+    AVX2 register -- with the row slabs spread over host threads (ctypes releases the GIL; rows are independent).  The checker for
+    the full-size configs: 1.6 M rows x K = 1024 in about a second on the GPU box's host."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
+    z = _f32(z_rows)
+    cb = _f32(codebook)
+    N, D = z.shape
+    K = cb.shape[0]
+    assert cb.shape[1] == D
+    idx = np.empty((N,), np.int64)
+    fn = lib().vqo_vq_indices_rows
+    if threads is None:
+        threads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 128))
+
+    def work(lo):
+        hi = min(N, lo + slab)
+        rc = fn(_p(z[lo:hi]), _p(cb), C.c_int64(hi - lo), D, K, _p(idx[lo:hi], C.c_int64))
+        if rc != 0:
+            raise MemoryError("vqo_vq_indices_rows")
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        list(ex.map(work, range(0, N, slab)))
+    return idx
+
+
 def onehot(idx, K):
     idx = np.ascontiguousarray(idx, np.int64).reshape(-1)
     out = np.empty((idx.shape[0], K), np.float32)

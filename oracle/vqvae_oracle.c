@@ -217,6 +217,71 @@ VQO_API int vqo_vq_forward(const float *z_nchw, const float *codebook,
     return 0;
 }
 
+/* ------------------------------------------------------------------------ */
+/* min_encoding_indices only, for row-major rows, FAST (round 6): the checker for
+ * BASELINE configs 4 / 5 at full size (1.6 M rows x K = 1024; 4.2 M rows x
+ * K = 8192, D = 128 -- 4.4 TFLOP, hours for the scalar loop above).  The SAME
+ * arithmetic as vqo_vq_forward (models/quantizer.py:45-54): per (row, code) one
+ * c-ordered fmaf chain from 0 -- here eight codes per AVX2 register (vfmadd231ps
+ * is fmaf in every lane: one rounding), four registers in flight, on a transposed
+ * copy of the codebook --, then fl(fl(zz + ee_k) - fl(2 m)) and the first-index /
+ * NaN-minimal argmin, scalar and in code order.  tests/test_oracle.py holds it
+ * against vqo_vq_forward and the reference's goldens bit for bit.  The caller
+ * (oracle/c_oracle.py: vq_indices_rows) spreads row slabs over host threads.     */
+#include <immintrin.h>
+VQO_API int vqo_vq_indices_rows(const float *z_rows, const float *codebook,
+                                int64_t N, int D, int K, int64_t *idx)
+{
+    const int Kp = (K + 31) & ~31;
+    float *et = (float *)aligned_alloc(32, sizeof(float) * (size_t)D * (size_t)Kp);
+    float *ee = (float *)malloc(sizeof(float) * (size_t)K);
+    float *m = (float *)aligned_alloc(32, sizeof(float) * (size_t)Kp);
+    if (!et || !ee || !m) { free(et); free(ee); free(m); return -1; }
+    memset(et, 0, sizeof(float) * (size_t)D * (size_t)Kp);
+    for (int k = 0; k < K; ++k)
+        for (int c = 0; c < D; ++c)                           /* block-major: [k / 32][c][k % 32], a block is 32 x D contiguous floats */
+            et[((size_t)(k >> 5) * D + c) * 32 + (k & 31)] = codebook[(size_t)k * D + c];
+    vqo_row_sqnorm(codebook, K, D, ee);                       /* :50 */
+    /* code blocks outside, rows inside (a block's 32 x D transposed codes stay in L1 across the rows); blocks in ascending order and a
+     * strict "better" keep torch.argmin's first-index rule                                                                          */
+    float *zz = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    float *bd = (float *)malloc(sizeof(float) * (size_t)(N > 0 ? N : 1));
+    if (!zz || !bd) { free(et); free(ee); free(m); free(zz); free(bd); return -1; }
+    vqo_row_sqnorm(z_rows, N, D, zz);                         /* :49 */
+    for (int k0 = 0; k0 < Kp; k0 += 32) {
+        const int kend = k0 + 32 < K ? k0 + 32 : K;
+        for (int64_t n = 0; n < N; ++n) {
+            const float *row = z_rows + n * D;
+            __m256 a0 = _mm256_setzero_ps(), a1 = a0, a2 = a0, a3 = a0;
+            const float *e = et + (size_t)(k0 >> 5) * D * 32;
+            for (int c = 0; c < D; ++c, e += 32) {            /* :51 -- every lane its own chain, c ascending */
+                const __m256 zb = _mm256_broadcast_ss(row + c);
+                a0 = _mm256_fmadd_ps(zb, _mm256_load_ps(e), a0);
+                a1 = _mm256_fmadd_ps(zb, _mm256_load_ps(e + 8), a1);
+                a2 = _mm256_fmadd_ps(zb, _mm256_load_ps(e + 16), a2);
+                a3 = _mm256_fmadd_ps(zb, _mm256_load_ps(e + 24), a3);
+            }
+            _mm256_store_ps(m, a0);
+            _mm256_store_ps(m + 8, a1);
+            _mm256_store_ps(m + 16, a2);
+            _mm256_store_ps(m + 24, a3);
+            int64_t best = k0 ? idx[n] : 0;
+            float best_d = k0 ? bd[n] : 0.0f;
+            for (int k = k0; k < kend; ++k) {
+                volatile float t = zz[n] + ee[k];             /* :49-50 add  */
+                volatile float u = 2.0f * m[k - k0];          /* :50 2 * mm  */
+                volatile float dk = t - u;                    /* :50 sub     */
+                if (k == 0 || vqo_less_or_nan(dk, best_d)) { best = k; best_d = dk; }
+            }
+            idx[n] = best;                                    /* :54 */
+            bd[n] = best_d;
+        }
+    }
+    free(zz); free(bd);
+    free(et); free(ee); free(m);
+    return 0;
+}
+
 /* min_encodings one-hot (N,K) fp32 -- models/quantizer.py:55-57.            */
 VQO_API void vqo_onehot(const int64_t *idx, int64_t N, int K, float *onehot)
 {

@@ -219,3 +219,28 @@ def test_trained_goldens_reproduce_from_the_unmodified_reference(name, golden_tr
         loss, x_hat, ppl = m(torch.from_numpy(golden_trained[f"{name}/x"]))
     assert cases.sha(x_hat) == golden_trained[f"{name}/sha"][3]
     assert loss.item() == golden_trained[f"{name}/loss"].item()
+
+
+@pytest.mark.parametrize("name", VQ_NAMES)
+def test_fast_index_oracle_equals_the_scalar_one(name, golden_vq):
+    """Round 6: vqo_vq_indices_rows (eight codes per AVX2 register, host threads over row slabs -- the checker of the full-size
+    configs) against the reference's goldens: every shape incl. ties, NaN / Inf rows, K not a multiple of 32, D = 7 ... 256."""
+    z, cb, beta = cases.vq_inputs(name)
+    rows = z.permute(0, 2, 3, 1).reshape(-1, z.shape[1]).contiguous().numpy()
+    for threads, slab in ((1, 8192), (4, 7)):
+        got = c_oracle.vq_indices_rows(rows, cb.numpy(), threads=threads, slab=slab)
+        np.testing.assert_array_equal(got, golden_vq[f"{name}/idx"].astype(np.int64))
+
+
+def test_fast_index_oracle_on_trained_rows_and_random_shapes(golden_trained):
+    for name in cases.TRAINED_CASES:
+        g_ze = golden_trained[f"{name}/z_e"]
+        rows = np.ascontiguousarray(np.transpose(g_ze, (0, 2, 3, 1)).reshape(-1, g_ze.shape[1]))
+        cb = cases.trained_state(name)["vector_quantization.embedding.weight"].numpy()
+        np.testing.assert_array_equal(c_oracle.vq_indices_rows(rows, cb), golden_trained[f"{name}/idx"].astype(np.int64))
+    g = torch.Generator().manual_seed(5)
+    for K, D, N in ((1024, 64, 3000), (8192, 128, 300), (33, 48, 100), (1, 64, 10)):
+        z = torch.randn(N, D, generator=g) * 0.07
+        cb = (torch.rand(K, D, generator=g) * 2 - 1) / K
+        want = c_oracle.vq_forward(z.view(N, D, 1, 1).numpy(), cb.numpy(), 0.25)["idx"].reshape(-1)
+        np.testing.assert_array_equal(c_oracle.vq_indices_rows(z.numpy(), cb.numpy()), want)
