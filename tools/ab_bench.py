@@ -7,7 +7,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for rnd in range(3):
     for lib in libs:
         env = dict(os.environ, VQVAE_HIP_LIB_OVERRIDE=lib)
-        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-other-workloads", "--steps", "20", "--min-seconds", "0.5"],
+        out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--no-cpu-baseline", "--no-power", "--no-other-workloads", "--steps", "20", "--min-seconds", "0.5"],
                              capture_output=True, text=True, env=env).stdout.strip().splitlines()[-1]
         d = json.loads(out)
         k = d["kernels"]

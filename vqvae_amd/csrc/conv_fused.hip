@@ -1197,18 +1197,20 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                 roff[mt][g] = (row >= 0 && row < 32) ? (unsigned)((row * 32 + 4 * (lane & 7)) * 4) : kOobOffset;
                 only1[mt][g] = row == 31;
             }
-        f32x4 ov[CO][MT][2];
-        if (py > 0) {
+        // pass 1 reads what pass 0 stored: one channel's four quads a channel ahead (round 6: all three channels' twelve quads at once
+        // were 48 registers on top of T's 96 and the next pass's parked activations -- most of the kernel's 56 spilled registers)
+        f32x4 ov[2][MT][2];
+        auto ov_load = [&](int co, f32x4(&o)[MT][2]) {
 #pragma unroll
-            for (int co = 0; co < CO; ++co)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g)
-                        ov[co][mt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, roff[mt][g], (unsigned)co * 4096u, 0));
-        }
+                for (int g = 0; g < 2; ++g)
+                    o[mt][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ors, roff[mt][g], (unsigned)co * 4096u, 0));
+        };
+        if (py > 0) ov_load(0, ov[0]);
 #pragma unroll
         for (int co = 0; co < CO; ++co) {
+            if (py > 0 && co + 1 < CO) ov_load(co + 1, ov[(co + 1) & 1]);
             const float bv = bias4 ? bias4[co] : 0.0f;
             const float w4d = h2_dw(hdr4)[co];                  // the output channel's own weight scale 2^-kw4[co] (wave-uniform)
             const float d40 = d4[0] * w4d, d41 = d4[1] * w4d;
@@ -1230,7 +1232,7 @@ __global__ __launch_bounds__(256, DT_MINW) void dec_tail8_h2_kernel(const float 
                     e.z = __builtin_fmaf(T0[r0 + 3], d40, b1);
                     e.w = ra0 + b2;
                     f32x4 base = {bv, bv, bv, bv};
-                    if (py > 0 && !only1[mt][g]) base = ov[co][mt][g];
+                    if (py > 0 && !only1[mt][g]) base = ov[co & 1][mt][g];
                     const f32x4 v = base + e;
                     // (the channel's offset in the VECTOR offset: a scalar-offset store followed by an overwrite of its data registers is the
                     // hazard hipcc leaves unguarded, tools/hazard_scan.py)
