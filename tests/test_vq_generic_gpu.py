@@ -50,10 +50,14 @@ def test_row_sqnorm_in_atens_order_bitwise_vs_torch(mode):
     (1, 48, 2, 4, 4, 1.0),           # single code
     (4096, 24, 1, 8, 8, 0.066),      # many codes per thread
 ])
-def test_vq_generic_matches_oracle_fresh(K, D, B, H, W, scale):
+@pytest.mark.parametrize("vector_units", [False, True], ids=["mfma_fp32", "vector_units"])
+def test_vq_generic_matches_oracle_fresh(K, D, B, H, W, scale, vector_units):
+    """Both implementations for these widths: round 6's matrix-core kernel (vq_anyd_kernel: rows and codes zero-padded to a multiple
+    of eight channels, v_mfma_f32_32x32x2_f32 = the reference's fmaf chain; the default) and round 5's per-thread chains
+    (vq_generic_kernel, behind VQVAE_VQ_BF16_FILTER)."""
     from oracle import c_oracle
     from vqvae_amd import _lib, functional as F
-    assert _lib.vq_kernel_name(K, D) == "vq_generic_kernel"
+    assert _lib.vq_kernel_name(K, D) == "vq_anyd_kernel" and _lib.vq_kernel_name(K, D, 0x1 | 0x8) == "vq_generic_kernel"
     g = torch.Generator().manual_seed(K * 7 + D + B)
     cb = ((torch.rand(K, D, generator=g) * 2 - 1) / K) if scale < 1 else torch.randn(K, D, generator=g)
     z = torch.randn(B, D, H, W, generator=g) * scale
@@ -62,7 +66,7 @@ def test_vq_generic_matches_oracle_fresh(K, D, B, H, W, scale):
         zd = z.to(_dev())
         if rowmajor:
             zd = zd.permute(0, 2, 3, 1).contiguous()
-        loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), 0.25, rowmajor=rowmajor)
+        loss, zq, ppl, idx, hist = F.vq_forward(zd, cb.to(_dev()), 0.25, rowmajor=rowmajor, bf16_filter=vector_units)
         torch.cuda.synchronize()
         if rowmajor:
             zq = zq.permute(0, 3, 1, 2).contiguous()
@@ -71,8 +75,46 @@ def test_vq_generic_matches_oracle_fresh(K, D, B, H, W, scale):
         np.testing.assert_allclose(loss.item(), ref["loss"], rtol=1e-6)
         np.testing.assert_allclose(ppl.item(), ref["perplexity"], rtol=1e-6)
         np.testing.assert_array_equal(hist.cpu().numpy(), ref["hist"])
-        _, none_zq, _, idx2, _ = F.vq_forward(zd, cb.to(_dev()), 0.25, rowmajor=rowmajor, want_zq=False)
+        _, none_zq, _, idx2, _ = F.vq_forward(zd, cb.to(_dev()), 0.25, rowmajor=rowmajor, want_zq=False, bf16_filter=vector_units)
         assert none_zq is None and torch.equal(idx2, idx)
+
+
+@pytest.mark.parametrize("K,D", [(512, 48), (100, 7), (300, 200), (64, 72), (9000, 40)])
+def test_vq_anyd_special_values_and_prepared_codebook(K, D):
+    """The matrix-core kernel's corners: NaN / Inf / overflowing rows (||z||^2 not < 1e38: vector-unit chains inside the kernel, torch.argmin's
+    NaN rule), an Inf in the codebook (every row takes that path), K beyond the LDS histogram, ragged last tile, a prepared codebook image
+    reused across calls -- against the oracle, and the two implementations against each other."""
+    from oracle import c_oracle
+    from vqvae_amd import functional as F
+    g = torch.Generator().manual_seed(K + D)
+    cb = torch.randn(K, D, generator=g)
+    n = 64 * 5 + 13
+    zr = torch.randn(n, D, generator=g)
+    zr[3, D // 2] = float("nan")
+    zr[10, 0] = float("inf")
+    zr[11, D - 1] = float("-inf")
+    zr[12, :] = 3.0e19                                 # zz overflows to +inf
+    zr[70, 1 % D] = 1.0e30
+    zr[n - 1, 0] = float("nan")
+    z = zr.view(n, 1, 1, D).permute(0, 3, 1, 2).contiguous()
+    for bad_cb in (False, True):
+        if bad_cb:
+            cb = cb.clone()
+            cb[K // 2, D // 3] = float("inf")
+        ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+        zd, cbd = z.to(_dev()), cb.to(_dev())
+        ws = F.vq_workspace(K, D, _dev())
+        a = F.vq_forward(zd, cbd, 0.25, workspace=ws)
+        b = F.vq_forward(zd, cbd, 0.25, workspace=ws, prepared=True)           # the same images again
+        c = F.vq_forward(zd, cbd, 0.25, bf16_filter=True)                       # round 5's kernel
+        torch.cuda.synchronize()
+        for out in (a, b, c):
+            np.testing.assert_array_equal(out[3].cpu().numpy(), ref["idx"])
+            got, want = out[1].cpu().numpy(), ref["z_q"]
+            assert np.array_equal(np.isnan(got), np.isnan(want))
+            m = ~np.isnan(want)
+            assert np.array_equal(got[m].view(np.uint32), want[m].view(np.uint32))
+            np.testing.assert_array_equal(out[4].cpu().numpy(), ref["hist"])
 
 
 def test_vq_generic_near_ties_and_duplicates_take_the_first_index():

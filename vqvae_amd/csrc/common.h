@@ -176,9 +176,10 @@ void act_absmax_impl(const float *x, int64_t B, long long elems_per_image, int *
 constexpr int kVqGenericMaxD = 256;      // (beyond 383 the reference's matmul is no longer one fmaf chain: MKL blocks the reduction)
 constexpr int kRowSqnormMaxD = 1024;     // the row-sum test hook alone
 bool vq_generic_ok(int K, int D);
-size_t vq_generic_workspace_bytes(int K);
+size_t vq_generic_workspace_bytes(int K, int D);
 int launch_vq_generic(const float *z, const float *cb, long long N, int HW, int K, int D, float beta, bool rowmajor, float *zq,
-                      long long *idx, int *hist, float *loss, float *ppl, char *ws, hipStream_t st, bool hist_zeroed);
+                      long long *idx, int *hist, float *loss, float *ppl, char *ws, hipStream_t st, bool hist_zeroed,
+                      bool vector_units = false, bool prepared = false);
 bool vq_fuse_ok(int K, int D, int64_t B, int flags);
 int vq_prepare_impl(const float *codebook, int K, int D, int flags, void *workspace, size_t workspace_bytes, hipStream_t st);
 VqFuse vq_fuse_args(const float *codebook, int K, void *workspace, float *z_q, int64_t *idx, int32_t *hist);

@@ -549,7 +549,9 @@ static bool vq_mfma_dim(int D) { return D == 32 || D == 64 || D == 128 || D == 2
 
 const char *vqvae_vq_kernel_name(int K, int D, int flags) {
     if (K < 1 || K > 16384 || (flags & VQVAE_VQ_REMOVED_FLAGS)) return "unsupported";
-    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? "vq_generic_kernel" : "unsupported";       // any other width: exact fp32 on the vector units (round 5)
+    // any other width: exact fp32 -- on the matrix cores since round 6 (zero-padded to a multiple of eight channels), round 5's
+    // vector-unit kernel behind VQVAE_VQ_BF16_FILTER for A/B runs
+    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? ((flags & VQVAE_VQ_BF16_FILTER) ? "vq_generic_kernel" : "vq_anyd_kernel") : "unsupported";
     if (D == 64 && !(flags & VQVAE_VQ_EXACT_SWEEP)) {
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_track_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_track_kernel_d64";
         if ((flags & VQVAE_VQ_ROWMAJOR) && vq_chunk_ok(K, D) && !(flags & VQVAE_VQ_BF16_FILTER)) return "vq_stream_sweep_kernel";
@@ -586,7 +588,7 @@ int vqvae_vq_screen_sweeps(int K, int D, int flags) {
 size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D) {
     if (K < 1 || K > 16384) return 0;
     (void)n_rows;
-    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? vq_generic_workspace_bytes(K) : 0;
+    if (!vq_mfma_dim(D)) return vq_generic_ok(K, D) ? vq_generic_workspace_bytes(K, D) : 0;
     return vq_plan(K, D).total;
 }
 
@@ -662,7 +664,7 @@ int vqvae::vq_forward_impl(const float *z_e, const float *codebook, int64_t B, i
     // kernel-selection flags have nothing to select there
     if (generic)
         return launch_vq_generic(z_e, codebook, N, HW, K, D, beta, (flags & VQVAE_VQ_ROWMAJOR) != 0, z_q, idx_ll, hist, loss, perplexity, ws, st,
-                                 hist_zeroed);
+                                 hist_zeroed, (flags & VQVAE_VQ_BF16_FILTER) != 0, (flags & VQVAE_VQ_CODEBOOK_PREPARED) != 0);
     switch (D) {
         case 32:  return launch_vq<32>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);
         case 64:  return launch_vq<64>(z_e, codebook, N, HW, K, beta, flags, z_q, idx_ll, hist, loss, perplexity, ws, st, hist_zeroed, zq_amax, zq_amax_done);

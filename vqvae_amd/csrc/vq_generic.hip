@@ -294,16 +294,360 @@ __global__ __launch_bounds__(256) void vq_generic_kernel(const float *__restrict
     if (tid == 0) partials[blockIdx.x] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
 }
 
+
+// =====================================================================================================================
+// Round 6: the same contract ON THE MATRIX CORES, for any width.  v_mfma_f32_32x32x2_f32 is bit for bit a k-ordered fp32 fmaf chain
+// (what vq_exact_kernel rests on for D in {32, 64, 128, 256}) and fmaf(0, 0, acc) = acc, so a row and a code padded
+// with ZERO channels to a multiple of eight give the reference's m[n, k] exactly: the N x K x D contraction of an odd width runs
+// at the fp32 MFMA rate (~80 TFLOP/s measured) instead of the 16 TFLOP/s of the per-thread chains above.  Everything the padding
+// would change stays in the true width: ||z||^2 and ||e||^2 in ATen's order for row length D, distances, keys, z + (e - z).
+//   workgroup = 64 rows (two MFMA column tiles) x all codes; the rows sit in LDS as two planes (even / odd channels: lane (row, h)
+//   reads four k-steps of its B operand with one 16-byte read), the codebook as an A-operand image in the workspace
+//   ([code tile][channel octet][parity][code][4 floats]: a wave's 32 x 2 lanes read 2 x 512 contiguous bytes per 16-byte load),
+//   wave w takes the code tiles w, w + 4, ...; per lane a running (distance, index) key -- codes arrive in ascending order -- folded
+//   across halves and waves by a 64-bit LDS minimum.  Rows whose ||z||^2 is not < 1e38 (NaN / Inf / overflow: the MFMA's special-value
+//   behaviour is not part of the pinned contract) and unusable codebooks take fmaf chains on the vector units, 256 threads per row.
+constexpr int kAnyRows = 64;
+
+__global__ __launch_bounds__(64) void vq_anyd_prepare_kernel(const float *__restrict__ cb, int K, int D, int Q, int ntile,
+                                                             float *__restrict__ ee, float *__restrict__ eeimg,
+                                                             float *__restrict__ aimg, int *__restrict__ flags) {
+    const int k = blockIdx.x * 64 + threadIdx.x;
+    if (k >= ntile * 32) return;
+    const int tile = k >> 5, m = k & 31;
+    float n2 = __builtin_inff();                             // padding codes can never win
+    if (k < K) {
+        const float *row = cb + (size_t)k * D;
+        n2 = aten_row_sum_generic([&](int c) { const float v = row[c]; return v * v; }, D);
+        ee[k] = n2;
+        if (!(n2 < 1.0e38f)) atomicOr(flags, 1);
+    }
+    // accumulator register r of lane half h holds code (r & 3) + 8 (r >> 2) + 4 h of the tile
+    eeimg[(tile * 2 + ((m >> 2) & 1)) * 16 + (m & 3) + 4 * (m >> 3)] = n2;
+    for (int c = 0; c < Q * 8; ++c) {
+        const float v = (k < K && c < D) ? cb[(size_t)k * D + c] : 0.0f;
+        aimg[((((size_t)tile * Q + (c >> 3)) * 2 + (c & 1)) * 32 + m) * 4 + ((c & 7) >> 1)] = v;
+    }
+}
+
+template <bool NCHW>
+__global__ __launch_bounds__(256) void vq_anyd_kernel(const float *__restrict__ z, const float *__restrict__ cb, const float *__restrict__ ee,
+                                                      const float *__restrict__ eeimg, const float *__restrict__ aimg,
+                                                      const int *__restrict__ flags, long long N, int HW, int K, int D, int Q, int S,
+                                                      int ntile, float *__restrict__ zq, long long *__restrict__ idx, int *__restrict__ hist,
+                                                      double *__restrict__ partials, int lds_hist, int vec4) {
+    constexpr int R = kAnyRows;
+    extern __shared__ __attribute__((aligned(16))) float zs[];            // [parity 2][row R][k-step S], zero-padded; then the histogram
+    __shared__ unsigned long long best_s[R];
+    __shared__ double red_s[4];
+    __shared__ float part_s[R * 32], zz_s[R];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, h = lane >> 5;
+    int *hist_s = reinterpret_cast<int *>(zs + 2 * R * S);
+    if (lds_hist)
+        for (int k = tid; k < K; k += 256) hist_s[k] = 0;
+    const int cb_bad = flags[0];
+    auto zat = [&](int r, int c) -> float & { return zs[(c & 1) * (R * S) + r * S + (c >> 1)]; };
+    double sacc = 0.0;
+    const long long ntiles = (N + R - 1) / R;
+    for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long long row0 = tile * R;
+        const int nr = (int)(N - row0 < R ? N - row0 : R);
+        __syncthreads();                                                  // the previous tile's rows are no longer read
+        const int Dp = Q * 8;
+        if (!NCHW && vec4) {
+            // row-major rows of a width that is a multiple of four: 16-byte loads, a few per thread and all in flight at once (the scalar
+            // form's twelve dependent load -> LDS-store rounds per tile were what bounded the kernel at D = 48); the padding k-steps once
+            const int D4 = D >> 2;
+#pragma unroll 4
+            for (int i = tid; i < R * D4; i += 256) {
+                const int r = i / D4, c4 = i - r * D4;
+                f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+                if (r < nr) v = *reinterpret_cast<const f32x4 *>(z + (row0 + r) * D + 4 * c4);
+                float *p0 = zs + r * S + 2 * c4, *p1 = p0 + R * S;
+                p0[0] = v.x; p0[1] = v.z;
+                p1[0] = v.y; p1[1] = v.w;
+            }
+            for (int i = tid; i < R * (Dp - D); i += 256) {
+                const int r = i / (Dp - D), c = D + i % (Dp - D);
+                zat(r, c) = 0.0f;
+            }
+        } else {
+#pragma unroll 4
+            for (int i = tid; i < R * Dp; i += 256) {
+                const int r = NCHW ? i % R : i / Dp, c = NCHW ? i / R : i % Dp;
+                float v = 0.0f;
+                if (r < nr && c < D) {
+                    const long long row = row0 + r;
+                    v = NCHW ? z[((row / HW) * D + c) * (long long)HW + row % HW] : z[row * D + c];
+                }
+                zat(r, c) = v;
+            }
+        }
+        if (tid < R) best_s[tid] = ~0ull;
+        __syncthreads();
+        // ---- ||z||^2 of the 64 rows in ATen's order for row length D (quantizer.py:49).  ATen's order is 32 independent lanes per row
+        // (ILP slot k, vector element t) that only meet at the end: thread (row, k) runs the eight lanes (k, 0..7) of its row -- cascade
+        // levels included --, one thread per row joins the 32 partials in ATen's order (leftover vectors into slot 0, slots 1..3 into
+        // slot 0, the scalar tail, then the eight elements): two barriers per tile
+        {
+            const int r = tid >> 2, k = tid & 3;
+            const int vec_size = D / 8, size_ilp = vec_size / 4;
+            if (D < 8) {
+                if (tid < R) zz_s[tid] = aten_row_sum_short([&](int c) { const float v = zat(tid, c); return v * v; }, D);
+            } else {
+                int level_power = 4;
+                {
+                    int cl2 = 0;
+                    while ((1 << cl2) < size_ilp) ++cl2;
+                    if (cl2 / 4 > level_power) level_power = cl2 / 4;
+                }
+                const int level_step = 1 << level_power, level_mask = level_step - 1;
+                auto sq = [&](int c) { const float v = zat(r, c); return v * v; };
+                float lv[4][8];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) lv[j][t] = 0.0f;
+                int i = 0;
+                while (i + level_step <= size_ilp) {
+                    for (int j = 0; j < level_step; ++j, ++i)
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) lv[0][t] = lv[0][t] + sq((i * 4 + k) * 8 + t);
+                    bool stop = false;
+#pragma unroll
+                    for (int j = 1; j < 4; ++j) {
+                        if (!stop) {
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                lv[j][t] = lv[j][t] + lv[j - 1][t];
+                                lv[j - 1][t] = 0.0f;
+                            }
+                            if ((i & (level_mask << (j * level_power))) != 0) stop = true;
+                        }
+                    }
+                }
+                for (; i < size_ilp; ++i)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) lv[0][t] = lv[0][t] + sq((i * 4 + k) * 8 + t);
+#pragma unroll
+                for (int j = 1; j < 4; ++j)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) lv[0][t] = lv[0][t] + lv[j][t];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) part_s[(r * 4 + k) * 8 + t] = lv[0][t];       // [row][k][t]
+                __syncthreads();
+                if (tid < R) {
+                    const int rr = tid;
+                    auto sqr = [&](int c) { const float v = zat(rr, c); return v * v; };
+                    float p0[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) p0[e] = part_s[rr * 32 + e];
+                    for (int v = size_ilp * 4; v < vec_size; ++v)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) p0[e] = p0[e] + sqr(v * 8 + e);
+#pragma unroll
+                    for (int kk = 1; kk < 4; ++kk)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) p0[e] = p0[e] + part_s[rr * 32 + kk * 8 + e];
+                    float fin = 0.0f;
+                    for (int c = vec_size * 8; c < D; ++c) fin = fin + sqr(c);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) fin = fin + p0[e];
+                    zz_s[rr] = fin;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- the sweep: wave w the code tiles w, w + 4, ...; both 32-row column tiles against every A operand ------------
+        {
+            const float zz0 = zz_s[l31], zz1 = zz_s[32 + l31];
+            // running (distance, index) per lane and column tile: codes arrive in ASCENDING order, so a strict < keeps torch.argmin's
+            // first index; no distance of a row this sweep decides is NaN (||z||^2, ||e||^2 < 1e38: the other rows are redone below)
+            float bd0 = __builtin_inff(), bd1 = __builtin_inff();
+            int bk0 = 0, bk1 = 0;
+            const float *bp = zs + h * (R * S) + l31 * S;
+            for (int t = wave; t < ntile; t += 4) {
+                f32x16 acc0, acc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.0f;
+                const float *ap = aimg + (((size_t)t * Q) * 2 + h) * 128 + l31 * 4;
+                f32x4 a = *reinterpret_cast<const f32x4 *>(ap);
+                for (int q = 0; q < Q; ++q) {
+                    const f32x4 an = *reinterpret_cast<const f32x4 *>(ap + (size_t)(q + 1 < Q ? q + 1 : q) * 256);     // a step ahead
+                    const f32x4 b0 = *reinterpret_cast<const f32x4 *>(bp + 4 * q);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4 *>(bp + 32 * S + 4 * q);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b0[i], acc0, 0, 0, 0);
+                        acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b1[i], acc1, 0, 0, 0);
+                    }
+                    a = an;
+                }
+                const float *eet = eeimg + (t * 2 + h) * 16;
+                const int code0 = t * 32 + 4 * h;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int code = code0 + (r & 3) + 8 * (r >> 2);
+                    const float e = eet[r];                               // (+inf for the padding codes of the last tile: never below)
+                    const float d0 = __builtin_fmaf(-2.0f, acc0[r], zz0 + e), d1 = __builtin_fmaf(-2.0f, acc1[r], zz1 + e);
+                    const bool l0 = d0 < bd0, l1 = d1 < bd1;
+                    bd0 = l0 ? d0 : bd0; bk0 = l0 ? code : bk0;
+                    bd1 = l1 ? d1 : bd1; bk1 = l1 ? code : bk1;
+                }
+            }
+            // the two halves of a column, then the four waves: (distance, index) keys through the 64-bit LDS minimum
+#pragma unroll
+            for (int rt = 0; rt < 2; ++rt) {
+                unsigned long long b = argmin_key(rt ? bd1 : bd0, rt ? bk1 : bk0);
+                const unsigned lo = __shfl_xor((unsigned)b, 32), hi = __shfl_xor((unsigned)(b >> 32), 32);
+                const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                b = other < b ? other : b;
+                if (h == 0) atomicMin(&best_s[32 * rt + l31], b);
+            }
+        }
+        __syncthreads();
+        // ---- rows outside the MFMA's pinned range: fmaf chains on the vector units, the whole workgroup per row --------------
+        {
+            bool any_bad = cb_bad != 0;
+            if (!any_bad)
+                for (int r = 0; r < nr; ++r) any_bad = any_bad || !(zz_s[r] < 1.0e38f);      // (LDS broadcast reads; uniform)
+            if (any_bad) {
+                if (tid < nr && (cb_bad || !(zz_s[tid] < 1.0e38f))) best_s[tid] = ~0ull;
+                __syncthreads();
+                for (int r = 0; r < nr; ++r) {
+                    const float zzr = zz_s[r];
+                    if (!cb_bad && zzr < 1.0e38f) continue;
+                    unsigned long long b = ~0ull;
+                    for (int k = tid; k < K; k += 256) {
+                        float m = 0.0f;
+                        for (int c = 0; c < D; ++c) m = __builtin_fmaf(zat(r, c), cb[(size_t)k * D + c], m);
+                        const unsigned long long key = argmin_key((zzr + ee[k]) - 2.0f * m, k);
+                        b = key < b ? key : b;
+                    }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const unsigned lo = __shfl_xor((unsigned)b, o), hi = __shfl_xor((unsigned)(b >> 32), o);
+                        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+                        b = other < b ? other : b;
+                    }
+                    if (lane == 0 && b != ~0ull) atomicMin(&best_s[r], b);
+                }
+                __syncthreads();
+            }
+        }
+        // ---- z_q = z + (e - z), the squared error, indices, histogram ------------------------------------------------------
+        if (!NCHW && vec4) {
+            const int D4 = D >> 2;
+#pragma unroll 4
+            for (int i = tid; i < R * D4; i += 256) {
+                const int r = i / D4, c4 = i - r * D4;
+                if (r < nr) {
+                    const int kb = (int)(unsigned)best_s[r];
+                    const f32x4 e = *reinterpret_cast<const f32x4 *>(cb + (size_t)kb * D + 4 * c4);
+                    const float *p0 = zs + r * S + 2 * c4, *p1 = p0 + R * S;
+                    const float z0 = p0[0], z1 = p1[0], z2 = p0[1], z3 = p1[1];
+                    const float d0 = e.x - z0, d1 = e.y - z1, d2 = e.z - z2, d3 = e.w - z3;
+                    sacc += (double)(d0 * d0);
+                    sacc += (double)(d1 * d1);
+                    sacc += (double)(d2 * d2);
+                    sacc += (double)(d3 * d3);
+                    if (zq) *reinterpret_cast<f32x4 *>(zq + (row0 + r) * D + 4 * c4) = f32x4{z0 + d0, z1 + d1, z2 + d2, z3 + d3};
+                }
+            }
+        } else {
+#pragma unroll 4
+            for (int i = tid; i < R * D; i += 256) {
+                const int r = NCHW ? i % R : i / D, c = NCHW ? i / R : i % D;
+                if (r < nr) {
+                    const int kb = (int)(unsigned)best_s[r];
+                    const float zv = zat(r, c), diff = cb[(size_t)kb * D + c] - zv;
+                    sacc += (double)(diff * diff);
+                    if (zq) {
+                        const long long row = row0 + r;
+                        const float q = zv + diff;
+                        if (NCHW) zq[((row / HW) * D + c) * (long long)HW + row % HW] = q; else zq[row * D + c] = q;
+                    }
+                }
+            }
+        }
+        if (tid < nr) {
+            const int kb = (int)(unsigned)best_s[tid];
+            idx[row0 + tid] = kb;
+            atomicAdd(lds_hist ? &hist_s[kb] : &hist[kb], 1);
+        }
+    }
+    __syncthreads();
+    if (lds_hist)
+        for (int k = tid; k < K; k += 256) {
+            const int cnt = hist_s[k];
+            if (cnt) atomicAdd(&hist[k], cnt);
+        }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+    if ((tid & 63) == 0) red_s[tid >> 6] = sacc;
+    __syncthreads();
+    if (tid == 0) partials[blockIdx.x] = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+}
+
 }  // namespace
 
 bool vq_generic_ok(int K, int D) { return K >= 1 && K <= 16384 && D >= 1 && D <= kVqGenericMaxD; }
 
-// workspace: ee (K floats), one loss partial per workgroup
+// workspace: ee (K floats), one loss partial per workgroup; round 6: + the matrix-core kernel's flags, ee image and A-operand image
 constexpr int kGenMaxGrid = 4096;
-size_t vq_generic_workspace_bytes(int K) { return align_up((size_t)K * 4, 256) + (size_t)kGenMaxGrid * 8; }
+struct AnydPlan {
+    int Q, S, ntile;
+    size_t off_partials, off_flags, off_eeimg, off_aimg, total;
+};
+static AnydPlan anyd_plan(int K, int D) {
+    AnydPlan p;
+    p.Q = (D + 7) / 8;
+    const int Dh = p.Q * 4;                                  // k-steps per row (two channels each)
+    p.S = (Dh % 8 == 0) ? Dh + 4 : Dh;                       // plane row stride = 4 mod 8 floats: sixteen lanes' 16-byte reads hit sixteen bank groups
+    p.ntile = (K + 31) / 32;
+    p.off_partials = align_up((size_t)K * 4, 256);
+    p.off_flags = p.off_partials + (size_t)kGenMaxGrid * 8;
+    p.off_eeimg = p.off_flags + 256;
+    p.off_aimg = p.off_eeimg + align_up((size_t)p.ntile * 32 * 4, 256);
+    p.total = p.off_aimg + (size_t)p.ntile * 32 * p.Q * 8 * 4;
+    return p;
+}
+size_t vq_generic_workspace_bytes(int K, int D) { return anyd_plan(K, D).total; }
 
+// vector_units: the round-5 kernel (per-thread fmaf chains), kept for A/B runs and as the second implementation the tests compare
+// the matrix-core one with (VQVAE_VQ_BF16_FILTER selects it for these widths: the flag has nothing else to select there)
 int launch_vq_generic(const float *z, const float *cb, long long N, int HW, int K, int D, float beta, bool rowmajor, float *zq,
-                      long long *idx, int *hist, float *loss, float *ppl, char *ws, hipStream_t st, bool hist_zeroed) {
+                      long long *idx, int *hist, float *loss, float *ppl, char *ws, hipStream_t st, bool hist_zeroed, bool vector_units,
+                      bool prepared) {
+    if (!vector_units) {
+        const AnydPlan p = anyd_plan(K, D);
+        float *ee = reinterpret_cast<float *>(ws), *eeimg = reinterpret_cast<float *>(ws + p.off_eeimg), *aimg = reinterpret_cast<float *>(ws + p.off_aimg);
+        int *flags = reinterpret_cast<int *>(ws + p.off_flags);
+        double *partials = reinterpret_cast<double *>(ws + p.off_partials);
+        if (!hist_zeroed && hipMemsetAsync(hist, 0, (size_t)K * sizeof(int), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+        if (!prepared) {
+            if (hipMemsetAsync(flags, 0, 256, st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
+            hipLaunchKernelGGL(vq_anyd_prepare_kernel, dim3((unsigned)((p.ntile * 32 + 63) / 64)), dim3(64), 0, st, cb, K, D, p.Q, p.ntile, ee, eeimg,
+                               aimg, flags);
+        }
+        const long long ntiles = (N + kAnyRows - 1) / kAnyRows;
+        const int lds_hist = K <= 8192 ? 1 : 0;
+        const size_t lds = (size_t)2 * kAnyRows * p.S * sizeof(float) + (lds_hist ? (size_t)K * sizeof(int) : 0);
+        const long long per_cu = lds > 36 * 1024 ? (lds > 72 * 1024 ? 1 : 2) : 4;
+        long long grid = ntiles < per_cu * num_cus() ? ntiles : per_cu * num_cus();
+        if (grid > kGenMaxGrid) grid = kGenMaxGrid;
+        prof_begin(VQVAE_PROF_VQ_MAIN, st);
+#define ANYD_LAUNCH(NCHW_)                                                                                                          \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(vq_anyd_kernel<NCHW_>), hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes - 16384); \
+    hipLaunchKernelGGL((vq_anyd_kernel<NCHW_>), dim3((unsigned)grid), dim3(256), lds, st, z, cb, ee, eeimg, aimg, flags, N, HW, K, D, p.Q, p.S, \
+                       p.ntile, zq, idx, hist, partials, lds_hist, vec4)
+        const int vec4 = (D % 4 == 0 && ((reinterpret_cast<uintptr_t>(z) | reinterpret_cast<uintptr_t>(cb) | reinterpret_cast<uintptr_t>(zq)) & 15) == 0) ? 1 : 0;
+        if (rowmajor) { ANYD_LAUNCH(false); } else { ANYD_LAUNCH(true); }
+#undef ANYD_LAUNCH
+        prof_end(VQVAE_PROF_VQ_MAIN, st);
+        if (hipGetLastError() != hipSuccess) return VQVAE_ERR_UNSUPPORTED;
+        return vq_finalize_impl(partials, (int)grid, hist, K, (int64_t)N, D, beta, loss, ppl, st);
+    }
     float *ee = reinterpret_cast<float *>(ws);
     double *partials = reinterpret_cast<double *>(ws + align_up((size_t)K * 4, 256));
     if (!hist_zeroed && hipMemsetAsync(hist, 0, (size_t)K * sizeof(int), st) != hipSuccess) return VQVAE_ERR_WORKSPACE;
