@@ -289,3 +289,25 @@ def test_quantizer_time_on_trained_z_e_stays_near_the_init_models(name, capsys):
     with capsys.disabled():
         print(f"\n   [{name}] stand-alone quantizer, 262 144 rows: {t_tr:.1f} us on the trained z_e, {t_init:.1f} us on the default-init model's")
     assert t_tr <= 2.0 * t_init
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_dead_code_cluster_on_the_two_sweep_filter_kernel(name, golden_trained):
+    """NCHW maps whose pixel count is not a multiple of 32 (7x7, 14x14 ...) run vq_filter_kernel_d64, whose candidate lists overflow on a
+    trained codebook the same way: those rows take vq_wave_argmin (round 6; one lane per row before: 1.8 ms instead of 75 us).  Bit-exact
+    against the C oracle, half of the rows aimed at the cluster."""
+    from oracle import c_oracle
+    from vqvae_amd import functional as F
+    h, rh, nl, K, D, beta, B, seed = cases.TRAINED_CASES[name]
+    cb = cases.trained_state(name)["vector_quantization.embedding.weight"]
+    g = torch.Generator().manual_seed(7)
+    zr = torch.from_numpy(golden_trained[f"{name}/z_e"]).permute(0, 2, 3, 1).reshape(-1, D)[:36 * 49].clone()
+    pick = torch.rand(zr.shape[0], generator=g) < 0.5
+    zr[pick] = (torch.randn(zr.shape[0], D, generator=g) * 10.0 ** (torch.rand(zr.shape[0], 1, generator=g) * 3 - 3))[pick]
+    z = zr.view(36, 7, 7, D).permute(0, 3, 1, 2).contiguous()
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), beta)
+    for bf in (False, True):
+        loss, zq, ppl, idx, hist = F.vq_forward(z.to(dev()), cb.to(dev()), beta, rowmajor=False, bf16_filter=bf)
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(idx.cpu().numpy(), ref["idx"])
+        assert np.array_equal(zq.cpu().numpy().view(np.uint32), ref["z_q"].view(np.uint32))

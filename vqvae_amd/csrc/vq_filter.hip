@@ -488,13 +488,20 @@ __global__ __launch_bounds__(512, 2) void vq_filter_kernel_d64(
                 }
                 if (refine[t]) kbest[t] = bk;
             }
-            if (__builtin_amdgcn_ballot_w64(bad[t])) {
-                int ks = 0;
-                if (bad[t] && h == 0)
-                    ks = vq_slow_argmin<D, ROWMAJOR>(z, ROWMAJOR ? (size_t)rc[t] * D : zbase[t], ROWMAJOR ? 1 : (size_t)HW,
-                                                     cb, ee_g, K, zz[t]);
-                ks = __shfl(ks, l31);
-                if (bad[t]) kbest[t] = ks;
+            {
+                // rows without a usable candidate list (NaN screens; OVERFLOW: a trained codebook's dead codes are one point at |z|'s
+                // scale, a row near them lists hundreds of candidates): torch.argmin over all codes, one row at a time by the whole
+                // wave (round 6; it was one lane per row: 1.8 ms instead of 75 us for 200 704 rows on a trained checkpoint)
+                unsigned long long bm = __builtin_amdgcn_ballot_w64(bad[t] && h == 0);
+                while (bm) {
+                    const int src = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(bm));
+                    bm &= bm - 1ull;
+                    const size_t zb_l = ROWMAJOR ? (size_t)rc[t] * D : zbase[t];
+                    const unsigned blo = __builtin_amdgcn_readlane((unsigned)zb_l, src), bhi = __builtin_amdgcn_readlane((unsigned)(zb_l >> 32), src);
+                    const float zzr = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(zz[t]), src));
+                    const int ks = vq_wave_argmin<D, ROWMAJOR>(z, ((size_t)bhi << 32) | blo, ROWMAJOR ? 1 : (size_t)HW, cb, ee_g, K, zzr, lane);
+                    if (l31 == src) kbest[t] = ks;
+                }
             }
         }
 
