@@ -153,9 +153,11 @@ VQVAE_API size_t vqvae_vq_workspace_bytes(int64_t n_rows, int K, int D);
  * Bit-exactness contract (tests/test_vq_gpu.py): idx and z_q are bit-identical
  * to the reference's for identical z_e bits, including first-index tie-breaking
  * and NaN-counts-as-minimum; loss / perplexity agree to rtol 1e-6.
- * Supported: 1 <= K <= 16384; D in {32, 64, 128, 256} on the matrix cores (the kernels named by vqvae_vq_kernel_name), any other
- * 1 <= D <= 256 on an exact-fp32 vector kernel with the same contract (vq_generic_kernel, round 5: main.py:21 leaves
- * --embedding_dim free and the reference "just runs"; correct, not fast -- the kernel-selection flags select nothing there).
+ * Supported: 1 <= K <= 16384; D in {32, 64, 128, 256} on the kernels named by vqvae_vq_kernel_name; any other 1 <= D <= 256
+ * (main.py:21 leaves --embedding_dim free and the reference "just runs") with the same contract on the fp32 matrix cores (round 6,
+ * vq_anyd_kernel: rows and codes zero-padded to a multiple of eight channels -- fmaf(0, 0, acc) = acc, so v_mfma_f32_32x32x2_f32 stays
+ * the reference's k-ordered chain; ~60-80 TFLOP/s of distance arithmetic); VQVAE_VQ_BF16_FILTER selects round 5's per-thread vector
+ * chains there (vq_generic_kernel, 16 TFLOP/s; kept for A/B runs), the other kernel-selection flags select nothing for these widths.
  * D > 256 stays VQVAE_ERR_UNSUPPORTED: from D = 384 on the reference's own z @ E^T is no longer one k-ordered fmaf chain (its sgemm
  * blocks the reduction), so there are no pinned bits to be exact against.
  */
