@@ -61,6 +61,63 @@ def test_vq_random_shapes_bit_exact(seed):
         np.testing.assert_allclose(loss.item(), ref["loss"], rtol=2e-6)
         np.testing.assert_allclose(ppl.item(), ref["perplexity"], rtol=1e-5)
 
+@pytest.mark.parametrize("seed", list(range(40)))
+def test_vq_random_widths_and_dead_code_clusters_bit_exact(seed):
+    """Round 6's two new quantizer paths under random shapes, against the C oracle bit for bit:
+      * ANY embedding width 1 <= D <= 256 on the fp32 matrix cores (vq_anyd_kernel; even seeds) and on round 5's vector kernel
+        (VQVAE_VQ_BF16_FILTER), ragged K / row counts, NCHW and row-major, a NaN / Inf row now and then;
+      * D = 64 codebooks with a CLUSTER of near-identical codes of random size (a trained checkpoint's dead codes; odd seeds): rows at the
+        cluster overflow the exact part's task table and are taken by the whole wave -- every launch form."""
+    from oracle import c_oracle
+    from vqvae_amd import functional as Fh
+    r = _rng(7000 + seed)
+    g = torch.Generator().manual_seed(7000 + seed)
+    if seed % 2 == 0:
+        D = int(r.choice([1, 2, 3, 5, 7, 8, 9, 12, 17, 24, 31, 33, 40, 48, 63, 65, 72, 96, 100, 127, 129, 160, 200, 255]))
+        K = int(r.choice([1, 2, 31, 33, 64, 100, 257, 512, 700, 1025]))
+        B, H, W = int(r.integers(1, 5)), int(r.integers(1, 11)), int(r.integers(1, 11))
+        scale = float(r.choice([0.07, 1.0, 30.0]))
+        cb = torch.randn(K, D, generator=g) * (1.0 / K if scale < 1 else 1.0)
+        z = torch.randn(B, D, H, W, generator=g) * scale
+        if seed % 6 == 0 and B * H * W > 3:
+            zr = z.permute(0, 2, 3, 1).reshape(-1, D)
+            zr[1, D // 2] = float("nan")
+            zr[2, 0] = float("inf")
+            z = zr.view(B, H, W, D).permute(0, 3, 1, 2).contiguous()
+        forms = [dict(), dict(bf16_filter=True)]
+    else:
+        D, K = 64, int(r.choice([96, 256, 512, 512, 1024]))
+        m = int(r.choice([3, 20, 63, 64, 65, 130, K // 2, K - 8]))                 # cluster size
+        m = max(2, min(m, K - 1))
+        cb = torch.randn(K, D, generator=g) * float(r.choice([1.0, 8.0]))
+        centre = torch.randn(D, generator=g) * float(r.choice([0.0, 1.0]))           # at the origin (dead codes) or anywhere
+        where = torch.randperm(K, generator=g)[:m]
+        cb[where] = centre + torch.randn(m, D, generator=g) * float(r.choice([1e-7, 1e-4, 2e-3]))
+        B, H, W = int(r.integers(1, 40)), 8, 8
+        n = B * 64
+        zr = cb[torch.randint(0, K, (n,), generator=g)] + 0.05 * torch.randn(n, D, generator=g)
+        hit = torch.rand(n, generator=g) < float(r.choice([0.01, 0.2, 0.9]))
+        zr[hit] = centre + torch.randn(n, D, generator=g)[hit] * float(r.choice([1e-5, 1e-2, 0.3]))
+        z = zr.view(B, H, W, D).permute(0, 3, 1, 2).contiguous()
+        forms = [dict(), dict(form=8), dict(form=16), dict(bf16_filter=True)]
+    ref = c_oracle.vq_forward(z.numpy(), cb.numpy(), 0.25)
+    for kw in forms:
+        for rowmajor in (False, True):
+            zd = z.to(dev())
+            if rowmajor:
+                zd = zd.permute(0, 2, 3, 1).contiguous()
+            loss, z_q, ppl, idx, hist = Fh.vq_forward(zd, cb.to(dev()), 0.25, rowmajor=rowmajor, **kw)
+            if rowmajor:
+                z_q = z_q.permute(0, 3, 1, 2)
+            what = f"seed={seed} K={K} D={D} N={B * H * W} {kw} rowmajor={rowmajor}"
+            assert np.array_equal(idx.cpu().numpy(), ref["idx"]), what
+            got, want = z_q.contiguous().cpu().numpy(), ref["z_q"]
+            assert np.array_equal(np.isnan(got), np.isnan(want)), what
+            ok = ~np.isnan(want)
+            assert np.array_equal(got[ok].view(np.uint32), want[ok].view(np.uint32)), what
+            assert np.array_equal(hist.cpu().numpy(), ref["hist"]), what
+
+
 
 CONV_SEEDS = list(range(90))
 
