@@ -915,10 +915,12 @@ def test_quantizer_inside_the_encoder_kernel_equals_the_separate_launch(B, K):
     np.testing.assert_allclose(a[2].item(), b[2].item(), rtol=1e-6)
 
 
-def test_quantizer_inside_the_encoder_kernel_hard_and_nonfinite_rows():
+@pytest.mark.parametrize("cluster", [32, 420], ids=["cluster_32", "cluster_420_overflows_the_task_table"])
+def test_quantizer_inside_the_encoder_kernel_hard_and_nonfinite_rows(cluster):
     """The fused quantizer's rare paths: a codebook with duplicated / near-tied codes (rows that are open, and rows whose
     candidates the stream x cell products do not cover -> the workgroup streams the codebook stages again) and images that
-    drive z_e to Inf / NaN (scalar torch.argmin path); against the separate launch, bit for bit."""
+    drive z_e to Inf / NaN (torch.argmin over all codes); against the separate launch, bit for bit.  Round 6: a cluster of 420
+    near-identical codes -- what a trained checkpoint's dead codes are -- overflows the 64-entry task table: the wave-wide argmin."""
     from vqvae_amd import functional as F
     from vqvae_amd.modules import VQVAE
     torch.manual_seed(1)
@@ -926,8 +928,8 @@ def test_quantizer_inside_the_encoder_kernel_hard_and_nonfinite_rows():
     with torch.no_grad():
         cb = m.vector_quantization.embedding.weight
         cb[8:16] = cb[0:8]                                   # exact duplicates: ties, first index wins
-        cb[16:48] = cb[0:1] + 1e-9 * torch.randn(32, 64, device=dev())    # a cluster of 32 near-ties around code 0
-        cb[100:164] = cb[300:301] * (1 + 1e-7 * torch.arange(64, device=dev()).view(-1, 1))
+        cb[16:16 + cluster] = cb[0:1] + 1e-9 * torch.randn(cluster, 64, device=dev())    # a cluster of near-ties around code 0
+        cb[450:500] = cb[300:301] * (1 + 1e-7 * torch.arange(50, device=dev()).view(-1, 1))
     m.invalidate_caches()
     x = torch.randn(64, 3, 32, 32, generator=torch.Generator().manual_seed(4)).to(dev())
     x[5] *= 1e20                                             # z_e overflows: Inf / NaN rows
