@@ -224,11 +224,6 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
             auto mm = [&](f32x16 (&acc)[2]) {
                 acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[0][0], seed, 0, 0, 0);
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[0]), zb[1][0], seed, 0, 0, 0);
-#ifdef VQS_KO_MFMA                                               // (timing-only: one k-step of NQ; the operands are still read)
-#pragma unroll
-                for (int q = 1; q < NQ; ++q) asm volatile("" ::"v"(a[q]));
-                return;
-#endif
 #pragma unroll
                 for (int q = 1; q < NQ; ++q) {
                     acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[q]), zb[0][q], acc[0], 0, 0, 0);
@@ -239,13 +234,7 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                 unsigned cell0 = (unsigned)(2 * ((c * TC + lt) & (kEpoch - 1))), cell1 = cell0 + 1u;
                 asm volatile("" : "+s"(cell0), "+s"(cell1));
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-#ifdef VQS_KO_TRACK                                              // (timing-only knock-outs, wrong results: tools/r06_sweep_ab.sh, profiles/r06_c5_pmc.txt)
-                    L[t].m1 = trk::max3(L[t].m1, acc[t][0], acc[t][15]);
-#else
-                    trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
-#endif
-                }
+                for (int t = 0; t < 2; ++t) trk::tile(L[t], acc[t], cell0, cell1, keymask, ninf, pinf);
             };
             if (nt_here == TC) {                            // every chunk but a ragged last one: straight-line, two sets
                 f32x16 acc[2][2];
@@ -289,10 +278,8 @@ __global__ __launch_bounds__(512, 2) void vq_stream_sweep_kernel(
                     L[t].m1 = L[t].m2 = L[t].m3 = ninf;
                 }
             }
-#ifndef VQS_KO_SYNC
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next chunk have landed
             __syncthreads();                                       // everyone is done with this chunk; the next is visible
-#endif
         }
 
         // ---- threshold per row, merge of the two lane halves, verdict (vq_track.h) ----
