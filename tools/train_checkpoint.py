@@ -6,9 +6,10 @@ training.VQStraightThrough, training.step_losses); the optimizer is torch's, as 
 
     python tools/train_checkpoint.py [--n_updates 5000] [--batch_size 32] [--out gpurun_out/trained]
 
-Writes <out>/vqvae_trained.pth in the reference's checkpoint layout (utils.py:109-113: {'model', 'results',
-'hyperparameters'}), <out>/train_log.txt (the reference's log line every --log_interval updates + the range guard's
-per-layer spreads along the way) and <out>/vqvae_trained_state.npz (the 23 state_dict tensors, fp32: what tests/golden/ keeps).
+Writes <out>/<tag>.pth in the reference's checkpoint layout (utils.py:109-113: {'model', 'results', 'hyperparameters'}),
+<out>/<tag>_log.txt (the reference's log line every --log_interval updates + the range guard's per-layer spreads along the way;
+committed as profiles/r06_train_*_log.txt) and <out>/<tag>_state.npz (the 23 state_dict tensors, fp32: what tests/golden/ keeps as
+trained_main_defaults_state.npz [defaults] and trained_b128x20k_state.npz [--batch_size 128 --n_updates 20000]).
 """
 from __future__ import annotations
 
