@@ -311,3 +311,41 @@ def test_dead_code_cluster_on_the_two_sweep_filter_kernel(name, golden_trained):
         torch.cuda.synchronize()
         np.testing.assert_array_equal(idx.cpu().numpy(), ref["idx"])
         assert np.array_equal(zq.cpu().numpy().view(np.uint32), ref["z_q"].view(np.uint32))
+
+
+def test_retraining_reproduces_the_committed_checkpoint_bit_for_bit(capsys):
+    """main.py:67-98's loop on the HIP training path is deterministic (no floating-point atomics anywhere; the quantizer's indices are
+    exact by contract): 5 000 updates of tools/train_checkpoint.py's loop on the same data must give the committed
+    trained_main_defaults checkpoint BIT FOR BIT -- with every kernel change since it was made (round 6: NaN-keeping ReLUs, the wave-wide
+    argmin, the ballot-prefix second screen) in the path.  ~10 s.  Skipped where the host's CPU makes other synthetic images
+    (tests/synthdata.py's bicubic / sin / exp round per ISA)."""
+    import hashlib
+    from vqvae_amd import conv, training as T
+    from vqvae_amd.modules import VQVAE
+    x01 = synthdata.images01(50000, 2026)
+    got_sha = hashlib.sha256(x01[:4096].numpy().tobytes()).hexdigest()[:16]
+    if got_sha != "f32cbcd26e5039ae":                # the images the GPU boxes' host CPU (EPYC 9575F) makes: what the checkpoint was trained on
+        pytest.skip(f"this host generates other synthetic training images ({got_sha}) than the checkpoint's host: another model would come out")
+    want = cases.trained_state("trained_main_defaults")
+    conv.set_conv_backend("hip")
+    x_train_var = synthdata.train_var(x01)
+    data = ((x01 - 0.5) / 0.5).to(dev())
+    torch.manual_seed(0)
+    model = VQVAE(128, 32, 2, 512, 64, 0.25).to(dev())
+    opt = torch.optim.Adam(model.parameters(), lr=3e-4, amsgrad=True)
+    model.train()
+    g = torch.Generator().manual_seed(1)
+    for i in range(5000):
+        sel = torch.randint(0, 50000, (32,), generator=g).to(dev())
+        x = data[sel].contiguous()
+        opt.zero_grad()
+        el, xh, pp = model(x)
+        stats = T.step_losses(el, xh, pp, x, x_train_var)
+        stats[1].backward()
+        opt.step()
+    torch.cuda.synchronize()
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    diff = {k: float((sd[k] - want[k]).abs().max()) for k in want if not torch.equal(sd[k].view(torch.int32), want[k].view(torch.int32))}
+    assert not diff, f"retrained checkpoint differs from the committed one in {len(diff)} tensors: {diff}"
+    with capsys.disabled():
+        print("\n   5 000 updates on the HIP training path reproduce tests/golden/trained_main_defaults_state.npz bit for bit")
